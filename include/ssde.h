@@ -1,0 +1,226 @@
+/*
+ * ssde.h -- C ABI of libssde_hip.so: the MI355X (gfx950) native hot path of
+ * yang-song/score_sde_pytorch (NCSN++/DDPM++ U-Net forward, PC-sampler update,
+ * DSM-training glue).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed from the caller (PyTorch owns
+ *     the memory); the library never allocates or frees tensor storage;
+ *   - all activations are NHWC fp32, weights are pre-packed by the host (see
+ *     "weight packing" below); no torch types appear in any signature;
+ *   - every launch function takes the hipStream_t to enqueue on (as void*) and
+ *     returns 0 on success, a negative code on failure; ssde_last_error()
+ *     returns a thread-local message for the last failure;
+ *   - no global mutable state except graph handles created by ssde_graph_*.
+ *
+ * Reference interfaces each entry point replaces are cited as file:line into
+ * yang-song/score_sde_pytorch.
+ */
+#ifndef SSDE_H_
+#define SSDE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSDE_ABI_VERSION 1
+
+/* ---- prologue applied to a source tensor while it is staged into LDS ---- */
+enum {
+  SSDE_PRO_NONE = 0,    /* x                                            */
+  SSDE_PRO_GN = 1,      /* GroupNorm(x)            (AttnBlockpp, layerspp.py:77)   */
+  SSDE_PRO_GN_SILU = 2, /* SiLU(GroupNorm(x))      (ResnetBlockBigGANpp, layerspp.py:243,264) */
+  SSDE_PRO_SILU = 3     /* SiLU(x)                 (Dense_0(act(temb)), layerspp.py:263) */
+};
+
+/* A source operand: the channel-concatenation of up to two NHWC tensors
+ * (torch.cat([h, hs.pop()], dim=1), ncsnpp.py:318, without materialising it)
+ * plus an optional fused GroupNorm/SiLU prologue. */
+typedef struct ssde_src {
+  const float* p0;       /* [N, H, W, c0]                                  */
+  const float* p1;       /* [N, H, W, c1] or NULL                          */
+  int32_t c0, c1;
+  int32_t pro_mode;      /* SSDE_PRO_*                                     */
+  int32_t gn_groups;     /* G; channels-per-group = (c0+c1)/G              */
+  const float* gn_mean;  /* [N, G]  from ssde_groupnorm_stats              */
+  const float* gn_rstd;  /* [N, G]                                         */
+  const float* gn_gamma; /* [c0+c1]                                        */
+  const float* gn_beta;  /* [c0+c1]                                        */
+} ssde_src;
+
+/* ---- convolution / pointwise GEMM -------------------------------------------
+ * out = scale * ( conv_kxk(pro(main)) + conv_1x1(pro(aux)) + bias + chan_add + resid )
+ * replaces: nn.Conv2d 3x3/1x1 via ddpm_conv3x3 / ddpm_conv1x1 (models/layers.py:100-124),
+ * NIN (models/layers.py:546-555), nn.Linear (ncsnpp.py:86-91, layerspp.py:227),
+ * the strided conv of conv_downsample_2d (models/up_or_down_sampling.py:178) and
+ * the residual tail "(x + h) / sqrt(2)" (layerspp.py:268-274, 87-91).
+ * Weight packing (host side): w_main [ceil(Cin/8)][k*k][cout_pad][8],
+ * w_aux [ceil(Cx/8)][cout_pad][8], cout_pad = roundup(c_out, 64), zero filled. */
+typedef struct ssde_conv_args {
+  ssde_src main;         /* k x k source; ksize == 0 -> unused             */
+  ssde_src aux;          /* 1 x 1 source at OUTPUT resolution; p0 == NULL -> unused */
+  const float* w_main;
+  const float* w_aux;
+  int32_t n, h_in, w_in; /* spatial size of main                           */
+  int32_t h_out, w_out, c_out;
+  int32_t ksize;         /* 0 or 3                                         */
+  int32_t stride;        /* 1 or 2                                         */
+  int32_t pad;           /* zero padding of main (applied after prologue)  */
+  int32_t tile;          /* SSDE_TILE_*; 0 = let the library choose        */
+  const float* bias;     /* [c_out] or NULL                                */
+  const float* chan_add; /* [N, chan_add_ld] per-(sample, channel) addend (Dense_0(act(temb))) or NULL */
+  int32_t chan_add_ld;
+  int32_t _pad0;
+  const float* resid;    /* [N, h_out, w_out, c_out] or NULL               */
+  float out_scale;       /* 1 or 1/sqrt(2)                                 */
+  int32_t _pad1;
+  float* dst;            /* [N, h_out, w_out, c_out]                       */
+} ssde_conv_args;
+
+enum { SSDE_TILE_AUTO = 0, SSDE_TILE_256x64 = 1, SSDE_TILE_128x64 = 2, SSDE_TILE_64x64 = 3, SSDE_TILE_256x32 = 4 };
+
+/* ---- GroupNorm statistics: mean / rstd per (sample, group) -----------------
+ * replaces the reduction half of nn.GroupNorm(min(C/4,32), C, eps=1e-6)
+ * (layerspp.py:67,219,231; ncsnpp.py:194-227); the normalise+affine(+SiLU) half is
+ * fused into the consumer's prologue. */
+typedef struct ssde_gn_stats_args {
+  const float* p0; const float* p1; int32_t c0, c1;   /* virtual concat */
+  int32_t n, hw, groups; float eps;
+  float* mean; float* rstd;      /* [N, G] */
+  float* scratch;                /* >= N*slices*G*2 floats when slices > 1 */
+  int32_t slices; int32_t _pad0;
+} ssde_gn_stats_args;
+
+/* ---- upfirdn2d (NHWC): zero-insert up, pad, FIR, decimate ------------------
+ * replaces op/upfirdn2d.py:145-200 + op/upfirdn2d_kernel.cu:107-207 as used by
+ * upsample_2d / downsample_2d / conv_downsample_2d (up_or_down_sampling.py:144-257)
+ * and naive_upsample_2d / naive_downsample_2d (:59-69, as 2x2 box kernels). */
+typedef struct ssde_upfirdn_args {
+  ssde_src src;                  /* p1 must be NULL; prologue allowed */
+  int32_t n, h_in, w_in, c;
+  int32_t h_out, w_out;
+  int32_t up, down, pad0, pad1;
+  int32_t kh, kw;                /* <= 4 */
+  float k[16];                   /* row-major [kh][kw], UNflipped (the op flips, as upfirdn2d does) */
+  float* dst;                    /* [N, h_out, w_out, c] */
+} ssde_upfirdn_args;
+
+/* ---- single-head self-attention core ----------------------------------------
+ * replaces layerspp.py:82-86: w = softmax(q.k * C^-1/2) over keys; h = w.v
+ * qkv: [N, L, 3C] (q | k | v per token, output of the fused NIN_0..2 GEMM). */
+typedef struct ssde_attn_args {
+  const float* qkv; float* dst;  /* dst [N, L, C] */
+  int32_t n, l, c; float scale;
+} ssde_attn_args;
+
+/* ---- time / noise-level embeddings -------------------------------------------
+ * kind 0: GaussianFourierProjection(log(cond)) (layerspp.py:39-41, ncsnpp.py:239)
+ * kind 1: get_timestep_embedding(cond, dim)     (layers.py:515-529)              */
+typedef struct ssde_embed_args {
+  const float* cond;             /* [N] sigma (kind 0) or timestep label (kind 1) */
+  const float* w;                /* kind 0: [dim/2] Fourier frequencies */
+  float* dst;                    /* [N, dim] */
+  int32_t n, dim, kind, _pad0;
+} ssde_embed_args;
+
+/* ---- layout boundary (reference tensors are NCHW, ncsnpp.py:232) ------------ */
+typedef struct ssde_to_nhwc_args {   /* dst[n,h,w,c] = a*src[n,c,h,w]+b, channels c..c_pad-1 zero */
+  const float* src; float* dst; int32_t n, c, h, w, c_pad; float a, b; int32_t _pad0;
+} ssde_to_nhwc_args;
+typedef struct ssde_to_nchw_args {   /* dst[n,c,h,w] = f(n) * src[n,h,w,c] */
+  const float* src; float* dst; int32_t n, c, h, w, c_src;
+  int32_t mode;                  /* 0: f=1; 1: f=1/v[n] (scale_by_sigma, ncsnpp.py:377-379); 2: f=-1/v[n] (VP score, models/utils.py:159) */
+  const float* v;                /* [N] */
+} ssde_to_nchw_args;
+
+/* ---- fused bias + activation (API parity with op/fused_act.py:86-97) -------- */
+typedef struct ssde_bias_act_args {
+  const float* src; const float* bias; float* dst;
+  int64_t numel; int32_t channels; int32_t inner;   /* bias index = (i / inner) % channels */
+  int32_t act;                    /* 1 linear, 3 leaky relu */
+  float alpha, scale;
+  int32_t _pad0;
+} ssde_bias_act_args;
+
+/* ---- predictor-corrector update (sampling.py:195-200, 262-282, 181-187) ----- */
+typedef struct ssde_sumsq_args {  /* out_a[n] = sum(a[n,:]^2), out_b likewise */
+  const float* a; const float* b; float* out_a; float* out_b; int32_t n, per;
+} ssde_sumsq_args;
+typedef struct ssde_randn_args {  /* Philox4x32-10 (rocRAND device API) standard normals */
+  float* dst; int64_t numel; uint64_t seed; const int32_t* step_ptr; int32_t stream_id; int32_t _pad0;
+} ssde_randn_args;
+typedef struct ssde_langevin_args {
+  /* step = (snr * mean_n(||z||) / mean_n(||g||))^2 * 2 * alpha ; x_mean = x + step*g ; x = x_mean + sqrt(2*step)*z */
+  float* x; float* x_mean; const float* grad; const float* noise;
+  const float* grad_sumsq; const float* noise_sumsq;  /* [N] from ssde_sumsq */
+  const float* alpha_tab; const int32_t* step_ptr;    /* alpha = alpha_tab ? alpha_tab[*step_ptr] : 1 */
+  int32_t n, per; float snr; int32_t _pad0;
+} ssde_langevin_args;
+typedef struct ssde_predictor_args {
+  /* x_mean = a*x + b*score ; x = x_mean + c*z   with (a,b,c) = coef[3*(*step_ptr) .. +2]
+   * reverse diffusion VE: a=1, b=G^2, c=G (sde_lib.py:246-254, sampling.py:195-200) */
+  float* x; float* x_mean; const float* score; const float* noise;
+  const float* coef; const int32_t* step_ptr;
+  int64_t numel;
+} ssde_predictor_args;
+typedef struct ssde_fill_args {   /* dst[i] = tab[*step_ptr] (vec_t / labels of the current step, sampling.py:405) */
+  float* dst; const float* tab; const int32_t* step_ptr; int32_t n; int32_t _pad0;
+} ssde_fill_args;
+typedef struct ssde_step_inc_args { int32_t* step_ptr; int32_t delta; int32_t _pad0; } ssde_step_inc_args;
+
+/* ---- single-op launch entry points ------------------------------------------ */
+int ssde_conv2d(const ssde_conv_args* a, void* stream);
+int ssde_groupnorm_stats(const ssde_gn_stats_args* a, void* stream);
+int ssde_upfirdn2d(const ssde_upfirdn_args* a, void* stream);
+int ssde_attention(const ssde_attn_args* a, void* stream);
+int ssde_embed(const ssde_embed_args* a, void* stream);
+int ssde_to_nhwc(const ssde_to_nhwc_args* a, void* stream);
+int ssde_to_nchw(const ssde_to_nchw_args* a, void* stream);
+int ssde_fused_bias_act(const ssde_bias_act_args* a, void* stream);
+int ssde_sumsq(const ssde_sumsq_args* a, void* stream);
+int ssde_randn(const ssde_randn_args* a, void* stream);
+int ssde_langevin_update(const ssde_langevin_args* a, void* stream);
+int ssde_predictor_update(const ssde_predictor_args* a, void* stream);
+int ssde_fill_from_table(const ssde_fill_args* a, void* stream);
+int ssde_step_inc(const ssde_step_inc_args* a, void* stream);
+
+/* ---- programs: a whole U-Net forward / PC step as one call -------------------
+ * A program is a flat array of tagged ops built once by the host (it replaces the
+ * Python module walk of NCSNpp.forward, ncsnpp.py:232-381, and of pc_sampler's
+ * loop body, sampling.py:403-407). */
+enum {
+  SSDE_OP_CONV = 1, SSDE_OP_GN_STATS = 2, SSDE_OP_UPFIRDN = 3, SSDE_OP_ATTN = 4, SSDE_OP_EMBED = 5,
+  SSDE_OP_TO_NHWC = 6, SSDE_OP_TO_NCHW = 7, SSDE_OP_BIAS_ACT = 8, SSDE_OP_SUMSQ = 9, SSDE_OP_RANDN = 10,
+  SSDE_OP_LANGEVIN = 11, SSDE_OP_PREDICTOR = 12, SSDE_OP_FILL = 13, SSDE_OP_STEP_INC = 14
+};
+typedef struct ssde_op {
+  int32_t kind; int32_t flops_class;   /* flops_class: free tag echoed by timing */
+  union {
+    ssde_conv_args conv; ssde_gn_stats_args gn; ssde_upfirdn_args fir; ssde_attn_args attn;
+    ssde_embed_args embed; ssde_to_nhwc_args to_nhwc; ssde_to_nchw_args to_nchw;
+    ssde_bias_act_args bias_act; ssde_sumsq_args sumsq; ssde_randn_args randn;
+    ssde_langevin_args langevin; ssde_predictor_args predictor; ssde_fill_args fill;
+    ssde_step_inc_args step_inc;
+  } u;
+} ssde_op;
+
+int ssde_program_run(const ssde_op* ops, int32_t n_ops, void* stream);
+/* same, bracketing every op with HIP events on `stream`; ms[i] = duration of op i */
+int ssde_program_run_timed(const ssde_op* ops, int32_t n_ops, void* stream, float* ms);
+/* capture the program into a hipGraph on `stream` (must be a non-default stream) */
+int ssde_graph_capture(const ssde_op* ops, int32_t n_ops, void* stream, void** graph_out);
+int ssde_graph_launch(void* graph, void* stream);
+int ssde_graph_destroy(void* graph);
+
+/* ---- misc --------------------------------------------------------------------- */
+int ssde_abi_version(void);
+int ssde_sizeof_op(void);             /* lets the ctypes mirror verify its layout */
+const char* ssde_last_error(void);
+int ssde_conv_lds_bytes(const ssde_conv_args* a);   /* diagnostic: LDS a launch would use */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSDE_H_ */

@@ -1,0 +1,147 @@
+"""CPU oracle for the predictor-corrector sampler and the DSM loss (TEST INFRASTRUCTURE ONLY).
+
+Restates, with injected noise (the reference draws torch.randn_like on the device, which a
+Philox/rocRAND stream cannot reproduce -- SURVEY F9):
+  * get_pc_sampler.pc_sampler             sampling.py:390-409
+  * LangevinCorrector.update_fn           sampling.py:262-282
+  * ReverseDiffusionPredictor.update_fn   sampling.py:195-200  (+ RSDE.discretize sde_lib.py:102-107)
+  * EulerMaruyamaPredictor.update_fn      sampling.py:181-187  (+ RSDE.sde sde_lib.py:93-100)
+  * VESDE / VPSDE / subVPSDE scalar maps  sde_lib.py:112-254
+  * get_score_fn                          models/utils.py:129-178
+  * get_sde_loss_fn.loss_fn               losses.py:73-99
+Pinned against the reference by oracle/gen_golden.py (see unet_oracle.py header).
+"""
+import numpy as np
+import torch
+
+from . import unet_oracle
+
+
+def _b(v):
+    return v[:, None, None, None]
+
+
+class _VE:
+    def __init__(self, sigma_min=0.01, sigma_max=50, N=1000):
+        self.sigma_min, self.sigma_max, self.N, self.T = sigma_min, sigma_max, N, 1
+        self.discrete_sigmas = torch.exp(torch.linspace(np.log(sigma_min), np.log(sigma_max), N))   # sde_lib.py:219
+
+    def sigma(self, t):                                                                              # sde_lib.py:233-236
+        return self.sigma_min * (self.sigma_max / self.sigma_min) ** t
+
+    def sde(self, x, t):                                                                             # sde_lib.py:226-231
+        g = self.sigma(t) * torch.sqrt(torch.tensor(2 * (np.log(self.sigma_max) - np.log(self.sigma_min))))
+        return torch.zeros_like(x), g
+
+    def marginal_prob(self, x, t):
+        return x, self.sigma(t)
+
+    def discretize(self, x, t):                                                                      # sde_lib.py:246-254
+        idx = (t * (self.N - 1) / self.T).long()
+        sigma = self.discrete_sigmas[idx]
+        adj = torch.where(idx == 0, torch.zeros_like(t), self.discrete_sigmas[idx - 1])
+        return torch.zeros_like(x), torch.sqrt(sigma ** 2 - adj ** 2)
+
+
+class _VP:
+    def __init__(self, beta_min=0.1, beta_max=20, N=1000, sub=False):
+        self.beta_0, self.beta_1, self.N, self.T, self.sub = beta_min, beta_max, N, 1, sub
+        self.discrete_betas = torch.linspace(beta_min / N, beta_max / N, N)                          # sde_lib.py:125
+        self.alphas = 1. - self.discrete_betas
+
+    def sde(self, x, t):                                                                             # sde_lib.py:135-139, 184-189
+        beta_t = self.beta_0 + t * (self.beta_1 - self.beta_0)
+        drift = -0.5 * _b(beta_t) * x
+        if self.sub:
+            disc = 1. - torch.exp(-2 * self.beta_0 * t - (self.beta_1 - self.beta_0) * t ** 2)
+            return drift, torch.sqrt(beta_t * disc)
+        return drift, torch.sqrt(beta_t)
+
+    def marginal_prob(self, x, t):                                                                   # sde_lib.py:141-145, 191-195
+        lmc = -0.25 * t ** 2 * (self.beta_1 - self.beta_0) - 0.5 * t * self.beta_0
+        if self.sub:
+            return _b(torch.exp(lmc)) * x, 1 - torch.exp(2. * lmc)
+        return torch.exp(_b(lmc)) * x, torch.sqrt(1. - torch.exp(2. * lmc))
+
+
+def make_sde(kind, **kw):
+    kind = kind.lower()
+    if kind == "vesde":
+        return _VE(**kw)
+    if kind == "vpsde":
+        return _VP(sub=False, **kw)
+    if kind == "subvpsde":
+        return _VP(sub=True, **kw)
+    raise ValueError(kind)
+
+
+def score_fn(cfg, sd, sde, x, t, continuous=True):
+    """models/utils.py:129-178 (continuous models)."""
+    assert continuous
+    if isinstance(sde, _VP):
+        labels = t * 999
+        out = unet_oracle.ncsnpp_forward(cfg, sd, x, labels)
+        std = sde.marginal_prob(torch.zeros_like(x), t)[1]
+        return -out / _b(std)
+    labels = sde.marginal_prob(torch.zeros_like(x), t)[1]
+    return unet_oracle.ncsnpp_forward(cfg, sd, x, labels)
+
+
+def pc_sample(cfg, sd, sde_kind, sde_kwargs, x_T, noises, snr, n_steps=1, eps=1e-3, denoise=True,
+              predictor="reverse_diffusion", corrector="langevin", max_steps=None):
+    """sampling.py:390-409 with noise injected: noises[i, 0] feeds the corrector, noises[i, 1] the predictor."""
+    sde = make_sde(sde_kind, **sde_kwargs)
+    B = x_T.shape[0]
+    x = x_T.clone()
+    x_mean = x
+    timesteps = torch.linspace(sde.T, eps, sde.N)
+    x_steps, score_norms = [], []
+    steps = sde.N if max_steps is None else max_steps
+    with torch.no_grad():
+        for i in range(steps):
+            t = torch.ones(B) * timesteps[i]
+            if corrector == "langevin":                                                   # sampling.py:262-282
+                alpha = torch.ones_like(t) if isinstance(sde, _VE) else sde.alphas[(t * (sde.N - 1) / sde.T).long()]
+                for _ in range(n_steps):
+                    grad = score_fn(cfg, sd, sde, x, t)
+                    z = noises[i, 0]
+                    score_norms.append(float(torch.norm(grad.reshape(B, -1), dim=-1).mean()))
+                    gnorm = torch.norm(grad.reshape(B, -1), dim=-1).mean()
+                    znorm = torch.norm(z.reshape(B, -1), dim=-1).mean()
+                    step = (snr * znorm / gnorm) ** 2 * 2 * alpha
+                    x_mean = x + _b(step) * grad
+                    x = x_mean + _b(torch.sqrt(step * 2)) * z
+            if predictor == "reverse_diffusion":                                          # sampling.py:195-200
+                f, G = sde.discretize(x, t)
+                s = score_fn(cfg, sd, sde, x, t)
+                score_norms.append(float(torch.norm(s.reshape(B, -1), dim=-1).mean()))
+                rev_f = f - _b(G) ** 2 * s                                                # sde_lib.py:105
+                x_mean = x - rev_f
+                x = x_mean + _b(G) * noises[i, 1]
+            elif predictor == "euler_maruyama":                                           # sampling.py:181-187
+                dt = -1. / sde.N
+                drift, diffusion = sde.sde(x, t)
+                s = score_fn(cfg, sd, sde, x, t)
+                score_norms.append(float(torch.norm(s.reshape(B, -1), dim=-1).mean()))
+                drift = drift - _b(diffusion) ** 2 * s                                    # sde_lib.py:96
+                x_mean = x + drift * dt
+                x = x_mean + _b(diffusion) * np.sqrt(-dt) * noises[i, 1]
+            elif predictor != "none":
+                raise ValueError(predictor)
+            x_steps.append(x.clone())
+    return dict(samples=(x_mean if denoise else x), x_steps=x_steps, score_norms=score_norms)
+
+
+def dsm_loss(cfg, sd, sde_kind, sde_kwargs, batch, t, z, reduce_mean=False, likelihood_weighting=False):
+    """losses.py:73-99 with injected (t, z); eval-mode network (dropout off)."""
+    sde = make_sde(sde_kind, **sde_kwargs)
+    mean, std = sde.marginal_prob(batch, t)
+    perturbed = mean + _b(std) * z
+    s = score_fn(cfg, sd, sde, perturbed, t)
+    red = (lambda v: torch.mean(v, dim=-1)) if reduce_mean else (lambda v: 0.5 * torch.sum(v, dim=-1))
+    if not likelihood_weighting:
+        losses = red(torch.square(s * _b(std) + z).reshape(batch.shape[0], -1))
+    else:
+        g2 = sde.sde(torch.zeros_like(batch), t)[1] ** 2
+        losses = red(torch.square(s + z / _b(std)).reshape(batch.shape[0], -1)) * g2
+    return torch.mean(losses)

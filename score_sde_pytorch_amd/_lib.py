@@ -1,0 +1,184 @@
+"""ctypes binding of libssde_hip.so (C ABI declared in include/ssde.h).
+
+The structures below mirror include/ssde.h field for field; `load()` verifies the
+mirror against the library (`ssde_sizeof_op`, `ssde_abi_version`) and fails loudly
+if the shared object is missing -- there is no CPU or eager-PyTorch fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libssde_hip.so")
+ABI_VERSION = 1
+
+PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_SILU = 0, 1, 2, 3
+TILE_AUTO, TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32 = 0, 1, 2, 3, 4
+(OP_CONV, OP_GN_STATS, OP_UPFIRDN, OP_ATTN, OP_EMBED, OP_TO_NHWC, OP_TO_NCHW, OP_BIAS_ACT, OP_SUMSQ,
+ OP_RANDN, OP_LANGEVIN, OP_PREDICTOR, OP_FILL, OP_STEP_INC) = range(1, 15)
+
+_fp = C.c_void_p  # device pointers are passed as integers
+
+
+class Src(C.Structure):
+    _fields_ = [("p0", _fp), ("p1", _fp), ("c0", C.c_int32), ("c1", C.c_int32),
+                ("pro_mode", C.c_int32), ("gn_groups", C.c_int32),
+                ("gn_mean", _fp), ("gn_rstd", _fp), ("gn_gamma", _fp), ("gn_beta", _fp)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("main", Src), ("aux", Src), ("w_main", _fp), ("w_aux", _fp),
+                ("n", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32),
+                ("h_out", C.c_int32), ("w_out", C.c_int32), ("c_out", C.c_int32),
+                ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("tile", C.c_int32),
+                ("bias", _fp), ("chan_add", _fp), ("chan_add_ld", C.c_int32), ("_pad0", C.c_int32),
+                ("resid", _fp), ("out_scale", C.c_float), ("_pad1", C.c_int32), ("dst", _fp)]
+
+
+class GnStatsArgs(C.Structure):
+    _fields_ = [("p0", _fp), ("p1", _fp), ("c0", C.c_int32), ("c1", C.c_int32),
+                ("n", C.c_int32), ("hw", C.c_int32), ("groups", C.c_int32), ("eps", C.c_float),
+                ("mean", _fp), ("rstd", _fp), ("scratch", _fp), ("slices", C.c_int32), ("_pad0", C.c_int32)]
+
+
+class UpfirdnArgs(C.Structure):
+    _fields_ = [("src", Src), ("n", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32), ("c", C.c_int32),
+                ("h_out", C.c_int32), ("w_out", C.c_int32),
+                ("up", C.c_int32), ("down", C.c_int32), ("pad0", C.c_int32), ("pad1", C.c_int32),
+                ("kh", C.c_int32), ("kw", C.c_int32), ("k", C.c_float * 16), ("dst", _fp)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("qkv", _fp), ("dst", _fp), ("n", C.c_int32), ("l", C.c_int32), ("c", C.c_int32), ("scale", C.c_float)]
+
+
+class EmbedArgs(C.Structure):
+    _fields_ = [("cond", _fp), ("w", _fp), ("dst", _fp), ("n", C.c_int32), ("dim", C.c_int32),
+                ("kind", C.c_int32), ("_pad0", C.c_int32)]
+
+
+class ToNhwcArgs(C.Structure):
+    _fields_ = [("src", _fp), ("dst", _fp), ("n", C.c_int32), ("c", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("c_pad", C.c_int32), ("a", C.c_float), ("b", C.c_float), ("_pad0", C.c_int32)]
+
+
+class ToNchwArgs(C.Structure):
+    _fields_ = [("src", _fp), ("dst", _fp), ("n", C.c_int32), ("c", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("c_src", C.c_int32), ("mode", C.c_int32), ("v", _fp)]
+
+
+class BiasActArgs(C.Structure):
+    _fields_ = [("src", _fp), ("bias", _fp), ("dst", _fp), ("numel", C.c_int64), ("channels", C.c_int32),
+                ("inner", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float), ("scale", C.c_float), ("_pad0", C.c_int32)]
+
+
+class SumsqArgs(C.Structure):
+    _fields_ = [("a", _fp), ("b", _fp), ("out_a", _fp), ("out_b", _fp), ("n", C.c_int32), ("per", C.c_int32)]
+
+
+class RandnArgs(C.Structure):
+    _fields_ = [("dst", _fp), ("numel", C.c_int64), ("seed", C.c_uint64), ("step_ptr", _fp),
+                ("stream_id", C.c_int32), ("_pad0", C.c_int32)]
+
+
+class LangevinArgs(C.Structure):
+    _fields_ = [("x", _fp), ("x_mean", _fp), ("grad", _fp), ("noise", _fp), ("grad_sumsq", _fp), ("noise_sumsq", _fp),
+                ("alpha_tab", _fp), ("step_ptr", _fp), ("n", C.c_int32), ("per", C.c_int32), ("snr", C.c_float),
+                ("_pad0", C.c_int32)]
+
+
+class PredictorArgs(C.Structure):
+    _fields_ = [("x", _fp), ("x_mean", _fp), ("score", _fp), ("noise", _fp), ("coef", _fp), ("step_ptr", _fp),
+                ("numel", C.c_int64)]
+
+
+class FillArgs(C.Structure):
+    _fields_ = [("dst", _fp), ("tab", _fp), ("step_ptr", _fp), ("n", C.c_int32), ("_pad0", C.c_int32)]
+
+
+class StepIncArgs(C.Structure):
+    _fields_ = [("step_ptr", _fp), ("delta", C.c_int32), ("_pad0", C.c_int32)]
+
+
+class _OpUnion(C.Union):
+    _fields_ = [("conv", ConvArgs), ("gn", GnStatsArgs), ("fir", UpfirdnArgs), ("attn", AttnArgs),
+                ("embed", EmbedArgs), ("to_nhwc", ToNhwcArgs), ("to_nchw", ToNchwArgs), ("bias_act", BiasActArgs),
+                ("sumsq", SumsqArgs), ("randn", RandnArgs), ("langevin", LangevinArgs), ("predictor", PredictorArgs),
+                ("fill", FillArgs), ("step_inc", StepIncArgs)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("flops_class", C.c_int32), ("u", _OpUnion)]
+
+
+_UNION_FIELD = {OP_CONV: "conv", OP_GN_STATS: "gn", OP_UPFIRDN: "fir", OP_ATTN: "attn", OP_EMBED: "embed",
+                OP_TO_NHWC: "to_nhwc", OP_TO_NCHW: "to_nchw", OP_BIAS_ACT: "bias_act", OP_SUMSQ: "sumsq",
+                OP_RANDN: "randn", OP_LANGEVIN: "langevin", OP_PREDICTOR: "predictor", OP_FILL: "fill",
+                OP_STEP_INC: "step_inc"}
+
+EXPORTS = ["ssde_conv2d", "ssde_groupnorm_stats", "ssde_upfirdn2d", "ssde_attention", "ssde_embed", "ssde_to_nhwc",
+           "ssde_to_nchw", "ssde_fused_bias_act", "ssde_sumsq", "ssde_randn", "ssde_langevin_update",
+           "ssde_predictor_update", "ssde_fill_from_table", "ssde_step_inc", "ssde_program_run",
+           "ssde_program_run_timed", "ssde_graph_capture", "ssde_graph_launch", "ssde_graph_destroy",
+           "ssde_abi_version", "ssde_sizeof_op", "ssde_last_error", "ssde_conv_lds_bytes"]
+
+_lib = None
+
+
+class SsdeError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the library is absent or mismatched."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SsdeError(
+            "libssde_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(score_sde_pytorch_amd has no CPU/eager fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise SsdeError("libssde_hip.so does not export %s" % name)
+    lib.ssde_last_error.restype = C.c_char_p
+    lib.ssde_program_run.argtypes = [C.POINTER(Op), C.c_int32, C.c_void_p]
+    lib.ssde_program_run_timed.argtypes = [C.POINTER(Op), C.c_int32, C.c_void_p, C.POINTER(C.c_float)]
+    lib.ssde_graph_capture.argtypes = [C.POINTER(Op), C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.ssde_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ssde_graph_destroy.argtypes = [C.c_void_p]
+    for name, typ in [("ssde_conv2d", ConvArgs), ("ssde_groupnorm_stats", GnStatsArgs), ("ssde_upfirdn2d", UpfirdnArgs),
+                      ("ssde_attention", AttnArgs), ("ssde_embed", EmbedArgs), ("ssde_to_nhwc", ToNhwcArgs),
+                      ("ssde_to_nchw", ToNchwArgs), ("ssde_fused_bias_act", BiasActArgs), ("ssde_sumsq", SumsqArgs),
+                      ("ssde_randn", RandnArgs), ("ssde_langevin_update", LangevinArgs),
+                      ("ssde_predictor_update", PredictorArgs), ("ssde_fill_from_table", FillArgs),
+                      ("ssde_step_inc", StepIncArgs)]:
+        getattr(lib, name).argtypes = [C.POINTER(typ), C.c_void_p]
+    lib.ssde_conv_lds_bytes.argtypes = [C.POINTER(ConvArgs)]
+    if lib.ssde_abi_version() != ABI_VERSION:
+        raise SsdeError("ABI mismatch: library %d, binding %d" % (lib.ssde_abi_version(), ABI_VERSION))
+    if lib.ssde_sizeof_op() != C.sizeof(Op):
+        raise SsdeError("struct layout mismatch: sizeof(ssde_op) library %d, ctypes %d" % (lib.ssde_sizeof_op(), C.sizeof(Op)))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().ssde_last_error()
+        raise SsdeError("%s failed (%d): %s" % (what or "libssde_hip call", rc, msg.decode() if msg else "?"))
+
+
+def make_op(kind, args, flops_class=0):
+    op = Op()
+    op.kind = kind
+    op.flops_class = flops_class
+    setattr(op.u, _UNION_FIELD[kind], args)
+    return op
+
+
+def op_array(ops):
+    arr = (Op * len(ops))()
+    for i, o in enumerate(ops):
+        arr[i] = o
+    return arr

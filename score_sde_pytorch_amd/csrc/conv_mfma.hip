@@ -1,0 +1,442 @@
+// Implicit-GEMM convolution for gfx950 on the exact-fp32 matrix pipe
+// (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, 64 FLOP/clk/SIMD = the fp32 peak).
+//
+//   out[m, j] = scale * ( sum_{tap,ci} pro(main)[pix(m)+tap, ci] * Wm[tap, ci, j]
+//                       + sum_{cx}     pro(aux )[pix(m),     cx] * Wa[cx, j]
+//                       + bias[j] + chan_add[n(m), j] + resid[m, j] )
+//
+// Reference semantics: nn.Conv2d 3x3 / 1x1 (models/layers.py:100-124), NIN
+// (models/layers.py:546-555), nn.Linear (layerspp.py:227,263), the strided conv
+// of conv_downsample_2d (up_or_down_sampling.py:178), fused with the GroupNorm
+// apply + SiLU that precede them (layerspp.py:243,264,77) and the residual tail
+// (layerspp.py:268-274).
+//
+// Data layout: activations NHWC fp32; a workgroup (4 waves) owns BM output pixels
+// (a TH x TW patch of IMGS images) x BN output channels.  Per input-channel chunk
+// the (TH+2)x(TW+2) halo is staged ONCE into LDS (rows padded by 4 floats: the
+// ds_read_b128 fragment reads are bank-conflict free) and re-used by all 9 taps;
+// weights are host-packed [cin/8][tap][cout][8] so a tap's BN x 8 panel is one
+// contiguous run.  An MFMA k-slot pair (h = lane>>5) is mapped to 4 consecutive
+// channels so one ds_read_b128 feeds 4 MFMAs per operand.
+#include "ssde_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct ConvGeom {
+  int N, Hin, Win, Hout, Wout, Cout, CoutPad;
+  int stride, pad;
+  int lTW, lTH;
+  int tiles_x, tiles_per_img;
+  int m_tiles, n_tiles;
+};
+
+struct ConvKParams {
+  ssde_src main, aux;
+  const float* w_main;
+  const float* w_aux;
+  ConvGeom g;
+  const float* bias;
+  const float* chan_add;
+  int chan_add_ld;
+  const float* resid;
+  float scale;
+  float* dst;
+};
+
+constexpr int kThreads = 256;
+
+// One reduction phase: KS x KS taps over source `s`, BKC input channels per stage.
+template <int KS, int BKC, int BM, int BN, int TM, int TN, int MAXI>
+__device__ __forceinline__ void conv_phase(const ssde_src& s, const float* __restrict__ wpk,
+                                           const ConvGeom& g, int stride, int pad, int Hs, int Ws,
+                                           int img0, int ty, int tx, int n0, int wm0, int wn0,
+                                           f32x16 (&acc)[TM][TN], float* smem) {
+  constexpr int T = KS * KS;
+  constexpr int F4 = BKC / 4;
+  constexpr int LDA = BKC + 4;
+  constexpr int NB8 = BKC / 8;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int TW = 1 << g.lTW, TH = 1 << g.lTH;
+  const int IMGS = BM >> (g.lTW + g.lTH);
+  const int HWd = (TW - 1) * stride + KS;
+  const int HH = (TH - 1) * stride + KS;
+  const int halo_px = IMGS * HH * HWd;
+  const int items = halo_px * F4;
+  float* As = smem;
+  float* Bs = smem + ((halo_px * LDA + 3) & ~3);
+
+  // ---- per-thread staging plan (identical for every channel chunk) ----
+  const int f4 = tid % F4;
+  int goff[MAXI];   // input pixel index, -1 = zero padding, -2 = no item
+  int gimg[MAXI];
+#pragma unroll
+  for (int it = 0; it < MAXI; ++it) {
+    const int q = tid + it * kThreads;
+    goff[it] = -2;
+    gimg[it] = 0;
+    if (q < items) {
+      const int hp = q / F4;
+      const int il = hp / (HH * HWd);
+      const int rem = hp - il * (HH * HWd);
+      const int hy = rem / HWd;
+      const int hx = rem - hy * HWd;
+      const int iy = ty * TH * stride - pad + hy;
+      const int ix = tx * TW * stride - pad + hx;
+      const int img = img0 + il;
+      const bool inb = (img < g.N) && (iy >= 0) && (iy < Hs) && (ix >= 0) && (ix < Ws);
+      goff[it] = inb ? (img * Hs + iy) * Ws + ix : -1;
+      gimg[it] = img;
+    }
+  }
+  // ---- per-lane fragment bases ----
+  int hb[TM], bb[TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int m = wm0 + a * 32 + li;
+    const int c = m & (TW - 1);
+    const int r = (m >> g.lTW) & (TH - 1);
+    const int il = m >> (g.lTW + g.lTH);
+    hb[a] = ((il * HH + r * stride) * HWd + c * stride) * LDA + lh * 4;
+  }
+#pragma unroll
+  for (int b = 0; b < TN; ++b) bb[b] = (wn0 + b * 32 + li) * LDA + lh * 4;
+
+  const int Ctot = s.c0 + s.c1;
+  const int ncin8 = (Ctot + 7) >> 3;
+  const int nchunks = (Ctot + BKC - 1) / BKC;
+  const int cpg = (s.pro_mode == SSDE_PRO_GN || s.pro_mode == SSDE_PRO_GN_SILU) ? Ctot / s.gn_groups : 1;
+  constexpr int B_ITEMS = T * BN * F4;
+  constexpr int B_ITERS = (B_ITEMS + kThreads - 1) / kThreads;
+
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int c_base = ch * BKC;
+    const float* base;
+    int C, cc;
+    if (c_base < s.c0) { base = s.p0; C = s.c0; cc = c_base; }
+    else               { base = s.p1; C = s.c1; cc = c_base - s.c0; }
+    const int cthr = cc + f4 * 4;
+    const bool chan_ok = cthr < C;
+
+    // issue all global loads of the stage first
+    float4 av[MAXI];
+#pragma unroll
+    for (int it = 0; it < MAXI; ++it) {
+      av[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (goff[it] >= 0 && chan_ok)
+        av[it] = *reinterpret_cast<const float4*>(base + (size_t)goff[it] * C + cthr);
+    }
+    float4 bv[B_ITERS];
+#pragma unroll
+    for (int it = 0; it < B_ITERS; ++it) {
+      const int q = tid + it * kThreads;
+      bv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (B_ITEMS % kThreads == 0 || q < B_ITEMS) {
+        const int f = q & 1;
+        const int j = (q >> 1) % BN;
+        const int r = (q >> 1) / BN;       // = cb * T + tap
+        const int tap = r % T, cb = r / T;
+        const int cin8 = ch * NB8 + cb;
+        if (cin8 < ncin8)
+          bv[it] = *reinterpret_cast<const float4*>(
+              wpk + ((size_t)(cin8 * T + tap) * g.CoutPad + n0 + j) * 8 + f * 4);
+      }
+    }
+    float4 gam = make_float4(1.f, 1.f, 1.f, 1.f), bet = make_float4(0.f, 0.f, 0.f, 0.f);
+    float mu[MAXI], rs[MAXI];
+    const bool use_gn = (s.pro_mode == SSDE_PRO_GN || s.pro_mode == SSDE_PRO_GN_SILU);
+    if (use_gn && (c_base + f4 * 4) < Ctot) {
+      gam = *reinterpret_cast<const float4*>(s.gn_gamma + c_base + f4 * 4);
+      bet = *reinterpret_cast<const float4*>(s.gn_beta + c_base + f4 * 4);
+      const int gidx = (c_base + f4 * 4) / cpg;
+#pragma unroll
+      for (int it = 0; it < MAXI; ++it) {
+        mu[it] = 0.f; rs[it] = 1.f;
+        if (goff[it] >= 0) {
+          mu[it] = s.gn_mean[gimg[it] * s.gn_groups + gidx];
+          rs[it] = s.gn_rstd[gimg[it] * s.gn_groups + gidx];
+        }
+      }
+    }
+
+    __syncthreads();   // previous stage's fragment reads are done
+
+    // ---- A: prologue transform + LDS store ----
+#pragma unroll
+    for (int it = 0; it < MAXI; ++it) {
+      if (goff[it] == -2) continue;
+      float4 v = av[it];
+      if (goff[it] >= 0 && chan_ok) {
+        if (use_gn) {
+          v.x = (v.x - mu[it]) * rs[it] * gam.x + bet.x;
+          v.y = (v.y - mu[it]) * rs[it] * gam.y + bet.y;
+          v.z = (v.z - mu[it]) * rs[it] * gam.z + bet.z;
+          v.w = (v.w - mu[it]) * rs[it] * gam.w + bet.w;
+        }
+        if (s.pro_mode == SSDE_PRO_GN_SILU || s.pro_mode == SSDE_PRO_SILU) {
+          v.x = ssde_silu(v.x); v.y = ssde_silu(v.y); v.z = ssde_silu(v.z); v.w = ssde_silu(v.w);
+        }
+      }
+      const int q = tid + it * kThreads;
+      *reinterpret_cast<float4*>(As + (q / F4) * LDA + f4 * 4) = v;
+    }
+    // ---- B: LDS store ----
+#pragma unroll
+    for (int it = 0; it < B_ITERS; ++it) {
+      const int q = tid + it * kThreads;
+      if (B_ITEMS % kThreads == 0 || q < B_ITEMS) {
+        const int f = q & 1;
+        const int j = (q >> 1) % BN;
+        const int r = (q >> 1) / BN;
+        const int tap = r % T, cb = r / T;
+        *reinterpret_cast<float4*>(Bs + (tap * BN + j) * LDA + cb * 8 + f * 4) = bv[it];
+      }
+    }
+    __syncthreads();
+
+    // ---- MFMA: every tap re-uses the staged halo ----
+#pragma unroll
+    for (int tap = 0; tap < T; ++tap) {
+      const int dy = tap / KS, dx = tap % KS;
+      const int aoff = (dy * HWd + dx) * LDA;
+#pragma unroll
+      for (int kk = 0; kk < NB8; ++kk) {
+        float4 af[TM], bf[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const float4*>(As + hb[a] + aoff + kk * 8);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const float4*>(Bs + bb[b] + tap * BN * LDA + kk * 8);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
+          }
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int TM, int TN, bool HAS3, bool HAS1>
+__global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvKParams p) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const ConvGeom& g = p.g;
+
+  // XCD-aware tile order: the n-tiles of one m-tile are consecutive on ONE XCD
+  // (blocks are dispatched round-robin over the 8 XCDs), so the activation halo
+  // is fetched from HBM once and re-read from that XCD's L2.
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, l = bid >> 3;
+  const int nt = l % g.n_tiles;
+  const int mt = (l / g.n_tiles) * 8 + xcd;
+  if (mt >= g.m_tiles) return;
+
+  const int IMGS = BM >> (g.lTW + g.lTH);
+  const int img0 = (mt / g.tiles_per_img) * IMGS;
+  const int trem = mt % g.tiles_per_img;
+  const int ty = trem / g.tiles_x, tx = trem % g.tiles_x;
+  const int n0 = nt * BN;
+
+  const int wave = threadIdx.x >> 6;
+  const int wm0 = (wave / WN) * (TM * 32);
+  const int wn0 = (wave % WN) * (TN * 32);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  if constexpr (HAS3)
+    conv_phase<3, 8, BM, BN, TM, TN, 5>(p.main, p.w_main, g, g.stride, g.pad, g.Hin, g.Win,
+                                         img0, ty, tx, n0, wm0, wn0, acc, smem);
+  if constexpr (HAS1)
+    conv_phase<1, 32, BM, BN, TM, TN, (BM * 8) / kThreads>(p.aux, p.w_aux, g, 1, 0, g.Hout, g.Wout,
+                                                          img0, ty, tx, n0, wm0, wn0, acc, smem);
+
+  // ---- epilogue: lane owns output channel j; 16 rows per 32x32 block ----
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int TW = 1 << g.lTW, TH = 1 << g.lTH;
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int j = n0 + wn0 + b * 32 + li;
+    if (j >= g.Cout) continue;
+    const float bj = p.bias ? p.bias[j] : 0.f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int c = m & (TW - 1);
+        const int rr = (m >> g.lTW) & (TH - 1);
+        const int img = img0 + (m >> (g.lTW + g.lTH));
+        if (img >= g.N) continue;
+        const size_t pix = ((size_t)img * g.Hout + ty * TH + rr) * g.Wout + tx * TW + c;
+        float v = acc[a][b][r] + bj;
+        if (p.chan_add) v += p.chan_add[(size_t)img * p.chan_add_ld + j];
+        if (p.resid) v += p.resid[pix * g.Cout + j];
+        p.dst[pix * g.Cout + j] = v * p.scale;
+      }
+    }
+  }
+}
+
+struct TileCfg { int bm, bn; };
+const TileCfg kTiles[5] = {{0, 0}, {256, 64}, {128, 64}, {64, 64}, {256, 32}};
+
+struct ConvPlan {
+  ConvKParams kp;
+  int tile;
+  int lds_bytes;
+  int grid;
+  bool has3, has1;
+};
+
+int src_check(const ssde_src& s, const char* what) {
+  SSDE_REQUIRE(s.p0 != nullptr && s.c0 > 0, "conv: %s source missing", what);
+  SSDE_REQUIRE(s.c0 % 4 == 0 && s.c1 % 4 == 0, "conv: %s channels must be multiples of 4 (got %d,%d)", what, s.c0, s.c1);
+  SSDE_REQUIRE(s.c1 == 0 || s.p1 != nullptr, "conv: %s second tensor missing", what);
+  SSDE_REQUIRE(s.c1 == 0 || s.c0 % 32 == 0, "conv: %s concat boundary must be a multiple of 32", what);
+  if (s.pro_mode == SSDE_PRO_GN || s.pro_mode == SSDE_PRO_GN_SILU) {
+    SSDE_REQUIRE(s.gn_groups > 0 && (s.c0 + s.c1) % s.gn_groups == 0 && ((s.c0 + s.c1) / s.gn_groups) % 4 == 0,
+                 "conv: %s GroupNorm needs channels-per-group %% 4 == 0", what);
+    SSDE_REQUIRE(s.gn_mean && s.gn_rstd && s.gn_gamma && s.gn_beta, "conv: %s GroupNorm pointers missing", what);
+  }
+  return SSDE_OK;
+}
+
+int halo_px(int bm, int w_out, int h_out, int stride, int ks, int* lTW, int* lTH) {
+  int tw = w_out < 16 ? w_out : 16;
+  int th = bm / tw; if (th > h_out) th = h_out;
+  *lTW = ssde_ilog2(tw); *lTH = ssde_ilog2(th);
+  const int imgs = bm / (tw * th);
+  return imgs * ((th - 1) * stride + ks) * ((tw - 1) * stride + ks);
+}
+
+int make_plan(const ssde_conv_args* a, ConvPlan* pl) {
+  SSDE_REQUIRE(a && a->dst, "conv: null args");
+  pl->has3 = a->ksize != 0;
+  pl->has1 = a->aux.p0 != nullptr;
+  SSDE_REQUIRE(pl->has3 || pl->has1, "conv: neither a k x k nor a 1 x 1 source");
+  SSDE_REQUIRE(a->ksize == 0 || a->ksize == 3, "conv: ksize must be 0 or 3 (1x1 goes through aux)");
+  SSDE_REQUIRE(a->n > 0 && a->h_out > 0 && a->w_out > 0 && a->c_out > 0, "conv: bad output shape");
+  SSDE_REQUIRE(ssde_is_pow2(a->h_out) && ssde_is_pow2(a->w_out), "conv: output H, W must be powers of two (got %dx%d)", a->h_out, a->w_out);
+  if (pl->has3) {
+    if (int rc = src_check(a->main, "main")) return rc;
+    SSDE_REQUIRE(a->w_main, "conv: w_main missing");
+    SSDE_REQUIRE(a->stride == 1 || a->stride == 2, "conv: stride must be 1 or 2");
+    SSDE_REQUIRE((a->h_in + 2 * a->pad - 3) / a->stride + 1 == a->h_out && (a->w_in + 2 * a->pad - 3) / a->stride + 1 == a->w_out,
+                 "conv: output shape inconsistent with input %dx%d stride %d pad %d", a->h_in, a->w_in, a->stride, a->pad);
+  }
+  if (pl->has1) {
+    if (int rc = src_check(a->aux, "aux")) return rc;
+    SSDE_REQUIRE(a->w_aux, "conv: w_aux missing");
+  }
+  const int M = a->n * a->h_out * a->w_out;
+  int tile = a->tile;
+  if (tile == SSDE_TILE_AUTO) {
+    if (a->c_out <= 32) tile = SSDE_TILE_256x32;
+    else {
+      const int nt = ssde_cdiv(a->c_out, 64);
+      if (ssde_cdiv(M, 256) * nt >= 512) tile = SSDE_TILE_256x64;
+      else if (ssde_cdiv(M, 128) * nt >= 384) tile = SSDE_TILE_128x64;
+      else tile = SSDE_TILE_64x64;
+    }
+    if (a->w_out * a->h_out * a->n < kTiles[tile].bm && tile != SSDE_TILE_256x32) tile = SSDE_TILE_64x64;
+  }
+  SSDE_REQUIRE(tile >= 1 && tile <= 4, "conv: bad tile id %d", tile);
+  int lTW = 0, lTH = 0;
+  if (pl->has3) {
+    // the halo of the chosen tile must fit the per-thread staging plan (5 x 256 float4 items)
+    while (true) {
+      const int px = halo_px(kTiles[tile].bm, a->w_out, a->h_out, a->stride, 3, &lTW, &lTH);
+      if (px * 2 <= 5 * kThreads) break;
+      SSDE_REQUIRE(tile == SSDE_TILE_256x64 || tile == SSDE_TILE_128x64, "conv: halo too large for any tile");
+      tile += 1;
+    }
+  } else {
+    halo_px(kTiles[tile].bm, a->w_out, a->h_out, 1, 1, &lTW, &lTH);
+  }
+  const int bm = kTiles[tile].bm, bn = kTiles[tile].bn;
+  const int tw = 1 << lTW, th = 1 << lTH, imgs = bm / (tw * th);
+  SSDE_REQUIRE(a->w_out % tw == 0 && a->h_out % th == 0, "conv: tile %dx%d does not divide output", th, tw);
+
+  ConvKParams& kp = pl->kp;
+  kp.main = a->main; kp.aux = a->aux; kp.w_main = a->w_main; kp.w_aux = a->w_aux;
+  ConvGeom& g = kp.g;
+  g.N = a->n; g.Hin = a->h_in; g.Win = a->w_in; g.Hout = a->h_out; g.Wout = a->w_out;
+  g.Cout = a->c_out; g.CoutPad = ssde_cdiv(a->c_out, 64) * 64;
+  g.stride = pl->has3 ? a->stride : 1; g.pad = pl->has3 ? a->pad : 0;
+  g.lTW = lTW; g.lTH = lTH;
+  g.tiles_x = a->w_out / tw;
+  g.tiles_per_img = g.tiles_x * (a->h_out / th);
+  g.m_tiles = ssde_cdiv(a->n, imgs) * g.tiles_per_img;
+  g.n_tiles = ssde_cdiv(a->c_out, bn);
+  kp.bias = a->bias; kp.chan_add = a->chan_add; kp.chan_add_ld = a->chan_add_ld;
+  kp.resid = a->resid; kp.scale = a->out_scale; kp.dst = a->dst;
+
+  int lds = 0;
+  if (pl->has3) {
+    const int px = imgs * ((th - 1) * g.stride + 3) * ((tw - 1) * g.stride + 3);
+    lds = (((px * 12 + 3) & ~3) + 9 * bn * 12) * 4;
+  }
+  if (pl->has1) {
+    const int l1 = (bm * 36 + bn * 36) * 4;
+    if (l1 > lds) lds = l1;
+  }
+  pl->lds_bytes = lds;
+  pl->tile = tile;
+  pl->grid = ssde_cdiv(g.m_tiles, 8) * 8 * g.n_tiles;
+  return SSDE_OK;
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_cfg(const ConvPlan& pl, hipStream_t st) {
+  dim3 grid(pl.grid), block(kThreads);
+#define SSDE_CONV_LAUNCH(H3, H1)                                                                     \
+  do {                                                                                               \
+    auto kfn = conv_mfma_kernel<WM, WN, TM, TN, H3, H1>;                                             \
+    if (pl.lds_bytes > 64 * 1024)                                                                    \
+      SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                         \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds_bytes)); \
+    hipLaunchKernelGGL(kfn, grid, block, pl.lds_bytes, st, pl.kp);                                   \
+  } while (0)
+  if (pl.has3 && pl.has1) SSDE_CONV_LAUNCH(true, true);
+  else if (pl.has3) SSDE_CONV_LAUNCH(true, false);
+  else SSDE_CONV_LAUNCH(false, true);
+#undef SSDE_CONV_LAUNCH
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}
+
+}  // namespace
+
+extern "C" int ssde_conv2d(const ssde_conv_args* a, void* stream) {
+  ConvPlan pl;
+  if (int rc = make_plan(a, &pl)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (pl.tile) {
+    case SSDE_TILE_256x64: return launch_cfg<4, 1, 2, 2>(pl, st);
+    case SSDE_TILE_128x64: return launch_cfg<4, 1, 1, 2>(pl, st);
+    case SSDE_TILE_64x64:  return launch_cfg<2, 2, 1, 1>(pl, st);
+    case SSDE_TILE_256x32: return launch_cfg<4, 1, 2, 1>(pl, st);
+  }
+  ssde_set_error("conv: unreachable tile %d", pl.tile);
+  return SSDE_EINVAL;
+}
+
+extern "C" int ssde_conv_lds_bytes(const ssde_conv_args* a) {
+  ConvPlan pl;
+  if (int rc = make_plan(a, &pl)) return rc;
+  return pl.lds_bytes;
+}

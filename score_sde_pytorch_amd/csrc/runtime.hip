@@ -1,0 +1,107 @@
+// Error reporting, program runner, hipGraph capture for libssde_hip.so.
+#include "ssde_common.h"
+#include <string.h>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+void ssde_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* ssde_last_error(void) { return g_err; }
+extern "C" int ssde_abi_version(void) { return SSDE_ABI_VERSION; }
+extern "C" int ssde_sizeof_op(void) { return (int)sizeof(ssde_op); }
+
+static int run_one(const ssde_op& op, void* stream) {
+  switch (op.kind) {
+    case SSDE_OP_CONV: return ssde_conv2d(&op.u.conv, stream);
+    case SSDE_OP_GN_STATS: return ssde_groupnorm_stats(&op.u.gn, stream);
+    case SSDE_OP_UPFIRDN: return ssde_upfirdn2d(&op.u.fir, stream);
+    case SSDE_OP_ATTN: return ssde_attention(&op.u.attn, stream);
+    case SSDE_OP_EMBED: return ssde_embed(&op.u.embed, stream);
+    case SSDE_OP_TO_NHWC: return ssde_to_nhwc(&op.u.to_nhwc, stream);
+    case SSDE_OP_TO_NCHW: return ssde_to_nchw(&op.u.to_nchw, stream);
+    case SSDE_OP_BIAS_ACT: return ssde_fused_bias_act(&op.u.bias_act, stream);
+    case SSDE_OP_SUMSQ: return ssde_sumsq(&op.u.sumsq, stream);
+    case SSDE_OP_RANDN: return ssde_randn(&op.u.randn, stream);
+    case SSDE_OP_LANGEVIN: return ssde_langevin_update(&op.u.langevin, stream);
+    case SSDE_OP_PREDICTOR: return ssde_predictor_update(&op.u.predictor, stream);
+    case SSDE_OP_FILL: return ssde_fill_from_table(&op.u.fill, stream);
+    case SSDE_OP_STEP_INC: return ssde_step_inc(&op.u.step_inc, stream);
+  }
+  ssde_set_error("program: unknown op kind %d", op.kind);
+  return SSDE_EINVAL;
+}
+
+extern "C" int ssde_program_run(const ssde_op* ops, int32_t n_ops, void* stream) {
+  SSDE_REQUIRE(ops && n_ops >= 0, "program: null ops");
+  for (int i = 0; i < n_ops; ++i) {
+    if (int rc = run_one(ops[i], stream)) {
+      char tmp[400];
+      strncpy(tmp, g_err, sizeof(tmp) - 1); tmp[sizeof(tmp) - 1] = 0;
+      ssde_set_error("op %d (kind %d): %s", i, ops[i].kind, tmp);
+      return rc;
+    }
+  }
+  return SSDE_OK;
+}
+
+extern "C" int ssde_program_run_timed(const ssde_op* ops, int32_t n_ops, void* stream, float* ms) {
+  SSDE_REQUIRE(ops && n_ops >= 0 && ms, "program: null args");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  std::vector<hipEvent_t> ev(n_ops + 1);
+  for (auto& e : ev) SSDE_HIP_CHECK(hipEventCreate(&e));
+  int rc = SSDE_OK;
+  SSDE_HIP_CHECK(hipEventRecord(ev[0], st));
+  for (int i = 0; i < n_ops && rc == SSDE_OK; ++i) {
+    rc = run_one(ops[i], stream);
+    if (rc == SSDE_OK && hipEventRecord(ev[i + 1], st) != hipSuccess) { ssde_set_error("hipEventRecord failed"); rc = SSDE_EHIP; }
+  }
+  if (rc == SSDE_OK) {
+    if (hipStreamSynchronize(st) != hipSuccess) { ssde_set_error("hipStreamSynchronize failed"); rc = SSDE_EHIP; }
+    for (int i = 0; i < n_ops && rc == SSDE_OK; ++i)
+      if (hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]) != hipSuccess) { ssde_set_error("hipEventElapsedTime failed"); rc = SSDE_EHIP; }
+  }
+  for (auto& e : ev) hipEventDestroy(e);
+  return rc;
+}
+
+struct SsdeGraph { hipGraph_t graph; hipGraphExec_t exec; };
+
+extern "C" int ssde_graph_capture(const ssde_op* ops, int32_t n_ops, void* stream, void** graph_out) {
+  SSDE_REQUIRE(ops && graph_out, "graph: null args");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  SSDE_REQUIRE(st != nullptr, "graph: capture needs a non-default stream");
+  SSDE_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  int rc = ssde_program_run(ops, n_ops, stream);
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(st, &graph);
+  if (rc != SSDE_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+  if (e != hipSuccess) { ssde_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return SSDE_EHIP; }
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) { hipGraphDestroy(graph); ssde_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e)); return SSDE_EHIP; }
+  SsdeGraph* g = new SsdeGraph{graph, exec};
+  *graph_out = g;
+  return SSDE_OK;
+}
+
+extern "C" int ssde_graph_launch(void* graph, void* stream) {
+  SSDE_REQUIRE(graph, "graph: null handle");
+  SsdeGraph* g = static_cast<SsdeGraph*>(graph);
+  SSDE_HIP_CHECK(hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream)));
+  return SSDE_OK;
+}
+
+extern "C" int ssde_graph_destroy(void* graph) {
+  if (!graph) return SSDE_OK;
+  SsdeGraph* g = static_cast<SsdeGraph*>(graph);
+  hipGraphExecDestroy(g->exec);
+  hipGraphDestroy(g->graph);
+  delete g;
+  return SSDE_OK;
+}

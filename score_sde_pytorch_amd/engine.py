@@ -1,0 +1,580 @@
+"""Lowers an NCSNpp module to a static program of HIP kernels (libssde_hip.so) and runs it.
+
+The reference walks ~60 nn.Modules per forward and issues ~900 eager kernels
+(models/ncsnpp.py:232-381).  Here the walk happens ONCE per
+(batch, resolution): `UNetEngine` records a flat op list (include/ssde.h `ssde_op`),
+plans activation storage by liveness (buffers are recycled as soon as their last
+consumer has been enqueued), packs weights into the layouts the kernels read, and
+afterwards a forward is a single C call (`ssde_program_run`) or a hipGraph replay.
+
+Fusions encoded in the program (per ResnetBlockBigGANpp, models/layerspp.py:242-274):
+  GroupNorm stats  -> 1 reduction kernel (normalise+affine+SiLU is applied while the
+                      consumer stages its LDS tile; the normalised tensor never exists)
+  Conv_0           -> conv kernel, epilogue adds bias and Dense_0(SiLU(temb)) (all 40+
+                      Dense_0 projections are ONE batched GEMM at the start)
+  Conv_1 (+Conv_2) -> conv kernel; the 1x1 skip conv is an extra K-range of the same
+                      GEMM; epilogue adds the identity skip and scales by 1/sqrt(2)
+  torch.cat        -> never materialised: a source is a pair of tensors
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+_FLT = 4
+INV_SQRT2 = float(1.0 / np.sqrt(2.0))
+
+# flops_class tags (echoed by ssde_program_run_timed; bench.py groups by them)
+FC_OTHER, FC_CONV3, FC_CONV1, FC_ATTN, FC_GN, FC_FIR = 0, 1, 2, 3, 4, 5
+
+
+class Buf:
+    """A symbolic activation buffer; storage is assigned by ProgramBuilder.finalize()."""
+    __slots__ = ("shape", "numel", "name", "persistent", "tensor", "first", "last")
+
+    def __init__(self, shape, name="", persistent=False):
+        self.shape = tuple(int(s) for s in shape)
+        self.numel = int(np.prod(self.shape))
+        self.name = name
+        self.persistent = persistent
+        self.tensor = None
+        self.first = None
+        self.last = None
+
+
+def _walk_refs(value, fn):
+    if isinstance(value, Buf):
+        fn(value)
+    elif isinstance(value, tuple) and len(value) == 2 and isinstance(value[0], Buf):
+        fn(value[0])
+    elif isinstance(value, dict):
+        for v in value.values():
+            _walk_refs(v, fn)
+
+
+def _ptr(value):
+    if value is None:
+        return None
+    off = 0
+    if isinstance(value, tuple):
+        value, off = value
+    t = value.tensor if isinstance(value, Buf) else value
+    assert t is not None, "buffer without storage"
+    return t.data_ptr() + off * _FLT
+
+
+def _fill(struct, fields):
+    for k, v in fields.items():
+        cur = getattr(struct, k)
+        if isinstance(v, dict):
+            _fill(cur, v)
+        elif isinstance(v, (list, tuple)) and not (len(v) == 2 and isinstance(v[0], (Buf, torch.Tensor))):
+            for i, x in enumerate(v):
+                cur[i] = x
+        elif isinstance(v, (Buf, torch.Tensor, tuple)) or v is None:
+            setattr(struct, k, _ptr(v))
+        else:
+            setattr(struct, k, v)
+
+
+_STRUCT = {L.OP_CONV: L.ConvArgs, L.OP_GN_STATS: L.GnStatsArgs, L.OP_UPFIRDN: L.UpfirdnArgs, L.OP_ATTN: L.AttnArgs,
+           L.OP_EMBED: L.EmbedArgs, L.OP_TO_NHWC: L.ToNhwcArgs, L.OP_TO_NCHW: L.ToNchwArgs,
+           L.OP_BIAS_ACT: L.BiasActArgs, L.OP_SUMSQ: L.SumsqArgs, L.OP_RANDN: L.RandnArgs,
+           L.OP_LANGEVIN: L.LangevinArgs, L.OP_PREDICTOR: L.PredictorArgs, L.OP_FILL: L.FillArgs,
+           L.OP_STEP_INC: L.StepIncArgs}
+
+
+class ProgramBuilder:
+    def __init__(self, device):
+        self.device = device
+        self.specs = []      # (kind, fields, flops_class, flops)
+        self.keep = []       # tensors that must outlive the program
+
+    def buf(self, *shape, name="", persistent=False):
+        return Buf(shape, name, persistent)
+
+    def tensor(self, t):
+        self.keep.append(t)
+        return t
+
+    def add(self, kind, fields, fclass=FC_OTHER, flops=0.0):
+        self.specs.append((kind, fields, fclass, float(flops)))
+
+    def extend(self, other):
+        self.specs.extend(other.specs)
+        self.keep.extend(other.keep)
+
+    def finalize(self):
+        """Liveness-planned storage + ctypes op array."""
+        bufs = {}
+        for i, (_, fields, _, _) in enumerate(self.specs):
+            def mark(b, i=i):
+                if b.first is None:
+                    b.first = i
+                b.last = i
+                bufs[id(b)] = b
+            _walk_refs(fields, mark)
+        by_first, by_last = {}, {}
+        for b in bufs.values():
+            by_first.setdefault(b.first, []).append(b)
+            by_last.setdefault(b.last, []).append(b)
+        free, blocks = [], []
+        for i in range(len(self.specs)):
+            for b in by_first.get(i, []):
+                if b.tensor is not None:
+                    continue
+                need = (b.numel + 1023) // 1024 * 1024
+                if b.persistent:
+                    b.tensor = torch.zeros(need, dtype=torch.float32, device=self.device)
+                    blocks.append(b.tensor)
+                    continue
+                best = None
+                for j, t in enumerate(free):
+                    if t.numel() >= need and (best is None or t.numel() < free[best].numel()):
+                        best = j
+                if best is not None and free[best].numel() <= 2 * need:
+                    b.tensor = free.pop(best)
+                else:
+                    b.tensor = torch.zeros(need, dtype=torch.float32, device=self.device)
+                    blocks.append(b.tensor)
+            for b in by_last.get(i, []):
+                if not b.persistent:
+                    free.append(b.tensor)
+        self.blocks = blocks
+        self.arena_bytes = sum(t.numel() for t in blocks) * _FLT
+        ops = []
+        for kind, fields, fclass, _ in self.specs:
+            args = _STRUCT[kind]()
+            _fill(args, fields)
+            ops.append(L.make_op(kind, args, fclass))
+        return Program(L.op_array(ops), [s[2] for s in self.specs], [s[3] for s in self.specs], self)
+
+
+class Program:
+    def __init__(self, ops, classes, flops, owner):
+        self.ops, self.n = ops, len(ops)
+        self.classes, self.flops = classes, flops
+        self._owner = owner   # keeps buffers / weights alive
+        self._graph = None
+
+    def run(self, stream=None):
+        lib = L.load()
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        L.check(lib.ssde_program_run(self.ops, self.n, C.c_void_p(st)), "ssde_program_run")
+
+    def run_timed(self):
+        lib = L.load()
+        ms = (C.c_float * self.n)()
+        st = torch.cuda.current_stream().cuda_stream
+        L.check(lib.ssde_program_run_timed(self.ops, self.n, C.c_void_p(st), ms), "ssde_program_run_timed")
+        return list(ms)
+
+    def capture(self, stream):
+        """Capture into a hipGraph on `stream` (a torch.cuda.Stream, not the default stream)."""
+        lib = L.load()
+        h = C.c_void_p()
+        L.check(lib.ssde_graph_capture(self.ops, self.n, C.c_void_p(stream.cuda_stream), C.byref(h)), "ssde_graph_capture")
+        self._graph = h
+        return h
+
+    def replay(self, stream):
+        L.check(L.load().ssde_graph_launch(self._graph, C.c_void_p(stream.cuda_stream)), "ssde_graph_launch")
+
+    def __del__(self):
+        if getattr(self, "_graph", None):
+            try:
+                L.load().ssde_graph_destroy(self._graph)
+            except Exception:
+                pass
+
+
+# --------------------------------------------------------------------------- weights
+def pack_conv_weight(w):
+    """[Cout, Cin, kh, kw] -> [ceil(Cin/8)][kh*kw][roundup(Cout,64)][8] (layout read by conv_mfma.hip)."""
+    cout, cin, kh, kw = w.shape
+    cin8, cpad, t = (cin + 7) // 8, (cout + 63) // 64 * 64, kh * kw
+    full = torch.zeros(cin8 * 8, t, cpad, dtype=torch.float32, device=w.device)
+    full[:cin, :, :cout] = w.detach().to(torch.float32).permute(1, 2, 3, 0).reshape(cin, t, cout)
+    return full.reshape(cin8, 8, t, cpad).permute(0, 2, 3, 1).contiguous()
+
+
+def pack_matrix(w):
+    """[Cout, Cin] (nn.Linear / 1x1 conv orientation) -> [ceil(Cin/8)][roundup(Cout,64)][8]."""
+    return pack_conv_weight(w.reshape(w.shape[0], w.shape[1], 1, 1))
+
+
+class WeightStore:
+    """Packed copies of module parameters with stable device addresses.
+
+    `refresh()` re-packs an entry in place when any of its source parameters changed
+    (`Tensor._version`, bumped by optimizer steps / load_state_dict), so programs and
+    captured graphs keep valid pointers."""
+
+    def __init__(self, device):
+        self.device = device
+        self.entries = []   # [packed, sources, fn, stamp]
+
+    def add(self, sources, fn):
+        with torch.no_grad():
+            packed = fn(*[s.detach() for s in sources]).to(self.device).contiguous()
+        self.entries.append([packed, list(sources), fn, self._stamp(sources)])
+        return packed
+
+    @staticmethod
+    def _stamp(sources):
+        return tuple((s.data_ptr(), s._version) for s in sources)
+
+    def refresh(self):
+        for e in self.entries:
+            st = self._stamp(e[1])
+            if st != e[3]:
+                with torch.no_grad():
+                    e[0].copy_(e[2](*[s.detach() for s in e[1]]).to(self.device))
+                e[3] = st
+
+
+# --------------------------------------------------------------------------- lowering helpers
+def _src(t, c, t2=None, c2=0, pro=L.PRO_NONE, gn=None):
+    d = dict(p0=t, p1=t2, c0=c, c1=c2, pro_mode=pro, gn_groups=0, gn_mean=None, gn_rstd=None, gn_gamma=None, gn_beta=None)
+    if gn is not None:
+        d.update(gn_groups=gn["groups"], gn_mean=gn["mean"], gn_rstd=gn["rstd"], gn_gamma=gn["gamma"], gn_beta=gn["beta"])
+    return d
+
+
+_NOSRC = dict(p0=None, p1=None, c0=0, c1=0, pro_mode=0, gn_groups=0, gn_mean=None, gn_rstd=None, gn_gamma=None, gn_beta=None)
+
+
+def fir_taps(k, gain=1.0):
+    """_setup_kernel (models/up_or_down_sampling.py:181-188): normalised outer product."""
+    k = np.asarray(k, dtype=np.float32)
+    if k.ndim == 1:
+        k = np.outer(k, k)
+    k = k / np.sum(k)
+    return (k * gain).astype(np.float32)
+
+
+class Lowering:
+    """Shared op emitters (used by the U-Net engine and by per-op wrappers in tests/op)."""
+
+    def __init__(self, builder, weights, batch):
+        self.b, self.w, self.n = builder, weights, batch
+
+    # -- GroupNorm statistics of a (possibly concatenated) NHWC source
+    def gn_stats(self, t, c, hw, gn_module, t2=None, c2=0):
+        ctot = c + c2
+        groups = gn_module.num_groups
+        mean = self.b.buf(self.n, groups, name="gn_mean")
+        rstd = self.b.buf(self.n, groups, name="gn_rstd")
+        slices = max(1, min(int(math.ceil(256 / self.n)), hw // 64)) if hw >= 128 else 1
+        scratch = self.b.buf(self.n * slices * groups * 2, name="gn_scratch") if slices > 1 else None
+        self.b.add(L.OP_GN_STATS, dict(p0=t, p1=t2, c0=c, c1=c2, n=self.n, hw=hw, groups=groups, eps=float(gn_module.eps),
+                                       mean=mean, rstd=rstd, scratch=scratch, slices=slices), FC_GN)
+        gamma = self.w.add([gn_module.weight], lambda x: x.to(torch.float32).clone())
+        beta = self.w.add([gn_module.bias], lambda x: x.to(torch.float32).clone())
+        assert ctot == gn_module.num_channels
+        return dict(groups=groups, mean=mean, rstd=rstd, gamma=gamma, beta=beta)
+
+    def conv(self, dst, h_out, w_out, c_out, main=None, w_main=None, h_in=0, w_in=0, stride=1, pad=1,
+             aux=None, w_aux=None, bias=None, chan_add=None, chan_add_ld=0, resid=None, scale=1.0, tile=L.TILE_AUTO):
+        px = self.n * h_out * w_out
+        flops = 0.0
+        if main is not None:
+            flops += 2.0 * px * 9 * (main["c0"] + main["c1"]) * c_out
+        if aux is not None:
+            flops += 2.0 * px * (aux["c0"] + aux["c1"]) * c_out
+        self.b.add(L.OP_CONV, dict(
+            main=main if main is not None else _NOSRC, aux=aux if aux is not None else _NOSRC,
+            w_main=w_main, w_aux=w_aux, n=self.n, h_in=h_in, w_in=w_in, h_out=h_out, w_out=w_out, c_out=c_out,
+            ksize=3 if main is not None else 0, stride=stride, pad=pad, tile=tile, bias=bias, chan_add=chan_add,
+            chan_add_ld=chan_add_ld, resid=resid, out_scale=float(scale), dst=dst),
+            FC_CONV3 if main is not None else FC_CONV1, flops)
+
+    def upfirdn(self, src, n_ch, h_in, w_in, taps, up=1, down=1, pad=(0, 0), name="fir"):
+        kh, kw = taps.shape
+        h_out = (h_in * up + pad[0] + pad[1] - kh) // down + 1
+        w_out = (w_in * up + pad[0] + pad[1] - kw) // down + 1
+        dst = self.b.buf(self.n, h_out, w_out, n_ch, name=name)
+        k16 = [0.0] * 16
+        for i, v in enumerate(taps.reshape(-1).tolist()):
+            k16[i] = float(v)
+        self.b.add(L.OP_UPFIRDN, dict(src=src, n=self.n, h_in=h_in, w_in=w_in, c=n_ch, h_out=h_out, w_out=w_out,
+                                      up=up, down=down, pad0=pad[0], pad1=pad[1], kh=kh, kw=kw, k=k16, dst=dst), FC_FIR)
+        return dst, h_out, w_out
+
+
+# --------------------------------------------------------------------------- the U-Net engine
+class UNetEngine:
+    """Static program for NCSNpp.forward at a fixed (batch, H, W)."""
+
+    def __init__(self, model, batch, height, width, device, build_output=True):
+        L.load()
+        if device.type != "cuda":
+            raise RuntimeError("UNetEngine needs a HIP device")
+        self.model, self.n, self.h, self.w, self.device = model, batch, height, width, device
+        cfg = model.config
+        self.cfg = cfg
+        self.b = ProgramBuilder(device)
+        self.weights = WeightStore(device)
+        self.low = Lowering(self.b, self.weights, batch)
+        self.channels = model.channels
+        # static I/O (addresses are baked into the program / graph)
+        self.x_in = self.b.buf(batch, self.channels, height, width, name="x_in", persistent=True)
+        self.cond = self.b.buf(batch, name="cond", persistent=True)
+        self.sig = self.b.buf(batch, name="sigma", persistent=True) if model.embedding_type == "positional" else self.cond
+        self.out = self.b.buf(batch, self.channels, height, width, name="out", persistent=True)
+        self._lower()
+        self.program = self.b.finalize()
+
+    # ------------------------------------------------------------------ lowering
+    def _lower(self):
+        model, b, low, n = self.model, self.b, self.low, self.n
+        mods = list(model.all_modules)
+        nf = model.nf
+        idx = 0
+        skip_scale = INV_SQRT2 if model.skip_rescale else 1.0
+        fir, fk = model.fir, model.fir_kernel
+
+        # ---- time embedding (ncsnpp.py:236-257)
+        if model.embedding_type == "fourier":
+            emb_dim = 2 * nf
+            table = self.weights.add([mods[idx].W], lambda w: w.to(torch.float32).clone()); idx += 1
+            kind = 0
+        else:
+            emb_dim = nf
+            half = nf // 2
+            e = math.log(10000) / (half - 1)
+            freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -e)   # layers.py:519-521
+            table = b.tensor(freqs.to(self.device))
+            kind = 1
+        emb = b.buf(n, emb_dim, name="emb")
+        b.add(L.OP_EMBED, dict(cond=self.cond, w=table, dst=emb, n=n, dim=emb_dim, kind=kind))
+        temb = None
+        if model.conditional:
+            lin0, lin1 = mods[idx], mods[idx + 1]; idx += 2
+            t0 = b.buf(n, 4 * nf, name="temb0")
+            low.conv(t0, 1, 1, 4 * nf, aux=_src(emb, emb_dim), w_aux=self.weights.add([lin0.weight], pack_matrix),
+                     bias=self.weights.add([lin0.bias], lambda x: x.to(torch.float32).clone()))
+            temb = b.buf(n, 4 * nf, name="temb")
+            low.conv(temb, 1, 1, 4 * nf, aux=_src(t0, 4 * nf, pro=L.PRO_SILU),
+                     w_aux=self.weights.add([lin1.weight], pack_matrix),
+                     bias=self.weights.add([lin1.bias], lambda x: x.to(torch.float32).clone()))
+            # every Dense_0(act(temb)) of every residual block as ONE GEMM (layerspp.py:263)
+            dense = [m.Dense_0 for m in mods if getattr(m, "kind", "") == "res"]
+            self._tproj_off, off = {}, 0
+            for d in dense:
+                self._tproj_off[id(d)] = off
+                off += d.out_features
+            self._tproj_ld = off
+            wd = self.weights.add([d.weight for d in dense], lambda *ws: pack_matrix(torch.cat(ws, dim=0)))
+            bd = self.weights.add([d.bias for d in dense], lambda *bs: torch.cat(bs).to(torch.float32))
+            self._tproj = b.buf(n, off, name="tproj")
+            low.conv(self._tproj, 1, 1, off, aux=_src(temb, 4 * nf, pro=L.PRO_SILU), w_aux=wd, bias=bd)
+
+        # ---- input boundary: NCHW -> NHWC (C padded to 4), 2x-1 for un-centred data (ncsnpp.py:259-261)
+        H, W = self.h, self.w
+        cpad = 4
+        x0 = b.buf(n, H, W, cpad, name="x_nhwc")
+        a, sh = (1.0, 0.0) if self.cfg.data.centered else (2.0, -1.0)
+        b.add(L.OP_TO_NHWC, dict(src=self.x_in, dst=x0, n=n, c=self.channels, h=H, w=W, c_pad=cpad, a=a, b=sh))
+        pyr, pyr_c = (x0, cpad) if model.progressive_input != "none" else (None, 0)
+
+        conv_in = mods[idx]; idx += 1
+        h = b.buf(n, H, W, nf, name="h0")
+        low.conv(h, H, W, nf, main=_src(x0, cpad), w_main=self._w3(conv_in, cin_pad=cpad), h_in=H, w_in=W,
+                 bias=self._bias(conv_in))
+        hs = [(h, nf, H, W)]
+        cur_c = nf
+
+        def is_attn(res):
+            return res in model.attn_resolutions
+
+        # ---- encoder (ncsnpp.py:270-303)
+        for lvl in range(model.num_resolutions):
+            for _ in range(model.num_res_blocks):
+                t, c, hh, ww = hs[-1]
+                h, cur_c = self._res(mods[idx], t, c, hh, ww); idx += 1
+                if is_attn(ww):
+                    h = self._attn(mods[idx], h, cur_c, hh, ww); idx += 1
+                hs.append((h, cur_c, hh, ww))
+            if lvl != model.num_resolutions - 1:
+                t, c, hh, ww = hs[-1]
+                h, cur_c = self._res(mods[idx], t, c, hh, ww); idx += 1
+                hh, ww = hh // 2, ww // 2
+                if model.progressive_input == "input_skip":
+                    taps = fir_taps(fk) if fir else fir_taps([1, 1])
+                    pd = (1, 1) if fir else (0, 0)
+                    pyr, _, _ = low.upfirdn(_src(pyr, pyr_c), pyr_c, hh * 2, ww * 2, taps, down=2, pad=pd, name="pyr_down")
+                    comb = mods[idx]; idx += 1
+                    if comb.method != "sum":
+                        raise NotImplementedError("progressive_combine='cat' is not lowered (no shipped config uses it)")
+                    hn = b.buf(n, hh, ww, cur_c, name="combine")
+                    low.conv(hn, hh, ww, cur_c, aux=_src(pyr, pyr_c), w_aux=self._w1(comb.Conv_0, cin_pad=pyr_c),
+                             bias=self._bias(comb.Conv_0), resid=h, scale=1.0)
+                    h = hn
+                elif model.progressive_input == "residual":
+                    down = mods[idx]; idx += 1
+                    if not fir:
+                        raise NotImplementedError("progressive_input='residual' without FIR is not lowered")
+                    # conv_downsample_2d: FIR with pad (2,2) then stride-2 VALID conv (up_or_down_sampling.py:144-178)
+                    pf, ph, pw = low.upfirdn(_src(pyr, pyr_c), pyr_c, hh * 2, ww * 2, fir_taps(fk), pad=(2, 2), name="pyr_fir")
+                    hn = b.buf(n, hh, ww, cur_c, name="pyr")
+                    low.conv(hn, hh, ww, cur_c, main=_src(pf, pyr_c), w_main=self._w3(down.Conv2d_0, cin_pad=pyr_c),
+                             h_in=ph, w_in=pw, stride=2, pad=0, bias=self._bias(down.Conv2d_0), resid=h, scale=skip_scale)
+                    pyr, pyr_c, h = hn, cur_c, hn
+                hs.append((h, cur_c, hh, ww))
+
+        # ---- bottleneck (ncsnpp.py:305-311)
+        t, c, hh, ww = hs[-1]
+        h, cur_c = self._res(mods[idx], t, c, hh, ww); idx += 1
+        h = self._attn(mods[idx], h, cur_c, hh, ww); idx += 1
+        h, cur_c = self._res(mods[idx], h, cur_c, hh, ww); idx += 1
+
+        # ---- decoder (ncsnpp.py:316-364)
+        pyramid = None
+        for lvl in reversed(range(model.num_resolutions)):
+            for _ in range(model.num_res_blocks + 1):
+                st, sc, sh_, sw_ = hs.pop()
+                assert (sh_, sw_) == (hh, ww)
+                h, cur_c = self._res(mods[idx], h, cur_c, hh, ww, t2=st, c2=sc); idx += 1
+            if is_attn(ww):
+                h = self._attn(mods[idx], h, cur_c, hh, ww); idx += 1
+            if model.progressive == "output_skip":
+                gn_m, conv_m = mods[idx], mods[idx + 1]; idx += 2
+                up_pyr = None
+                if pyramid is not None:
+                    taps = fir_taps(fk, gain=4.0) if fir else fir_taps([1, 1], gain=4.0)
+                    pd = (2, 1) if fir else (1, 0)
+                    up_pyr, _, _ = low.upfirdn(_src(pyramid, 4), 4, hh // 2, ww // 2, taps, up=2, pad=pd, name="pyr_up")
+                gn = low.gn_stats(h, cur_c, hh * ww, gn_m)
+                pn = b.buf(n, hh, ww, 4, name="pyramid")
+                low.conv(pn, hh, ww, 4, main=_src(h, cur_c, pro=L.PRO_GN_SILU, gn=gn), w_main=self._w3(conv_m, cout_pad=4),
+                         h_in=hh, w_in=ww, bias=self._bias(conv_m, pad_to=4), resid=up_pyr)
+                pyramid = pn
+            if lvl != 0:
+                h, cur_c = self._res(mods[idx], h, cur_c, hh, ww); idx += 1
+                hh, ww = hh * 2, ww * 2
+        assert not hs
+
+        # ---- head (ncsnpp.py:368-379)
+        if model.progressive == "output_skip":
+            o = pyramid
+        else:
+            gn_m, conv_m = mods[idx], mods[idx + 1]; idx += 2
+            gn = low.gn_stats(h, cur_c, hh * ww, gn_m)
+            o = b.buf(n, hh, ww, 4, name="head")
+            low.conv(o, hh, ww, 4, main=_src(h, cur_c, pro=L.PRO_GN_SILU, gn=gn), w_main=self._w3(conv_m, cout_pad=4),
+                     h_in=hh, w_in=ww, bias=self._bias(conv_m, pad_to=4))
+        assert idx == len(mods), (idx, len(mods))
+        mode = 1 if self.cfg.model.scale_by_sigma else 0
+        b.add(L.OP_TO_NCHW, dict(src=o, dst=self.out, n=n, c=self.channels, h=hh, w=ww, c_src=4, mode=mode,
+                                 v=self.sig if mode else None))
+
+    # -- packed parameter helpers
+    def _w3(self, m, cin_pad=None, cout_pad=None):
+        def fn(w):
+            if cin_pad and w.shape[1] < cin_pad:
+                w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cin_pad - w.shape[1]))
+            if cout_pad and w.shape[0] < cout_pad:
+                w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_pad - w.shape[0]))
+            return pack_conv_weight(w)
+        return self.weights.add([m.weight], fn)
+
+    def _w1(self, m, cin_pad=None):
+        def fn(w):
+            w = w.reshape(w.shape[0], w.shape[1])
+            if cin_pad and w.shape[1] < cin_pad:
+                w = torch.nn.functional.pad(w, (0, cin_pad - w.shape[1]))
+            return pack_matrix(w)
+        return self.weights.add([m.weight], fn)
+
+    def _bias(self, m, pad_to=None):
+        def fn(x):
+            x = x.to(torch.float32)
+            if pad_to and x.numel() < pad_to:
+                x = torch.nn.functional.pad(x, (0, pad_to - x.numel()))
+            return x.clone()
+        return self.weights.add([m.bias], fn)
+
+    # -- ResnetBlockBigGANpp (layerspp.py:242-274)
+    def _res(self, m, t, c, hh, ww, t2=None, c2=0):
+        b, low, n = self.b, self.low, self.n
+        cin, cout = c + c2, m.out_ch
+        assert cin == m.in_ch, (cin, m.in_ch)
+        scale = INV_SQRT2 if m.skip_rescale else 1.0
+        gn0 = low.gn_stats(t, c, hh * ww, m.GroupNorm_0, t2, c2)
+        chan_add, ld = None, 0
+        if hasattr(m, "Dense_0"):
+            chan_add, ld = (self._tproj, self._tproj_off[id(m.Dense_0)]), self._tproj_ld
+        if m.up or m.down:
+            assert t2 is None
+            if m.up:
+                taps = fir_taps(m.fir_kernel, gain=4.0) if m.fir else fir_taps([1, 1], gain=4.0)
+                kw = dict(up=2, pad=(2, 1) if m.fir else (1, 0))
+            else:
+                taps = fir_taps(m.fir_kernel) if m.fir else fir_taps([1, 1])
+                kw = dict(down=2, pad=(1, 1) if m.fir else (0, 0))
+            hr, ho, wo = low.upfirdn(_src(t, c, pro=L.PRO_GN_SILU, gn=gn0), c, hh, ww, taps, name="res_h_rs", **kw)
+            xr, _, _ = low.upfirdn(_src(t, c), c, hh, ww, taps, name="res_x_rs", **kw)
+            main0, skip_t, skip_c, skip_t2, skip_c2 = _src(hr, c), xr, c, None, 0
+            hh, ww = ho, wo
+        else:
+            main0 = _src(t, c, t2, c2, pro=L.PRO_GN_SILU, gn=gn0)
+            skip_t, skip_c, skip_t2, skip_c2 = t, c, t2, c2
+        h1 = b.buf(n, hh, ww, cout, name="res_h1")
+        low.conv(h1, hh, ww, cout, main=main0, w_main=self._w3(m.Conv_0), h_in=hh, w_in=ww, bias=self._bias(m.Conv_0),
+                 chan_add=chan_add, chan_add_ld=ld)
+        gn1 = low.gn_stats(h1, cout, hh * ww, m.GroupNorm_1)
+        out = b.buf(n, hh, ww, cout, name="res_out")
+        main1 = _src(h1, cout, pro=L.PRO_GN_SILU, gn=gn1)
+        if hasattr(m, "Conv_2"):
+            bsum = self.weights.add([m.Conv_1.bias, m.Conv_2.bias], lambda x, y: (x + y).to(torch.float32))
+            low.conv(out, hh, ww, cout, main=main1, w_main=self._w3(m.Conv_1), h_in=hh, w_in=ww,
+                     aux=_src(skip_t, skip_c, skip_t2, skip_c2), w_aux=self._w1(m.Conv_2), bias=bsum, scale=scale)
+        else:
+            assert skip_t2 is None
+            low.conv(out, hh, ww, cout, main=main1, w_main=self._w3(m.Conv_1), h_in=hh, w_in=ww, bias=self._bias(m.Conv_1),
+                     resid=skip_t, scale=scale)
+        return out, cout
+
+    # -- AttnBlockpp (layerspp.py:75-91)
+    def _attn(self, m, t, c, hh, ww):
+        b, low, n = self.b, self.low, self.n
+        gn = low.gn_stats(t, c, hh * ww, m.GroupNorm_0)
+        wqkv = self.weights.add([m.NIN_0.W, m.NIN_1.W, m.NIN_2.W],
+                                lambda q, k, v: pack_matrix(torch.cat([q.t(), k.t(), v.t()], dim=0)))
+        bqkv = self.weights.add([m.NIN_0.b, m.NIN_1.b, m.NIN_2.b], lambda q, k, v: torch.cat([q, k, v]).to(torch.float32))
+        qkv = b.buf(n, hh, ww, 3 * c, name="qkv")
+        low.conv(qkv, hh, ww, 3 * c, aux=_src(t, c, pro=L.PRO_GN, gn=gn), w_aux=wqkv, bias=bqkv)
+        ao = b.buf(n, hh, ww, c, name="attn_o")
+        L_ = hh * ww
+        b.add(L.OP_ATTN, dict(qkv=qkv, dst=ao, n=n, l=L_, c=c, scale=float(int(c) ** (-0.5))), FC_ATTN,
+              4.0 * n * L_ * L_ * c)
+        out = b.buf(n, hh, ww, c, name="attn_out")
+        low.conv(out, hh, ww, c, aux=_src(ao, c), w_aux=self.weights.add([m.NIN_3.W], lambda w: pack_matrix(w.t())),
+                 bias=self.weights.add([m.NIN_3.b], lambda x: x.to(torch.float32).clone()), resid=t,
+                 scale=INV_SQRT2 if m.skip_rescale else 1.0)
+        return out
+
+    # ------------------------------------------------------------------ execution
+    def load_inputs(self, x, cond):
+        self.x_in.tensor[: x.numel()].copy_(x.reshape(-1))
+        self.cond.tensor[: self.n].copy_(cond.reshape(-1).to(torch.float32))
+        if self.sig is not self.cond:
+            self.sig.tensor[: self.n].copy_(self.model.sigmas.to(torch.float32)[cond.long()])
+
+    def output_view(self):
+        return self.out.tensor[: self.n * self.channels * self.h * self.w].view(self.n, self.channels, self.h, self.w)
+
+    def forward(self, x, cond):
+        if tuple(x.shape) != (self.n, self.channels, self.h, self.w):
+            raise ValueError("engine built for %s, got %s" % ((self.n, self.channels, self.h, self.w), tuple(x.shape)))
+        self.weights.refresh()
+        self.load_inputs(x.contiguous(), cond)
+        self.program.run()
+        return self.output_view().clone()
+
+    def flops_per_forward(self):
+        return sum(self.program.flops)

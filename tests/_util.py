@@ -1,0 +1,79 @@
+"""Shared test helpers: deterministic weights, small configs, tolerances."""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from score_sde_pytorch_amd import configs as cfgs  # noqa: E402
+
+
+def small_config(kind="ncsnpp", image_size=16, nf=32, ch_mult=(1, 2), num_res_blocks=1, attn=(8,)):
+    """Down-sized variants of the BASELINE configs that keep every code path of the full ones."""
+    base = {"ncsnpp": "ve/cifar10_ncsnpp_continuous", "ddpmpp": "subvp/cifar10_ddpmpp_continuous",
+            "ffhq": "ve/ffhq_256_ncsnpp_continuous"}[kind]
+    cfg = cfgs.get_config(base, nf=nf, ch_mult=tuple(ch_mult), num_res_blocks=num_res_blocks,
+                          attn_resolutions=tuple(attn), dropout=0.0)
+    cfg.data.image_size = image_size
+    return cfg
+
+
+def seeded_state_dict(model_or_shapes, seed=1):
+    """Deterministic, non-degenerate weights for any ncsnpp-style state dict.
+
+    The reference initialises the last conv of every block at scale 1e-10, which
+    makes a random-init network an identity map; parity tests re-randomise EVERY tensor so that
+    all branches carry signal.  Only torch's CPU generator is used, so the same seed gives the
+    same weights in the build container (reference import) and on the GPU box.
+    """
+    shapes = model_or_shapes if isinstance(model_or_shapes, dict) else \
+        {k: tuple(v.shape) for k, v in model_or_shapes.state_dict().items()}
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name, shape in shapes.items():
+        leaf = name.split(".")[-1]
+        if name == "sigmas":
+            continue
+        if "GroupNorm" in name or (len(shape) == 1 and name.split(".")[-2].isdigit() and False):
+            t = (1.0 + 0.1 * torch.randn(shape, generator=g)) if leaf == "weight" else 0.1 * torch.randn(shape, generator=g)
+        elif len(shape) == 1 and leaf == "W":           # Fourier frequencies
+            t = torch.randn(shape, generator=g) * 16.0
+        elif len(shape) == 1:                           # biases (and top-level GroupNorm handled below)
+            t = 0.1 * torch.randn(shape, generator=g)
+        else:
+            if leaf == "W":                             # NIN: [in, out]
+                fan_in, fan_out = shape[0], shape[1]
+            else:
+                rf = int(np.prod(shape[2:])) if len(shape) > 2 else 1
+                fan_in, fan_out = shape[1] * rf, shape[0] * rf
+            bound = math.sqrt(3.0 / ((fan_in + fan_out) / 2.0))
+            t = (torch.rand(shape, generator=g) * 2 - 1) * bound
+        out[name] = t.to(torch.float32)
+    return out
+
+
+def fix_top_level_groupnorm(sd, model):
+    """Top-level nn.GroupNorm modules (all_modules.<i>.weight with 1-D shape) need scale ~1, not a bias-like draw."""
+    import torch.nn as nn
+    for i, m in enumerate(model.all_modules):
+        if isinstance(m, nn.GroupNorm):
+            sd["all_modules.%d.weight" % i] = 1.0 + sd["all_modules.%d.weight" % i]
+    return sd
+
+
+def load_seeded(model, seed=1):
+    sd = fix_top_level_groupnorm(seeded_state_dict(model, seed), model)
+    missing = model.load_state_dict(sd, strict=False)
+    assert set(missing.missing_keys) <= {"sigmas"}, missing
+    return sd
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
