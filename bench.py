@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""Headline benchmark: PC-sampler throughput of NCSN++ cont. VE-SDE on CIFAR-10 (BASELINE configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (per GPU): configs/ve/cifar10_ncsnpp_continuous, batch 256, reverse_diffusion predictor +
+Langevin corrector, snr 0.16, N=1000 discretisation steps.  One "step" = ONE full PC iteration on
+the batch = 2 U-Net evaluations + rocRAND noise + norms + Langevin update + predictor update, replayed
+as one hipGraph.  All N iterations are identical work, so images/sec = n_gpus * batch / (1000 * t_step);
+the timed region holds exactly K iterations with the state resident in HBM.  Sampling shards by
+replication (one independent sampler per GPU, no collectives) -> "scaling": "weak".
+Weights: deterministic random init of the full architecture (every tensor re-randomised);
+data: synthetic prior noise.  fp32 end to end (dtype "f32"), as the reference.
+
+The JSON line also carries
+  roofline     -- the dominant kernel (conv_mfma: every 3x3 / fused 3x3+1x1 convolution launch of one
+                  U-Net evaluation): algorithmic FLOPs / HIP-event time on the launch stream, against
+                  the 157.3 TFLOP/s fp32 MFMA peak;
+  cpu_baseline -- the CPU oracle (a torch-CPU port of the reference path, oracle/) timed on this host
+                  for a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--sde-steps", type=int, default=1000)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (the HIP path has no CPU fallback)"
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import _util
+    from score_sde_pytorch_amd import sde_lib, sampling, engine as E
+    from score_sde_pytorch_amd.models import utils as mutils
+
+    cfg = _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous")
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    sd = _util.load_seeded(model, seed=1)
+    model = model.to(dev).eval()
+    B, R = args.batch, cfg.data.image_size
+    sde = sde_lib.VESDE(cfg.model.sigma_min, cfg.model.sigma_max, N=args.sde_steps)
+    sampler = sampling.get_pc_sampler(sde, (B, 3, R, R), sampling.get_predictor(cfg.sampling.predictor),
+                                      sampling.get_corrector(cfg.sampling.corrector), lambda v: v, snr=cfg.sampling.snr,
+                                      n_steps=cfg.sampling.n_steps_each, probability_flow=False, continuous=True,
+                                      denoise=True, eps=1e-5, device=dev)
+    torch.manual_seed(1234 + rank)
+    x_T = sde.prior_sampling((B, 3, R, R))
+    sampler(model, x_init=x_T, max_steps=0, seed=rank)     # builds the engine, loads the state
+    eng = sampler.engine
+    prog = eng.step_program(with_rng=True, seed=rank)
+    use_graph = not args.no_graph
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    eng.run_steps(prog, args.warmup, use_graph)
+    sync_all()
+    t0 = time.perf_counter()
+    eng.run_steps(prog, args.steps, use_graph)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    finite = bool(torch.isfinite(eng.x).all())
+    images_per_sec = world * B / (args.sde_steps * ms_per_step * 1e-3)
+
+    out = {
+        "metric": "pc_sampler_images_per_sec", "value": images_per_sec, "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs/ve/cifar10_ncsnpp_continuous PC sampler (reverse_diffusion+langevin), "
+                               "batch %d/GPU, N=%d, 32x32; 1 step = 1 PC iteration = 2 U-Net evaluations" % (B, args.sde_steps),
+                   "batch_per_gpu": B, "sde_steps": args.sde_steps, "nfe_per_step": eng.nfe_per_step(),
+                   "path": eng.last_path, "state_finite": finite,
+                   "unet_gflop_per_image": eng.unet.flops_per_forward() / B / 1e9,
+                   "parallelism": "replicas x%d (no collectives)" % world},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel = conv_mfma launches of one U-Net evaluation, HIP events on the launch stream
+        up = eng.unet.program
+        reps = 3
+        acc = np.zeros(up.n)
+        up.run_timed()
+        for _ in range(reps):
+            acc += np.array(up.run_timed())
+        ms = acc / reps
+        cls = np.array(up.classes)
+        fl = np.array(up.flops)
+        conv3 = cls == E.FC_CONV3
+        t_conv3 = float(ms[conv3].sum()) * 1e-3
+        achieved = float(fl[conv3].sum()) / t_conv3 / 1e12
+        by_class = {}
+        for name, c in [("conv3x3_fused", E.FC_CONV3), ("conv1x1_gemm", E.FC_CONV1), ("attention", E.FC_ATTN),
+                        ("groupnorm_stats", E.FC_GN), ("upfirdn", E.FC_FIR), ("other", E.FC_OTHER)]:
+            m = cls == c
+            by_class[name] = {"launches": int(m.sum()), "ms": float(ms[m].sum()), "gflop": float(fl[m].sum()) / 1e9}
+        out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                           "kernel": "conv_mfma_kernel (3x3 + fused 1x1 skip), %d launches per U-Net evaluation" % int(conv3.sum()),
+                           "unet_eval_ms_eager_events": float(ms.sum()), "by_class": by_class}
+        out["config"]["end_to_end_tflops"] = eng.nfe_per_step() * eng.unet.flops_per_forward() / (ms_per_step * 1e-3) / 1e12
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import sampler_oracle
+        torch.set_num_threads(os.cpu_count())
+        cores = torch.get_num_threads()
+        full_sd = {k: v.cpu() for k, v in sd.items()}
+        full_sd["sigmas"] = model.sigmas.cpu()
+        cb = args.cpu_batch
+        g = torch.Generator().manual_seed(3)
+        x0 = torch.randn(cb, 3, R, R, generator=g) * cfg.model.sigma_max
+        nz = torch.randn(2, 2, cb, 3, R, R, generator=g)
+        kw = dict(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=args.sde_steps)
+        sampler_oracle.pc_sample(cfg, full_sd, "vesde", kw, x0[:2], nz[:, :, :2], snr=cfg.sampling.snr, eps=1e-5, max_steps=1)
+        t0 = time.perf_counter()
+        sampler_oracle.pc_sample(cfg, full_sd, "vesde", kw, x0, nz, snr=cfg.sampling.snr, eps=1e-5, max_steps=2)
+        t_cpu = (time.perf_counter() - t0) / 2
+        out["cpu_baseline"] = {"value": cb / (args.sde_steps * t_cpu), "unit": "images/s", "cores": cores, "kind": "port",
+                               "sample": "2 PC iterations (4 U-Net evaluations) at batch %d with the torch-CPU oracle "
+                                         "(oracle/sampler_oracle.py), extrapolated to N=%d: %.2f s per iteration"
+                                         % (cb, args.sde_steps, t_cpu)}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -126,9 +126,7 @@ def main():
     full_sd = dict(sd); full_sd["sigmas"] = ref_model.sigmas
     B, N = 8, 10
     sde = ref_sde_lib.VESDE(sigma_min=0.01, sigma_max=50, N=N)
-    g = torch.Generator().manual_seed(7)
-    x_T = torch.randn(B, 3, 32, 32, generator=g) * 50.0
-    noises = torch.randn(N, 2, B, 3, 32, 32, generator=g)
+    x_T, noises = _util.pc_case_inputs(B, N)
 
     # reference run with injected noise: patch torch.randn_like / prior_sampling
     it = iter(noises.reshape(2 * N, B, 3, 32, 32))
@@ -158,9 +156,15 @@ def main():
     err = float((out["samples"] - samples_ref).abs().max() / samples_ref.abs().max())
     print("pc_sampler oracle-vs-reference rel err %.3g (|x| max %.3g)" % (err, float(samples_ref.abs().max())))
     assert err < 1e-4, err
-    np.savez_compressed(os.path.join(out_dir, "pc_cifar_ncsnpp_n10.npz"), x_T=x_T.numpy(), noises=noises.numpy(),
-                        samples=samples_ref.numpy(), score_norms=np.asarray(out["score_norms"], dtype=np.float64),
-                        x_steps=np.stack([t.numpy() for t in out["x_steps"]]))
+    # per-step parity of the oracle against the reference trajectory (spy on the predictor update)
+    assert len(traj_x) == N
+    for i in range(N):
+        e = float((out["x_steps"][i] - traj_x[i]).abs().max() / traj_x[i].abs().max())
+        assert e < 1e-4, (i, e)
+    # x_T and the noises are regenerated from the seed by the tests (recipe: tests/_util.pc_case_inputs)
+    np.savez_compressed(os.path.join(out_dir, "pc_cifar_ncsnpp_n10.npz"), samples=samples_ref.numpy(),
+                        score_norms=np.asarray(out["score_norms"], dtype=np.float64),
+                        x_step0=traj_x[0].numpy(), x_step4=traj_x[4].numpy(), x_step9=traj_x[9].numpy())
     print("golden vectors written to", out_dir)
 
 

@@ -181,7 +181,11 @@ extern "C" int ssde_attention(const ssde_attn_args* a, void* stream) {
   SSDE_REQUIRE(a->c > 0 && a->c % 32 == 0, "attention: channels must be a multiple of 32 (got %d)", a->c);
   const int lds = kAttnLdsFloats * 4;
   auto kfn = attn_kernel;
-  SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  static bool attr_set = false;   // set once, outside any stream capture
+  if (!attr_set) {
+    SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
   hipLaunchKernelGGL(kfn, dim3(ssde_cdiv(a->l, kQB), a->n), dim3(256), lds, static_cast<hipStream_t>(stream),
                      a->qkv, a->dst, a->n, a->l, a->c, a->scale);
   SSDE_LAUNCH_CHECK();

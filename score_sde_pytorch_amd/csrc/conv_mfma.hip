@@ -361,8 +361,8 @@ int make_plan(const ssde_conv_args* a, ConvPlan* pl) {
     while (true) {
       const int px = halo_px(kTiles[tile].bm, a->w_out, a->h_out, a->stride, 3, &lTW, &lTH);
       if (px * 2 <= 5 * kThreads) break;
-      SSDE_REQUIRE(tile == SSDE_TILE_256x64 || tile == SSDE_TILE_128x64, "conv: halo too large for any tile");
-      tile += 1;
+      SSDE_REQUIRE(tile != SSDE_TILE_64x64, "conv: halo too large for any tile");
+      tile = (tile == SSDE_TILE_256x32) ? SSDE_TILE_64x64 : tile + 1;   // 256x64 -> 128x64 -> 64x64
     }
   } else {
     halo_px(kTiles[tile].bm, a->w_out, a->h_out, 1, 1, &lTW, &lTH);

@@ -162,6 +162,8 @@ class Program:
 
     def run(self, stream=None):
         lib = L.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("libssde_hip programs run on the MI355X only (no CPU fallback)")
         st = torch.cuda.current_stream().cuda_stream if stream is None else stream
         L.check(lib.ssde_program_run(self.ops, self.n, C.c_void_p(st)), "ssde_program_run")
 
@@ -309,10 +311,10 @@ class Lowering:
 class UNetEngine:
     """Static program for NCSNpp.forward at a fixed (batch, H, W)."""
 
-    def __init__(self, model, batch, height, width, device, build_output=True):
+    def __init__(self, model, batch, height, width, device, vp_score=False):
         L.load()
-        if device.type != "cuda":
-            raise RuntimeError("UNetEngine needs a HIP device")
+        # device 'cpu' is accepted for DRY lowering only (plan validation, FLOP census in the CPU tests);
+        # running a program needs the MI355X.
         self.model, self.n, self.h, self.w, self.device = model, batch, height, width, device
         cfg = model.config
         self.cfg = cfg
@@ -323,8 +325,15 @@ class UNetEngine:
         # static I/O (addresses are baked into the program / graph)
         self.x_in = self.b.buf(batch, self.channels, height, width, name="x_in", persistent=True)
         self.cond = self.b.buf(batch, name="cond", persistent=True)
-        self.sig = self.b.buf(batch, name="sigma", persistent=True) if model.embedding_type == "positional" else self.cond
+        # discrete-label models index the sigma table for scale_by_sigma (ncsnpp.py:245,377-379)
+        self.sig = self.b.buf(batch, name="sigma", persistent=True) \
+            if (model.embedding_type == "positional" and cfg.model.scale_by_sigma) else self.cond
         self.out = self.b.buf(batch, self.channels, height, width, name="out", persistent=True)
+        # vp_score: emit score = -h / std[n] (models/utils.py:159) instead of the raw network output
+        self.vp_score = vp_score
+        self.std = self.b.buf(batch, name="std", persistent=True) if vp_score else None
+        if vp_score and cfg.model.scale_by_sigma:
+            raise NotImplementedError("scale_by_sigma together with a VP score head is not lowered")
         self._lower()
         self.program = self.b.finalize()
 
@@ -468,9 +477,9 @@ class UNetEngine:
             low.conv(o, hh, ww, 4, main=_src(h, cur_c, pro=L.PRO_GN_SILU, gn=gn), w_main=self._w3(conv_m, cout_pad=4),
                      h_in=hh, w_in=ww, bias=self._bias(conv_m, pad_to=4))
         assert idx == len(mods), (idx, len(mods))
-        mode = 1 if self.cfg.model.scale_by_sigma else 0
-        b.add(L.OP_TO_NCHW, dict(src=o, dst=self.out, n=n, c=self.channels, h=hh, w=ww, c_src=4, mode=mode,
-                                 v=self.sig if mode else None))
+        mode = 2 if self.vp_score else (1 if self.cfg.model.scale_by_sigma else 0)
+        vec = self.std if mode == 2 else (self.sig if mode == 1 else None)
+        b.add(L.OP_TO_NCHW, dict(src=o, dst=self.out, n=n, c=self.channels, h=hh, w=ww, c_src=4, mode=mode, v=vec))
 
     # -- packed parameter helpers
     def _w3(self, m, cin_pad=None, cout_pad=None):
@@ -562,7 +571,7 @@ class UNetEngine:
     def load_inputs(self, x, cond):
         self.x_in.tensor[: x.numel()].copy_(x.reshape(-1))
         self.cond.tensor[: self.n].copy_(cond.reshape(-1).to(torch.float32))
-        if self.sig is not self.cond:
+        if self.sig is not self.cond and self.sig.tensor is not None:
             self.sig.tensor[: self.n].copy_(self.model.sigmas.to(torch.float32)[cond.long()])
 
     def output_view(self):
@@ -578,3 +587,16 @@ class UNetEngine:
 
     def flops_per_forward(self):
         return sum(self.program.flops)
+
+    def validate_plans(self):
+        """Host-side check of every conv launch plan (tile choice, halo fit, LDS size); returns LDS bytes per conv."""
+        lib = L.load()
+        out = []
+        for i in range(self.program.n):
+            op = self.program.ops[i]
+            if op.kind == L.OP_CONV:
+                r = lib.ssde_conv_lds_bytes(C.byref(op.u.conv))
+                if r < 0:
+                    raise L.SsdeError("op %d: %s" % (i, lib.ssde_last_error().decode()))
+                out.append(r)
+        return out

@@ -1,0 +1,340 @@
+"""Predictor-corrector and probability-flow samplers.
+
+Plugin surface identical to the reference's sampling.py: `register_predictor`,
+`register_corrector`, `get_predictor`, `get_corrector`, `get_sampling_fn`, `Predictor`,
+`Corrector`, the stock predictors/correctors, `shared_predictor_update_fn`,
+`shared_corrector_update_fn`, `get_pc_sampler`, `get_ode_sampler` (sampling.py:30-485).
+User-registered predictors/correctors keep working: they go through the generic python
+loop, with every score evaluation running as one HIP program.
+
+Fast path (what BASELINE measures): when predictor, corrector and SDE are the stock classes,
+`pc_sampler` lowers one whole PC iteration -- label fill, U-Net forward, rocRAND noise,
+per-sample norms, Langevin update, U-Net forward, noise, predictor update, step counter --
+into ONE static program captured as a hipGraph and replayed N times.  Per-step scalars
+(sigma_i, G_i, ...) live in device tables indexed by a device-resident step counter, so the
+graph is replayed with unchanged arguments and the host issues one call per PC step instead
+of ~1,900 kernel launches.  Sampling needs no collectives: one independent
+sampler per GPU.
+"""
+import abc
+import functools
+
+import numpy as np
+import torch
+from scipy import integrate
+
+from . import sde_lib
+from .models import utils as mutils
+from .models.utils import from_flattened_numpy, to_flattened_numpy, get_score_fn
+
+_CORRECTORS = {}
+_PREDICTORS = {}
+
+
+def _registrar(table, cls, name):
+    def _do(c):
+        key = c.__name__ if name is None else name
+        if key in table:
+            raise ValueError(f'Already registered model with name: {key}')
+        table[key] = c
+        return c
+    return _do if cls is None else _do(cls)
+
+
+def register_predictor(cls=None, *, name=None):
+    """Class decorator registering a Predictor under `name` (sampling.py:34-50)."""
+    return _registrar(_PREDICTORS, cls, name)
+
+
+def register_corrector(cls=None, *, name=None):
+    """Class decorator registering a Corrector under `name` (sampling.py:53-69)."""
+    return _registrar(_CORRECTORS, cls, name)
+
+
+def get_predictor(name):
+    return _PREDICTORS[name]
+
+
+def get_corrector(name):
+    return _CORRECTORS[name]
+
+
+def get_sampling_fn(config, sde, shape, inverse_scaler, eps):
+    """Build the sampler named by `config.sampling.method` ('pc' or 'ode'), sampling.py:80-123."""
+    method = config.sampling.method.lower()
+    if method == 'ode':
+        return get_ode_sampler(sde=sde, shape=shape, inverse_scaler=inverse_scaler,
+                               denoise=config.sampling.noise_removal, eps=eps, device=config.device)
+    if method == 'pc':
+        return get_pc_sampler(sde=sde, shape=shape,
+                              predictor=get_predictor(config.sampling.predictor.lower()),
+                              corrector=get_corrector(config.sampling.corrector.lower()),
+                              inverse_scaler=inverse_scaler, snr=config.sampling.snr,
+                              n_steps=config.sampling.n_steps_each,
+                              probability_flow=config.sampling.probability_flow,
+                              continuous=config.training.continuous, denoise=config.sampling.noise_removal,
+                              eps=eps, device=config.device)
+    raise ValueError(f"Sampler name {config.sampling.method} unknown.")
+
+
+def _b(v):
+    return v[:, None, None, None]
+
+
+class Predictor(abc.ABC):
+    """update_fn(x, t) -> (x, x_mean); owns the reverse SDE built from `score_fn` (sampling.py:126-148)."""
+
+    def __init__(self, sde, score_fn, probability_flow=False):
+        super().__init__()
+        self.sde = sde
+        self.rsde = sde.reverse(score_fn, probability_flow)
+        self.score_fn = score_fn
+
+    @abc.abstractmethod
+    def update_fn(self, x, t):
+        pass
+
+
+class Corrector(abc.ABC):
+    """update_fn(x, t) -> (x, x_mean) (sampling.py:151-173)."""
+
+    def __init__(self, sde, score_fn, snr, n_steps):
+        super().__init__()
+        self.sde, self.score_fn, self.snr, self.n_steps = sde, score_fn, snr, n_steps
+
+    @abc.abstractmethod
+    def update_fn(self, x, t):
+        pass
+
+
+@register_predictor(name='euler_maruyama')
+class EulerMaruyamaPredictor(Predictor):
+    """x <- x + drift dt + g sqrt(-dt) z with dt = -1/N (sampling.py:176-187)."""
+
+    def update_fn(self, x, t):
+        dt = -1. / self.rsde.N
+        z = torch.randn_like(x)
+        drift, diffusion = self.rsde.sde(x, t)
+        x_mean = x + drift * dt
+        return x_mean + _b(diffusion) * np.sqrt(-dt) * z, x_mean
+
+
+@register_predictor(name='reverse_diffusion')
+class ReverseDiffusionPredictor(Predictor):
+    """x <- x - rev_f + G z from the SDE's own discretisation (sampling.py:190-200)."""
+
+    def update_fn(self, x, t):
+        f, G = self.rsde.discretize(x, t)
+        z = torch.randn_like(x)
+        x_mean = x - f
+        return x_mean + _b(G) * z, x_mean
+
+
+@register_predictor(name='ancestral_sampling')
+class AncestralSamplingPredictor(Predictor):
+    """DDPM / SMLD ancestral step (sampling.py:203-239); VE and VP only."""
+
+    def __init__(self, sde, score_fn, probability_flow=False):
+        super().__init__(sde, score_fn, probability_flow)
+        if not isinstance(sde, (sde_lib.VPSDE, sde_lib.VESDE)):
+            raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+        assert not probability_flow, "Probability flow not supported by ancestral sampling"
+
+    def vesde_update_fn(self, x, t):
+        sde = self.sde
+        idx = (t * (sde.N - 1) / sde.T).long()
+        table = sde.discrete_sigmas.to(t.device)
+        sigma = table[idx]
+        prev = torch.where(idx == 0, torch.zeros_like(t), table[idx - 1])
+        score = self.score_fn(x, t)
+        x_mean = x + score * _b(sigma ** 2 - prev ** 2)
+        std = torch.sqrt((prev ** 2 * (sigma ** 2 - prev ** 2)) / (sigma ** 2))
+        return x_mean + _b(std) * torch.randn_like(x), x_mean
+
+    def vpsde_update_fn(self, x, t):
+        sde = self.sde
+        idx = (t * (sde.N - 1) / sde.T).long()
+        beta = sde.discrete_betas.to(t.device)[idx]
+        score = self.score_fn(x, t)
+        x_mean = (x + _b(beta) * score) / _b(torch.sqrt(1. - beta))
+        return x_mean + _b(torch.sqrt(beta)) * torch.randn_like(x), x_mean
+
+    def update_fn(self, x, t):
+        if isinstance(self.sde, sde_lib.VESDE):
+            return self.vesde_update_fn(x, t)
+        return self.vpsde_update_fn(x, t)
+
+
+@register_predictor(name='none')
+class NonePredictor(Predictor):
+    def __init__(self, sde, score_fn, probability_flow=False):
+        pass
+
+    def update_fn(self, x, t):
+        return x, x
+
+
+def _check_corrector_sde(sde):
+    if not isinstance(sde, (sde_lib.VPSDE, sde_lib.VESDE, sde_lib.subVPSDE)):
+        raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+
+
+def _langevin_alpha(sde, t):
+    if isinstance(sde, (sde_lib.VPSDE, sde_lib.subVPSDE)):
+        return sde.alphas.to(t.device)[(t * (sde.N - 1) / sde.T).long()]
+    return torch.ones_like(t)
+
+
+@register_corrector(name='langevin')
+class LangevinCorrector(Corrector):
+    """Langevin MCMC with the step size set from BATCH-MEAN norms (sampling.py:253-282)."""
+
+    def __init__(self, sde, score_fn, snr, n_steps):
+        super().__init__(sde, score_fn, snr, n_steps)
+        _check_corrector_sde(sde)
+
+    def update_fn(self, x, t):
+        alpha = _langevin_alpha(self.sde, t)
+        x_mean = x
+        for _ in range(self.n_steps):
+            grad = self.score_fn(x, t)
+            noise = torch.randn_like(x)
+            grad_norm = torch.norm(grad.reshape(grad.shape[0], -1), dim=-1).mean()
+            noise_norm = torch.norm(noise.reshape(noise.shape[0], -1), dim=-1).mean()
+            step_size = (self.snr * noise_norm / grad_norm) ** 2 * 2 * alpha
+            x_mean = x + _b(step_size) * grad
+            x = x_mean + _b(torch.sqrt(step_size * 2)) * noise
+        return x, x_mean
+
+
+@register_corrector(name='ald')
+class AnnealedLangevinDynamics(Corrector):
+    """NCSN's annealed Langevin dynamics, step from the marginal std (sampling.py:285-319)."""
+
+    def __init__(self, sde, score_fn, snr, n_steps):
+        super().__init__(sde, score_fn, snr, n_steps)
+        _check_corrector_sde(sde)
+
+    def update_fn(self, x, t):
+        alpha = _langevin_alpha(self.sde, t)
+        std = self.sde.marginal_prob(x, t)[1]
+        x_mean = x
+        for _ in range(self.n_steps):
+            grad = self.score_fn(x, t)
+            noise = torch.randn_like(x)
+            step_size = (self.snr * std) ** 2 * 2 * alpha
+            x_mean = x + _b(step_size) * grad
+            x = x_mean + noise * _b(torch.sqrt(step_size * 2))
+        return x, x_mean
+
+
+@register_corrector(name='none')
+class NoneCorrector(Corrector):
+    def __init__(self, sde, score_fn, snr, n_steps):
+        pass
+
+    def update_fn(self, x, t):
+        return x, x
+
+
+def shared_predictor_update_fn(x, t, sde, model, predictor, probability_flow, continuous):
+    """One predictor update with a freshly built score_fn (sampling.py:333-341)."""
+    score_fn = mutils.get_score_fn(sde, model, train=False, continuous=continuous)
+    cls = NonePredictor if predictor is None else predictor
+    return cls(sde, score_fn, probability_flow).update_fn(x, t)
+
+
+def shared_corrector_update_fn(x, t, sde, model, corrector, continuous, snr, n_steps):
+    """One corrector update with a freshly built score_fn (sampling.py:344-352)."""
+    score_fn = mutils.get_score_fn(sde, model, train=False, continuous=continuous)
+    cls = NoneCorrector if corrector is None else corrector
+    return cls(sde, score_fn, snr, n_steps).update_fn(x, t)
+
+
+def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_steps=1, probability_flow=False,
+                   continuous=False, denoise=True, eps=1e-3, device='cuda'):
+    """Predictor-corrector sampler factory (sampling.py:355-411).
+
+    Returns `pc_sampler(model) -> (samples, nfe)`.  Two extra keyword arguments exist for parity
+    testing (the reference's RNG stream cannot be reproduced): `x_init` (the prior sample)
+    and `noises` ([N, 2, *shape]: corrector / predictor noise per step).  `pc_sampler.last_path` tells
+    which path ran ('fused-graph', 'fused-eager' or 'generic')."""
+    predictor_update_fn = functools.partial(shared_predictor_update_fn, sde=sde, predictor=predictor,
+                                            probability_flow=probability_flow, continuous=continuous)
+    corrector_update_fn = functools.partial(shared_corrector_update_fn, sde=sde, corrector=corrector,
+                                            continuous=continuous, snr=snr, n_steps=n_steps)
+    fused_cache = {}
+
+    def pc_sampler(model, x_init=None, noises=None, seed=0, use_graph=True, max_steps=None):
+        from . import pc_engine
+        with torch.no_grad():
+            x = (sde.prior_sampling(shape) if x_init is None else x_init).to(device)
+            plan = pc_engine.plan_fused(sde, predictor, corrector, model, continuous, x)
+            if plan is not None:
+                key = id(model)
+                eng = fused_cache.get(key)
+                if eng is None:
+                    eng = pc_engine.FusedPCSampler(model, sde, plan, shape, snr=snr, n_steps=n_steps,
+                                                   probability_flow=probability_flow, eps=eps, device=x.device)
+                    fused_cache[key] = eng
+                x_fin, x_mean = eng.run(x, noises=noises, seed=seed, use_graph=use_graph, max_steps=max_steps)
+                pc_sampler.last_path = eng.last_path
+                pc_sampler.engine = eng
+                return inverse_scaler(x_mean if denoise else x_fin), sde.N * (n_steps + 1)
+            # generic path: arbitrary registered predictors / correctors / SDE subclasses
+            pc_sampler.last_path = 'generic'
+            timesteps = torch.linspace(sde.T, eps, sde.N, device=device)
+            x_mean = x
+            steps = sde.N if max_steps is None else max_steps
+            real_randn_like = torch.randn_like
+            for i in range(steps):
+                vec_t = torch.ones(shape[0], device=timesteps.device) * timesteps[i]
+                if noises is not None:
+                    torch.randn_like = lambda t, _z=noises[i, 0]: _z.to(t.device)
+                try:
+                    x, x_mean = corrector_update_fn(x, vec_t, model=model)
+                    if noises is not None:
+                        torch.randn_like = lambda t, _z=noises[i, 1]: _z.to(t.device)
+                    x, x_mean = predictor_update_fn(x, vec_t, model=model)
+                finally:
+                    torch.randn_like = real_randn_like
+            return inverse_scaler(x_mean if denoise else x), sde.N * (n_steps + 1)
+
+    pc_sampler.last_path = None
+    return pc_sampler
+
+
+def get_ode_sampler(sde, shape, inverse_scaler, denoise=False, rtol=1e-5, atol=1e-5, method='RK45', eps=1e-3,
+                    device='cuda'):
+    """Probability-flow ODE sampler driven by scipy's adaptive RK45 (sampling.py:414-485).
+
+    The drift evaluation (one U-Net forward per function evaluation) runs as a HIP program; the
+    integrator itself still lives on the host as in the reference (SURVEY 8f-1 lists the on-device
+    Dormand-Prince driver as the next row)."""
+
+    def denoise_update_fn(model, x):
+        score_fn = get_score_fn(sde, model, train=False, continuous=True)
+        vec_eps = torch.ones(x.shape[0], device=x.device) * eps
+        _, x = ReverseDiffusionPredictor(sde, score_fn, probability_flow=False).update_fn(x, vec_eps)
+        return x
+
+    def drift_fn(model, x, t):
+        score_fn = get_score_fn(sde, model, train=False, continuous=True)
+        return sde.reverse(score_fn, probability_flow=True).sde(x, t)[0]
+
+    def ode_sampler(model, z=None):
+        with torch.no_grad():
+            x = sde.prior_sampling(shape).to(device) if z is None else z
+
+            def ode_func(t, flat):
+                xt = from_flattened_numpy(flat, shape).to(device).type(torch.float32)
+                vec_t = torch.ones(shape[0], device=xt.device) * t
+                return to_flattened_numpy(drift_fn(model, xt, vec_t))
+
+            sol = integrate.solve_ivp(ode_func, (sde.T, eps), to_flattened_numpy(x), rtol=rtol, atol=atol, method=method)
+            x = torch.tensor(sol.y[:, -1]).reshape(shape).to(device).type(torch.float32)
+            if denoise:
+                x = denoise_update_fn(model, x)
+            return inverse_scaler(x), sol.nfev
+
+    return ode_sampler

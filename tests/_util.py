@@ -77,3 +77,12 @@ def load_seeded(model, seed=1):
 def rel_err(a, b):
     a, b = a.double().cpu(), b.double().cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def pc_case_inputs(batch=8, n_steps=10, sigma_max=50.0, size=32, seed=7):
+    """x_T and injected noises of the PC-sampler golden case (BASELINE config #1); shared by
+    oracle/gen_golden.py and the tests so the fixture need not store them."""
+    g = torch.Generator().manual_seed(seed)
+    x_T = torch.randn(batch, 3, size, size, generator=g) * sigma_max
+    noises = torch.randn(n_steps, 2, batch, 3, size, size, generator=g)
+    return x_T, noises
