@@ -47,7 +47,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--dump-ops", type=str, default="")
     return ap.parse_args()
 
 
@@ -145,27 +147,45 @@ def main():
                            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                            "kernel": "conv_mfma_kernel (3x3 + fused 1x1 skip), %d launches per U-Net evaluation" % int(conv3.sum()),
                            "unet_eval_ms_eager_events": float(ms.sum()), "by_class": by_class}
+        if args.dump_ops:
+            rows = []
+            for i in range(up.n):
+                op = up.ops[i]
+                row = {"i": i, "kind": int(op.kind), "cls": int(cls[i]), "ms": float(ms[i]), "gflop": float(fl[i]) / 1e9}
+                if op.kind == 1:
+                    c = op.u.conv
+                    row.update(h=c.h_out, w=c.w_out, cout=c.c_out, cin=c.main.c0 + c.main.c1, caux=c.aux.c0 + c.aux.c1,
+                               ks=c.ksize, stride=c.stride, pro=c.main.pro_mode)
+                    row["tflops"] = row["gflop"] / max(row["ms"], 1e-9)
+                rows.append(row)
+            with open(args.dump_ops, "w") as f:
+                json.dump(rows, f)
         out["config"]["end_to_end_tflops"] = eng.nfe_per_step() * eng.unet.flops_per_forward() / (ms_per_step * 1e-3) / 1e12
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import sampler_oracle
-        torch.set_num_threads(os.cpu_count())
-        cores = torch.get_num_threads()
+        # bounded sample: oneDNN scales badly past a few dozen threads on small convolutions (a 256-thread run
+        # of this sample took minutes), so the port is timed on a fixed, stated number of host threads
+        cores = max(1, min(args.cpu_threads, os.cpu_count()))
+        torch.set_num_threads(cores)
         full_sd = {k: v.cpu() for k, v in sd.items()}
         full_sd["sigmas"] = model.sigmas.cpu()
-        cb = args.cpu_batch
         g = torch.Generator().manual_seed(3)
-        x0 = torch.randn(cb, 3, R, R, generator=g) * cfg.model.sigma_max
-        nz = torch.randn(2, 2, cb, 3, R, R, generator=g)
         kw = dict(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=args.sde_steps)
-        sampler_oracle.pc_sample(cfg, full_sd, "vesde", kw, x0[:2], nz[:, :, :2], snr=cfg.sampling.snr, eps=1e-5, max_steps=1)
-        t0 = time.perf_counter()
-        sampler_oracle.pc_sample(cfg, full_sd, "vesde", kw, x0, nz, snr=cfg.sampling.snr, eps=1e-5, max_steps=2)
-        t_cpu = (time.perf_counter() - t0) / 2
+
+        def cpu_iter(cb, steps):
+            x0 = torch.randn(cb, 3, R, R, generator=g) * cfg.model.sigma_max
+            nz = torch.randn(steps, 2, cb, 3, R, R, generator=g)
+            t0 = time.perf_counter()
+            sampler_oracle.pc_sample(cfg, full_sd, "vesde", kw, x0, nz, snr=cfg.sampling.snr, eps=1e-5, max_steps=steps)
+            return (time.perf_counter() - t0) / steps
+        t_probe = cpu_iter(2, 1)                       # warm-up + per-image cost probe
+        cb = int(max(2, min(args.cpu_batch, 20.0 / max(t_probe / 2, 1e-3))))
+        t_cpu = cpu_iter(cb, 1)
         out["cpu_baseline"] = {"value": cb / (args.sde_steps * t_cpu), "unit": "images/s", "cores": cores, "kind": "port",
-                               "sample": "2 PC iterations (4 U-Net evaluations) at batch %d with the torch-CPU oracle "
-                                         "(oracle/sampler_oracle.py), extrapolated to N=%d: %.2f s per iteration"
-                                         % (cb, args.sde_steps, t_cpu)}
+                               "sample": "1 PC iteration (2 U-Net evaluations) at batch %d with the torch-CPU oracle "
+                                         "(oracle/sampler_oracle.py) on %d threads, extrapolated to N=%d: %.2f s per iteration"
+                                         % (cb, cores, args.sde_steps, t_cpu)}
 
     if rank == 0:
         print(json.dumps(out))
