@@ -1,0 +1,79 @@
+"""CPU: the oracle (oracle/) against the golden outputs of the REFERENCE implementation
+(tests/golden/*.npz, generated in the build container by oracle/gen_golden.py).  The oracle is a
+torch-CPU restatement evaluated with the same ATen kernels as the reference, so parity here is
+bit-level (tolerance 2e-6 relative only to absorb a different thread count in oneDNN reductions)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import _util
+from _util import rel_err
+
+CASES = {
+    "unet_small_ncsnpp": lambda: _util.small_config("ncsnpp"),
+    "unet_small_ddpmpp": lambda: _util.small_config("ddpmpp"),
+    "unet_small_ffhq": lambda: _util.small_config("ffhq", image_size=32, ch_mult=(1, 1, 2), attn=(16,)),
+    "unet_small_ncsnpp_3lvl": lambda: _util.small_config("ncsnpp", image_size=32, ch_mult=(1, 2, 2), num_res_blocks=2, attn=(16,)),
+}
+
+
+def _sd_for(cfg):
+    from score_sde_pytorch_amd.models import utils as mutils
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    sd = dict(_util.load_seeded(model, seed=1))
+    sd["sigmas"] = model.sigmas.clone()
+    return sd
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_unet_oracle_reproduces_reference(name):
+    from oracle import unet_oracle
+    gold = np.load(os.path.join(_util.GOLDEN, name + ".npz"))
+    cfg = CASES[name]()
+    sd = _sd_for(cfg)
+    with torch.no_grad():
+        y = unet_oracle.ncsnpp_forward(cfg, sd, torch.from_numpy(gold["x"]), torch.from_numpy(gold["cond"]))
+    assert rel_err(y, torch.from_numpy(gold["y"])) < 2e-6
+
+
+def test_unet_oracle_full_cifar_ncsnpp():
+    """the full 62.8 M-parameter network at B=2 (a few seconds on CPU)"""
+    from oracle import unet_oracle
+    gold = np.load(os.path.join(_util.GOLDEN, "unet_cifar_ncsnpp.npz"))
+    cfg = _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous")
+    sd = _sd_for(cfg)
+    with torch.no_grad():
+        y = unet_oracle.ncsnpp_forward(cfg, sd, torch.from_numpy(gold["x"]), torch.from_numpy(gold["cond"]))
+    assert rel_err(y, torch.from_numpy(gold["y"])) < 2e-6
+
+
+def test_pc_sampler_oracle_prefix_reproduces_reference():
+    """first PC iteration of BASELINE config #1 (B=8, N=10) against the reference trajectory"""
+    from oracle import sampler_oracle
+    gold = np.load(os.path.join(_util.GOLDEN, "pc_cifar_ncsnpp_n10.npz"))
+    cfg = _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous")
+    sd = _sd_for(cfg)
+    x_T, noises = _util.pc_case_inputs(8, 10)
+    out = sampler_oracle.pc_sample(cfg, sd, "vesde", dict(sigma_min=0.01, sigma_max=50, N=10), x_T, noises, snr=0.16,
+                                   eps=1e-5, max_steps=1)
+    assert rel_err(out["x_steps"][0], torch.from_numpy(gold["x_step0"])) < 2e-6
+    assert abs(out["score_norms"][0] - gold["score_norms"][0]) / gold["score_norms"][0] < 2e-6
+
+
+def test_oracle_upfirdn_edge_cases():
+    """ragged / degenerate shapes of upfirdn2d: 1x1 input, odd sizes, all three FIR modes keep their shape law"""
+    from oracle import unet_oracle as uo
+    k = torch.tensor(uo.setup_fir_kernel([1, 3, 3, 1]))
+    for h, w in [(1, 1), (3, 5), (7, 2)]:
+        x = torch.arange(h * w, dtype=torch.float32).reshape(1, 1, h, w) + 1
+        up = uo.upfirdn2d(x, k * 4, up=2, pad=(2, 1))
+        assert up.shape[-2:] == (2 * h, 2 * w)
+        # the [1,3,3,1] FIR has unit DC gain: upsampling a constant keeps it constant away from the border
+        full = uo.upfirdn2d(torch.ones(1, 1, 8, 8), k * 4, up=2, pad=(2, 1))
+        assert torch.allclose(full[..., 2:-2, 2:-2], torch.ones(1, 1, 12, 12))
+    x = torch.randn(2, 3, 8, 8)
+    assert uo.downsample_2d(x, [1, 3, 3, 1]).shape == (2, 3, 4, 4)
+    assert torch.allclose(uo.naive_downsample_2d(uo.naive_upsample_2d(x)), x)
