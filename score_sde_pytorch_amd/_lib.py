@@ -128,16 +128,8 @@ class SsdeError(RuntimeError):
     pass
 
 
-def load():
-    """Load (once) and return the ctypes handle; raises if the library is absent or mismatched."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise SsdeError(
-            "libssde_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(score_sde_pytorch_amd has no CPU/eager fallback)" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+def bind(lib):
+    """Declare argument types on a loaded library and verify it against this mirror."""
     for name in EXPORTS:
         if not hasattr(lib, name):
             raise SsdeError("libssde_hip.so does not export %s" % name)
@@ -159,6 +151,19 @@ def load():
         raise SsdeError("ABI mismatch: library %d, binding %d" % (lib.ssde_abi_version(), ABI_VERSION))
     if lib.ssde_sizeof_op() != C.sizeof(Op):
         raise SsdeError("struct layout mismatch: sizeof(ssde_op) library %d, ctypes %d" % (lib.ssde_sizeof_op(), C.sizeof(Op)))
+    return lib
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the library is absent or mismatched."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SsdeError(
+            "libssde_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(score_sde_pytorch_amd has no CPU/eager fallback)" % LIB_PATH)
+    lib = bind(C.CDLL(LIB_PATH))
     _lib = lib
     return lib
 

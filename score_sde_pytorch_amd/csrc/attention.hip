@@ -23,7 +23,7 @@ constexpr int kAttnLdsFloats = kQB * kLDP + 32 * kLDP;
 
 __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv, float* __restrict__ dst,
                                                    int N, int L, int C, float scale) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  SSDE_LDS(smem);
   float* Qs = smem;                       // [64][36]
   float* Ks = smem + kQB * kLDC;          // [256][36]
   float* Ps = smem;                       // [64][260]   (after step 1)

@@ -226,7 +226,7 @@ __device__ __forceinline__ void conv_phase(const ssde_src& s, const float* __res
 template <int WM, int WN, int TM, int TN, bool HAS3, bool HAS1>
 __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvKParams p) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  SSDE_LDS(smem);
   const ConvGeom& g = p.g;
 
   // XCD-aware tile order: the n-tiles of one m-tile are consecutive on ONE XCD

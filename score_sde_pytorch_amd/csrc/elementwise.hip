@@ -77,7 +77,8 @@ __global__ void bias_act_kernel(const float* __restrict__ src, const float* __re
 // ---- per-sample sum of squares (sampling.py:276-277) ----------------------------------
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                     float* __restrict__ oa, float* __restrict__ ob, int per) {
-  __shared__ float red[2][4];
+  SSDE_LDS(smem);
+  float (*red)[4] = reinterpret_cast<float (*)[4]>(smem);   // [2][4]
   const int n = blockIdx.x, tid = threadIdx.x;
   const float* pa = a + (size_t)n * per;
   const float* pb = b ? b + (size_t)n * per : nullptr;
@@ -123,8 +124,9 @@ __global__ __launch_bounds__(256) void langevin_kernel(float* __restrict__ x, fl
                                                        const float* __restrict__ gss, const float* __restrict__ zss,
                                                        const float* __restrict__ alpha_tab, const int* __restrict__ step_ptr,
                                                        int n, size_t numel, float snr) {
-  __shared__ float red[2][4];
-  __shared__ float s_step[2];
+  SSDE_LDS(smem);
+  float (*red)[4] = reinterpret_cast<float (*)[4]>(smem);   // [2][4]
+  float* s_step = smem + 8;
   const int tid = threadIdx.x;
   float sg = 0.f, sz = 0.f;
   for (int i = tid; i < n; i += 256) { sg += sqrtf(gss[i]); sz += sqrtf(zss[i]); }
@@ -222,7 +224,7 @@ extern "C" int ssde_fused_bias_act(const ssde_bias_act_args* a, void* stream) {
 extern "C" int ssde_sumsq(const ssde_sumsq_args* a, void* stream) {
   SSDE_REQUIRE(a && a->a && a->out_a && a->n > 0 && a->per > 0, "sumsq: bad args");
   SSDE_REQUIRE(!a->b || a->out_b, "sumsq: out_b missing");
-  hipLaunchKernelGGL(sumsq_kernel, dim3(a->n), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(sumsq_kernel, dim3(a->n), dim3(256), 64, static_cast<hipStream_t>(stream),
                      a->a, a->b, a->out_a, a->out_b, a->per);
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;
@@ -241,7 +243,7 @@ extern "C" int ssde_langevin_update(const ssde_langevin_args* a, void* stream) {
   SSDE_REQUIRE(a && a->x && a->x_mean && a->grad && a->noise && a->grad_sumsq && a->noise_sumsq, "langevin: null args");
   SSDE_REQUIRE(a->n > 0 && a->per > 0, "langevin: bad shape");
   const size_t numel = (size_t)a->n * a->per;
-  hipLaunchKernelGGL(langevin_kernel, dim3(grid_for(numel)), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(langevin_kernel, dim3(grid_for(numel)), dim3(256), 64, static_cast<hipStream_t>(stream),
                      a->x, a->x_mean, a->grad, a->noise, a->grad_sumsq, a->noise_sumsq, a->alpha_tab, a->step_ptr,
                      a->n, numel, a->snr);
   SSDE_LAUNCH_CHECK();

@@ -22,8 +22,9 @@ struct GnParams {
 
 // grid = (slices, n).  Thread (pl, cl): channel float4 `cl`, pixels pl, pl+PL, ...
 __global__ __launch_bounds__(kGnThreads) void gn_stats_kernel(const GnParams p) {
-  __shared__ float s_sum[kGnThreads];
-  __shared__ float s_sq[kGnThreads];
+  SSDE_LDS(smem);
+  float* s_sum = smem;
+  float* s_sq = smem + kGnThreads;
   const int n = blockIdx.y, slice = blockIdx.x;
   const int C = p.c0 + p.c1;
   const int CL = C >> 2;                 // float4 lanes per pixel
@@ -131,7 +132,7 @@ extern "C" int ssde_groupnorm_stats(const ssde_gn_stats_args* a, void* stream) {
   SSDE_REQUIRE(slices == 1 || a->scratch, "gn_stats: scratch needed for slices > 1");
   GnParams p{a->p0, a->p1, a->c0, a->c1, a->n, a->hw, a->groups, slices, a->eps, a->mean, a->rstd, a->scratch};
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(slices, a->n), dim3(kGnThreads), 0, st, p);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(slices, a->n), dim3(kGnThreads), 2 * kGnThreads * sizeof(float), st, p);
   SSDE_LAUNCH_CHECK();
   if (slices > 1) {
     const int tot = a->n * a->groups;

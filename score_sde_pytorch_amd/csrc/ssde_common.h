@@ -35,6 +35,11 @@ static inline int ssde_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; retur
 static inline int ssde_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline bool ssde_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// Every LDS byte is carved from the dynamic region: a static __shared__ precedes the dynamic region
+// unpadded and can knock its base off 16-byte alignment (cdna_hip_programming.md Guideline 17).  The
+// float4 element type keeps the base 16-byte aligned for ds_read_b128.
+#define SSDE_LDS(var) HIP_DYNAMIC_SHARED(float4, var##_f4) float* var = reinterpret_cast<float*>(var##_f4)
+
 #ifdef __HIPCC__
 // x * sigmoid(x); v_exp_f32 + v_rcp_f32 (each ~1 ulp)
 __device__ __forceinline__ float ssde_silu(float x) {
