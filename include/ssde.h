@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SSDE_ABI_VERSION 1
+#define SSDE_ABI_VERSION 2
 
 /* ---- prologue applied to a source tensor while it is staged into LDS ---- */
 enum {
@@ -48,6 +48,16 @@ typedef struct ssde_src {
   const float* gn_rstd;  /* [N, G]                                         */
   const float* gn_gamma; /* [c0+c1]                                        */
   const float* gn_beta;  /* [c0+c1]                                        */
+  /* train-mode dropout applied AFTER the prologue (Dropout_0(act(GroupNorm_1(h))), layerspp.py:264-265):
+   * element e of the virtual concat tensor is zeroed when hash32(e * 0x9E3779B1 + (*drop_seed ^ drop_salt))
+   * < drop_thresh, kept and multiplied by drop_scale = 1/(1-p) otherwise.  The mask is a pure function of
+   * (seed word, salt, element index), so forward, weight-gradient and input-gradient kernels regenerate it
+   * instead of storing it.  drop_thresh == 0 disables it. */
+  uint32_t drop_thresh;
+  float drop_scale;
+  const uint32_t* drop_seed;  /* device word, rewritten by the host / a step kernel every training step */
+  uint32_t drop_salt;
+  int32_t _pad;
 } ssde_src;
 
 /* ---- convolution / pointwise GEMM -------------------------------------------
@@ -72,8 +82,8 @@ typedef struct ssde_conv_args {
   const float* bias;     /* [c_out] or NULL                                */
   const float* chan_add; /* [N, chan_add_ld] per-(sample, channel) addend (Dense_0(act(temb))) or NULL */
   int32_t chan_add_ld;
-  int32_t _pad0;
-  const float* resid;    /* [N, h_out, w_out, c_out] or NULL               */
+  int32_t resid_post;    /* 0: out = scale*(... + resid) (residual tail); 1: out = scale*(...) + resid (gradient accumulation) */
+  const float* resid;    /* [N, h_out, w_out, c_out] or NULL (may alias dst) */
   float out_scale;       /* 1 or 1/sqrt(2)                                 */
   int32_t _pad1;
   float* dst;            /* [N, h_out, w_out, c_out]                       */
@@ -105,6 +115,8 @@ typedef struct ssde_upfirdn_args {
   int32_t kh, kw;                /* <= 4 */
   float k[16];                   /* row-major [kh][kw], UNflipped (the op flips, as upfirdn2d does) */
   float* dst;                    /* [N, h_out, w_out, c] */
+  int32_t accumulate;            /* dst += result (gradient accumulation in backward programs) */
+  int32_t _pad0;
 } ssde_upfirdn_args;
 
 /* ---- single-head self-attention core ----------------------------------------
@@ -126,13 +138,17 @@ typedef struct ssde_embed_args {
 } ssde_embed_args;
 
 /* ---- layout boundary (reference tensors are NCHW, ncsnpp.py:232) ------------ */
-typedef struct ssde_to_nhwc_args {   /* dst[n,h,w,c] = a*src[n,c,h,w]+b, channels c..c_pad-1 zero */
-  const float* src; float* dst; int32_t n, c, h, w, c_pad; float a, b; int32_t _pad0;
+typedef struct ssde_to_nhwc_args {   /* dst[n,h,w,c] = a*f(n)*src[n,c,h,w]+b, channels c..c_pad-1 zero */
+  const float* src; float* dst; int32_t n, c, h, w, c_pad; float a, b;
+  int32_t mode;                  /* f(n) as for ssde_to_nchw: backward of the output head */
+  const float* v;                /* [N] or NULL */
 } ssde_to_nhwc_args;
-typedef struct ssde_to_nchw_args {   /* dst[n,c,h,w] = f(n) * src[n,h,w,c] */
+typedef struct ssde_to_nchw_args {   /* dst[n,c,h,w] = alpha * f(n) * src[n,h,w,c] */
   const float* src; float* dst; int32_t n, c, h, w, c_src;
   int32_t mode;                  /* 0: f=1; 1: f=1/v[n] (scale_by_sigma, ncsnpp.py:377-379); 2: f=-1/v[n] (VP score, models/utils.py:159) */
   const float* v;                /* [N] */
+  float alpha;                   /* 0 is read as 1 (forward programs leave it unset) */
+  int32_t accumulate;            /* dst += ... */
 } ssde_to_nchw_args;
 
 /* ---- fused bias + activation (API parity with op/fused_act.py:86-97) -------- */
@@ -170,6 +186,115 @@ typedef struct ssde_fill_args {   /* dst[i] = tab[*step_ptr] (vec_t / labels of 
 } ssde_fill_args;
 typedef struct ssde_step_inc_args { int32_t* step_ptr; int32_t delta; int32_t _pad0; } ssde_step_inc_args;
 
+
+/* =============================== training path ====================================
+ * Backward of the U-Net program and the DSM training step (losses.py:73-99,177-208,
+ * models/ema.py:32-51).  Gradients of parameters are written in the REFERENCE layouts
+ * (OIHW conv weights, [out,in] Linear, [in,out] NIN) straight into a flat gradient
+ * buffer, so a reference optimizer / checkpoint sees the usual tensors.
+ * The input-gradient of a convolution is the forward kernel itself (ssde_conv2d) run on
+ * the output gradient with host-repacked (transposed, 180-degree rotated) weights. */
+
+/* ---- weight gradient: dw += scale * sum_pixels g[pix, co] * pro(src)[pix (+) tap, ci] -------- */
+typedef struct ssde_wgrad_args {
+  ssde_src src;            /* the convolution's input operand incl. its prologue (recomputed, not stored) */
+  const float* g;          /* gradient of the convolution output, rows = output pixels [N*h_out*w_out] */
+  int32_t g_ld, g_off;     /* row stride of g and first column used */
+  int32_t n, h_in, w_in, h_out, w_out;
+  int32_t c_out;           /* number of g columns (output channels of this weight) */
+  int32_t ksize;           /* 3 or 1 */
+  int32_t stride, pad;
+  int32_t cin_store;       /* input channels that exist in dw (<= c0+c1: padded channels are skipped) */
+  int32_t transpose_out;   /* ksize 1 only: dw is [cin_store][c_out] (NIN.W, models/layers.py:550) */
+  int32_t splits;          /* pixel-dimension split (0 = library chooses); partial sums meet by atomic add */
+  float scale;
+  float* dw;               /* [c_out][cin_store][k][k] (OIHW) ; must be zero-initialised once per step */
+} ssde_wgrad_args;
+
+/* ---- column sums of a gradient: bias and Dense_0(temb) addend gradients ------------------- */
+typedef struct ssde_colsum_args {
+  const float* g; int32_t g_ld, g_off;   /* [N*hw, g_ld], columns g_off .. g_off+c */
+  int32_t n, hw, c;
+  float scale;
+  float* per_sample;       /* [N, ps_ld] (+ ps_off): per_sample[n, ps_off+j] = scale * sum_hw g  or NULL */
+  int32_t ps_ld, ps_off;
+  float* total;            /* [c]: scale * sum_{n,hw} g  or NULL */
+  float* total2;           /* optional second destination of the same sums (Conv_1.bias and Conv_2.bias share one) */
+  float* scratch;          /* >= N*c floats when per_sample == NULL */
+} ssde_colsum_args;
+
+/* ---- backward through a prologue: dx = d pro(x) / dx applied to dp ------------------------ *
+ * GroupNorm backward (nn.GroupNorm autograd): with u = xhat*gamma+beta, y = silu(u) [* dropout mask],
+ *   du = dp * mask * silu'(u);  dgamma += sum du*xhat;  dbeta += sum du;  dxh = du*gamma
+ *   dx = rstd * (dxh - mean_g(dxh) - xhat * mean_g(dxh*xhat))
+ * ssde_gn_bwd_reduce computes the per-(sample,group) means and the per-channel dgamma/dbeta;
+ * ssde_prologue_bwd applies the formula (or the plain / SiLU-only variants) and adds the result
+ * into the gradient tensors of the (possibly concatenated) sources. */
+typedef struct ssde_gn_bwd_reduce_args {
+  ssde_src src;            /* x with its GroupNorm prologue (mean/rstd/gamma/beta as in the forward) */
+  const float* dp;         /* [N*hw, c0+c1] gradient w.r.t. the prologue output */
+  int32_t n, hw;
+  float* sums;             /* [N, G, 2]: mean_g(dxh), mean_g(dxh*xhat) */
+  float* dgamma; float* dbeta;   /* [c0+c1] written (not accumulated) */
+  float* scratch;          /* >= N*slices*(G*2 + C*2) floats */
+  int32_t slices; int32_t _pad0;
+} ssde_gn_bwd_reduce_args;
+
+typedef struct ssde_prologue_bwd_args {
+  ssde_src src;            /* forward source (p0/p1 may be NULL for SSDE_PRO_NONE) */
+  const float* dp;         /* [N*hw, dp_ld] */
+  int32_t dp_ld, dp_off;
+  int32_t n, hw;
+  const float* sums;       /* from ssde_gn_bwd_reduce (GN modes) */
+  float scale;
+  int32_t acc0, acc1;      /* 1: g += ..., 0: g = ... */
+  float* g0; float* g1;    /* gradients of p0 [N*hw, c0] and p1 [N*hw, c1] (NULL: that source needs no gradient) */
+} ssde_prologue_bwd_args;
+
+/* ---- attention backward (autograd of layerspp.py:82-86) ---------------------------------- */
+typedef struct ssde_attn_bwd_args {
+  const float* qkv;        /* [N, L, 3C] forward input */
+  const float* o;          /* [N, L, C]  forward output */
+  const float* d_o;        /* [N, L, C]  gradient of the output */
+  float* dqkv;             /* [N, L, 3C] written */
+  float* stats;            /* [N, L, 4] scratch: row max, row sum, D = sum_c dO*O */
+  int32_t n, l, c; float scale;
+} ssde_attn_bwd_args;
+
+/* ---- denoising-score-matching loss head (losses.py:84-99) --------------------------------- *
+ * perturb: x_t = a[n]*x + s[n]*z ;  loss: r = score*s[n] + z (likelihood_weighting=False) or
+ * r = score + z/s[n] (True, weighted by g2[n]); per-sample reduce (0.5*sum or mean), batch mean;
+ * dscore = d loss / d score, fused in the same pass. */
+typedef struct ssde_perturb_args {
+  const float* x; const float* z; const float* a; const float* s; float* dst; int32_t n, per;
+} ssde_perturb_args;
+typedef struct ssde_dsm_loss_args {
+  const float* score; const float* z; const float* s; const float* g2;  /* g2 NULL unless likelihood weighting */
+  float* dscore;           /* [N, per] or NULL (eval) */
+  float* losses;           /* [N] per-sample loss */
+  float* loss;             /* [1] batch mean */
+  int32_t n, per; int32_t reduce_mean; int32_t likelihood_weighting;
+  float grad_scale;        /* multiplies dscore (1/world_size for data-parallel mean) */
+  int32_t _pad0;
+} ssde_dsm_loss_args;
+
+/* ---- fused optimizer: global-norm clip + Adam + EMA over flat buffers ---------------------- *
+ * torch.nn.utils.clip_grad_norm_ (losses.py:49-50), torch.optim.Adam.step (losses.py:29,51) and
+ * ExponentialMovingAverage.update (models/ema.py:46-51) in two launches. hyper (device, 8 floats):
+ * [lr, beta1, beta2, eps, weight_decay, grad_clip(<0 off), bias_corr1, bias_corr2_sqrt] + [ema one_minus_decay] at [8] */
+typedef struct ssde_sumsq_flat_args { const float* x; int64_t numel; float* partial; float* out; } ssde_sumsq_flat_args;
+typedef struct ssde_adam_args {
+  float* p; const float* g; float* m; float* v; float* ema;   /* ema may be NULL */
+  int64_t numel;
+  const float* hyper;      /* device [12] */
+  const float* gnorm_sq;   /* device [1] from ssde_sumsq_flat, or NULL (no clipping) */
+} ssde_adam_args;
+
+typedef struct ssde_memset_args { void* dst; int64_t bytes; int32_t value; int32_t _pad0; } ssde_memset_args;
+typedef struct ssde_axpy_args {   /* dst = (acc ? dst : 0) + alpha * x, optional SiLU' gate: * silu'(gate) */
+  const float* x; const float* gate; float* dst; int64_t numel; float alpha; int32_t acc;
+} ssde_axpy_args;
+
 /* ---- single-op launch entry points ------------------------------------------ */
 int ssde_conv2d(const ssde_conv_args* a, void* stream);
 int ssde_groupnorm_stats(const ssde_gn_stats_args* a, void* stream);
@@ -185,6 +310,17 @@ int ssde_langevin_update(const ssde_langevin_args* a, void* stream);
 int ssde_predictor_update(const ssde_predictor_args* a, void* stream);
 int ssde_fill_from_table(const ssde_fill_args* a, void* stream);
 int ssde_step_inc(const ssde_step_inc_args* a, void* stream);
+int ssde_conv_wgrad(const ssde_wgrad_args* a, void* stream);
+int ssde_colsum(const ssde_colsum_args* a, void* stream);
+int ssde_gn_bwd_reduce(const ssde_gn_bwd_reduce_args* a, void* stream);
+int ssde_prologue_bwd(const ssde_prologue_bwd_args* a, void* stream);
+int ssde_attention_bwd(const ssde_attn_bwd_args* a, void* stream);
+int ssde_perturb(const ssde_perturb_args* a, void* stream);
+int ssde_dsm_loss(const ssde_dsm_loss_args* a, void* stream);
+int ssde_sumsq_flat(const ssde_sumsq_flat_args* a, void* stream);
+int ssde_adam_clip_ema(const ssde_adam_args* a, void* stream);
+int ssde_memset(const ssde_memset_args* a, void* stream);
+int ssde_axpy(const ssde_axpy_args* a, void* stream);
 
 /* ---- programs: a whole U-Net forward / PC step as one call -------------------
  * A program is a flat array of tagged ops built once by the host (it replaces the
@@ -193,7 +329,10 @@ int ssde_step_inc(const ssde_step_inc_args* a, void* stream);
 enum {
   SSDE_OP_CONV = 1, SSDE_OP_GN_STATS = 2, SSDE_OP_UPFIRDN = 3, SSDE_OP_ATTN = 4, SSDE_OP_EMBED = 5,
   SSDE_OP_TO_NHWC = 6, SSDE_OP_TO_NCHW = 7, SSDE_OP_BIAS_ACT = 8, SSDE_OP_SUMSQ = 9, SSDE_OP_RANDN = 10,
-  SSDE_OP_LANGEVIN = 11, SSDE_OP_PREDICTOR = 12, SSDE_OP_FILL = 13, SSDE_OP_STEP_INC = 14
+  SSDE_OP_LANGEVIN = 11, SSDE_OP_PREDICTOR = 12, SSDE_OP_FILL = 13, SSDE_OP_STEP_INC = 14,
+  SSDE_OP_WGRAD = 15, SSDE_OP_COLSUM = 16, SSDE_OP_GN_BWD_REDUCE = 17, SSDE_OP_PROLOGUE_BWD = 18,
+  SSDE_OP_ATTN_BWD = 19, SSDE_OP_PERTURB = 20, SSDE_OP_DSM_LOSS = 21, SSDE_OP_SUMSQ_FLAT = 22,
+  SSDE_OP_ADAM = 23, SSDE_OP_MEMSET = 24, SSDE_OP_AXPY = 25
 };
 typedef struct ssde_op {
   int32_t kind; int32_t flops_class;   /* flops_class: free tag echoed by timing */
@@ -203,6 +342,9 @@ typedef struct ssde_op {
     ssde_bias_act_args bias_act; ssde_sumsq_args sumsq; ssde_randn_args randn;
     ssde_langevin_args langevin; ssde_predictor_args predictor; ssde_fill_args fill;
     ssde_step_inc_args step_inc;
+    ssde_wgrad_args wgrad; ssde_colsum_args colsum; ssde_gn_bwd_reduce_args gn_bwd; ssde_prologue_bwd_args pro_bwd;
+    ssde_attn_bwd_args attn_bwd; ssde_perturb_args perturb; ssde_dsm_loss_args dsm_loss;
+    ssde_sumsq_flat_args sumsq_flat; ssde_adam_args adam; ssde_memset_args memset; ssde_axpy_args axpy;
   } u;
 } ssde_op;
 

@@ -11,10 +11,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libssde_hip.so")
-SOURCES = ["runtime.hip", "conv_mfma.hip", "groupnorm.hip", "resample.hip", "attention.hip", "elementwise.hip"]
+SOURCES = ["runtime.hip", "conv_mfma.hip", "wgrad.hip", "groupnorm.hip", "resample.hip", "attention.hip",
+           "elementwise.hip", "backward.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fgpu-rdc" if False else "-fno-gpu-rdc",
-         "-Wall", "-Wno-unused-function"]
+         "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 
 
 def _newer(src, dst):

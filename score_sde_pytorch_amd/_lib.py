@@ -9,12 +9,13 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libssde_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_SILU = 0, 1, 2, 3
 TILE_AUTO, TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32 = 0, 1, 2, 3, 4
 (OP_CONV, OP_GN_STATS, OP_UPFIRDN, OP_ATTN, OP_EMBED, OP_TO_NHWC, OP_TO_NCHW, OP_BIAS_ACT, OP_SUMSQ,
- OP_RANDN, OP_LANGEVIN, OP_PREDICTOR, OP_FILL, OP_STEP_INC) = range(1, 15)
+ OP_RANDN, OP_LANGEVIN, OP_PREDICTOR, OP_FILL, OP_STEP_INC, OP_WGRAD, OP_COLSUM, OP_GN_BWD_REDUCE, OP_PROLOGUE_BWD,
+ OP_ATTN_BWD, OP_PERTURB, OP_DSM_LOSS, OP_SUMSQ_FLAT, OP_ADAM, OP_MEMSET, OP_AXPY) = range(1, 26)
 
 _fp = C.c_void_p  # device pointers are passed as integers
 
@@ -22,7 +23,9 @@ _fp = C.c_void_p  # device pointers are passed as integers
 class Src(C.Structure):
     _fields_ = [("p0", _fp), ("p1", _fp), ("c0", C.c_int32), ("c1", C.c_int32),
                 ("pro_mode", C.c_int32), ("gn_groups", C.c_int32),
-                ("gn_mean", _fp), ("gn_rstd", _fp), ("gn_gamma", _fp), ("gn_beta", _fp)]
+                ("gn_mean", _fp), ("gn_rstd", _fp), ("gn_gamma", _fp), ("gn_beta", _fp),
+                ("drop_thresh", C.c_uint32), ("drop_scale", C.c_float), ("drop_seed", _fp),
+                ("drop_salt", C.c_uint32), ("_pad", C.c_int32)]
 
 
 class ConvArgs(C.Structure):
@@ -30,7 +33,7 @@ class ConvArgs(C.Structure):
                 ("n", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32),
                 ("h_out", C.c_int32), ("w_out", C.c_int32), ("c_out", C.c_int32),
                 ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("tile", C.c_int32),
-                ("bias", _fp), ("chan_add", _fp), ("chan_add_ld", C.c_int32), ("_pad0", C.c_int32),
+                ("bias", _fp), ("chan_add", _fp), ("chan_add_ld", C.c_int32), ("resid_post", C.c_int32),
                 ("resid", _fp), ("out_scale", C.c_float), ("_pad1", C.c_int32), ("dst", _fp)]
 
 
@@ -44,7 +47,8 @@ class UpfirdnArgs(C.Structure):
     _fields_ = [("src", Src), ("n", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32), ("c", C.c_int32),
                 ("h_out", C.c_int32), ("w_out", C.c_int32),
                 ("up", C.c_int32), ("down", C.c_int32), ("pad0", C.c_int32), ("pad1", C.c_int32),
-                ("kh", C.c_int32), ("kw", C.c_int32), ("k", C.c_float * 16), ("dst", _fp)]
+                ("kh", C.c_int32), ("kw", C.c_int32), ("k", C.c_float * 16), ("dst", _fp),
+                ("accumulate", C.c_int32), ("_pad0", C.c_int32)]
 
 
 class AttnArgs(C.Structure):
@@ -58,12 +62,12 @@ class EmbedArgs(C.Structure):
 
 class ToNhwcArgs(C.Structure):
     _fields_ = [("src", _fp), ("dst", _fp), ("n", C.c_int32), ("c", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
-                ("c_pad", C.c_int32), ("a", C.c_float), ("b", C.c_float), ("_pad0", C.c_int32)]
+                ("c_pad", C.c_int32), ("a", C.c_float), ("b", C.c_float), ("mode", C.c_int32), ("v", _fp)]
 
 
 class ToNchwArgs(C.Structure):
     _fields_ = [("src", _fp), ("dst", _fp), ("n", C.c_int32), ("c", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
-                ("c_src", C.c_int32), ("mode", C.c_int32), ("v", _fp)]
+                ("c_src", C.c_int32), ("mode", C.c_int32), ("v", _fp), ("alpha", C.c_float), ("accumulate", C.c_int32)]
 
 
 class BiasActArgs(C.Structure):
@@ -99,11 +103,70 @@ class StepIncArgs(C.Structure):
     _fields_ = [("step_ptr", _fp), ("delta", C.c_int32), ("_pad0", C.c_int32)]
 
 
+class WgradArgs(C.Structure):
+    _fields_ = [("src", Src), ("g", _fp), ("g_ld", C.c_int32), ("g_off", C.c_int32),
+                ("n", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32), ("h_out", C.c_int32), ("w_out", C.c_int32),
+                ("c_out", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("cin_store", C.c_int32), ("transpose_out", C.c_int32), ("splits", C.c_int32), ("scale", C.c_float),
+                ("dw", _fp)]
+
+
+class ColsumArgs(C.Structure):
+    _fields_ = [("g", _fp), ("g_ld", C.c_int32), ("g_off", C.c_int32), ("n", C.c_int32), ("hw", C.c_int32),
+                ("c", C.c_int32), ("scale", C.c_float), ("per_sample", _fp), ("ps_ld", C.c_int32), ("ps_off", C.c_int32),
+                ("total", _fp), ("total2", _fp), ("scratch", _fp)]
+
+
+class GnBwdReduceArgs(C.Structure):
+    _fields_ = [("src", Src), ("dp", _fp), ("n", C.c_int32), ("hw", C.c_int32), ("sums", _fp),
+                ("dgamma", _fp), ("dbeta", _fp), ("scratch", _fp), ("slices", C.c_int32), ("_pad0", C.c_int32)]
+
+
+class PrologueBwdArgs(C.Structure):
+    _fields_ = [("src", Src), ("dp", _fp), ("dp_ld", C.c_int32), ("dp_off", C.c_int32), ("n", C.c_int32), ("hw", C.c_int32),
+                ("sums", _fp), ("scale", C.c_float), ("acc0", C.c_int32), ("acc1", C.c_int32), ("g0", _fp), ("g1", _fp)]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [("qkv", _fp), ("o", _fp), ("d_o", _fp), ("dqkv", _fp), ("stats", _fp),
+                ("n", C.c_int32), ("l", C.c_int32), ("c", C.c_int32), ("scale", C.c_float)]
+
+
+class PerturbArgs(C.Structure):
+    _fields_ = [("x", _fp), ("z", _fp), ("a", _fp), ("s", _fp), ("dst", _fp), ("n", C.c_int32), ("per", C.c_int32)]
+
+
+class DsmLossArgs(C.Structure):
+    _fields_ = [("score", _fp), ("z", _fp), ("s", _fp), ("g2", _fp), ("dscore", _fp), ("losses", _fp), ("loss", _fp),
+                ("n", C.c_int32), ("per", C.c_int32), ("reduce_mean", C.c_int32), ("likelihood_weighting", C.c_int32),
+                ("grad_scale", C.c_float), ("_pad0", C.c_int32)]
+
+
+class SumsqFlatArgs(C.Structure):
+    _fields_ = [("x", _fp), ("numel", C.c_int64), ("partial", _fp), ("out", _fp)]
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [("p", _fp), ("g", _fp), ("m", _fp), ("v", _fp), ("ema", _fp), ("numel", C.c_int64),
+                ("hyper", _fp), ("gnorm_sq", _fp)]
+
+
+class MemsetArgs(C.Structure):
+    _fields_ = [("dst", _fp), ("bytes", C.c_int64), ("value", C.c_int32), ("_pad0", C.c_int32)]
+
+
+class AxpyArgs(C.Structure):
+    _fields_ = [("x", _fp), ("gate", _fp), ("dst", _fp), ("numel", C.c_int64), ("alpha", C.c_float), ("acc", C.c_int32)]
+
+
 class _OpUnion(C.Union):
     _fields_ = [("conv", ConvArgs), ("gn", GnStatsArgs), ("fir", UpfirdnArgs), ("attn", AttnArgs),
                 ("embed", EmbedArgs), ("to_nhwc", ToNhwcArgs), ("to_nchw", ToNchwArgs), ("bias_act", BiasActArgs),
                 ("sumsq", SumsqArgs), ("randn", RandnArgs), ("langevin", LangevinArgs), ("predictor", PredictorArgs),
-                ("fill", FillArgs), ("step_inc", StepIncArgs)]
+                ("fill", FillArgs), ("step_inc", StepIncArgs),
+                ("wgrad", WgradArgs), ("colsum", ColsumArgs), ("gn_bwd", GnBwdReduceArgs), ("pro_bwd", PrologueBwdArgs),
+                ("attn_bwd", AttnBwdArgs), ("perturb", PerturbArgs), ("dsm_loss", DsmLossArgs),
+                ("sumsq_flat", SumsqFlatArgs), ("adam", AdamArgs), ("memset", MemsetArgs), ("axpy", AxpyArgs)]
 
 
 class Op(C.Structure):
@@ -113,13 +176,17 @@ class Op(C.Structure):
 _UNION_FIELD = {OP_CONV: "conv", OP_GN_STATS: "gn", OP_UPFIRDN: "fir", OP_ATTN: "attn", OP_EMBED: "embed",
                 OP_TO_NHWC: "to_nhwc", OP_TO_NCHW: "to_nchw", OP_BIAS_ACT: "bias_act", OP_SUMSQ: "sumsq",
                 OP_RANDN: "randn", OP_LANGEVIN: "langevin", OP_PREDICTOR: "predictor", OP_FILL: "fill",
-                OP_STEP_INC: "step_inc"}
+                OP_STEP_INC: "step_inc", OP_WGRAD: "wgrad", OP_COLSUM: "colsum", OP_GN_BWD_REDUCE: "gn_bwd",
+                OP_PROLOGUE_BWD: "pro_bwd", OP_ATTN_BWD: "attn_bwd", OP_PERTURB: "perturb", OP_DSM_LOSS: "dsm_loss",
+                OP_SUMSQ_FLAT: "sumsq_flat", OP_ADAM: "adam", OP_MEMSET: "memset", OP_AXPY: "axpy"}
 
 EXPORTS = ["ssde_conv2d", "ssde_groupnorm_stats", "ssde_upfirdn2d", "ssde_attention", "ssde_embed", "ssde_to_nhwc",
            "ssde_to_nchw", "ssde_fused_bias_act", "ssde_sumsq", "ssde_randn", "ssde_langevin_update",
            "ssde_predictor_update", "ssde_fill_from_table", "ssde_step_inc", "ssde_program_run",
            "ssde_program_run_timed", "ssde_graph_capture", "ssde_graph_launch", "ssde_graph_destroy",
-           "ssde_abi_version", "ssde_sizeof_op", "ssde_last_error", "ssde_conv_lds_bytes"]
+           "ssde_abi_version", "ssde_sizeof_op", "ssde_last_error", "ssde_conv_lds_bytes",
+           "ssde_conv_wgrad", "ssde_colsum", "ssde_gn_bwd_reduce", "ssde_prologue_bwd", "ssde_attention_bwd",
+           "ssde_perturb", "ssde_dsm_loss", "ssde_sumsq_flat", "ssde_adam_clip_ema", "ssde_memset", "ssde_axpy"]
 
 _lib = None
 
@@ -144,7 +211,11 @@ def bind(lib):
                       ("ssde_to_nchw", ToNchwArgs), ("ssde_fused_bias_act", BiasActArgs), ("ssde_sumsq", SumsqArgs),
                       ("ssde_randn", RandnArgs), ("ssde_langevin_update", LangevinArgs),
                       ("ssde_predictor_update", PredictorArgs), ("ssde_fill_from_table", FillArgs),
-                      ("ssde_step_inc", StepIncArgs)]:
+                      ("ssde_step_inc", StepIncArgs), ("ssde_conv_wgrad", WgradArgs), ("ssde_colsum", ColsumArgs),
+                      ("ssde_gn_bwd_reduce", GnBwdReduceArgs), ("ssde_prologue_bwd", PrologueBwdArgs),
+                      ("ssde_attention_bwd", AttnBwdArgs), ("ssde_perturb", PerturbArgs), ("ssde_dsm_loss", DsmLossArgs),
+                      ("ssde_sumsq_flat", SumsqFlatArgs), ("ssde_adam_clip_ema", AdamArgs), ("ssde_memset", MemsetArgs),
+                      ("ssde_axpy", AxpyArgs)]:
         getattr(lib, name).argtypes = [C.POINTER(typ), C.c_void_p]
     lib.ssde_conv_lds_bytes.argtypes = [C.POINTER(ConvArgs)]
     if lib.ssde_abi_version() != ABI_VERSION:

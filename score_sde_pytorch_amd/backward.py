@@ -1,0 +1,340 @@
+"""Backward lowering: reverse-mode differentiation of a U-Net program into a program of HIP kernels.
+
+The reference gets its backward from torch autograd over ~900 eager ops (losses.py:196
+`loss.backward()`).  Here the forward is already a flat list of fused ops (engine.py); `TrainEngine`
+walks that list in reverse ONCE and emits, per forward op, the kernels of its adjoint:
+
+  conv (k x k main + 1 x 1 aux + bias + temb addend + residual, scaled)
+      -> column sums            bias / Dense_0 addend gradients           (backward.hip)
+         weight gradients       pixel-split MFMA GEMM, prologue recomputed (wgrad.hip)
+         input gradient         the FORWARD conv kernel on the output gradient with
+                                transposed + 180-degree-rotated weights    (conv_mfma.hip)
+         prologue backward      GroupNorm / SiLU / dropout adjoint, fused  (backward.hip)
+         residual               scaled accumulate
+  upfirdn2d  -> upfirdn2d with up/down swapped, the flipped kernel and the gradient pads of
+                op/upfirdn2d.py:111-116 (UpFirDn2d.backward)
+  attention  -> two kernels that recompute the probabilities (attention.hip)
+  NCHW/NHWC boundary ops -> each other.
+
+Parameter gradients land in a flat fp32 buffer laid out exactly like the parameters themselves
+(`FlatParams`), so `p.grad` is a view for torch users and the fused optimizer (losses.py) sees two
+flat arrays.  Forward and backward share ONE liveness-planned arena: a forward activation stays
+resident exactly until its last backward consumer has been enqueued.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import engine as E
+from .engine import _src
+
+FC_WGRAD, FC_BWD = 6, 7
+
+
+class FlatParams:
+    """All trainable parameters of a model as views into one flat fp32 buffer (+ a same-shaped gradient buffer)."""
+
+    def __init__(self, model, device):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.index, off = {}, 0
+        for p in self.params:
+            self.index[id(p)] = (off, p.numel())
+            off += (p.numel() + 3) // 4 * 4          # 16-byte aligned starts
+        self.numel = off
+        self.data = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for p in self.params:
+                o, n = self.index[id(p)]
+                self.data[o:o + n].copy_(p.detach().reshape(-1).to(device, torch.float32))
+                p.data = self.data[o:o + n].view(p.shape)
+        self.device = device
+
+    def owns(self, model):
+        ps = [p for p in model.parameters() if p.requires_grad]
+        if len(ps) != len(self.params):
+            return False
+        base = self.data.data_ptr()
+        for p in ps:
+            e = self.index.get(id(p))
+            if e is None or p.data_ptr() != base + e[0] * 4:
+                return False
+        return True
+
+    def grad_view(self, p):
+        o, n = self.index[id(p)]
+        return self.grad[o:o + n].view(p.shape)
+
+    def attach_grads(self):
+        """Expose the flat gradient buffer through `p.grad` (views, no copies)."""
+        for p in self.params:
+            p.grad = self.grad_view(p)
+
+
+def flat_params_of(model, device):
+    fp = getattr(model, "_flat_params", None)
+    if fp is None or fp.device != device or not fp.owns(model):
+        fp = FlatParams(model, device)
+        model._flat_params = fp
+    return fp
+
+
+class TrainEngine(E.UNetEngine):
+    """Forward (train mode) + backward program of NCSNpp at a fixed (batch, H, W)."""
+
+    def __init__(self, model, batch, height, width, device, vp_score=False, input_grad=False):
+        self.flat = flat_params_of(model, device)
+        super().__init__(model, batch, height, width, device, vp_score=vp_score, train=True, input_grad=input_grad,
+                         finalize=False)
+        self.n_fwd = len(self.b.specs)
+        # d loss / d out in the boundary layout (NCHW), written by the caller (loss head or autograd)
+        self.gout = self.b.buf(batch, self.channels, height, width, name="gout", persistent=True)
+        self.gx = self.b.buf(batch, self.channels, height, width, name="gx", persistent=True) if input_grad else None
+        self._G = {}
+        self._lower_backward()
+        self.program = self.b.finalize()
+        self.n_bwd = self.program.n - self.n_fwd
+
+    # ------------------------------------------------------------------ helpers
+    def _needs(self, buf):
+        if buf is None:
+            return False
+        if isinstance(buf, tuple):
+            buf = buf[0]
+        return id(buf) not in self._nograd
+
+    def _gentry(self, buf):
+        e = self._G.get(id(buf))
+        if e is None:
+            e = self._G[id(buf)] = [self.b.buf(*buf.shape, name="g_" + buf.name), False]
+        return e
+
+    def _param_of(self, packed):
+        return self.weights.meta[id(packed)]["parts"][0]["param"]
+
+    # ------------------------------------------------------------------ the tape walk
+    def _lower_backward(self):
+        b = self.b
+        self._nograd = {id(self.x_in), id(self.cond), id(self._emb)}
+        if self.sig is not self.cond:
+            self._nograd.add(id(self.sig))
+        if self.std is not None:
+            self._nograd.add(id(self.std))
+        if not self.input_grad:
+            self._nograd.add(id(self._x0))
+        fwd = list(b.specs[: self.n_fwd])
+        b.add(L.OP_MEMSET, dict(dst=self.flat.grad, bytes=self.flat.numel * 4, value=0), FC_BWD)
+        handlers = {L.OP_CONV: self._bwd_conv, L.OP_UPFIRDN: self._bwd_fir, L.OP_ATTN: self._bwd_attn,
+                    L.OP_TO_NCHW: self._bwd_to_nchw, L.OP_TO_NHWC: self._bwd_to_nhwc}
+        for kind, f, _, _ in reversed(fwd):
+            h = handlers.get(kind)
+            if h is not None:
+                h(f)
+
+    def _bwd_to_nchw(self, f):
+        e = self._gentry(f["src"])
+        self.b.add(L.OP_TO_NHWC, dict(src=self.gout, dst=e[0], n=f["n"], c=f["c"], h=f["h"], w=f["w"], c_pad=f["c_src"],
+                                      a=1.0, b=0.0, mode=f["mode"], v=f["v"]), FC_BWD)
+        e[1] = True
+
+    def _bwd_to_nhwc(self, f):
+        if not self.input_grad:
+            return
+        e = self._G.get(id(f["dst"]))
+        if e is None:
+            return
+        self.b.add(L.OP_TO_NCHW, dict(src=e[0], dst=self.gx, n=f["n"], c=f["c"], h=f["h"], w=f["w"], c_src=f["c_pad"],
+                                      mode=0, v=None, alpha=float(f["a"]), accumulate=0), FC_BWD)
+
+    def _accum(self, target, dp, dp_ld, dp_off, c, n, hw, scale):
+        """grad(target) (+)= scale * dp[:, dp_off:dp_off+c]"""
+        if not self._needs(target):
+            return
+        e = self._gentry(target)
+        src = dict(E._NOSRC); src.update(c0=c)
+        self.b.add(L.OP_PROLOGUE_BWD, dict(src=src, dp=dp, dp_ld=dp_ld, dp_off=dp_off, n=n, hw=hw, sums=None, scale=float(scale),
+                                           acc0=int(e[1]), acc1=0, g0=e[0], g1=None), FC_BWD)
+        e[1] = True
+
+    def _bwd_prologue(self, src, dP, n, hw):
+        b = self.b
+        ctot = src["c0"] + src["c1"]
+        e0 = self._gentry(src["p0"]) if self._needs(src["p0"]) else None
+        e1 = self._gentry(src["p1"]) if self._needs(src["p1"]) else None
+        sums = None
+        if src["pro_mode"] in (L.PRO_GN, L.PRO_GN_SILU):
+            groups = src["gn_groups"]
+            sums = b.buf(n, groups, 2, name="gn_bwd_sums")
+            slices = max(1, min(int(math.ceil(256 / n)), hw // 64)) if hw >= 128 else 1
+            scratch = b.buf(n * slices * ctot * 2, name="gn_bwd_scratch")
+            b.add(L.OP_GN_BWD_REDUCE, dict(src=src, dp=dP, n=n, hw=hw, sums=sums,
+                                           dgamma=self.flat.grad_view(self._param_of(src["gn_gamma"])),
+                                           dbeta=self.flat.grad_view(self._param_of(src["gn_beta"])),
+                                           scratch=scratch, slices=slices), FC_BWD)
+        if e0 is None and e1 is None:
+            return
+        b.add(L.OP_PROLOGUE_BWD, dict(src=src, dp=dP, dp_ld=ctot, dp_off=0, n=n, hw=hw, sums=sums, scale=1.0,
+                                      acc0=int(e0[1]) if e0 else 0, acc1=int(e1[1]) if e1 else 0,
+                                      g0=e0[0] if e0 else None, g1=e1[0] if e1 else None), FC_BWD)
+        if e0:
+            e0[1] = True
+        if e1:
+            e1[1] = True
+
+    def _bwd_bias(self, f, g, g_ld, n, hw, scale):
+        b = self.b
+        per, ps_ld, ps_off = None, 0, 0
+        if f["chan_add"] is not None:
+            tbuf, off = f["chan_add"]
+            e = self._gentry(tbuf)
+            per, ps_ld, ps_off = e[0], f["chan_add_ld"], off
+            e[1] = True
+        parts, mode = [], "cat"
+        if f["bias"] is not None:
+            meta = self.weights.meta[id(f["bias"])]
+            parts, mode = meta["parts"], meta["mode"]
+        if mode == "sum":
+            assert len(parts) == 2
+            c = parts[0]["n"]
+            scratch = b.buf(n * c, name="colsum_scratch") if per is None else None
+            b.add(L.OP_COLSUM, dict(g=g, g_ld=g_ld, g_off=0, n=n, hw=hw, c=c, scale=float(scale), per_sample=per, ps_ld=ps_ld,
+                                    ps_off=ps_off, total=self.flat.grad_view(parts[0]["param"]),
+                                    total2=self.flat.grad_view(parts[1]["param"]), scratch=scratch), FC_BWD)
+            return
+        if not parts and per is not None:
+            b.add(L.OP_COLSUM, dict(g=g, g_ld=g_ld, g_off=0, n=n, hw=hw, c=f["c_out"], scale=float(scale), per_sample=per,
+                                    ps_ld=ps_ld, ps_off=ps_off, total=None, total2=None, scratch=None), FC_BWD)
+            return
+        for i, part in enumerate(parts):
+            use_per = per if (i == 0 and len(parts) == 1) else None
+            assert per is None or len(parts) == 1
+            scratch = b.buf(n * part["n"], name="colsum_scratch") if use_per is None else None
+            b.add(L.OP_COLSUM, dict(g=g, g_ld=g_ld, g_off=part["off"], n=n, hw=hw, c=part["n"], scale=float(scale),
+                                    per_sample=use_per, ps_ld=ps_ld, ps_off=ps_off,
+                                    total=self.flat.grad_view(part["param"]), total2=None, scratch=scratch), FC_BWD)
+
+    def _bwd_branch(self, f, src, wpacked, g, g_ld, scale, ksize):
+        b, low, n = self.b, self.low, f["n"]
+        ho, wo = f["h_out"], f["w_out"]
+        if ksize == 3:
+            h_in, w_in, stride, pad = f["h_in"], f["w_in"], f["stride"], f["pad"]
+        else:
+            h_in, w_in, stride, pad = ho, wo, 1, 0
+        meta = self.weights.meta[id(wpacked)]
+        ctot = src["c0"] + src["c1"]
+        for part in meta["parts"]:
+            flops = 2.0 * n * ho * wo * ksize * ksize * meta["cin_store"] * part["rows"]
+            b.add(L.OP_WGRAD, dict(src=src, g=g, g_ld=g_ld, g_off=part["row0"], n=n, h_in=h_in, w_in=w_in, h_out=ho, w_out=wo,
+                                   c_out=part["rows"], ksize=ksize, stride=stride, pad=pad, cin_store=meta["cin_store"],
+                                   transpose_out=int(part["transpose"]), splits=0, scale=float(scale),
+                                   dw=self.flat.grad_view(part["param"])), FC_WGRAD, flops)
+        if not (self._needs(src["p0"]) or self._needs(src["p1"])):
+            return
+        direct = src["pro_mode"] == L.PRO_NONE and src["p1"] is None
+        if direct:
+            e = self._gentry(src["p0"])
+            dst, resid = e[0], (e[0] if e[1] else None)
+            e[1] = True
+        else:
+            dst, resid = b.buf(n, h_in, w_in, ctot, name="dP"), None
+        gsrc = _src(g, g_ld)
+        if ksize == 3:
+            wd = self.weights.derived(wpacked, lambda w: E.pack_conv_weight(w.permute(1, 0, 2, 3).flip(2, 3)), "dgrad")
+            if stride == 1:
+                low.conv(dst, h_in, w_in, ctot, main=gsrc, w_main=wd, h_in=ho, w_in=wo, stride=1, pad=1, resid=resid, resid_post=1, scale=scale)
+            else:
+                # transposed strided conv = zero-insertion (upfirdn, up=2, 1x1 kernel) + stride-1 conv with pad 2, cropped
+                assert stride == 2 and pad == 0
+                gz, hz, wz = low.upfirdn(gsrc, g_ld, ho, wo, np.ones((1, 1), np.float32), up=2, pad=(0, 0), name="g_zero_ins")
+                low.conv(dst, h_in, w_in, ctot, main=_src(gz, g_ld), w_main=wd, h_in=hz, w_in=wz, stride=1, pad=2,
+                         resid=resid, resid_post=1, scale=scale)
+        else:
+            wd = self.weights.derived(wpacked, lambda m: E.pack_matrix(m.t().contiguous()), "dgrad")
+            low.conv(dst, ho, wo, ctot, aux=gsrc, w_aux=wd, resid=resid, resid_post=1, scale=scale)
+        if not direct:
+            self._bwd_prologue(src, dst, n, h_in * w_in)
+
+    def _bwd_conv(self, f):
+        e = self._G.get(id(f["dst"]))
+        if e is None:
+            return
+        g, scale, n = e[0], f["out_scale"], f["n"]
+        hw, g_ld = f["h_out"] * f["w_out"], f["dst"].shape[-1]
+        if f["resid"] is not None:
+            self._accum(f["resid"], g, g_ld, 0, g_ld, n, hw, scale)
+        if f["bias"] is not None or f["chan_add"] is not None:
+            self._bwd_bias(f, g, g_ld, n, hw, scale)
+        if f["ksize"] == 3:
+            self._bwd_branch(f, f["main"], f["w_main"], g, g_ld, scale, 3)
+        if f["aux"]["p0"] is not None:
+            self._bwd_branch(f, f["aux"], f["w_aux"], g, g_ld, scale, 1)
+
+    def _bwd_fir(self, f):
+        e = self._G.get(id(f["dst"]))
+        src = f["src"]
+        if e is None or not self._needs(src["p0"]):
+            return
+        b, n, c = self.b, f["n"], f["c"]
+        up, down, pad0, kh, kw = f["up"], f["down"], f["pad0"], f["kh"], f["kw"]
+        # UpFirDn2d.backward (op/upfirdn2d.py:111-116): same op on the gradient with up/down swapped,
+        # the flipped kernel and these pads
+        gp0 = kw - pad0 - 1
+        gp1 = f["w_in"] * up - f["w_out"] * down + pad0 - up + 1
+        assert gp0 >= 0 and gp1 >= 0, "negative gradient pads are not lowered"
+        k = np.asarray(f["k"][: kh * kw], dtype=np.float32).reshape(kh, kw)[::-1, ::-1]
+        k16 = [0.0] * 16
+        for i, v in enumerate(k.reshape(-1).tolist()):
+            k16[i] = float(v)
+        direct = src["pro_mode"] == L.PRO_NONE
+        if direct:
+            t = self._gentry(src["p0"])
+            dst, acc = t[0], int(t[1])
+            t[1] = True
+        else:
+            dst, acc = b.buf(n, f["h_in"], f["w_in"], c, name="dP_fir"), 0
+        b.add(L.OP_UPFIRDN, dict(src=_src(e[0], c), n=n, h_in=f["h_out"], w_in=f["w_out"], c=c, h_out=f["h_in"], w_out=f["w_in"],
+                                 up=down, down=up, pad0=gp0, pad1=gp1, kh=kh, kw=kw, k=k16, dst=dst, accumulate=acc), E.FC_FIR)
+        if not direct:
+            self._bwd_prologue(src, dst, n, f["h_in"] * f["w_in"])
+
+    def _bwd_attn(self, f):
+        e = self._G.get(id(f["dst"]))
+        if e is None:
+            return
+        gq = self._gentry(f["qkv"])
+        stats = self.b.buf(f["n"], f["l"], 4, name="attn_stats")
+        self.b.add(L.OP_ATTN_BWD, dict(qkv=f["qkv"], o=f["dst"], d_o=e[0], dqkv=gq[0], stats=stats, n=f["n"], l=f["l"], c=f["c"],
+                                       scale=f["scale"]), E.FC_ATTN, 14.0 * f["n"] * f["l"] * f["l"] * f["c"])
+        gq[1] = True
+
+    # ------------------------------------------------------------------ execution
+    def set_dropout_seed(self, seed):
+        if self.drop_seed is not None:
+            self.drop_seed.fill_(int(seed) & 0x7FFFFFFF)
+
+    def run_forward(self):
+        self.program.run_range(0, self.n_fwd)
+
+    def run_backward(self):
+        self.program.run_range(self.n_fwd, self.n_bwd)
+
+    def forward_train(self, x, cond, seed=0):
+        if tuple(x.shape) != (self.n, self.channels, self.h, self.w):
+            raise ValueError("engine built for %s, got %s" % ((self.n, self.channels, self.h, self.w), tuple(x.shape)))
+        self.weights.refresh()
+        self.set_dropout_seed(seed)
+        self.load_inputs(x.contiguous(), cond)
+        self.run_forward()
+        return self.output_view()
+
+    def backward(self, grad_out):
+        """Runs the backward program for d loss / d out = grad_out [N, C, H, W]; parameter gradients land in
+        `self.flat.grad` (zeroed first), d loss / d x in `gx_view()` when built with input_grad."""
+        self.gout.tensor[: grad_out.numel()].copy_(grad_out.reshape(-1))
+        self.run_backward()
+
+    def gx_view(self):
+        return self.gx.tensor[: self.n * self.channels * self.h * self.w].view(self.n, self.channels, self.h, self.w)

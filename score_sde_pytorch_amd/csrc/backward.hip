@@ -1,0 +1,442 @@
+// HBM-bound kernels of the training step: bias / temb-addend gradients (column sums), GroupNorm
+// backward (reduction + apply, fused with SiLU' and the regenerated dropout mask), the DSM loss head
+// (losses.py:84-99) and the fused clip + Adam + EMA update over flat buffers (losses.py:41-51,
+// models/ema.py:46-51).  All tensors NHWC fp32 unless stated; every kernel reads each operand once
+// with 16-byte lane accesses.
+#include "ssde_common.h"
+
+namespace {
+
+inline unsigned grid_for(size_t total, int block = 256, unsigned cap = 256 * 16) {
+  size_t b = (total + block - 1) / block;
+  if (b < 1) b = 1;
+  return (unsigned)(b > cap ? cap : b);
+}
+
+// ---- column sums ------------------------------------------------------------------------------
+// grid (ceil(CL/64), N): block = 64 float4 channel lanes x 4 pixel lanes (one wave per pixel lane)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, int g_ld, int g_off, int hw, int c,
+                                                     float scale, float* __restrict__ out, int out_ld, int out_off) {
+  SSDE_LDS(smem);                                      // [4][64] float4
+  float4* red = reinterpret_cast<float4*>(smem);
+  const int n = blockIdx.y;
+  const int cl = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int pl = threadIdx.x >> 6;
+  const int col = g_off + cl * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cl * 4 < c && col + 4 <= g_ld) {
+    const float* base = g + (size_t)n * hw * g_ld + col;
+    int px = pl;
+    for (; px + 12 < hw; px += 16) {
+      const float4 a = *reinterpret_cast<const float4*>(base + (size_t)px * g_ld);
+      const float4 b = *reinterpret_cast<const float4*>(base + (size_t)(px + 4) * g_ld);
+      const float4 d = *reinterpret_cast<const float4*>(base + (size_t)(px + 8) * g_ld);
+      const float4 e = *reinterpret_cast<const float4*>(base + (size_t)(px + 12) * g_ld);
+      s.x += (a.x + b.x) + (d.x + e.x); s.y += (a.y + b.y) + (d.y + e.y);
+      s.z += (a.z + b.z) + (d.z + e.z); s.w += (a.w + b.w) + (d.w + e.w);
+    }
+    for (; px < hw; px += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(base + (size_t)px * g_ld);
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (pl == 0 && cl * 4 < c) {
+    const float4 a = red[threadIdx.x], b = red[threadIdx.x + 64], d = red[threadIdx.x + 128], e = red[threadIdx.x + 192];
+    const float v[4] = {(a.x + b.x) + (d.x + e.x), (a.y + b.y) + (d.y + e.y), (a.z + b.z) + (d.z + e.z), (a.w + b.w) + (d.w + e.w)};
+    for (int k = 0; k < 4; ++k)
+      if (cl * 4 + k < c) out[(size_t)n * out_ld + out_off + cl * 4 + k] = v[k] * scale;
+  }
+}
+
+// total[j] = sum_n per[n, off + j]  (fixed order: deterministic)
+__global__ void colsum_total_kernel(const float* __restrict__ per, int ld, int off, int n, int c,
+                                    float* __restrict__ t0, float* __restrict__ t1) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= c) return;
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s += per[(size_t)i * ld + off + j];
+  t0[j] = s;
+  if (t1) t1[j] = s;
+}
+
+// ---- GroupNorm backward: reduction -----------------------------------------------------------------
+constexpr int kGbThreads = 1024;
+
+struct GbParams {
+  ssde_src src; const float* dp; int n, hw, slices;
+  float* sums; float* dgamma; float* dbeta; float* scratch;
+};
+
+// grid (slices, N): thread (pl, cl) walks pixels pl, pl+PL, ... of float4 channel lane cl and accumulates,
+// per channel, S1 = sum du*xhat and S0 = sum du, du = dp * keep * silu'(u).  scratch[n][slice][C][2].
+__global__ __launch_bounds__(kGbThreads) void gn_bwd_reduce_kernel(const GbParams p) {
+  SSDE_LDS(smem);                                     // [1024][8]
+  const int n = blockIdx.y, slice = blockIdx.x, tid = threadIdx.x;
+  const ssde_src& s = p.src;
+  const int C = s.c0 + s.c1, CL = C >> 2, PL = kGbThreads / CL;
+  const int cpg = C / s.gn_groups;
+  const SsdePro pro = ssde_pro_decode(s);
+  const int per_slice = (p.hw + p.slices - 1) / p.slices;
+  const int px0 = slice * per_slice, px1 = min(p.hw, px0 + per_slice);
+  float a1[4] = {0.f, 0.f, 0.f, 0.f}, a0[4] = {0.f, 0.f, 0.f, 0.f};
+  if (tid < CL * PL) {
+    const int cl = tid % CL, pl = tid / CL, ch = cl * 4;
+    const float* base; int Cs, cc;
+    if (ch < s.c0) { base = s.p0; Cs = s.c0; cc = ch; } else { base = s.p1; Cs = s.c1; cc = ch - s.c0; }
+    const int g = ch / cpg;
+    const float mu = s.gn_mean[n * s.gn_groups + g], rs = s.gn_rstd[n * s.gn_groups + g];
+    const float4 gam = *reinterpret_cast<const float4*>(s.gn_gamma + ch);
+    const float4 bet = *reinterpret_cast<const float4*>(s.gn_beta + ch);
+    const float gm[4] = {gam.x, gam.y, gam.z, gam.w}, bt[4] = {bet.x, bet.y, bet.z, bet.w};
+    for (int px = px0 + pl; px < px1; px += PL) {
+      const size_t pix = (size_t)n * p.hw + px;
+      const float4 xv = *reinterpret_cast<const float4*>(base + pix * Cs + cc);
+      const float4 dv = *reinterpret_cast<const float4*>(p.dp + pix * C + ch);
+      const float x[4] = {xv.x, xv.y, xv.z, xv.w}, d[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xh = (x[k] - mu) * rs;
+        float du = d[k];
+        if (pro.silu) du *= ssde_silu_grad(xh * gm[k] + bt[k]);
+        if (pro.drop) du *= ssde_keep((uint32_t)pix * (uint32_t)C + (uint32_t)(ch + k), pro);
+        a1[k] += du * xh;
+        a0[k] += du;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { smem[tid * 8 + k] = a1[k]; smem[tid * 8 + 4 + k] = a0[k]; }
+  __syncthreads();
+  if (tid < CL) {
+    float t1[4] = {0.f, 0.f, 0.f, 0.f}, t0[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { t1[k] += smem[(pl * CL + tid) * 8 + k]; t0[k] += smem[(pl * CL + tid) * 8 + 4 + k]; }
+    float* o = p.scratch + (((size_t)n * p.slices + slice) * C + tid * 4) * 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { o[2 * k] = t1[k]; o[2 * k + 1] = t0[k]; }
+  }
+}
+
+// role A (blockIdx.y == 0): sums[n][g] = (mean_g dxh, mean_g dxh*xhat), dxh = du*gamma
+// role B (blockIdx.y == 1): dgamma[c], dbeta[c] = sum over samples and slices
+__global__ void gn_bwd_finalize_kernel(const GbParams p) {
+  const ssde_src& s = p.src;
+  const int C = s.c0 + s.c1, G = s.gn_groups, cpg = C / G;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.y == 0) {
+    if (idx >= p.n * G) return;
+    const int n = idx / G, g = idx % G;
+    float A = 0.f, B = 0.f;
+    for (int sl = 0; sl < p.slices; ++sl) {
+      const float* o = p.scratch + (((size_t)n * p.slices + sl) * C + g * cpg) * 2;
+      for (int c = 0; c < cpg; ++c) { const float gm = s.gn_gamma[g * cpg + c]; B += gm * o[2 * c]; A += gm * o[2 * c + 1]; }
+    }
+    const float inv = 1.0f / ((float)cpg * (float)p.hw);
+    p.sums[idx * 2] = A * inv;
+    p.sums[idx * 2 + 1] = B * inv;
+  } else {
+    if (idx >= C) return;
+    float dg = 0.f, db = 0.f;
+    for (int n = 0; n < p.n; ++n)
+      for (int sl = 0; sl < p.slices; ++sl) {
+        const float* o = p.scratch + (((size_t)n * p.slices + sl) * C + idx) * 2;
+        dg += o[0]; db += o[1];
+      }
+    p.dgamma[idx] = dg;
+    p.dbeta[idx] = db;
+  }
+}
+
+// ---- prologue backward: apply ---------------------------------------------------------------------------
+struct PbParams {
+  ssde_src src; const float* dp; int dp_ld, dp_off; int n, hw; const float* sums; float scale;
+  int acc0, acc1; float* g0; float* g1;
+};
+
+__global__ __launch_bounds__(256) void prologue_bwd_kernel(const PbParams p) {
+  const ssde_src& s = p.src;
+  const int C = s.c0 + s.c1, CL = C >> 2;
+  const SsdePro pro = ssde_pro_decode(s);
+  const int cpg = pro.gn ? C / s.gn_groups : 1;
+  const size_t total = (size_t)p.n * p.hw * CL;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cl = (int)(idx % CL);
+    const size_t pix = idx / CL;
+    const int n = (int)(pix / p.hw);
+    const int ch = cl * 4;
+    const bool first = ch < s.c0;
+    float* gdst = first ? p.g0 : p.g1;
+    if (!gdst) continue;
+    const int Cs = first ? s.c0 : s.c1, cc = first ? ch : ch - s.c0;
+    const float4 dv = *reinterpret_cast<const float4*>(p.dp + pix * p.dp_ld + p.dp_off + ch);
+    float d[4] = {dv.x, dv.y, dv.z, dv.w};
+    if (pro.gn || pro.silu) {
+      const float* xsrc = first ? s.p0 : s.p1;
+      const float4 xv = *reinterpret_cast<const float4*>(xsrc + pix * Cs + cc);
+      const float x[4] = {xv.x, xv.y, xv.z, xv.w};
+      if (pro.gn) {
+        const int g = ch / cpg;
+        const float mu = s.gn_mean[n * s.gn_groups + g], rs = s.gn_rstd[n * s.gn_groups + g];
+        const float A = p.sums[(n * s.gn_groups + g) * 2], B = p.sums[(n * s.gn_groups + g) * 2 + 1];
+        const float4 gam = *reinterpret_cast<const float4*>(s.gn_gamma + ch);
+        const float4 bet = *reinterpret_cast<const float4*>(s.gn_beta + ch);
+        const float gm[4] = {gam.x, gam.y, gam.z, gam.w}, bt[4] = {bet.x, bet.y, bet.z, bet.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xh = (x[k] - mu) * rs;
+          float du = d[k];
+          if (pro.silu) du *= ssde_silu_grad(xh * gm[k] + bt[k]);
+          if (pro.drop) du *= ssde_keep((uint32_t)pix * (uint32_t)C + (uint32_t)(ch + k), pro);
+          d[k] = rs * (du * gm[k] - A - xh * B);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] *= ssde_silu_grad(x[k]);
+      }
+    }
+    float4* o = reinterpret_cast<float4*>(gdst + pix * Cs + cc);
+    float4 r = make_float4(d[0] * p.scale, d[1] * p.scale, d[2] * p.scale, d[3] * p.scale);
+    if (first ? p.acc0 : p.acc1) { const float4 old = *o; r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
+    *o = r;
+  }
+}
+
+// ---- DSM loss head ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void perturb_kernel(const float* __restrict__ x, const float* __restrict__ z,
+                                                      const float* __restrict__ a, const float* __restrict__ s,
+                                                      float* __restrict__ dst, int per, size_t numel) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / per);
+    // mean + std[:, None, None, None] * z  (losses.py:86-87); mean = a[n] * x
+    const float mean = a ? __fmul_rn(a[n], x[i]) : x[i];
+    dst[i] = __fadd_rn(mean, __fmul_rn(s[n], z[i]));
+  }
+}
+
+// one block per sample: losses[n] and dscore[n, :]
+__global__ __launch_bounds__(256) void dsm_loss_kernel(const float* __restrict__ score, const float* __restrict__ z,
+                                                       const float* __restrict__ s, const float* __restrict__ g2,
+                                                       float* __restrict__ dscore, float* __restrict__ losses,
+                                                       int n_total, int per, int reduce_mean, int lw, float grad_scale) {
+  SSDE_LDS(smem);
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float sd = s[n];
+  const float w = lw ? g2[n] : 1.0f;
+  // d(mean_n losses)/d score = w * red' * 2 r * dr/dscore / N ; red = 0.5*sum (factor 1) or mean (factor 2/per)
+  const float red = reduce_mean ? 2.0f / (float)per : 1.0f;
+  const float gfac = w * red * (lw ? 1.0f : sd) / (float)n_total * grad_scale;
+  float acc = 0.f;
+  for (int i = tid; i < per; i += 256) {
+    const size_t k = (size_t)n * per + i;
+    const float r = lw ? __fadd_rn(score[k], __fdiv_rn(z[k], sd)) : __fadd_rn(__fmul_rn(score[k], sd), z[k]);
+    acc += r * r;
+    if (dscore) dscore[k] = r * gfac;
+  }
+  acc = ssde_wave_sum(acc);
+  if ((tid & 63) == 0) smem[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    const float t = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+    losses[n] = (reduce_mean ? t / (float)per : 0.5f * t) * w;
+  }
+}
+
+__global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+  SSDE_LDS(smem);
+  const int tid = threadIdx.x;
+  float acc = 0.f;
+  for (int i = tid; i < n; i += 256) acc += v[i];
+  acc = ssde_wave_sum(acc);
+  if ((tid & 63) == 0) smem[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) out[0] = ((smem[0] + smem[1]) + (smem[2] + smem[3])) / (float)n;
+}
+
+// ---- optimizer ------------------------------------------------------------------------------------------------
+constexpr int kSumsqBlocks = 1024;
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, size_t numel, float* __restrict__ partial) {
+  SSDE_LDS(smem);
+  const int tid = threadIdx.x;
+  float acc = 0.f;
+  const size_t n4 = numel >> 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+    acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0 && tid == 0) for (size_t i = n4 * 4; i < numel; ++i) acc += x[i] * x[i];
+  acc = ssde_wave_sum(acc);
+  if ((tid & 63) == 0) smem[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) partial[blockIdx.x] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+  SSDE_LDS(smem);
+  const int tid = threadIdx.x;
+  float acc = 0.f;
+  for (int i = tid; i < n; i += 256) acc += partial[i];
+  acc = ssde_wave_sum(acc);
+  if ((tid & 63) == 0) smem[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) out[0] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+}
+
+// hyper: [0] lr [1] beta1 [2] beta2 [3] eps [4] weight_decay [5] grad_clip (<0: off) [6] 1-beta1^t [7] sqrt(1-beta2^t)
+//        [8] EMA one_minus_decay
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, float* __restrict__ ema, size_t numel,
+                                                   const float* __restrict__ hyper, const float* __restrict__ gnorm_sq) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], clip = hyper[5];
+  const float bc1 = hyper[6], bc2s = hyper[7], omd = hyper[8];
+  float coef = 1.0f;
+  if (gnorm_sq && clip >= 0.f) {
+    // clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
+    const float c = clip / (sqrtf(gnorm_sq[0]) + 1e-6f);
+    coef = c < 1.0f ? c : 1.0f;
+  }
+  const float step_size = lr / bc1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (size_t)gridDim.x * blockDim.x) {
+    float pi = p[i];
+    float gi = g[i] * coef;
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);            // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = sqrtf(vi) / bc2s + eps;
+    pi -= step_size * (mi / denom);                               // param.addcdiv_(exp_avg, denom, value=-step_size)
+    m[i] = mi; v[i] = vi; p[i] = pi;
+    if (ema) { const float e = ema[i]; ema[i] = e - omd * (e - pi); }   // s_param.sub_(one_minus_decay * (s_param - param))
+  }
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, const float* __restrict__ gate,
+                                                   float* __restrict__ dst, size_t numel, float alpha, int acc) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (size_t)gridDim.x * blockDim.x) {
+    float v = alpha * x[i];
+    if (gate) v *= ssde_silu_grad(gate[i]);
+    dst[i] = acc ? dst[i] + v : v;
+  }
+}
+
+int src_ok(const ssde_src& s, const char* who, bool need_x) {
+  const int C = s.c0 + s.c1;
+  SSDE_REQUIRE(C > 0 && s.c0 % 4 == 0 && s.c1 % 4 == 0, "%s: channels must be multiples of 4", who);
+  SSDE_REQUIRE(!need_x || (s.p0 && (s.c1 == 0 || s.p1)), "%s: source tensors missing", who);
+  if (s.pro_mode == SSDE_PRO_GN || s.pro_mode == SSDE_PRO_GN_SILU) {
+    SSDE_REQUIRE(s.gn_groups > 0 && C % s.gn_groups == 0 && (C / s.gn_groups) % 4 == 0, "%s: GroupNorm channels-per-group %% 4", who);
+    SSDE_REQUIRE(s.gn_mean && s.gn_rstd && s.gn_gamma && s.gn_beta, "%s: GroupNorm pointers missing", who);
+  }
+  SSDE_REQUIRE(s.drop_thresh == 0 || s.drop_seed, "%s: dropout seed pointer missing", who);
+  return SSDE_OK;
+}
+
+}  // namespace
+
+extern "C" int ssde_colsum(const ssde_colsum_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->g && a->n > 0 && a->hw > 0 && a->c > 0, "colsum: bad args");
+  SSDE_REQUIRE(a->g_ld % 4 == 0 && a->g_off % 4 == 0, "colsum: g columns must be 16-byte aligned");
+  SSDE_REQUIRE(a->per_sample || a->scratch, "colsum: per_sample or scratch needed");
+  SSDE_REQUIRE(a->per_sample || a->total, "colsum: nothing to compute");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* per = a->per_sample ? a->per_sample : a->scratch;
+  const int ld = a->per_sample ? a->ps_ld : a->c, off = a->per_sample ? a->ps_off : 0;
+  const int cl = ssde_cdiv(a->c, 4);
+  hipLaunchKernelGGL(colsum_kernel, dim3(ssde_cdiv(cl, 64), a->n), dim3(256), 4 * 64 * 16, st,
+                     a->g, a->g_ld, a->g_off, a->hw, a->c, a->scale, per, ld, off);
+  SSDE_LAUNCH_CHECK();
+  if (a->total) {
+    hipLaunchKernelGGL(colsum_total_kernel, dim3(ssde_cdiv(a->c, 256)), dim3(256), 0, st, per, ld, off, a->n, a->c, a->total, a->total2);
+    SSDE_LAUNCH_CHECK();
+  }
+  return SSDE_OK;
+}
+
+extern "C" int ssde_gn_bwd_reduce(const ssde_gn_bwd_reduce_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->dp && a->sums && a->dgamma && a->dbeta && a->scratch, "gn_bwd_reduce: null args");
+  if (int rc = src_ok(a->src, "gn_bwd_reduce", true)) return rc;
+  SSDE_REQUIRE(a->src.pro_mode == SSDE_PRO_GN || a->src.pro_mode == SSDE_PRO_GN_SILU, "gn_bwd_reduce: source has no GroupNorm prologue");
+  const int C = a->src.c0 + a->src.c1;
+  SSDE_REQUIRE(C <= 4 * kGbThreads && a->n > 0 && a->hw > 0, "gn_bwd_reduce: bad shape");
+  const int slices = a->slices > 0 ? a->slices : 1;
+  GbParams p{a->src, a->dp, a->n, a->hw, slices, a->sums, a->dgamma, a->dbeta, a->scratch};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(slices, a->n), dim3(kGbThreads), kGbThreads * 8 * 4, st, p);
+  SSDE_LAUNCH_CHECK();
+  const int work = a->n * a->src.gn_groups > C ? a->n * a->src.gn_groups : C;
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(ssde_cdiv(work, 256), 2), dim3(256), 0, st, p);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}
+
+extern "C" int ssde_prologue_bwd(const ssde_prologue_bwd_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->dp && (a->g0 || a->g1), "prologue_bwd: null args");
+  const bool need_x = a->src.pro_mode != SSDE_PRO_NONE;
+  if (int rc = src_ok(a->src, "prologue_bwd", need_x)) return rc;
+  const bool gn = a->src.pro_mode == SSDE_PRO_GN || a->src.pro_mode == SSDE_PRO_GN_SILU;
+  SSDE_REQUIRE(!gn || a->sums, "prologue_bwd: GroupNorm sums missing");
+  SSDE_REQUIRE(a->dp_ld % 4 == 0 && a->dp_off % 4 == 0, "prologue_bwd: dp columns must be 16-byte aligned");
+  SSDE_REQUIRE(a->n > 0 && a->hw > 0, "prologue_bwd: bad shape");
+  PbParams p{a->src, a->dp, a->dp_ld, a->dp_off, a->n, a->hw, a->sums, a->scale, a->acc0, a->acc1, a->g0, a->g1};
+  const size_t total = (size_t)a->n * a->hw * ((a->src.c0 + a->src.c1) / 4);
+  hipLaunchKernelGGL(prologue_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}
+
+extern "C" int ssde_perturb(const ssde_perturb_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->x && a->z && a->s && a->dst && a->n > 0 && a->per > 0, "perturb: bad args");
+  const size_t numel = (size_t)a->n * a->per;
+  hipLaunchKernelGGL(perturb_kernel, dim3(grid_for(numel)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     a->x, a->z, a->a, a->s, a->dst, a->per, numel);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}
+
+extern "C" int ssde_dsm_loss(const ssde_dsm_loss_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->score && a->z && a->s && a->losses && a->loss && a->n > 0 && a->per > 0, "dsm_loss: bad args");
+  SSDE_REQUIRE(!a->likelihood_weighting || a->g2, "dsm_loss: g2 needed for likelihood weighting");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(dsm_loss_kernel, dim3(a->n), dim3(256), 64, st, a->score, a->z, a->s, a->g2, a->dscore, a->losses,
+                     a->n, a->per, a->reduce_mean, a->likelihood_weighting, a->grad_scale == 0.f ? 1.0f : a->grad_scale);
+  SSDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 64, st, a->losses, a->n, a->loss);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}
+
+extern "C" int ssde_sumsq_flat(const ssde_sumsq_flat_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->x && a->partial && a->out && a->numel > 0, "sumsq_flat: bad args (partial needs %d floats)", kSumsqBlocks);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int blocks = (int)grid_for((size_t)a->numel / 4, 256, kSumsqBlocks);
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 64, st, a->x, (size_t)a->numel, a->partial);
+  SSDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 64, st, a->partial, blocks, a->out);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}
+
+extern "C" int ssde_adam_clip_ema(const ssde_adam_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->p && a->g && a->m && a->v && a->hyper && a->numel > 0, "adam: bad args");
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)a->numel, 256, 256 * 32)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     a->p, a->g, a->m, a->v, a->ema, (size_t)a->numel, a->hyper, a->gnorm_sq);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}
+
+extern "C" int ssde_memset(const ssde_memset_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->dst && a->bytes >= 0, "memset: bad args");
+  if (a->bytes == 0) return SSDE_OK;
+  SSDE_HIP_CHECK(hipMemsetAsync(a->dst, a->value, (size_t)a->bytes, static_cast<hipStream_t>(stream)));
+  return SSDE_OK;
+}
+
+extern "C" int ssde_axpy(const ssde_axpy_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->x && a->dst && a->numel > 0, "axpy: bad args");
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((size_t)a->numel)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     a->x, a->gate, a->dst, (size_t)a->numel, a->alpha, a->acc);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}

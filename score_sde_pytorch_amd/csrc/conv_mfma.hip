@@ -41,6 +41,7 @@ struct ConvKParams {
   const float* chan_add;
   int chan_add_ld;
   const float* resid;
+  int resid_post;
   float scale;
   float* dst;
 };
@@ -108,7 +109,8 @@ __device__ __forceinline__ void conv_phase(const ssde_src& s, const float* __res
   const int Ctot = s.c0 + s.c1;
   const int ncin8 = (Ctot + 7) >> 3;
   const int nchunks = (Ctot + BKC - 1) / BKC;
-  const int cpg = (s.pro_mode == SSDE_PRO_GN || s.pro_mode == SSDE_PRO_GN_SILU) ? Ctot / s.gn_groups : 1;
+  const SsdePro pro = ssde_pro_decode(s);
+  const int cpg = pro.gn ? Ctot / s.gn_groups : 1;
   constexpr int B_ITEMS = T * BN * F4;
   constexpr int B_ITERS = (B_ITEMS + kThreads - 1) / kThreads;
 
@@ -147,8 +149,9 @@ __device__ __forceinline__ void conv_phase(const ssde_src& s, const float* __res
     }
     float4 gam = make_float4(1.f, 1.f, 1.f, 1.f), bet = make_float4(0.f, 0.f, 0.f, 0.f);
     float mu[MAXI], rs[MAXI];
-    const bool use_gn = (s.pro_mode == SSDE_PRO_GN || s.pro_mode == SSDE_PRO_GN_SILU);
-    if (use_gn && (c_base + f4 * 4) < Ctot) {
+#pragma unroll
+    for (int it = 0; it < MAXI; ++it) { mu[it] = 0.f; rs[it] = 1.f; }
+    if (pro.gn && (c_base + f4 * 4) < Ctot) {
       gam = *reinterpret_cast<const float4*>(s.gn_gamma + c_base + f4 * 4);
       bet = *reinterpret_cast<const float4*>(s.gn_beta + c_base + f4 * 4);
       const int gidx = (c_base + f4 * 4) / cpg;
@@ -164,22 +167,13 @@ __device__ __forceinline__ void conv_phase(const ssde_src& s, const float* __res
 
     __syncthreads();   // previous stage's fragment reads are done
 
-    // ---- A: prologue transform + LDS store ----
+    // ---- A: prologue transform (GroupNorm apply, SiLU, dropout) + LDS store ----
 #pragma unroll
     for (int it = 0; it < MAXI; ++it) {
       if (goff[it] == -2) continue;
       float4 v = av[it];
-      if (goff[it] >= 0 && chan_ok) {
-        if (use_gn) {
-          v.x = (v.x - mu[it]) * rs[it] * gam.x + bet.x;
-          v.y = (v.y - mu[it]) * rs[it] * gam.y + bet.y;
-          v.z = (v.z - mu[it]) * rs[it] * gam.z + bet.z;
-          v.w = (v.w - mu[it]) * rs[it] * gam.w + bet.w;
-        }
-        if (s.pro_mode == SSDE_PRO_GN_SILU || s.pro_mode == SSDE_PRO_SILU) {
-          v.x = ssde_silu(v.x); v.y = ssde_silu(v.y); v.z = ssde_silu(v.z); v.w = ssde_silu(v.w);
-        }
-      }
+      if (goff[it] >= 0 && chan_ok)
+        v = ssde_pro_apply(v, mu[it], rs[it], gam, bet, (uint32_t)goff[it] * (uint32_t)Ctot + (uint32_t)(c_base + f4 * 4), pro);
       const int q = tid + it * kThreads;
       *reinterpret_cast<float4*>(As + (q / F4) * LDA + f4 * 4) = v;
     }
@@ -280,12 +274,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvKParam
         const int c = m & (TW - 1);
         const int rr = (m >> g.lTW) & (TH - 1);
         const int img = img0 + (m >> (g.lTW + g.lTH));
-        if (img >= g.N) continue;
-        const size_t pix = ((size_t)img * g.Hout + ty * TH + rr) * g.Wout + tx * TW + c;
+        const int oy = ty * TH + rr, ox = tx * TW + c;
+        if (img >= g.N || oy >= g.Hout || ox >= g.Wout) continue;
+        const size_t pix = ((size_t)img * g.Hout + oy) * g.Wout + ox;
         float v = acc[a][b][r] + bj;
         if (p.chan_add) v += p.chan_add[(size_t)img * p.chan_add_ld + j];
-        if (p.resid) v += p.resid[pix * g.Cout + j];
-        p.dst[pix * g.Cout + j] = v * p.scale;
+        if (p.resid && !p.resid_post) v += p.resid[pix * g.Cout + j];
+        v *= p.scale;
+        if (p.resid && p.resid_post) v += p.resid[pix * g.Cout + j];
+        p.dst[pix * g.Cout + j] = v;
       }
     }
   }
@@ -315,9 +312,14 @@ int src_check(const ssde_src& s, const char* what) {
   return SSDE_OK;
 }
 
+int pow2_floor(int v) { int p = 1; while (p * 2 <= v) p *= 2; return p; }
+
+// tile geometry: TW x TH output pixels (powers of two; the output itself may be any size, edge tiles are
+// bounds-checked) of IMGS images
 int halo_px(int bm, int w_out, int h_out, int stride, int ks, int* lTW, int* lTH) {
-  int tw = w_out < 16 ? w_out : 16;
+  int tw = pow2_floor(w_out < 16 ? w_out : 16);
   int th = bm / tw; if (th > h_out) th = h_out;
+  th = pow2_floor(th);
   *lTW = ssde_ilog2(tw); *lTH = ssde_ilog2(th);
   const int imgs = bm / (tw * th);
   return imgs * ((th - 1) * stride + ks) * ((tw - 1) * stride + ks);
@@ -330,13 +332,13 @@ int make_plan(const ssde_conv_args* a, ConvPlan* pl) {
   SSDE_REQUIRE(pl->has3 || pl->has1, "conv: neither a k x k nor a 1 x 1 source");
   SSDE_REQUIRE(a->ksize == 0 || a->ksize == 3, "conv: ksize must be 0 or 3 (1x1 goes through aux)");
   SSDE_REQUIRE(a->n > 0 && a->h_out > 0 && a->w_out > 0 && a->c_out > 0, "conv: bad output shape");
-  SSDE_REQUIRE(ssde_is_pow2(a->h_out) && ssde_is_pow2(a->w_out), "conv: output H, W must be powers of two (got %dx%d)", a->h_out, a->w_out);
   if (pl->has3) {
     if (int rc = src_check(a->main, "main")) return rc;
     SSDE_REQUIRE(a->w_main, "conv: w_main missing");
     SSDE_REQUIRE(a->stride == 1 || a->stride == 2, "conv: stride must be 1 or 2");
-    SSDE_REQUIRE((a->h_in + 2 * a->pad - 3) / a->stride + 1 == a->h_out && (a->w_in + 2 * a->pad - 3) / a->stride + 1 == a->w_out,
-                 "conv: output shape inconsistent with input %dx%d stride %d pad %d", a->h_in, a->w_in, a->stride, a->pad);
+    // the output may be a top-left crop of the full convolution result (used by strided input-gradients)
+    SSDE_REQUIRE((a->h_in + 2 * a->pad - 3) / a->stride + 1 >= a->h_out && (a->w_in + 2 * a->pad - 3) / a->stride + 1 >= a->w_out,
+                 "conv: output %dx%d larger than input %dx%d stride %d pad %d allows", a->h_out, a->w_out, a->h_in, a->w_in, a->stride, a->pad);
   }
   if (pl->has1) {
     if (int rc = src_check(a->aux, "aux")) return rc;
@@ -369,7 +371,6 @@ int make_plan(const ssde_conv_args* a, ConvPlan* pl) {
   }
   const int bm = kTiles[tile].bm, bn = kTiles[tile].bn;
   const int tw = 1 << lTW, th = 1 << lTH, imgs = bm / (tw * th);
-  SSDE_REQUIRE(a->w_out % tw == 0 && a->h_out % th == 0, "conv: tile %dx%d does not divide output", th, tw);
 
   ConvKParams& kp = pl->kp;
   kp.main = a->main; kp.aux = a->aux; kp.w_main = a->w_main; kp.w_aux = a->w_aux;
@@ -378,12 +379,12 @@ int make_plan(const ssde_conv_args* a, ConvPlan* pl) {
   g.Cout = a->c_out; g.CoutPad = ssde_cdiv(a->c_out, 64) * 64;
   g.stride = pl->has3 ? a->stride : 1; g.pad = pl->has3 ? a->pad : 0;
   g.lTW = lTW; g.lTH = lTH;
-  g.tiles_x = a->w_out / tw;
-  g.tiles_per_img = g.tiles_x * (a->h_out / th);
+  g.tiles_x = ssde_cdiv(a->w_out, tw);
+  g.tiles_per_img = g.tiles_x * ssde_cdiv(a->h_out, th);
   g.m_tiles = ssde_cdiv(a->n, imgs) * g.tiles_per_img;
   g.n_tiles = ssde_cdiv(a->c_out, bn);
   kp.bias = a->bias; kp.chan_add = a->chan_add; kp.chan_add_ld = a->chan_add_ld;
-  kp.resid = a->resid; kp.scale = a->out_scale; kp.dst = a->dst;
+  kp.resid = a->resid; kp.resid_post = a->resid_post; kp.scale = a->out_scale; kp.dst = a->dst;
 
   int lds = 0;
   if (pl->has3) {

@@ -33,14 +33,17 @@ __global__ void embed_kernel(const float* __restrict__ cond, const float* __rest
 // ---- layout boundary ----------------------------------------------------------------
 // x = 2x - 1 for un-centred data is folded in (ncsnpp.py:259-261).
 __global__ void to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int c, int h, int w,
-                               int c_pad, float a, float b) {
+                               int c_pad, float a, float b, int mode, const float* __restrict__ vec) {
   const size_t total = (size_t)n * h * w;
   const size_t hw = (size_t)h * w;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const size_t img = idx / hw, pix = idx - img * hw;
+    float f = a;
+    if (mode == 1) f = __fdiv_rn(a, vec[img]);
+    else if (mode == 2) f = __fdiv_rn(-a, vec[img]);
     for (int ch = 0; ch < c_pad; ++ch) {
       float v = 0.f;
-      if (ch < c) v = __fadd_rn(__fmul_rn(a, src[(img * c + ch) * hw + pix]), b);
+      if (ch < c) v = __fadd_rn(__fmul_rn(f, src[(img * c + ch) * hw + pix]), b);
       dst[idx * c_pad + ch] = v;
     }
   }
@@ -48,7 +51,7 @@ __global__ void to_nhwc_kernel(const float* __restrict__ src, float* __restrict_
 
 // mode 1: h / sigma (scale_by_sigma, ncsnpp.py:377-379); mode 2: -h / std (models/utils.py:159)
 __global__ void to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int c, int h, int w,
-                               int c_src, int mode, const float* __restrict__ v) {
+                               int c_src, int mode, const float* __restrict__ v, float alpha, int accumulate) {
   const size_t hw = (size_t)h * w;
   const size_t total = (size_t)n * c * hw;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -59,7 +62,8 @@ __global__ void to_nchw_kernel(const float* __restrict__ src, float* __restrict_
     float x = src[(img * hw + pix) * c_src + ch];
     if (mode == 1) x = __fdiv_rn(x, v[img]);
     else if (mode == 2) x = __fdiv_rn(-x, v[img]);
-    dst[idx] = x;
+    if (alpha != 1.0f) x = __fmul_rn(alpha, x);
+    dst[idx] = accumulate ? dst[idx] + x : x;
   }
 }
 
@@ -195,8 +199,10 @@ extern "C" int ssde_embed(const ssde_embed_args* a, void* stream) {
 
 extern "C" int ssde_to_nhwc(const ssde_to_nhwc_args* a, void* stream) {
   SSDE_REQUIRE(a && a->src && a->dst && a->n > 0 && a->c > 0 && a->c_pad >= a->c, "to_nhwc: bad args");
+  SSDE_REQUIRE(a->mode == 0 || a->v, "to_nhwc: per-sample vector missing");
   hipLaunchKernelGGL(to_nhwc_kernel, dim3(grid_for((size_t)a->n * a->h * a->w)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), a->src, a->dst, a->n, a->c, a->h, a->w, a->c_pad, a->a, a->b);
+                     static_cast<hipStream_t>(stream), a->src, a->dst, a->n, a->c, a->h, a->w, a->c_pad, a->a, a->b,
+                     a->mode, a->v);
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;
 }
@@ -205,7 +211,8 @@ extern "C" int ssde_to_nchw(const ssde_to_nchw_args* a, void* stream) {
   SSDE_REQUIRE(a && a->src && a->dst && a->n > 0 && a->c > 0 && a->c_src >= a->c, "to_nchw: bad args");
   SSDE_REQUIRE(a->mode == 0 || a->v, "to_nchw: per-sample vector missing");
   hipLaunchKernelGGL(to_nchw_kernel, dim3(grid_for((size_t)a->n * a->c * a->h * a->w)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), a->src, a->dst, a->n, a->c, a->h, a->w, a->c_src, a->mode, a->v);
+                     static_cast<hipStream_t>(stream), a->src, a->dst, a->n, a->c, a->h, a->w, a->c_src, a->mode, a->v,
+                     a->alpha == 0.f ? 1.0f : a->alpha, a->accumulate);
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;
 }

@@ -19,13 +19,14 @@ struct FirParams {
   int n, h_in, w_in, c, h_out, w_out, up, down, pad0, pad1, kh, kw;
   float kf[16];   // flipped kernel
   float* dst;
+  int accumulate;
 };
 
 __global__ __launch_bounds__(256) void upfirdn_kernel(const FirParams p) {
   const int c4n = p.c >> 2;
   const size_t total = (size_t)p.n * p.h_out * p.w_out * c4n;
-  const bool use_gn = p.src.pro_mode == SSDE_PRO_GN || p.src.pro_mode == SSDE_PRO_GN_SILU;
-  const bool use_silu = p.src.pro_mode == SSDE_PRO_GN_SILU || p.src.pro_mode == SSDE_PRO_SILU;
+  const SsdePro pro = ssde_pro_decode(p.src);
+  const bool use_gn = pro.gn;
   const int cpg = use_gn ? p.c / p.src.gn_groups : 1;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int c4 = (int)(idx % c4n);
@@ -56,16 +57,15 @@ __global__ __launch_bounds__(256) void upfirdn_kernel(const FirParams p) {
         const int ix = ux / p.up;
         if (ix >= p.w_in) continue;
         float4 v = *reinterpret_cast<const float4*>(xin + ((size_t)iy * p.w_in + ix) * p.c);
-        if (use_gn) {
-          v.x = (v.x - mu) * rs * gam.x + bet.x; v.y = (v.y - mu) * rs * gam.y + bet.y;
-          v.z = (v.z - mu) * rs * gam.z + bet.z; v.w = (v.w - mu) * rs * gam.w + bet.w;
-        }
-        if (use_silu) { v.x = ssde_silu(v.x); v.y = ssde_silu(v.y); v.z = ssde_silu(v.z); v.w = ssde_silu(v.w); }
+        v = ssde_pro_apply(v, mu, rs, gam, bet,
+                           (uint32_t)(((size_t)n * p.h_in + iy) * p.w_in + ix) * (uint32_t)p.c + (uint32_t)ch, pro);
         const float w = p.kf[ky * p.kw + kx];
         acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
       }
     }
-    *reinterpret_cast<float4*>(p.dst + (((size_t)n * p.h_out + oy) * p.w_out + ox) * p.c + ch) = acc;
+    float4* o = reinterpret_cast<float4*>(p.dst + (((size_t)n * p.h_out + oy) * p.w_out + ox) * p.c + ch);
+    if (p.accumulate) { const float4 old = *o; acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w; }
+    *o = acc;
   }
 }
 
@@ -94,6 +94,7 @@ extern "C" int ssde_upfirdn2d(const ssde_upfirdn_args* a, void* stream) {
   for (int y = 0; y < a->kh; ++y)
     for (int x = 0; x < a->kw; ++x) p.kf[y * a->kw + x] = a->k[(a->kh - 1 - y) * a->kw + (a->kw - 1 - x)];
   p.dst = a->dst;
+  p.accumulate = a->accumulate;
   const size_t total = (size_t)a->n * a->h_out * a->w_out * (a->c / 4);
   size_t blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;

@@ -32,6 +32,17 @@ static int run_one(const ssde_op& op, void* stream) {
     case SSDE_OP_PREDICTOR: return ssde_predictor_update(&op.u.predictor, stream);
     case SSDE_OP_FILL: return ssde_fill_from_table(&op.u.fill, stream);
     case SSDE_OP_STEP_INC: return ssde_step_inc(&op.u.step_inc, stream);
+    case SSDE_OP_WGRAD: return ssde_conv_wgrad(&op.u.wgrad, stream);
+    case SSDE_OP_COLSUM: return ssde_colsum(&op.u.colsum, stream);
+    case SSDE_OP_GN_BWD_REDUCE: return ssde_gn_bwd_reduce(&op.u.gn_bwd, stream);
+    case SSDE_OP_PROLOGUE_BWD: return ssde_prologue_bwd(&op.u.pro_bwd, stream);
+    case SSDE_OP_ATTN_BWD: return ssde_attention_bwd(&op.u.attn_bwd, stream);
+    case SSDE_OP_PERTURB: return ssde_perturb(&op.u.perturb, stream);
+    case SSDE_OP_DSM_LOSS: return ssde_dsm_loss(&op.u.dsm_loss, stream);
+    case SSDE_OP_SUMSQ_FLAT: return ssde_sumsq_flat(&op.u.sumsq_flat, stream);
+    case SSDE_OP_ADAM: return ssde_adam_clip_ema(&op.u.adam, stream);
+    case SSDE_OP_MEMSET: return ssde_memset(&op.u.memset, stream);
+    case SSDE_OP_AXPY: return ssde_axpy(&op.u.axpy, stream);
   }
   ssde_set_error("program: unknown op kind %d", op.kind);
   return SSDE_EINVAL;

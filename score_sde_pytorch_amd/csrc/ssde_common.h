@@ -45,6 +45,53 @@ static inline bool ssde_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 __device__ __forceinline__ float ssde_silu(float x) {
   return x * __frcp_rn(1.0f + __expf(-x));
 }
+// d silu(u) / du = sig * (1 + u * (1 - sig))
+__device__ __forceinline__ float ssde_silu_grad(float u) {
+  const float sg = __frcp_rn(1.0f + __expf(-u));
+  return sg * (1.0f + u * (1.0f - sg));
+}
+
+// ---- prologue (GroupNorm apply, SiLU, dropout) shared by every kernel that stages a source ----
+struct SsdePro {
+  bool gn, silu, drop;
+  uint32_t thresh, key;
+  float dscale;
+};
+__device__ __forceinline__ SsdePro ssde_pro_decode(const ssde_src& s) {
+  SsdePro p;
+  p.gn = (s.pro_mode == SSDE_PRO_GN || s.pro_mode == SSDE_PRO_GN_SILU);
+  p.silu = (s.pro_mode == SSDE_PRO_GN_SILU || s.pro_mode == SSDE_PRO_SILU);
+  p.drop = s.drop_thresh != 0u;
+  p.thresh = s.drop_thresh;
+  p.dscale = s.drop_scale;
+  p.key = p.drop ? (*s.drop_seed ^ s.drop_salt) : 0u;
+  return p;
+}
+__device__ __forceinline__ uint32_t ssde_hash32(uint32_t x) {   // murmur3 finaliser
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+// dropout multiplier (0 or 1/(1-p)) of element `elem` of the virtual concat tensor
+__device__ __forceinline__ float ssde_keep(uint32_t elem, const SsdePro& p) {
+  return ssde_hash32(elem * 0x9E3779B1u + p.key) >= p.thresh ? p.dscale : 0.f;
+}
+// pro(x) on 4 consecutive channels; elem0 = linear index of v.x in the virtual concat tensor
+__device__ __forceinline__ float4 ssde_pro_apply(float4 v, float mu, float rs, const float4& gam, const float4& bet,
+                                                 uint32_t elem0, const SsdePro& p) {
+  if (p.gn) {
+    v.x = (v.x - mu) * rs * gam.x + bet.x;
+    v.y = (v.y - mu) * rs * gam.y + bet.y;
+    v.z = (v.z - mu) * rs * gam.z + bet.z;
+    v.w = (v.w - mu) * rs * gam.w + bet.w;
+  }
+  if (p.silu) { v.x = ssde_silu(v.x); v.y = ssde_silu(v.y); v.z = ssde_silu(v.z); v.w = ssde_silu(v.w); }
+  if (p.drop) {
+    v.x *= ssde_keep(elem0, p); v.y *= ssde_keep(elem0 + 1u, p);
+    v.z *= ssde_keep(elem0 + 2u, p); v.w *= ssde_keep(elem0 + 3u, p);
+  }
+  return v;
+}
+
 __device__ __forceinline__ float ssde_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

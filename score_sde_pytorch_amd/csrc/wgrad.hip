@@ -1,0 +1,276 @@
+// Weight gradient of the fused convolutions (autograd of nn.Conv2d / NIN / nn.Linear as used at
+// models/layers.py:100-124,546-555 and layerspp.py:227,263) on the exact-fp32 matrix pipe:
+//
+//   dw[co, ci, tap] += scale * sum_{pixels m} g[m, co] * pro(src)[m (+) tap, ci]
+//
+// This is a GEMM whose reduction dimension is the pixel index (N*H*W: 1e5 at batch 128), so it is
+// split over workgroups along pixels; partial tiles meet in dw by fp32 atomic add (dw is zeroed once
+// per step together with the whole flat gradient buffer).  pro(src) -- GroupNorm apply, SiLU and the
+// train-mode dropout mask -- is RECOMPUTED while the halo tile is staged, exactly as the forward
+// kernel does (conv_mfma.hip), so the normalised / activated tensor is never stored for backward.
+//
+// Workgroup (4 waves) = BCO x BCI x T accumulators: T = 9 taps -> 64 x 64 (each wave one 32x32 block
+// per tap, 144 accumulator registers); T = 1 -> 128 x 128 (each wave 2x2 blocks).  Per pixel chunk
+// (PX output pixels of IMGS images) the output-gradient rows and the input halo are staged once into
+// LDS pixel-major; a wave's MFMA k-slot pair is two adjacent pixels, so both fragment reads are
+// conflict-free ds_read_b32 of 32 consecutive floats and the halo is re-used by all 9 taps.
+// dw is written in the REFERENCE layout (OIHW, or [in][out] for NIN with transpose_out).
+#include "ssde_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct WgParams {
+  ssde_src src;
+  const float* g;
+  int g_ld, g_off;
+  int N, Hin, Win, Hout, Wout, Cout, Ctot, cin_store;
+  int stride, pad;
+  int lTW, lTH, lPX;
+  int tiles_x, tiles_per_img, chunks, chunks_per_split;
+  int co_tiles, ci_tiles;
+  int transpose_out;
+  float scale;
+  float* dw;
+};
+
+template <int KS, int CO_B, int CI_B>
+__global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(const WgParams p) {
+  constexpr int T = KS * KS;
+  constexpr int BCO = 2 * CO_B * 32, BCI = 2 * CI_B * 32;
+  constexpr int GF4 = BCO / 4, PF4 = BCI / 4;
+  constexpr int GU = 4, PU = 4;             // loads in flight per thread while staging
+  SSDE_LDS(smem);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wco = wave >> 1, wci = wave & 1;
+
+  const int ntiles = p.co_tiles * p.ci_tiles;
+  const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
+  const int co0 = (tile / p.ci_tiles) * BCO, ci0 = (tile % p.ci_tiles) * BCI;
+  const int ch_begin = split * p.chunks_per_split;
+  const int ch_end = min(p.chunks, ch_begin + p.chunks_per_split);
+
+  const int TW = 1 << p.lTW, TH = 1 << p.lTH, PX = 1 << p.lPX;
+  const int IMGS = PX >> (p.lTW + p.lTH);
+  const int HWd = (TW - 1) * p.stride + KS, HH = (TH - 1) * p.stride + KS;
+  const int halo_px = IMGS * HH * HWd;
+  float* gs = smem;                 // [PX][BCO]
+  float* ps = smem + PX * BCO;      // [halo_px][BCI]
+
+  const SsdePro pro = ssde_pro_decode(p.src);
+  const int cpg = pro.gn ? p.Ctot / p.src.gn_groups : 1;
+
+  f32x16 acc[T][CO_B][CI_B];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int a = 0; a < CO_B; ++a)
+#pragma unroll
+      for (int b = 0; b < CI_B; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][a][b][r] = 0.f;
+
+  for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
+    const int img0 = (chunk / p.tiles_per_img) * IMGS;
+    const int trem = chunk % p.tiles_per_img;
+    const int ty = trem / p.tiles_x, tx = trem % p.tiles_x;
+    __syncthreads();   // previous chunk's fragment reads are done
+
+    // ---- stage the output-gradient rows: gs[m][c] = g[pix(m), g_off + co0 + c] ----
+    for (int q0 = 0; q0 < PX * GF4; q0 += kThreads * GU) {
+      float4 v[GU];
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        const int q = q0 + u * kThreads + tid;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < PX * GF4) {
+          const int m = q / GF4, c = (q - m * GF4) * 4;
+          const int il = m >> (p.lTW + p.lTH);
+          const int oy = ty * TH + ((m >> p.lTW) & (TH - 1)), ox = tx * TW + (m & (TW - 1));
+          const int img = img0 + il;
+          const int col = p.g_off + co0 + c;
+          if (img < p.N && oy < p.Hout && ox < p.Wout && col + 4 <= p.g_ld)
+            v[u] = *reinterpret_cast<const float4*>(p.g + (((size_t)img * p.Hout + oy) * p.Wout + ox) * p.g_ld + col);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        const int q = q0 + u * kThreads + tid;
+        if (q < PX * GF4) *reinterpret_cast<float4*>(gs + (size_t)q * 4) = v[u];
+      }
+    }
+    // ---- stage the input halo with its prologue: ps[hp][c] = pro(src)[pixel(hp), ci0 + c] ----
+    for (int q0 = 0; q0 < halo_px * PF4; q0 += kThreads * PU) {
+      float4 v[PU];
+      int pixi[PU], chv[PU], imgv[PU];
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+        const int q = q0 + u * kThreads + tid;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pixi[u] = -1; chv[u] = 0; imgv[u] = 0;
+        if (q < halo_px * PF4) {
+          const int hp = q / PF4, c = (q - hp * PF4) * 4;
+          const int il = hp / (HH * HWd);
+          const int rem = hp - il * (HH * HWd);
+          const int hy = rem / HWd, hx = rem - hy * HWd;
+          const int iy = ty * TH * p.stride - p.pad + hy, ix = tx * TW * p.stride - p.pad + hx;
+          const int img = img0 + il;
+          const int ch = ci0 + c;
+          if (img < p.N && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win && ch < p.Ctot) {
+            const int pix = (img * p.Hin + iy) * p.Win + ix;
+            pixi[u] = pix; chv[u] = ch; imgv[u] = img;
+            v[u] = (ch < p.src.c0) ? *reinterpret_cast<const float4*>(p.src.p0 + (size_t)pix * p.src.c0 + ch)
+                                   : *reinterpret_cast<const float4*>(p.src.p1 + (size_t)pix * p.src.c1 + (ch - p.src.c0));
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+        const int q = q0 + u * kThreads + tid;
+        if (q < halo_px * PF4) {
+          float4 x = v[u];
+          if (pixi[u] >= 0) {
+            float mu = 0.f, rs = 1.f;
+            float4 gam = make_float4(1.f, 1.f, 1.f, 1.f), bet = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pro.gn) {
+              const int gi = imgv[u] * p.src.gn_groups + chv[u] / cpg;
+              mu = p.src.gn_mean[gi]; rs = p.src.gn_rstd[gi];
+              gam = *reinterpret_cast<const float4*>(p.src.gn_gamma + chv[u]);
+              bet = *reinterpret_cast<const float4*>(p.src.gn_beta + chv[u]);
+            }
+            x = ssde_pro_apply(x, mu, rs, gam, bet, (uint32_t)pixi[u] * (uint32_t)p.Ctot + (uint32_t)chv[u], pro);
+          }
+          *reinterpret_cast<float4*>(ps + (size_t)q * 4) = x;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- MFMA: k-slot pair = pixels (2ks, 2ks+1) ----
+#pragma unroll 2
+    for (int ks = 0; ks < PX / 2; ++ks) {
+      const int m = 2 * ks + lh;
+      const int il = m >> (p.lTW + p.lTH);
+      const int r = (m >> p.lTW) & (TH - 1), c = m & (TW - 1);
+      const float* ga = gs + m * BCO + wco * (CO_B * 32) + li;
+      const float* pb = ps + ((il * HH + r * p.stride) * HWd + c * p.stride) * BCI + wci * (CI_B * 32) + li;
+      float af[CO_B];
+#pragma unroll
+      for (int a = 0; a < CO_B; ++a) af[a] = ga[a * 32];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int dy = t / KS, dx = t % KS;
+#pragma unroll
+        for (int b = 0; b < CI_B; ++b) {
+          const float bf = pb[(dy * HWd + dx) * BCI + b * 32];
+#pragma unroll
+          for (int a = 0; a < CO_B; ++a)
+            acc[t][a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf, acc[t][a][b], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: lane owns input channel ci (column), 16 output channels (rows) per block ----
+  if (ch_begin >= ch_end) return;
+#pragma unroll
+  for (int b = 0; b < CI_B; ++b) {
+    const int ci = ci0 + wci * (CI_B * 32) + b * 32 + li;
+    if (ci >= p.cin_store) continue;
+#pragma unroll
+    for (int a = 0; a < CO_B; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wco * (CO_B * 32) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (co >= p.Cout) continue;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const size_t idx = p.transpose_out ? (size_t)ci * p.Cout + co : ((size_t)co * p.cin_store + ci) * T + t;
+          unsafeAtomicAdd(p.dw + idx, acc[t][a][b][r] * p.scale);
+        }
+      }
+  }
+}
+
+template <int KS, int CO_B, int CI_B>
+int launch(const WgParams& p, int splits, int lds_bytes, hipStream_t st) {
+  auto kfn = wgrad_kernel<KS, CO_B, CI_B>;
+  static bool attr_set = false;   // once per instantiation, before any stream capture
+  if (!attr_set) {
+    SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kfn, dim3(p.co_tiles * p.ci_tiles * splits), dim3(kThreads), lds_bytes, st, p);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}
+
+int pow2_floor(int v) { int q = 1; while (q * 2 <= v) q *= 2; return q; }
+
+}  // namespace
+
+extern "C" int ssde_conv_wgrad(const ssde_wgrad_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->g && a->dw && a->src.p0, "wgrad: null args");
+  SSDE_REQUIRE(a->ksize == 3 || a->ksize == 1, "wgrad: ksize must be 1 or 3");
+  SSDE_REQUIRE(a->stride == 1 || a->stride == 2, "wgrad: stride must be 1 or 2");
+  const ssde_src& s = a->src;
+  const int Ctot = s.c0 + s.c1;
+  SSDE_REQUIRE(s.c0 > 0 && s.c0 % 4 == 0 && s.c1 % 4 == 0 && (s.c1 == 0 || s.p1), "wgrad: source channels must be multiples of 4");
+  SSDE_REQUIRE(a->cin_store > 0 && a->cin_store <= Ctot, "wgrad: cin_store %d outside 1..%d", a->cin_store, Ctot);
+  SSDE_REQUIRE(a->g_ld % 4 == 0 && a->g_off % 4 == 0 && a->g_off + a->c_out <= a->g_ld + 3, "wgrad: bad g columns");
+  SSDE_REQUIRE(a->n > 0 && a->h_out > 0 && a->w_out > 0 && a->c_out > 0, "wgrad: bad shape");
+  SSDE_REQUIRE(!a->transpose_out || a->ksize == 1, "wgrad: transpose_out needs ksize 1");
+  if (a->ksize == 1) SSDE_REQUIRE(a->h_in == a->h_out && a->w_in == a->w_out && a->stride == 1 && a->pad == 0, "wgrad: 1x1 geometry");
+  else SSDE_REQUIRE((a->h_in + 2 * a->pad - 3) / a->stride + 1 >= a->h_out && (a->w_in + 2 * a->pad - 3) / a->stride + 1 >= a->w_out,
+                    "wgrad: output larger than the convolution produces");
+  if (s.pro_mode == SSDE_PRO_GN || s.pro_mode == SSDE_PRO_GN_SILU) {
+    SSDE_REQUIRE(s.gn_groups > 0 && Ctot % s.gn_groups == 0 && (Ctot / s.gn_groups) % 4 == 0, "wgrad: GroupNorm channels-per-group %% 4");
+    SSDE_REQUIRE(s.gn_mean && s.gn_rstd && s.gn_gamma && s.gn_beta, "wgrad: GroupNorm pointers missing");
+  }
+  SSDE_REQUIRE(s.drop_thresh == 0 || s.drop_seed, "wgrad: dropout seed pointer missing");
+
+  WgParams p;
+  p.src = s; p.g = a->g; p.g_ld = a->g_ld; p.g_off = a->g_off;
+  p.N = a->n; p.Hin = a->h_in; p.Win = a->w_in; p.Hout = a->h_out; p.Wout = a->w_out;
+  p.Cout = a->c_out; p.Ctot = Ctot; p.cin_store = a->cin_store;
+  p.stride = a->stride; p.pad = a->pad; p.transpose_out = a->transpose_out; p.scale = a->scale; p.dw = a->dw;
+  const int hw = a->h_out * a->w_out;
+  int px;
+  if (a->ksize == 1) px = 64;
+  else if (a->stride == 2) px = 32;
+  else px = hw >= 128 ? 128 : 64;
+  const int tw = pow2_floor(a->w_out < 16 ? a->w_out : 16);
+  int th = px / tw; if (th > a->h_out) th = a->h_out;
+  th = pow2_floor(th);
+  const int imgs = px / (tw * th);
+  p.lTW = ssde_ilog2(tw); p.lTH = ssde_ilog2(th); p.lPX = ssde_ilog2(px);
+  p.tiles_x = ssde_cdiv(a->w_out, tw);
+  p.tiles_per_img = p.tiles_x * ssde_cdiv(a->h_out, th);
+  p.chunks = ssde_cdiv(a->n, imgs) * p.tiles_per_img;
+  const int bco = a->ksize == 3 ? 64 : 128, bci = bco;
+  p.co_tiles = ssde_cdiv(a->c_out, bco);
+  p.ci_tiles = ssde_cdiv(a->cin_store, bci);
+  const int ntiles = p.co_tiles * p.ci_tiles;
+  int splits = a->splits;
+  if (splits <= 0) {
+    // ~2 workgroups per CU, but never less than 2 chunks per workgroup (the epilogue's atomics must amortise)
+    splits = ssde_cdiv(512, ntiles);
+    const int max_splits = p.chunks >= 2 ? p.chunks / 2 : 1;
+    if (splits > max_splits) splits = max_splits;
+  }
+  if (splits > p.chunks) splits = p.chunks;
+  if (splits < 1) splits = 1;
+  p.chunks_per_split = ssde_cdiv(p.chunks, splits);
+  splits = ssde_cdiv(p.chunks, p.chunks_per_split);
+  const int ks = a->ksize;
+  const int halo = imgs * ((th - 1) * a->stride + ks) * ((tw - 1) * a->stride + ks);
+  const int lds = (px * bco + halo * bci) * 4;
+  SSDE_REQUIRE(lds <= 160 * 1024, "wgrad: %d bytes of LDS needed", lds);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a->ksize == 3) return launch<3, 1, 1>(p, splits, lds, st);
+  return launch<1, 2, 2>(p, splits, lds, st);
+}

@@ -84,7 +84,10 @@ _STRUCT = {L.OP_CONV: L.ConvArgs, L.OP_GN_STATS: L.GnStatsArgs, L.OP_UPFIRDN: L.
            L.OP_EMBED: L.EmbedArgs, L.OP_TO_NHWC: L.ToNhwcArgs, L.OP_TO_NCHW: L.ToNchwArgs,
            L.OP_BIAS_ACT: L.BiasActArgs, L.OP_SUMSQ: L.SumsqArgs, L.OP_RANDN: L.RandnArgs,
            L.OP_LANGEVIN: L.LangevinArgs, L.OP_PREDICTOR: L.PredictorArgs, L.OP_FILL: L.FillArgs,
-           L.OP_STEP_INC: L.StepIncArgs}
+           L.OP_STEP_INC: L.StepIncArgs, L.OP_WGRAD: L.WgradArgs, L.OP_COLSUM: L.ColsumArgs,
+           L.OP_GN_BWD_REDUCE: L.GnBwdReduceArgs, L.OP_PROLOGUE_BWD: L.PrologueBwdArgs, L.OP_ATTN_BWD: L.AttnBwdArgs,
+           L.OP_PERTURB: L.PerturbArgs, L.OP_DSM_LOSS: L.DsmLossArgs, L.OP_SUMSQ_FLAT: L.SumsqFlatArgs,
+           L.OP_ADAM: L.AdamArgs, L.OP_MEMSET: L.MemsetArgs, L.OP_AXPY: L.AxpyArgs}
 
 
 class ProgramBuilder:
@@ -160,12 +163,29 @@ class Program:
         self._owner = owner   # keeps buffers / weights alive
         self._graph = None
 
-    def run(self, stream=None):
+    def _launch(self, ops_ptr, count, stream=None):
         lib = L.load()
         if not torch.cuda.is_available():
             raise RuntimeError("libssde_hip programs run on the MI355X only (no CPU fallback)")
         st = torch.cuda.current_stream().cuda_stream if stream is None else stream
-        L.check(lib.ssde_program_run(self.ops, self.n, C.c_void_p(st)), "ssde_program_run")
+        L.check(lib.ssde_program_run(ops_ptr, count, C.c_void_p(st)), "ssde_program_run")
+
+    def run(self, stream=None):
+        self._launch(self.ops, self.n, stream)
+
+    def run_range(self, start, count, stream=None):
+        """Run ops [start, start+count) (forward and backward halves of a training program)."""
+        assert 0 <= start and start + count <= self.n
+        ptr = C.cast(C.byref(self.ops, start * C.sizeof(L.Op)), C.POINTER(L.Op))
+        self._launch(ptr, count, stream)
+
+    def run_range_timed(self, start, count):
+        lib = L.load()
+        ms = (C.c_float * count)()
+        ptr = C.cast(C.byref(self.ops, start * C.sizeof(L.Op)), C.POINTER(L.Op))
+        st = torch.cuda.current_stream().cuda_stream
+        L.check(lib.ssde_program_run_timed(ptr, count, C.c_void_p(st), ms), "ssde_program_run_timed")
+        return list(ms)
 
     def run_timed(self):
         lib = L.load()
@@ -213,40 +233,111 @@ class WeightStore:
 
     `refresh()` re-packs an entry in place when any of its source parameters changed
     (`Tensor._version`, bumped by optimizer steps / load_state_dict), so programs and
-    captured graphs keep valid pointers."""
+    captured graphs keep valid pointers.  Every entry also records its provenance
+    (`meta[id(packed)]`: the logical weight, and which rows of it belong to which
+    parameter) -- the backward lowering uses it to build input-gradient weights and to
+    aim weight-gradient kernels at the parameters' own `.grad` storage."""
 
     def __init__(self, device):
         self.device = device
         self.entries = []   # [packed, sources, fn, stamp]
+        self.meta = {}
 
-    def add(self, sources, fn):
+    def add(self, sources, fn, meta=None):
         with torch.no_grad():
             packed = fn(*[s.detach() for s in sources]).to(self.device).contiguous()
         self.entries.append([packed, list(sources), fn, self._stamp(sources)])
+        if meta is not None:
+            self.meta[id(packed)] = meta
         return packed
+
+    # -- typed registrations -------------------------------------------------------------------
+    def conv3(self, param, cin_pad=None, cout_pad=None):
+        """[Cout, Cin, 3, 3] conv weight, optionally zero-padded to cin_pad / cout_pad channels."""
+        def logical(w):
+            w = w.to(torch.float32)
+            if cin_pad and w.shape[1] < cin_pad:
+                w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cin_pad - w.shape[1]))
+            if cout_pad and w.shape[0] < cout_pad:
+                w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_pad - w.shape[0]))
+            return w
+        meta = dict(kind="conv3", sources=[param], logical=logical,
+                    parts=[dict(param=param, row0=0, rows=param.shape[0], transpose=False)], cin_store=param.shape[1])
+        return self.add([param], lambda w: pack_conv_weight(logical(w)), meta)
+
+    def matrix(self, parts, cin_pad=None):
+        """Rows-concatenated [Cout_i, Cin] matrices; parts = [(param, transpose)], transpose for NIN's [in, out]."""
+        params = [p for p, _ in parts]
+
+        def logical(*ws):
+            ms = []
+            for w, (_, tr) in zip(ws, parts):
+                w = w.to(torch.float32)
+                w = w.t() if tr else w.reshape(w.shape[0], -1)
+                ms.append(w)
+            m = torch.cat(ms, dim=0) if len(ms) > 1 else ms[0]
+            if cin_pad and m.shape[1] < cin_pad:
+                m = torch.nn.functional.pad(m, (0, cin_pad - m.shape[1]))
+            return m
+        rows, desc = 0, []
+        for p_, tr in parts:
+            n_rows = p_.shape[1] if tr else p_.shape[0]
+            cin = p_.shape[0] if tr else int(np.prod(p_.shape[1:]))
+            desc.append(dict(param=p_, row0=rows, rows=n_rows, transpose=tr))
+            rows += n_rows
+        meta = dict(kind="matrix", sources=params, logical=logical, parts=desc, cin_store=cin)
+        return self.add(params, lambda *ws: pack_matrix(logical(*ws)), meta)
+
+    def vector(self, params, mode="cat", pad_to=None):
+        """Per-channel vectors: biases (concatenated, or summed when two convolutions share one epilogue), GroupNorm affine."""
+        def fn(*vs):
+            vs = [v.to(torch.float32) for v in vs]
+            x = torch.cat(vs) if mode == "cat" else sum(vs[1:], vs[0])
+            if pad_to and x.numel() < pad_to:
+                x = torch.nn.functional.pad(x, (0, pad_to - x.numel()))
+            return x.clone()
+        off, desc = 0, []
+        for p_ in params:
+            desc.append(dict(param=p_, off=0 if mode == "sum" else off, n=p_.numel()))
+            off += p_.numel()
+        return self.add(params, fn, dict(kind="vector", mode=mode, sources=list(params), parts=desc))
+
+    def derived(self, packed, fn, tag):
+        """A second packing of an existing entry's logical weight (input-gradient weights): fn(logical) -> packed."""
+        meta = self.meta[id(packed)]
+        key = (id(packed), tag)
+        if key not in self.meta:
+            self.meta[key] = self.add(meta["sources"], lambda *ws: fn(meta["logical"](*ws)))
+        return self.meta[key]
 
     @staticmethod
     def _stamp(sources):
         return tuple((s.data_ptr(), s._version) for s in sources)
 
-    def refresh(self):
+    def refresh(self, force=False):
         for e in self.entries:
             st = self._stamp(e[1])
-            if st != e[3]:
+            if force or st != e[3]:
                 with torch.no_grad():
                     e[0].copy_(e[2](*[s.detach() for s in e[1]]).to(self.device))
                 e[3] = st
 
 
 # --------------------------------------------------------------------------- lowering helpers
-def _src(t, c, t2=None, c2=0, pro=L.PRO_NONE, gn=None):
-    d = dict(p0=t, p1=t2, c0=c, c1=c2, pro_mode=pro, gn_groups=0, gn_mean=None, gn_rstd=None, gn_gamma=None, gn_beta=None)
+def _src(t, c, t2=None, c2=0, pro=L.PRO_NONE, gn=None, drop=None):
+    d = dict(p0=t, p1=t2, c0=c, c1=c2, pro_mode=pro, gn_groups=0, gn_mean=None, gn_rstd=None, gn_gamma=None, gn_beta=None,
+             drop_thresh=0, drop_scale=1.0, drop_seed=None, drop_salt=0)
     if gn is not None:
         d.update(gn_groups=gn["groups"], gn_mean=gn["mean"], gn_rstd=gn["rstd"], gn_gamma=gn["gamma"], gn_beta=gn["beta"])
+    if drop is not None:
+        p, seed_t, salt = drop
+        d.update(drop_thresh=min(int(round(p * 2.0 ** 32)), 2 ** 32 - 1), drop_scale=1.0 / (1.0 - p), drop_seed=seed_t,
+                 drop_salt=salt & 0xFFFFFFFF)
     return d
 
 
-_NOSRC = dict(p0=None, p1=None, c0=0, c1=0, pro_mode=0, gn_groups=0, gn_mean=None, gn_rstd=None, gn_gamma=None, gn_beta=None)
+_NOSRC = dict(p0=None, p1=None, c0=0, c1=0, pro_mode=0, gn_groups=0, gn_mean=None, gn_rstd=None, gn_gamma=None, gn_beta=None,
+              drop_thresh=0, drop_scale=1.0, drop_seed=None, drop_salt=0)
 
 
 def fir_taps(k, gain=1.0):
@@ -274,13 +365,14 @@ class Lowering:
         scratch = self.b.buf(self.n * slices * groups * 2, name="gn_scratch") if slices > 1 else None
         self.b.add(L.OP_GN_STATS, dict(p0=t, p1=t2, c0=c, c1=c2, n=self.n, hw=hw, groups=groups, eps=float(gn_module.eps),
                                        mean=mean, rstd=rstd, scratch=scratch, slices=slices), FC_GN)
-        gamma = self.w.add([gn_module.weight], lambda x: x.to(torch.float32).clone())
-        beta = self.w.add([gn_module.bias], lambda x: x.to(torch.float32).clone())
+        gamma = self.w.vector([gn_module.weight])
+        beta = self.w.vector([gn_module.bias])
         assert ctot == gn_module.num_channels
         return dict(groups=groups, mean=mean, rstd=rstd, gamma=gamma, beta=beta)
 
     def conv(self, dst, h_out, w_out, c_out, main=None, w_main=None, h_in=0, w_in=0, stride=1, pad=1,
-             aux=None, w_aux=None, bias=None, chan_add=None, chan_add_ld=0, resid=None, scale=1.0, tile=L.TILE_AUTO):
+             aux=None, w_aux=None, bias=None, chan_add=None, chan_add_ld=0, resid=None, scale=1.0, tile=L.TILE_AUTO,
+             resid_post=0):
         px = self.n * h_out * w_out
         flops = 0.0
         if main is not None:
@@ -291,7 +383,7 @@ class Lowering:
             main=main if main is not None else _NOSRC, aux=aux if aux is not None else _NOSRC,
             w_main=w_main, w_aux=w_aux, n=self.n, h_in=h_in, w_in=w_in, h_out=h_out, w_out=w_out, c_out=c_out,
             ksize=3 if main is not None else 0, stride=stride, pad=pad, tile=tile, bias=bias, chan_add=chan_add,
-            chan_add_ld=chan_add_ld, resid=resid, out_scale=float(scale), dst=dst),
+            chan_add_ld=chan_add_ld, resid_post=resid_post, resid=resid, out_scale=float(scale), dst=dst),
             FC_CONV3 if main is not None else FC_CONV1, flops)
 
     def upfirdn(self, src, n_ch, h_in, w_in, taps, up=1, down=1, pad=(0, 0), name="fir"):
@@ -311,8 +403,12 @@ class Lowering:
 class UNetEngine:
     """Static program for NCSNpp.forward at a fixed (batch, H, W)."""
 
-    def __init__(self, model, batch, height, width, device, vp_score=False):
+    def __init__(self, model, batch, height, width, device, vp_score=False, train=False, input_grad=False,
+                 finalize=True):
         L.load()
+        # train=True: Dropout_0 of every residual block is live (layerspp.py:265) and a backward program is
+        # appended by score_sde_pytorch_amd.backward.TrainEngine; input_grad adds d out / d x to it.
+        self.train, self.input_grad = train, input_grad
         # device 'cpu' is accepted for DRY lowering only (plan validation, FLOP census in the CPU tests);
         # running a program needs the MI355X.
         self.model, self.n, self.h, self.w, self.device = model, batch, height, width, device
@@ -334,8 +430,14 @@ class UNetEngine:
         self.std = self.b.buf(batch, name="std", persistent=True) if vp_score else None
         if vp_score and cfg.model.scale_by_sigma:
             raise NotImplementedError("scale_by_sigma together with a VP score head is not lowered")
+        self.drop_seed = None
+        if train and float(cfg.model.dropout) > 0:
+            self.drop_seed = torch.zeros(1, dtype=torch.int32, device=device)
+            self.b.tensor(self.drop_seed)
+        self._n_res = 0
         self._lower()
-        self.program = self.b.finalize()
+        if finalize:
+            self.program = self.b.finalize()
 
     # ------------------------------------------------------------------ lowering
     def _lower(self):
@@ -359,17 +461,18 @@ class UNetEngine:
             table = b.tensor(freqs.to(self.device))
             kind = 1
         emb = b.buf(n, emb_dim, name="emb")
+        self._emb = emb
         b.add(L.OP_EMBED, dict(cond=self.cond, w=table, dst=emb, n=n, dim=emb_dim, kind=kind))
         temb = None
         if model.conditional:
             lin0, lin1 = mods[idx], mods[idx + 1]; idx += 2
             t0 = b.buf(n, 4 * nf, name="temb0")
-            low.conv(t0, 1, 1, 4 * nf, aux=_src(emb, emb_dim), w_aux=self.weights.add([lin0.weight], pack_matrix),
-                     bias=self.weights.add([lin0.bias], lambda x: x.to(torch.float32).clone()))
+            low.conv(t0, 1, 1, 4 * nf, aux=_src(emb, emb_dim), w_aux=self.weights.matrix([(lin0.weight, False)]),
+                     bias=self.weights.vector([lin0.bias]))
             temb = b.buf(n, 4 * nf, name="temb")
             low.conv(temb, 1, 1, 4 * nf, aux=_src(t0, 4 * nf, pro=L.PRO_SILU),
-                     w_aux=self.weights.add([lin1.weight], pack_matrix),
-                     bias=self.weights.add([lin1.bias], lambda x: x.to(torch.float32).clone()))
+                     w_aux=self.weights.matrix([(lin1.weight, False)]),
+                     bias=self.weights.vector([lin1.bias]))
             # every Dense_0(act(temb)) of every residual block as ONE GEMM (layerspp.py:263)
             dense = [m.Dense_0 for m in mods if getattr(m, "kind", "") == "res"]
             self._tproj_off, off = {}, 0
@@ -377,8 +480,8 @@ class UNetEngine:
                 self._tproj_off[id(d)] = off
                 off += d.out_features
             self._tproj_ld = off
-            wd = self.weights.add([d.weight for d in dense], lambda *ws: pack_matrix(torch.cat(ws, dim=0)))
-            bd = self.weights.add([d.bias for d in dense], lambda *bs: torch.cat(bs).to(torch.float32))
+            wd = self.weights.matrix([(d.weight, False) for d in dense])
+            bd = self.weights.vector([d.bias for d in dense])
             self._tproj = b.buf(n, off, name="tproj")
             low.conv(self._tproj, 1, 1, off, aux=_src(temb, 4 * nf, pro=L.PRO_SILU), w_aux=wd, bias=bd)
 
@@ -386,6 +489,7 @@ class UNetEngine:
         H, W = self.h, self.w
         cpad = 4
         x0 = b.buf(n, H, W, cpad, name="x_nhwc")
+        self._x0 = x0
         a, sh = (1.0, 0.0) if self.cfg.data.centered else (2.0, -1.0)
         b.add(L.OP_TO_NHWC, dict(src=self.x_in, dst=x0, n=n, c=self.channels, h=H, w=W, c_pad=cpad, a=a, b=sh))
         pyr, pyr_c = (x0, cpad) if model.progressive_input != "none" else (None, 0)
@@ -483,29 +587,13 @@ class UNetEngine:
 
     # -- packed parameter helpers
     def _w3(self, m, cin_pad=None, cout_pad=None):
-        def fn(w):
-            if cin_pad and w.shape[1] < cin_pad:
-                w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, cin_pad - w.shape[1]))
-            if cout_pad and w.shape[0] < cout_pad:
-                w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_pad - w.shape[0]))
-            return pack_conv_weight(w)
-        return self.weights.add([m.weight], fn)
+        return self.weights.conv3(m.weight, cin_pad, cout_pad)
 
     def _w1(self, m, cin_pad=None):
-        def fn(w):
-            w = w.reshape(w.shape[0], w.shape[1])
-            if cin_pad and w.shape[1] < cin_pad:
-                w = torch.nn.functional.pad(w, (0, cin_pad - w.shape[1]))
-            return pack_matrix(w)
-        return self.weights.add([m.weight], fn)
+        return self.weights.matrix([(m.weight, False)], cin_pad=cin_pad)
 
     def _bias(self, m, pad_to=None):
-        def fn(x):
-            x = x.to(torch.float32)
-            if pad_to and x.numel() < pad_to:
-                x = torch.nn.functional.pad(x, (0, pad_to - x.numel()))
-            return x.clone()
-        return self.weights.add([m.bias], fn)
+        return self.weights.vector([m.bias], pad_to=pad_to)
 
     # -- ResnetBlockBigGANpp (layerspp.py:242-274)
     def _res(self, m, t, c, hh, ww, t2=None, c2=0):
@@ -537,9 +625,11 @@ class UNetEngine:
                  chan_add=chan_add, chan_add_ld=ld)
         gn1 = low.gn_stats(h1, cout, hh * ww, m.GroupNorm_1)
         out = b.buf(n, hh, ww, cout, name="res_out")
-        main1 = _src(h1, cout, pro=L.PRO_GN_SILU, gn=gn1)
+        self._n_res += 1
+        drop = (float(m.dropout), self.drop_seed, 0x9E3779B1 * self._n_res) if self.drop_seed is not None else None
+        main1 = _src(h1, cout, pro=L.PRO_GN_SILU, gn=gn1, drop=drop)
         if hasattr(m, "Conv_2"):
-            bsum = self.weights.add([m.Conv_1.bias, m.Conv_2.bias], lambda x, y: (x + y).to(torch.float32))
+            bsum = self.weights.vector([m.Conv_1.bias, m.Conv_2.bias], mode="sum")
             low.conv(out, hh, ww, cout, main=main1, w_main=self._w3(m.Conv_1), h_in=hh, w_in=ww,
                      aux=_src(skip_t, skip_c, skip_t2, skip_c2), w_aux=self._w1(m.Conv_2), bias=bsum, scale=scale)
         else:
@@ -552,9 +642,8 @@ class UNetEngine:
     def _attn(self, m, t, c, hh, ww):
         b, low, n = self.b, self.low, self.n
         gn = low.gn_stats(t, c, hh * ww, m.GroupNorm_0)
-        wqkv = self.weights.add([m.NIN_0.W, m.NIN_1.W, m.NIN_2.W],
-                                lambda q, k, v: pack_matrix(torch.cat([q.t(), k.t(), v.t()], dim=0)))
-        bqkv = self.weights.add([m.NIN_0.b, m.NIN_1.b, m.NIN_2.b], lambda q, k, v: torch.cat([q, k, v]).to(torch.float32))
+        wqkv = self.weights.matrix([(m.NIN_0.W, True), (m.NIN_1.W, True), (m.NIN_2.W, True)])
+        bqkv = self.weights.vector([m.NIN_0.b, m.NIN_1.b, m.NIN_2.b])
         qkv = b.buf(n, hh, ww, 3 * c, name="qkv")
         low.conv(qkv, hh, ww, 3 * c, aux=_src(t, c, pro=L.PRO_GN, gn=gn), w_aux=wqkv, bias=bqkv)
         ao = b.buf(n, hh, ww, c, name="attn_o")
@@ -562,8 +651,8 @@ class UNetEngine:
         b.add(L.OP_ATTN, dict(qkv=qkv, dst=ao, n=n, l=L_, c=c, scale=float(int(c) ** (-0.5))), FC_ATTN,
               4.0 * n * L_ * L_ * c)
         out = b.buf(n, hh, ww, c, name="attn_out")
-        low.conv(out, hh, ww, c, aux=_src(ao, c), w_aux=self.weights.add([m.NIN_3.W], lambda w: pack_matrix(w.t())),
-                 bias=self.weights.add([m.NIN_3.b], lambda x: x.to(torch.float32).clone()), resid=t,
+        low.conv(out, hh, ww, c, aux=_src(ao, c), w_aux=self.weights.matrix([(m.NIN_3.W, True)]),
+                 bias=self.weights.vector([m.NIN_3.b]), resid=t,
                  scale=INV_SQRT2 if m.skip_rescale else 1.0)
         return out
 

@@ -66,6 +66,8 @@ def conv2d(x=None, weight=None, bias=None, stride=1, pad=1, x2=None, pro=L.PRO_N
         c_out = weight.shape[0]
         h_out = (h_in + 2 * pad - 3) // stride + 1
         w_out = (w_in + 2 * pad - 3) // stride + 1
+        if out_hw is not None:      # top-left crop of the full result (transposed strided convolutions)
+            h_out, w_out = out_hw
         _fill_src(a.main, x, x2, pro, gn)
         wp = pack_conv_weight(weight.to(x.device)); keep.append(wp)
         a.w_main, a.ksize, a.stride, a.pad, a.h_in, a.w_in = _p(wp), 3, stride, pad, h_in, w_in
@@ -165,3 +167,136 @@ def randn(numel, seed, device, step_ptr=None, stream_id=0):
     a.dst, a.numel, a.seed, a.step_ptr, a.stream_id = _p(dst), numel, seed, _p(step_ptr), stream_id
     L.check(L.load().ssde_randn(C.byref(a), _stream()), "ssde_randn")
     return dst
+
+
+# ------------------------------------------------------------------------------- training-path ops
+def set_dropout(s, p, seed_t, salt):
+    """Arm the train-mode dropout of a source (ssde.h: drop_thresh / drop_scale / drop_seed / drop_salt)."""
+    s.drop_thresh = min(int(round(p * 2.0 ** 32)), 2 ** 32 - 1) if p > 0 else 0
+    s.drop_scale = 1.0 / (1.0 - p) if p > 0 else 1.0
+    s.drop_seed = _p(seed_t) if p > 0 else None
+    s.drop_salt = salt & 0xFFFFFFFF
+
+
+def conv_wgrad(x, g, ksize, dw, stride=1, pad=1, x2=None, pro=L.PRO_NONE, gn=None, g_off=0, c_out=None, cin_store=None,
+               transpose_out=False, scale=1.0, splits=0, dropout=None):
+    """dw += scale * sum_pixels g[:, g_off:g_off+c_out]^T pro(x)[shifted]; x, g NHWC; dw in the reference layout."""
+    _need_cuda(x, g, dw)
+    a = L.WgradArgs()
+    _fill_src(a.src, x, x2, pro, gn)
+    if dropout is not None:
+        set_dropout(a.src, *dropout)
+    a.g, a.g_ld, a.g_off = _p(g), g.shape[-1], g_off
+    a.n, a.h_in, a.w_in, a.h_out, a.w_out = x.shape[0], x.shape[1], x.shape[2], g.shape[1], g.shape[2]
+    a.c_out = c_out if c_out is not None else g.shape[-1] - g_off
+    ctot = x.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
+    a.ksize, a.stride, a.pad = ksize, stride, pad
+    a.cin_store = cin_store if cin_store is not None else ctot
+    a.transpose_out, a.splits, a.scale, a.dw = int(transpose_out), splits, scale, _p(dw)
+    L.check(L.load().ssde_conv_wgrad(C.byref(a), _stream()), "ssde_conv_wgrad")
+    return dw
+
+
+def colsum(g, c=None, g_off=0, scale=1.0, per_sample=None, ps_off=0, total=None, total2=None):
+    _need_cuda(g)
+    n = g.shape[0]
+    hw = int(np.prod(g.shape[1:-1])) if g.dim() > 2 else 1
+    a = L.ColsumArgs()
+    a.g, a.g_ld, a.g_off, a.n, a.hw = _p(g), g.shape[-1], g_off, n, hw
+    a.c = c if c is not None else g.shape[-1] - g_off
+    a.scale = scale
+    scratch = None
+    if per_sample is not None:
+        a.per_sample, a.ps_ld, a.ps_off = _p(per_sample), per_sample.shape[-1], ps_off
+    else:
+        scratch = torch.empty(n * a.c, device=g.device)
+        a.scratch = _p(scratch)
+    a.total, a.total2 = _p(total), _p(total2)
+    L.check(L.load().ssde_colsum(C.byref(a), _stream()), "ssde_colsum")
+
+
+def gn_backward(x, dp, gn, pro, x2=None, dropout=None, slices=1, scale=1.0, acc=(False, False), want=(True, True)):
+    """GroupNorm(+SiLU)(+dropout) backward: returns (dx, dx2, dgamma, dbeta) for dp = d loss / d pro(x)."""
+    _need_cuda(x, dp)
+    n = x.shape[0]
+    hw = int(np.prod(x.shape[1:-1]))
+    ctot = x.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
+    groups = gn[4]
+    r = L.GnBwdReduceArgs()
+    _fill_src(r.src, x, x2, pro, gn)
+    if dropout is not None:
+        set_dropout(r.src, *dropout)
+    sums = torch.empty(n, groups, 2, device=x.device)
+    dgamma, dbeta = torch.empty(ctot, device=x.device), torch.empty(ctot, device=x.device)
+    scratch = torch.empty(n * slices * ctot * 2, device=x.device)
+    r.dp, r.n, r.hw, r.sums, r.dgamma, r.dbeta, r.scratch, r.slices = _p(dp), n, hw, _p(sums), _p(dgamma), _p(dbeta), _p(scratch), slices
+    L.check(L.load().ssde_gn_bwd_reduce(C.byref(r), _stream()), "ssde_gn_bwd_reduce")
+    dx = torch.zeros_like(x) if want[0] else None
+    dx2 = torch.zeros_like(x2) if (x2 is not None and want[1]) else None
+    prologue_bwd(x, dp, pro, dx, dx2, x2=x2, gn=gn, sums=sums, dropout=dropout, scale=scale, acc=acc)
+    return dx, dx2, dgamma, dbeta
+
+
+def prologue_bwd(x, dp, pro, g0, g1=None, x2=None, gn=None, sums=None, dropout=None, scale=1.0, acc=(False, False),
+                 dp_off=0, c0=None, c1=0):
+    a = L.PrologueBwdArgs()
+    if x is not None:
+        _fill_src(a.src, x, x2, pro, gn)
+    else:
+        a.src.c0, a.src.c1, a.src.pro_mode = c0, c1, pro
+    if dropout is not None:
+        set_dropout(a.src, *dropout)
+    ref = x if x is not None else (g0 if g0 is not None else g1)
+    a.dp, a.dp_ld, a.dp_off = _p(dp), dp.shape[-1], dp_off
+    a.n = ref.shape[0]
+    a.hw = int(np.prod(ref.shape[1:-1])) if ref.dim() > 2 else 1
+    a.sums, a.scale, a.acc0, a.acc1, a.g0, a.g1 = _p(sums), scale, int(acc[0]), int(acc[1]), _p(g0), _p(g1)
+    L.check(L.load().ssde_prologue_bwd(C.byref(a), _stream()), "ssde_prologue_bwd")
+
+
+def attention_bwd(qkv, o, d_o, channels):
+    _need_cuda(qkv, o, d_o)
+    n, l = qkv.shape[0], qkv.shape[1]
+    dqkv = torch.empty_like(qkv)
+    stats = torch.empty(n, l, 4, device=qkv.device)
+    a = L.AttnBwdArgs()
+    a.qkv, a.o, a.d_o, a.dqkv, a.stats = _p(qkv), _p(o), _p(d_o), _p(dqkv), _p(stats)
+    a.n, a.l, a.c, a.scale = n, l, channels, float(int(channels) ** (-0.5))
+    L.check(L.load().ssde_attention_bwd(C.byref(a), _stream()), "ssde_attention_bwd")
+    return dqkv
+
+
+def dsm_loss(score, z, s, g2=None, reduce_mean=False, likelihood_weighting=False, want_grad=True, grad_scale=1.0):
+    _need_cuda(score, z, s)
+    n = score.shape[0]
+    per = score.numel() // n
+    dscore = torch.empty_like(score) if want_grad else None
+    losses, loss = torch.empty(n, device=score.device), torch.empty(1, device=score.device)
+    a = L.DsmLossArgs()
+    a.score, a.z, a.s, a.g2, a.dscore, a.losses, a.loss = _p(score), _p(z), _p(s), _p(g2), _p(dscore), _p(losses), _p(loss)
+    a.n, a.per, a.reduce_mean, a.likelihood_weighting, a.grad_scale = n, per, int(reduce_mean), int(likelihood_weighting), grad_scale
+    L.check(L.load().ssde_dsm_loss(C.byref(a), _stream()), "ssde_dsm_loss")
+    return loss, losses, dscore
+
+
+def perturb(x, z, s, a_coef=None):
+    _need_cuda(x, z, s)
+    dst = torch.empty_like(x)
+    a = L.PerturbArgs()
+    a.x, a.z, a.a, a.s, a.dst, a.n, a.per = _p(x), _p(z), _p(a_coef), _p(s), _p(dst), x.shape[0], x.numel() // x.shape[0]
+    L.check(L.load().ssde_perturb(C.byref(a), _stream()), "ssde_perturb")
+    return dst
+
+
+def sumsq_flat(x):
+    partial, out = torch.empty(1024, device=x.device), torch.empty(1, device=x.device)
+    a = L.SumsqFlatArgs()
+    a.x, a.numel, a.partial, a.out = _p(x), x.numel(), _p(partial), _p(out)
+    L.check(L.load().ssde_sumsq_flat(C.byref(a), _stream()), "ssde_sumsq_flat")
+    return out
+
+
+def adam_clip_ema(p, g, m, v, ema, hyper, gnorm_sq=None):
+    a = L.AdamArgs()
+    a.p, a.g, a.m, a.v, a.ema, a.numel, a.hyper, a.gnorm_sq = _p(p), _p(g), _p(m), _p(v), _p(ema), p.numel(), _p(hyper), _p(gnorm_sq)
+    L.check(L.load().ssde_adam_clip_ema(C.byref(a), _stream()), "ssde_adam_clip_ema")

@@ -28,15 +28,15 @@ def lib():
 @contextlib.contextmanager
 def emulated():
     from score_sde_pytorch_amd import _lib as L, hipops, engine
-    saved = (L._lib, hipops._need_cuda, hipops._stream, engine.Program.run)
+    saved = (L._lib, hipops._need_cuda, hipops._stream, engine.Program._launch)
     L._lib = lib()
     hipops._need_cuda = lambda *ts: None
     hipops._stream = lambda: C.c_void_p(0)
 
-    def run(self, stream=None):
-        L.check(L._lib.ssde_program_run(self.ops, self.n, C.c_void_p(0)), "ssde_program_run[emu]")
-    engine.Program.run = run
+    def _launch(self, ops_ptr, count, stream=None):
+        L.check(L._lib.ssde_program_run(ops_ptr, count, C.c_void_p(0)), "ssde_program_run[emu]")
+    engine.Program._launch = _launch
     try:
         yield L._lib
     finally:
-        L._lib, hipops._need_cuda, hipops._stream, engine.Program.run = saved
+        L._lib, hipops._need_cuda, hipops._stream, engine.Program._launch = saved

@@ -35,8 +35,8 @@ def test_conv_plan_validation_errors_are_reported():
     a.main.p0, a.main.c0, a.w_main, a.ksize, a.stride, a.pad = 0x1000, 6, 0x1000, 3, 1, 1
     a.n, a.h_in, a.w_in, a.h_out, a.w_out, a.c_out = 1, 8, 8, 8, 8, 8
     assert lib.ssde_conv_lds_bytes(C.byref(a)) < 0 and b"multiples of 4" in lib.ssde_last_error()
-    a.main.c0, a.h_out = 8, 7
-    assert lib.ssde_conv_lds_bytes(C.byref(a)) < 0 and b"powers of two" in lib.ssde_last_error()
+    a.main.c0, a.h_out = 8, 9
+    assert lib.ssde_conv_lds_bytes(C.byref(a)) < 0 and b"larger than" in lib.ssde_last_error()
     a.h_out, a.stride = 8, 3
     assert lib.ssde_conv_lds_bytes(C.byref(a)) < 0 and b"stride" in lib.ssde_last_error()
 
