@@ -85,9 +85,9 @@ def flat_params_of(model, device):
 class TrainEngine(E.UNetEngine):
     """Forward (train mode) + backward program of NCSNpp at a fixed (batch, H, W)."""
 
-    def __init__(self, model, batch, height, width, device, vp_score=False, input_grad=False):
+    def __init__(self, model, batch, height, width, device, vp_score=False, input_grad=False, dropout=True):
         self.flat = flat_params_of(model, device)
-        super().__init__(model, batch, height, width, device, vp_score=vp_score, train=True, input_grad=input_grad,
+        super().__init__(model, batch, height, width, device, vp_score=vp_score, train=bool(dropout), input_grad=input_grad,
                          finalize=False)
         self.n_fwd = len(self.b.specs)
         # d loss / d out in the boundary layout (NCHW), written by the caller (loss head or autograd)

@@ -1,0 +1,357 @@
+"""Training losses and the one-step training function (drop-in for the reference's losses.py).
+
+Same names, arguments and error behaviour: `get_optimizer` (:26-35), `optimization_manager` (:38-52),
+`get_sde_loss_fn` (:55-101), `get_smld_loss_fn` (:104-125), `get_ddpm_loss_fn` (:128-148),
+`get_step_fn` (:151-210).  Two execution paths sit behind `step_fn(state, batch)`:
+
+* generic (any model / optimizer / optimize_fn / loss): the reference's own sequence --
+  zero_grad, loss_fn, loss.backward(), optimize_fn, EMA update -- where `model(x, labels)` of our
+  NCSNpp differentiates through the HIP backward program (autograd.py);
+* fused (selected when the model is our NCSNpp on the GPU, the optimizer came from `get_optimizer`,
+  optimize_fn from `optimization_manager`, EMA from models.ema and the loss is the continuous SDE loss):
+  perturb kernel -> forward program -> DSM loss head (loss + d loss/d score in one pass) -> backward
+  program -> [one RCCL all-reduce of the flat gradient] -> global-norm clip + Adam + EMA in two
+  launches over flat buffers.  Random draws use torch's device generator exactly as the reference does
+  (torch.rand for t, torch.randn_like for z), so a seeded run perturbs the data identically.
+
+Data parallelism (replaces nn.DataParallel): one process per GPU; when torch.distributed is
+initialised the fused step averages gradients with ONE all-reduce per step (parallel.py).
+"""
+import numpy as np
+import torch
+import torch.optim as optim
+
+from . import sde_lib
+from .models import utils as mutils
+from .sde_lib import VESDE, VPSDE
+
+
+class FusedAdam(optim.Adam):
+    """torch.optim.Adam whose state can live in flat buffers shared with libssde_hip's fused update.
+
+    Behaves exactly like torch.optim.Adam (step(), state_dict(), load_state_dict()); `flatten_like`
+    re-homes exp_avg / exp_avg_sq into two flat fp32 buffers laid out like backward.FlatParams, after
+    which both torch's own step() and the fused kernel update the same memory."""
+
+    def flatten_like(self, flat):
+        cached = getattr(self, "_ssde_flat", None)
+        if cached is not None and cached[0] is flat:
+            return cached[1], cached[2]
+        dev = flat.data.device
+        m = torch.zeros(flat.numel, dtype=torch.float32, device=dev)
+        v = torch.zeros(flat.numel, dtype=torch.float32, device=dev)
+        for p in flat.params:
+            o, n = flat.index[id(p)]
+            st = self.state[p]
+            if "exp_avg" in st:
+                m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            step = st.get("step", None)
+            st["step"] = step if torch.is_tensor(step) else torch.tensor(float(step or 0.0))
+            st["exp_avg"] = m[o:o + n].view(p.shape)
+            st["exp_avg_sq"] = v[o:o + n].view(p.shape)
+        self._ssde_flat = (flat, m, v)
+        return m, v
+
+
+def get_optimizer(config, params):
+    """Returns an Adam optimizer built from `config.optim` (losses.py:26-35)."""
+    if config.optim.optimizer == 'Adam':
+        optimizer = FusedAdam(params, lr=config.optim.lr, betas=(config.optim.beta1, 0.999), eps=config.optim.eps,
+                              weight_decay=config.optim.weight_decay)
+    else:
+        raise NotImplementedError(f'Optimizer {config.optim.optimizer} not supported yet!')
+    return optimizer
+
+
+def optimization_manager(config):
+    """Returns an optimize_fn based on `config` (losses.py:38-52): lr warm-up, global-norm clip, step."""
+
+    def optimize_fn(optimizer, params, step, lr=config.optim.lr, warmup=config.optim.warmup, grad_clip=config.optim.grad_clip):
+        if warmup > 0:
+            for g in optimizer.param_groups:
+                g['lr'] = lr * np.minimum(step / warmup, 1.0)
+        if grad_clip >= 0:
+            torch.nn.utils.clip_grad_norm_(params, max_norm=grad_clip)
+        optimizer.step()
+
+    # read by the fused step (the arithmetic above, executed by ssde_adam_clip_ema)
+    optimize_fn.ssde_hyper = dict(lr=config.optim.lr, warmup=config.optim.warmup, grad_clip=config.optim.grad_clip)
+    return optimize_fn
+
+
+def get_sde_loss_fn(sde, train, reduce_mean=True, continuous=True, likelihood_weighting=True, eps=1e-5):
+    """Continuous-time denoising score matching loss (losses.py:55-101)."""
+    reduce_op = torch.mean if reduce_mean else lambda *args, **kwargs: 0.5 * torch.sum(*args, **kwargs)
+
+    def loss_fn(model, batch):
+        score_fn = mutils.get_score_fn(sde, model, train=train, continuous=continuous)
+        t = torch.rand(batch.shape[0], device=batch.device) * (sde.T - eps) + eps
+        z = torch.randn_like(batch)
+        mean, std = sde.marginal_prob(batch, t)
+        perturbed_data = mean + std[:, None, None, None] * z
+        score = score_fn(perturbed_data, t)
+        if not likelihood_weighting:
+            losses = torch.square(score * std[:, None, None, None] + z)
+            losses = reduce_op(losses.reshape(losses.shape[0], -1), dim=-1)
+        else:
+            g2 = sde.sde(torch.zeros_like(batch), t)[1] ** 2
+            losses = torch.square(score + z / std[:, None, None, None])
+            losses = reduce_op(losses.reshape(losses.shape[0], -1), dim=-1) * g2
+        return torch.mean(losses)
+
+    loss_fn.ssde_spec = dict(kind="sde", sde=sde, train=train, reduce_mean=reduce_mean, continuous=continuous,
+                             likelihood_weighting=likelihood_weighting, eps=eps)
+    return loss_fn
+
+
+def get_smld_loss_fn(vesde, train, reduce_mean=False):
+    """Legacy discrete SMLD (NCSN) loss (losses.py:104-125)."""
+    assert isinstance(vesde, VESDE), "SMLD training only works for VESDEs."
+    smld_sigma_array = torch.flip(vesde.discrete_sigmas, dims=(0,))
+    reduce_op = torch.mean if reduce_mean else lambda *args, **kwargs: 0.5 * torch.sum(*args, **kwargs)
+
+    def loss_fn(model, batch):
+        model_fn = mutils.get_model_fn(model, train=train)
+        labels = torch.randint(0, vesde.N, (batch.shape[0],), device=batch.device)
+        sigmas = smld_sigma_array.to(batch.device)[labels]
+        noise = torch.randn_like(batch) * sigmas[:, None, None, None]
+        perturbed_data = noise + batch
+        score = model_fn(perturbed_data, labels)
+        target = -noise / (sigmas ** 2)[:, None, None, None]
+        losses = torch.square(score - target)
+        losses = reduce_op(losses.reshape(losses.shape[0], -1), dim=-1) * sigmas ** 2
+        return torch.mean(losses)
+
+    return loss_fn
+
+
+def get_ddpm_loss_fn(vpsde, train, reduce_mean=True):
+    """Legacy discrete DDPM loss (losses.py:128-148)."""
+    assert isinstance(vpsde, VPSDE), "DDPM training only works for VPSDEs."
+    reduce_op = torch.mean if reduce_mean else lambda *args, **kwargs: 0.5 * torch.sum(*args, **kwargs)
+
+    def loss_fn(model, batch):
+        model_fn = mutils.get_model_fn(model, train=train)
+        labels = torch.randint(0, vpsde.N, (batch.shape[0],), device=batch.device)
+        sqrt_alphas_cumprod = vpsde.sqrt_alphas_cumprod.to(batch.device)
+        sqrt_1m_alphas_cumprod = vpsde.sqrt_1m_alphas_cumprod.to(batch.device)
+        noise = torch.randn_like(batch)
+        perturbed_data = sqrt_alphas_cumprod[labels, None, None, None] * batch + \
+            sqrt_1m_alphas_cumprod[labels, None, None, None] * noise
+        score = model_fn(perturbed_data, labels)
+        losses = torch.square(score - noise)
+        losses = reduce_op(losses.reshape(losses.shape[0], -1), dim=-1)
+        return torch.mean(losses)
+
+    return loss_fn
+
+
+# --------------------------------------------------------------------------- fused DSM step
+class FusedTrainStep:
+    """perturb -> forward -> loss head -> backward -> [all-reduce] -> clip + Adam + EMA, all libssde_hip kernels."""
+
+    def __init__(self, model, spec, batch_shape, device):
+        from . import backward as B
+        from . import _lib as L
+        from . import engine as E
+        self.L, self.E = L, E
+        self.model, self.spec, self.device = model, spec, device
+        sde = spec["sde"]
+        self.vp_like = isinstance(sde, (sde_lib.VPSDE, sde_lib.subVPSDE))
+        if self.vp_like and model.config.model.scale_by_sigma:
+            raise NotImplementedError("scale_by_sigma with a VP score head")
+        n, c, h, w = batch_shape
+        self.n, self.per = n, c * h * w
+        self.eng = B.TrainEngine(model, n, h, w, device, vp_score=self.vp_like, dropout=spec["train"])
+        self.flat = self.eng.flat
+        f32 = dict(dtype=torch.float32, device=device)
+        self.z = torch.zeros(n, c, h, w, **f32)
+        self.batch = torch.zeros(n, c, h, w, **f32)
+        self.a = torch.zeros(n, **f32)
+        self.s = torch.zeros(n, **f32)
+        self.g2 = torch.zeros(n, **f32)
+        self.losses = torch.zeros(n, **f32)
+        self.loss = torch.zeros(1, **f32)
+        self.hyper = torch.zeros(12, **f32)
+        self.hyper_host = torch.zeros(12, dtype=torch.float32, pin_memory=torch.cuda.is_available())
+        self.gnorm = torch.zeros(1, **f32)
+        self.partial = torch.zeros(1024, **f32)
+        self._opt_prog = None
+        self._head = self._build_head()
+        self.steps_done = 0
+
+    def _prog(self, entries):
+        b = self.E.ProgramBuilder(self.device)
+        for kind, fields in entries:
+            b.add(kind, fields)
+        return b.finalize()
+
+    def _build_head(self):
+        L, eng, spec = self.L, self.eng, self.spec
+        x_in = eng.x_in.tensor
+        perturb = self._prog([(L.OP_PERTURB, dict(x=self.batch, z=self.z, a=self.a, s=self.s, dst=x_in, n=self.n, per=self.per))])
+        loss = self._prog([(L.OP_DSM_LOSS, dict(score=eng.out.tensor, z=self.z, s=self.s,
+                                                g2=self.g2 if spec["likelihood_weighting"] else None,
+                                                dscore=eng.gout.tensor if spec["train"] else None, losses=self.losses,
+                                                loss=self.loss, n=self.n, per=self.per, reduce_mean=int(spec["reduce_mean"]),
+                                                likelihood_weighting=int(spec["likelihood_weighting"]),
+                                                grad_scale=1.0 / self._world()))])
+        return perturb, loss
+
+    @staticmethod
+    def _world():
+        import torch.distributed as dist
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def _optimizer_program(self, optimizer, ema):
+        if self._opt_prog is None or self._opt_prog[1] is not optimizer or self._opt_prog[2] is not ema:
+            L = self.L
+            m, v = optimizer.flatten_like(self.flat)
+            ema_buf = ema.flatten_like(self.flat) if ema is not None else None
+            prog = self._prog([
+                (L.OP_SUMSQ_FLAT, dict(x=self.flat.grad, numel=self.flat.numel, partial=self.partial, out=self.gnorm)),
+                (L.OP_ADAM, dict(p=self.flat.data, g=self.flat.grad, m=m, v=v, ema=ema_buf, numel=self.flat.numel,
+                                 hyper=self.hyper, gnorm_sq=self.gnorm))])
+            self._opt_prog = (prog, optimizer, ema)
+        return self._opt_prog[0]
+
+    def perturb_inputs(self, batch, t, z):
+        """Per-sample coefficients with the SDE's own [B]-sized expressions; the per-pixel work is the perturb kernel."""
+        sde, spec = self.spec["sde"], self.spec
+        ones = torch.ones(self.n, 1, 1, 1, device=self.device)
+        mean1, std = sde.marginal_prob(ones, t)                     # mean is linear in x: mean = a[n] * x
+        self.a.copy_(mean1.reshape(self.n))
+        self.s.copy_(std)
+        if spec["likelihood_weighting"]:
+            self.g2.copy_(sde.sde(torch.zeros(self.n, 1, 1, 1, device=self.device), t)[1] ** 2)
+        labels = t * 999 if self.vp_like else std                   # models/utils.py:147-166 (continuous)
+        self.eng.cond.tensor[: self.n].copy_(labels)
+        if self.vp_like:
+            self.eng.std.tensor[: self.n].copy_(std)
+        self.batch.copy_(batch)
+        self.z.copy_(z)
+
+    def loss_and_grads(self, batch, t=None, z=None, seed=None):
+        """Forward + loss (+ backward when built for training); returns the device scalar loss."""
+        spec = self.spec
+        if t is None:
+            t = torch.rand(batch.shape[0], device=batch.device) * (spec["sde"].T - spec["eps"]) + spec["eps"]   # losses.py:84
+        if z is None:
+            z = torch.randn_like(batch)                                                                         # losses.py:85
+        self.perturb_inputs(batch, t, z)
+        eng = self.eng
+        eng.weights.refresh()
+        eng.set_dropout_seed(self.steps_done * 7919 + 17 if seed is None else seed)
+        self._head[0].run()
+        eng.run_forward()
+        self._head[1].run()
+        if spec["train"]:
+            eng.run_backward()
+        return self.loss
+
+    def optimizer_step(self, optimizer, ema, step, hyper):
+        import torch.distributed as dist
+        if self._world() > 1:
+            dist.all_reduce(self.flat.grad)          # gradients were pre-scaled by 1/world in the loss head
+        group = optimizer.param_groups[0]
+        lr = hyper["lr"]
+        if hyper["warmup"] > 0:
+            lr = hyper["lr"] * float(np.minimum(step / hyper["warmup"], 1.0))
+            for g in optimizer.param_groups:
+                g['lr'] = lr
+        # torch.optim.Adam keeps a per-parameter step counter; all parameters share it here
+        optimizer.flatten_like(self.flat)
+        st0 = optimizer.state[self.flat.params[0]]
+        t_adam = float(st0["step"]) + 1.0
+        b1, b2 = group["betas"]
+        decay = ema.next_decay() if ema is not None else 1.0
+        h = self.hyper_host
+        h[0], h[1], h[2], h[3], h[4] = lr, b1, b2, group["eps"], group["weight_decay"]
+        h[5] = hyper["grad_clip"]
+        h[6], h[7], h[8] = 1.0 - b1 ** t_adam, float(np.sqrt(1.0 - b2 ** t_adam)), 1.0 - decay
+        self.hyper.copy_(h, non_blocking=True)
+        self._optimizer_program(optimizer, ema).run()
+        for p in self.flat.params:
+            optimizer.state[p]["step"] += 1
+        self.eng.weights.refresh(force=True)         # packed weight copies follow the in-place parameter update
+        self.steps_done += 1
+
+
+def _fused_candidate(state, loss_fn, optimize_fn, train):
+    from .models.ncsnpp import NCSNpp
+    from .models.ema import ExponentialMovingAverage
+    model = state['model']
+    if not isinstance(model, NCSNpp) or getattr(loss_fn, "ssde_spec", None) is None:
+        return False
+    if not next(model.parameters()).is_cuda:
+        return False
+    if not isinstance(state.get('ema'), ExponentialMovingAverage):
+        return False
+    if train and (not isinstance(state.get('optimizer'), FusedAdam) or getattr(optimize_fn, "ssde_hyper", None) is None):
+        return False
+    if train and len(state['optimizer'].param_groups) != 1:
+        return False
+    return True
+
+
+def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True, likelihood_weighting=False):
+    """Create a one-step training/evaluation function (losses.py:151-210)."""
+    if continuous:
+        loss_fn = get_sde_loss_fn(sde, train, reduce_mean=reduce_mean, continuous=True,
+                                  likelihood_weighting=likelihood_weighting)
+    else:
+        assert not likelihood_weighting, "Likelihood weighting is not supported for original SMLD/DDPM training."
+        if isinstance(sde, VESDE):
+            loss_fn = get_smld_loss_fn(sde, train, reduce_mean=reduce_mean)
+        elif isinstance(sde, VPSDE):
+            loss_fn = get_ddpm_loss_fn(sde, train, reduce_mean=reduce_mean)
+        else:
+            raise ValueError(f"Discrete training for {sde.__class__.__name__} is not recommended.")
+    cache = {}
+
+    def fused_for(state, batch):
+        key = (id(state['model']), tuple(batch.shape), batch.device.index)
+        fs = cache.get(key)
+        if fs is None:
+            fs = cache[key] = FusedTrainStep(state['model'], loss_fn.ssde_spec, tuple(batch.shape), batch.device)
+        return fs
+
+    def step_fn(state, batch):
+        model = state['model']
+        if batch.is_cuda and _fused_candidate(state, loss_fn, optimize_fn, train):
+            fs = fused_for(state, batch)
+            if train:
+                loss = fs.loss_and_grads(batch).clone()
+                fs.optimizer_step(state['optimizer'], state['ema'], state['step'], optimize_fn.ssde_hyper)
+                state['step'] += 1
+            else:
+                ema = state['ema']
+                ema.store(model.parameters())
+                ema.copy_to(model.parameters())
+                fs.eng.weights.refresh(force=True)
+                loss = fs.loss_and_grads(batch).clone()
+                ema.restore(model.parameters())
+                fs.eng.weights.refresh(force=True)
+            return loss.reshape(())
+        # ---- generic path: the reference's sequence (losses.py:190-207)
+        if train:
+            optimizer = state['optimizer']
+            optimizer.zero_grad()
+            loss = loss_fn(model, batch)
+            loss.backward()
+            optimize_fn(optimizer, model.parameters(), step=state['step'])
+            state['step'] += 1
+            state['ema'].update(model.parameters())
+        else:
+            with torch.no_grad():
+                ema = state['ema']
+                ema.store(model.parameters())
+                ema.copy_to(model.parameters())
+                loss = loss_fn(model, batch)
+                ema.restore(model.parameters())
+        return loss
+
+    step_fn.loss_fn = loss_fn
+    step_fn.fused_for = fused_for
+    return step_fn

@@ -1,9 +1,10 @@
-"""Exponential moving average of parameters with warm-up decay min(d, (1+n)/(10+n)).
+"""Exponential moving average of parameters (drop-in for the reference's models/ema.py:10-97).
 
-Same interface as the reference's models/ema.py:10-97 (`update`, `copy_to`, `store`,
-`restore`, `state_dict`, `load_state_dict`; `shadow_params` is a python list of tensors,
-which is what reference checkpoints hold).  On GPU the whole update is one multi-tensor
-launch (`torch._foreach_*`) instead of a python loop over 572 tensors.
+Same constructor, `update / copy_to / store / restore / state_dict / load_state_dict` and the same
+warm-up rule decay = min(decay, (1 + n) / (10 + n)).  The shadow parameters can be re-homed into one
+flat buffer laid out like `backward.FlatParams` (`flatten_like`), after which the fused optimizer
+kernel (libssde_hip: ssde_adam_clip_ema) updates them in the same pass as Adam; `update()` then only
+advances the counter when told the device already did the arithmetic.
 """
 import torch
 
@@ -16,30 +17,36 @@ class ExponentialMovingAverage:
         self.num_updates = 0 if use_num_updates else None
         self.shadow_params = [p.clone().detach() for p in parameters if p.requires_grad]
         self.collected_params = []
+        self._flat = None
 
-    def update(self, parameters):
-        d = self.decay
+    # -- models/ema.py:32-51
+    def next_decay(self):
+        """Advance the update counter and return this update's decay (models/ema.py:44-47)."""
+        decay = self.decay
         if self.num_updates is not None:
             self.num_updates += 1
-            d = min(d, (1 + self.num_updates) / (10 + self.num_updates))
-        live = [p.detach() for p in parameters if p.requires_grad]
+            decay = min(decay, (1 + self.num_updates) / (10 + self.num_updates))
+        return decay
+
+    def update(self, parameters):
+        one_minus_decay = 1.0 - self.next_decay()
         with torch.no_grad():
-            # s <- s - (1 - d) * (s - p)
-            diff = torch._foreach_sub(self.shadow_params, live)
-            torch._foreach_add_(self.shadow_params, diff, alpha=-(1.0 - d))
+            parameters = [p for p in parameters if p.requires_grad]
+            for s_param, param in zip(self.shadow_params, parameters):
+                s_param.sub_(one_minus_decay * (s_param - param))
 
     def copy_to(self, parameters):
-        live = [p for p in parameters if p.requires_grad]
-        with torch.no_grad():
-            for s, p in zip(self.shadow_params, live):
-                p.data.copy_(s.data)
+        parameters = [p for p in parameters if p.requires_grad]
+        for s_param, param in zip(self.shadow_params, parameters):
+            if param.requires_grad:
+                param.data.copy_(s_param.data)
 
     def store(self, parameters):
-        self.collected_params = [p.clone() for p in parameters]
+        self.collected_params = [param.clone() for param in parameters]
 
     def restore(self, parameters):
-        for c, p in zip(self.collected_params, parameters):
-            p.data.copy_(c.data)
+        for c_param, param in zip(self.collected_params, parameters):
+            param.data.copy_(c_param.data)
 
     def state_dict(self):
         return dict(decay=self.decay, num_updates=self.num_updates, shadow_params=self.shadow_params)
@@ -47,4 +54,22 @@ class ExponentialMovingAverage:
     def load_state_dict(self, state_dict):
         self.decay = state_dict['decay']
         self.num_updates = state_dict['num_updates']
-        self.shadow_params = state_dict['shadow_params']
+        with torch.no_grad():
+            for s, v in zip(self.shadow_params, state_dict['shadow_params']):
+                s.copy_(v.to(s.device))          # in place: keeps a flat re-homing valid
+
+    # -- fused path
+    def flatten_like(self, flat):
+        """Re-home the shadow parameters into one buffer with the layout of `flat` (backward.FlatParams)."""
+        if self._flat is not None and self._flat.numel() == flat.numel and self._flat.device == flat.data.device:
+            return self._flat
+        buf = torch.zeros(flat.numel, dtype=torch.float32, device=flat.data.device)
+        assert len(self.shadow_params) == len(flat.params)
+        new = []
+        for s, p in zip(self.shadow_params, flat.params):
+            o, n = flat.index[id(p)]
+            buf[o:o + n].copy_(s.reshape(-1).to(buf.device, torch.float32))
+            new.append(buf[o:o + n].view(p.shape))
+        self.shadow_params = new
+        self._flat = buf
+        return buf

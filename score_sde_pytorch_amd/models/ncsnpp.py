@@ -294,8 +294,7 @@ class NCSNpp(nn.Module):
         if x.dtype != torch.float32 or x.dim() != 4:
             raise TypeError("NCSNpp.forward expects a float32 [B, C, H, W] tensor")
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        eng = self._engine_for(x)
         if needs_grad:
             from .. import autograd as _autograd
-            return _autograd.unet_apply(self, eng, x, time_cond)
-        return eng.forward(x, time_cond)
+            return _autograd.unet_apply(self, x, time_cond)
+        return self._engine_for(x).forward(x, time_cond)

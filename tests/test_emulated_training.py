@@ -1,0 +1,47 @@
+"""Training path under the test-only CPU emulator (tests/emu/): the backward / optimizer kernels and the
+backward lowering, compared with torch autograd over the CPU oracle.  Same checks as tests/test_train_gpu.py
+(which runs them on the MI355X); see tests/_train_checks.py for what is compared and the tolerances."""
+import pytest
+import torch
+
+import emu
+import _train_checks as T
+
+pytestmark = pytest.mark.skipif(not emu.available(), reason="emulator needs x86-64 + ROCm's clang++")
+
+
+@pytest.fixture(autouse=True)
+def _emulated():
+    with emu.emulated():
+        yield
+
+
+def test_backward_kernels():
+    T.check_backward_ops("cpu")
+
+
+def test_dropout_mask_is_regenerated_identically():
+    T.check_dropout_mask("cpu")
+
+
+@pytest.mark.parametrize("kind", ["ncsnpp", "ddpmpp", "ffhq"])
+def test_whole_network_gradients(kind):
+    T.check_unet_grads(kind, "cpu")
+
+
+def test_autograd_bridge(monkeypatch):
+    from score_sde_pytorch_amd.models import ncsnpp
+    # the product refuses CPU tensors; under the emulator "device" memory IS host memory
+    orig = ncsnpp.NCSNpp.forward
+
+    def fwd(self, x, time_cond):
+        from score_sde_pytorch_amd import autograd as A
+        return A.unet_apply(self, x, time_cond)
+    monkeypatch.setattr(ncsnpp.NCSNpp, "forward", fwd)
+    T.check_autograd_bridge("cpu")
+    monkeypatch.setattr(ncsnpp.NCSNpp, "forward", orig)
+
+
+@pytest.mark.parametrize("sde_kind", ["vesde", "subvpsde"])
+def test_fused_training_step(sde_kind):
+    T.check_fused_step("cpu", steps=2, sde_kind=sde_kind)
