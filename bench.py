@@ -50,7 +50,89 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--dump-ops", type=str, default="")
+    ap.add_argument("--no-train", action="store_true", help="skip the DSM training-step measurement")
+    ap.add_argument("--train-batch", type=int, default=128)
+    ap.add_argument("--train-steps", type=int, default=0, help="timed training steps (0: same as --steps, capped at 10)")
+    ap.add_argument("--dump-train-ops", type=str, default="")
     return ap.parse_args()
+
+
+def bench_train(args, cfg, dev, dist, world, rank, sync_all):
+    """sec/train-step of the fused DSM step (BASELINE configs[2]): batch 128/GPU, dropout 0.1, Adam + clip + EMA,
+    one all-reduce of the flat gradient per step when world > 1."""
+    import _util
+    from score_sde_pytorch_amd import sde_lib, losses, backward as B, engine as E
+    from score_sde_pytorch_amd.models import utils as mutils, ema as ema_mod
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    _util.load_seeded(model, seed=1)
+    model = model.to(dev).train()
+    sde = sde_lib.VESDE(cfg.model.sigma_min, cfg.model.sigma_max, cfg.model.num_scales)
+    opt = losses.get_optimizer(cfg, model.parameters())
+    ema = ema_mod.ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate)
+    optimize_fn = losses.optimization_manager(cfg)
+    step_fn = losses.get_step_fn(sde, train=True, optimize_fn=optimize_fn, reduce_mean=cfg.training.reduce_mean,
+                                 continuous=True, likelihood_weighting=cfg.training.likelihood_weighting)
+    state = dict(optimizer=opt, model=model, ema=ema, step=0)
+    Bt, R = args.train_batch, cfg.data.image_size
+    torch.manual_seed(100 + rank)
+    batch = torch.rand(Bt, 3, R, R, device=dev)
+    k = args.train_steps or min(args.steps, 10)
+    w = max(1, min(args.warmup, 3))
+    for _ in range(w):
+        loss = step_fn(state, batch)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        loss = step_fn(state, batch)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    sec = dt / k
+    fs = step_fn.fused_for(state, batch)
+    eng = fs.eng
+    fl = np.array(eng.program.flops)
+    out = {"metric": "sec_per_train_step", "value": sec, "unit": "s/step", "higher_is_better": False,
+           "batch_per_gpu": Bt, "global_batch": Bt * world, "images_per_sec": world * Bt / sec, "steps": k, "warmup": w,
+           "loss": float(loss), "dropout": float(cfg.model.dropout), "path": "fused (losses.FusedTrainStep)",
+           "algorithmic_tflops": float(fl.sum()) / sec / 1e12, "gflop_per_image": float(fl.sum()) / Bt / 1e9,
+           "grad_allreduce_mb": eng.flat.numel * 4 / 1e6 if world > 1 else 0.0,
+           "arena_gb": eng.b.arena_bytes / 1e9}
+    if rank == 0 and not args.no_roofline:
+        ms = np.array(eng.program.run_range_timed(0, eng.program.n))
+        ms = np.array(eng.program.run_range_timed(0, eng.program.n))
+        cls = np.array(eng.program.classes)
+        idx = np.arange(eng.program.n)
+        by = {}
+        for name, c in [("conv3x3_fwd+dgrad", E.FC_CONV3), ("conv1x1_fwd+dgrad", E.FC_CONV1), ("wgrad", B.FC_WGRAD),
+                        ("attention", E.FC_ATTN), ("groupnorm_stats", E.FC_GN), ("upfirdn", E.FC_FIR),
+                        ("backward_elementwise", B.FC_BWD), ("other", E.FC_OTHER)]:
+            m = cls == c
+            by[name] = {"launches": int(m.sum()), "ms": float(ms[m].sum()), "gflop": float(fl[m].sum()) / 1e9}
+        out["fwd_ms_events"] = float(ms[idx < eng.n_fwd].sum())
+        out["bwd_ms_events"] = float(ms[idx >= eng.n_fwd].sum())
+        out["by_class"] = by
+        wg = cls == B.FC_WGRAD
+        out["wgrad_tflops"] = float(fl[wg].sum()) / max(float(ms[wg].sum()), 1e-9) / 1e9
+        if args.dump_train_ops:
+            rows = []
+            for i in range(eng.program.n):
+                op = eng.program.ops[i]
+                row = {"i": i, "kind": int(op.kind), "cls": int(cls[i]), "ms": float(ms[i]), "gflop": float(fl[i]) / 1e9,
+                       "bwd": bool(i >= eng.n_fwd)}
+                if op.kind == 1:
+                    c = op.u.conv
+                    row.update(h=c.h_out, w=c.w_out, cout=c.c_out, cin=c.main.c0 + c.main.c1, caux=c.aux.c0 + c.aux.c1, ks=c.ksize)
+                elif op.kind == 15:
+                    c = op.u.wgrad
+                    row.update(h=c.h_out, w=c.w_out, cout=c.c_out, cin=c.src.c0 + c.src.c1, ks=c.ksize)
+                rows.append(row)
+            with open(args.dump_train_ops, "w") as f:
+                json.dump(rows, f)
+    return out
 
 
 def main():
@@ -186,6 +268,13 @@ def main():
                                "sample": "1 PC iteration (2 U-Net evaluations) at batch %d with the torch-CPU oracle "
                                          "(oracle/sampler_oracle.py) on %d threads, extrapolated to N=%d: %.2f s per iteration"
                                          % (cb, cores, args.sde_steps, t_cpu)}
+
+    if not args.no_train:
+        # second headline quantity of BASELINE.json's metric ("... + sec/train-step"): reported inside the same JSON line
+        del sampler, eng, prog
+        torch.cuda.empty_cache()
+        tr = bench_train(args, _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous"), dev, dist, world, rank, sync_all)
+        out["train"] = tr
 
     if rank == 0:
         print(json.dumps(out))

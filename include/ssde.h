@@ -206,9 +206,14 @@ typedef struct ssde_wgrad_args {
   int32_t stride, pad;
   int32_t cin_store;       /* input channels that exist in dw (<= c0+c1: padded channels are skipped) */
   int32_t transpose_out;   /* ksize 1 only: dw is [cin_store][c_out] (NIN.W, models/layers.py:550) */
-  int32_t splits;          /* pixel-dimension split (0 = library chooses); partial sums meet by atomic add */
+  int32_t splits;          /* pixel-dimension split (0 = library chooses, bounded by scratch_floats) */
   float scale;
-  float* dw;               /* [c_out][cin_store][k][k] (OIHW) ; must be zero-initialised once per step */
+  float* dw;               /* [c_out][cin_store][k][k] (OIHW); dw += result */
+  /* split > 1: every workgroup writes its partial tile to `scratch` with coalesced stores and a second
+   * kernel sums the splits in a fixed order (deterministic, no atomics).  ssde_wgrad_scratch_floats()
+   * returns the floats needed for the split the library would choose with unlimited scratch. */
+  float* scratch;
+  int64_t scratch_floats;
 } ssde_wgrad_args;
 
 /* ---- column sums of a gradient: bias and Dense_0(temb) addend gradients ------------------- */
@@ -220,7 +225,7 @@ typedef struct ssde_colsum_args {
   int32_t ps_ld, ps_off;
   float* total;            /* [c]: scale * sum_{n,hw} g  or NULL */
   float* total2;           /* optional second destination of the same sums (Conv_1.bias and Conv_2.bias share one) */
-  float* scratch;          /* >= N*c floats when per_sample == NULL */
+  float* scratch;          /* N * (min(32, max(1, hw/64)) + 1) * c floats (pixel-slice partials + per-sample sums) */
 } ssde_colsum_args;
 
 /* ---- backward through a prologue: dx = d pro(x) / dx applied to dp ------------------------ *
@@ -361,6 +366,7 @@ int ssde_abi_version(void);
 int ssde_sizeof_op(void);             /* lets the ctypes mirror verify its layout */
 const char* ssde_last_error(void);
 int ssde_conv_lds_bytes(const ssde_conv_args* a);   /* diagnostic: LDS a launch would use */
+int64_t ssde_wgrad_scratch_floats(const ssde_wgrad_args* a);   /* scratch the preferred split needs (0: none), < 0: error */
 
 #ifdef __cplusplus
 }

@@ -108,7 +108,7 @@ class WgradArgs(C.Structure):
                 ("n", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32), ("h_out", C.c_int32), ("w_out", C.c_int32),
                 ("c_out", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("cin_store", C.c_int32), ("transpose_out", C.c_int32), ("splits", C.c_int32), ("scale", C.c_float),
-                ("dw", _fp)]
+                ("dw", _fp), ("scratch", _fp), ("scratch_floats", C.c_int64)]
 
 
 class ColsumArgs(C.Structure):
@@ -186,7 +186,8 @@ EXPORTS = ["ssde_conv2d", "ssde_groupnorm_stats", "ssde_upfirdn2d", "ssde_attent
            "ssde_program_run_timed", "ssde_graph_capture", "ssde_graph_launch", "ssde_graph_destroy",
            "ssde_abi_version", "ssde_sizeof_op", "ssde_last_error", "ssde_conv_lds_bytes",
            "ssde_conv_wgrad", "ssde_colsum", "ssde_gn_bwd_reduce", "ssde_prologue_bwd", "ssde_attention_bwd",
-           "ssde_perturb", "ssde_dsm_loss", "ssde_sumsq_flat", "ssde_adam_clip_ema", "ssde_memset", "ssde_axpy"]
+           "ssde_perturb", "ssde_dsm_loss", "ssde_sumsq_flat", "ssde_adam_clip_ema", "ssde_memset", "ssde_axpy",
+           "ssde_wgrad_scratch_floats"]
 
 _lib = None
 
@@ -218,6 +219,8 @@ def bind(lib):
                       ("ssde_axpy", AxpyArgs)]:
         getattr(lib, name).argtypes = [C.POINTER(typ), C.c_void_p]
     lib.ssde_conv_lds_bytes.argtypes = [C.POINTER(ConvArgs)]
+    lib.ssde_wgrad_scratch_floats.argtypes = [C.POINTER(WgradArgs)]
+    lib.ssde_wgrad_scratch_floats.restype = C.c_int64
     if lib.ssde_abi_version() != ABI_VERSION:
         raise SsdeError("ABI mismatch: library %d, binding %d" % (lib.ssde_abi_version(), ABI_VERSION))
     if lib.ssde_sizeof_op() != C.sizeof(Op):

@@ -199,19 +199,20 @@ class TrainEngine(E.UNetEngine):
         if mode == "sum":
             assert len(parts) == 2
             c = parts[0]["n"]
-            scratch = b.buf(n * c, name="colsum_scratch") if per is None else None
+            scratch = b.buf(n * (max(1, min(32, hw // 64)) + 1) * c, name="colsum_scratch")
             b.add(L.OP_COLSUM, dict(g=g, g_ld=g_ld, g_off=0, n=n, hw=hw, c=c, scale=float(scale), per_sample=per, ps_ld=ps_ld,
                                     ps_off=ps_off, total=self.flat.grad_view(parts[0]["param"]),
                                     total2=self.flat.grad_view(parts[1]["param"]), scratch=scratch), FC_BWD)
             return
         if not parts and per is not None:
             b.add(L.OP_COLSUM, dict(g=g, g_ld=g_ld, g_off=0, n=n, hw=hw, c=f["c_out"], scale=float(scale), per_sample=per,
-                                    ps_ld=ps_ld, ps_off=ps_off, total=None, total2=None, scratch=None), FC_BWD)
+                                    ps_ld=ps_ld, ps_off=ps_off, total=None, total2=None,
+                                    scratch=b.buf(n * (max(1, min(32, hw // 64)) + 1) * f["c_out"], name="colsum_scratch")), FC_BWD)
             return
         for i, part in enumerate(parts):
             use_per = per if (i == 0 and len(parts) == 1) else None
             assert per is None or len(parts) == 1
-            scratch = b.buf(n * part["n"], name="colsum_scratch") if use_per is None else None
+            scratch = b.buf(n * (max(1, min(32, hw // 64)) + 1) * part["n"], name="colsum_scratch")
             b.add(L.OP_COLSUM, dict(g=g, g_ld=g_ld, g_off=part["off"], n=n, hw=hw, c=part["n"], scale=float(scale),
                                     per_sample=use_per, ps_ld=ps_ld, ps_off=ps_off,
                                     total=self.flat.grad_view(part["param"]), total2=None, scratch=scratch), FC_BWD)
@@ -227,10 +228,14 @@ class TrainEngine(E.UNetEngine):
         ctot = src["c0"] + src["c1"]
         for part in meta["parts"]:
             flops = 2.0 * n * ho * wo * ksize * ksize * meta["cin_store"] * part["rows"]
-            b.add(L.OP_WGRAD, dict(src=src, g=g, g_ld=g_ld, g_off=part["row0"], n=n, h_in=h_in, w_in=w_in, h_out=ho, w_out=wo,
-                                   c_out=part["rows"], ksize=ksize, stride=stride, pad=pad, cin_store=meta["cin_store"],
-                                   transpose_out=int(part["transpose"]), splits=0, scale=float(scale),
-                                   dw=self.flat.grad_view(part["param"])), FC_WGRAD, flops)
+            fields = dict(src=src, g=g, g_ld=g_ld, g_off=part["row0"], n=n, h_in=h_in, w_in=w_in, h_out=ho, w_out=wo,
+                          c_out=part["rows"], ksize=ksize, stride=stride, pad=pad, cin_store=meta["cin_store"],
+                          transpose_out=int(part["transpose"]), splits=0, scale=float(scale),
+                          dw=self.flat.grad_view(part["param"]), scratch=None, scratch_floats=0)
+            need = self._wgrad_scratch(fields)
+            if need > 0:
+                fields.update(scratch=b.buf(need, name="wgrad_slabs"), scratch_floats=need)
+            b.add(L.OP_WGRAD, fields, FC_WGRAD, flops)
         if not (self._needs(src["p0"]) or self._needs(src["p1"])):
             return
         direct = src["pro_mode"] == L.PRO_NONE and src["p1"] is None
@@ -256,6 +261,20 @@ class TrainEngine(E.UNetEngine):
             low.conv(dst, ho, wo, ctot, aux=gsrc, w_aux=wd, resid=resid, resid_post=1, scale=scale)
         if not direct:
             self._bwd_prologue(src, dst, n, h_in * w_in)
+
+    @staticmethod
+    def _wgrad_scratch(fields):
+        """Ask the library how much slab scratch its preferred pixel split of this launch needs (shape-only query)."""
+        a = L.WgradArgs()
+        for k in ("g_ld", "g_off", "n", "h_in", "w_in", "h_out", "w_out", "c_out", "ksize", "stride", "pad", "cin_store",
+                  "transpose_out"):
+            setattr(a, k, fields[k])
+        s = fields["src"]
+        a.src.c0, a.src.c1, a.src.pro_mode, a.src.gn_groups = s["c0"], s["c1"], s["pro_mode"], s["gn_groups"]
+        r = int(L.load().ssde_wgrad_scratch_floats(C.byref(a)))
+        if r < 0:
+            L.check(r, "ssde_wgrad_scratch_floats")
+        return r
 
     def _bwd_conv(self, f):
         e = self._G.get(id(f["dst"]))

@@ -14,20 +14,23 @@ inline unsigned grid_for(size_t total, int block = 256, unsigned cap = 256 * 16)
 }
 
 // ---- column sums ------------------------------------------------------------------------------
-// grid (ceil(CL/64), N): block = 64 float4 channel lanes x 4 pixel lanes (one wave per pixel lane)
+// grid (ceil(CL/64), slices, N): block = 64 float4 channel lanes x 4 pixel lanes (one wave per pixel lane)
+// over the pixels of one slice of one sample; out row = n * slices + slice
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, int g_ld, int g_off, int hw, int c,
                                                      float scale, float* __restrict__ out, int out_ld, int out_off) {
   SSDE_LDS(smem);                                      // [4][64] float4
   float4* red = reinterpret_cast<float4*>(smem);
-  const int n = blockIdx.y;
+  const int n = blockIdx.z, slices = gridDim.y, slice = blockIdx.y;
   const int cl = blockIdx.x * 64 + (threadIdx.x & 63);
   const int pl = threadIdx.x >> 6;
   const int col = g_off + cl * 4;
+  const int per_slice = (hw + slices - 1) / slices;
+  const int p0 = slice * per_slice, p1 = min(hw, p0 + per_slice);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (cl * 4 < c && col + 4 <= g_ld) {
     const float* base = g + (size_t)n * hw * g_ld + col;
-    int px = pl;
-    for (; px + 12 < hw; px += 16) {
+    int px = p0 + pl;
+    for (; px + 12 < p1; px += 16) {
       const float4 a = *reinterpret_cast<const float4*>(base + (size_t)px * g_ld);
       const float4 b = *reinterpret_cast<const float4*>(base + (size_t)(px + 4) * g_ld);
       const float4 d = *reinterpret_cast<const float4*>(base + (size_t)(px + 8) * g_ld);
@@ -35,7 +38,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g
       s.x += (a.x + b.x) + (d.x + e.x); s.y += (a.y + b.y) + (d.y + e.y);
       s.z += (a.z + b.z) + (d.z + e.z); s.w += (a.w + b.w) + (d.w + e.w);
     }
-    for (; px < hw; px += 4) {
+    for (; px < p1; px += 4) {
       const float4 a = *reinterpret_cast<const float4*>(base + (size_t)px * g_ld);
       s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
     }
@@ -46,8 +49,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g
     const float4 a = red[threadIdx.x], b = red[threadIdx.x + 64], d = red[threadIdx.x + 128], e = red[threadIdx.x + 192];
     const float v[4] = {(a.x + b.x) + (d.x + e.x), (a.y + b.y) + (d.y + e.y), (a.z + b.z) + (d.z + e.z), (a.w + b.w) + (d.w + e.w)};
     for (int k = 0; k < 4; ++k)
-      if (cl * 4 + k < c) out[(size_t)n * out_ld + out_off + cl * 4 + k] = v[k] * scale;
+      if (cl * 4 + k < c) out[((size_t)n * slices + slice) * out_ld + out_off + cl * 4 + k] = v[k] * scale;
   }
+}
+
+// per[n, off + j] = sum_slices part[n * slices + s, j]   (fixed order)
+__global__ void colsum_slices_kernel(const float* __restrict__ part, int slices, int c, float* __restrict__ per, int ld, int off) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (j >= c) return;
+  float s = 0.f;
+  for (int i = 0; i < slices; ++i) s += part[((size_t)n * slices + i) * c + j];
+  per[(size_t)n * ld + off + j] = s;
 }
 
 // total[j] = sum_n per[n, off + j]  (fixed order: deterministic)
@@ -338,15 +350,28 @@ int src_ok(const ssde_src& s, const char* who, bool need_x) {
 extern "C" int ssde_colsum(const ssde_colsum_args* a, void* stream) {
   SSDE_REQUIRE(a && a->g && a->n > 0 && a->hw > 0 && a->c > 0, "colsum: bad args");
   SSDE_REQUIRE(a->g_ld % 4 == 0 && a->g_off % 4 == 0, "colsum: g columns must be 16-byte aligned");
-  SSDE_REQUIRE(a->per_sample || a->scratch, "colsum: per_sample or scratch needed");
   SSDE_REQUIRE(a->per_sample || a->total, "colsum: nothing to compute");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  float* per = a->per_sample ? a->per_sample : a->scratch;
+  // pixel slices: >= 64 pixels per block, at most 32 slices; scratch holds [N*slices][c] partials (+ [N][c] when
+  // no per_sample destination exists)
+  int slices = a->hw / 64;
+  if (slices > 32) slices = 32;
+  if (slices < 1) slices = 1;
+  SSDE_REQUIRE((slices == 1 && a->per_sample) || a->scratch, "colsum: scratch of N*(slices+1)*c floats needed (slices=%d)", slices);
+  float* per = a->per_sample ? a->per_sample : a->scratch + (size_t)a->n * slices * a->c;
   const int ld = a->per_sample ? a->ps_ld : a->c, off = a->per_sample ? a->ps_off : 0;
   const int cl = ssde_cdiv(a->c, 4);
-  hipLaunchKernelGGL(colsum_kernel, dim3(ssde_cdiv(cl, 64), a->n), dim3(256), 4 * 64 * 16, st,
-                     a->g, a->g_ld, a->g_off, a->hw, a->c, a->scale, per, ld, off);
-  SSDE_LAUNCH_CHECK();
+  if (slices == 1) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(ssde_cdiv(cl, 64), 1, a->n), dim3(256), 4 * 64 * 16, st,
+                       a->g, a->g_ld, a->g_off, a->hw, a->c, a->scale, per, ld, off);
+    SSDE_LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL(colsum_kernel, dim3(ssde_cdiv(cl, 64), slices, a->n), dim3(256), 4 * 64 * 16, st,
+                       a->g, a->g_ld, a->g_off, a->hw, a->c, a->scale, a->scratch, a->c, 0);
+    SSDE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_slices_kernel, dim3(ssde_cdiv(a->c, 256), a->n), dim3(256), 0, st, a->scratch, slices, a->c, per, ld, off);
+    SSDE_LAUNCH_CHECK();
+  }
   if (a->total) {
     hipLaunchKernelGGL(colsum_total_kernel, dim3(ssde_cdiv(a->c, 256)), dim3(256), 0, st, per, ld, off, a->n, a->c, a->total, a->total2);
     SSDE_LAUNCH_CHECK();

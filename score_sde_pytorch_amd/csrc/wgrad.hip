@@ -4,10 +4,13 @@
 //   dw[co, ci, tap] += scale * sum_{pixels m} g[m, co] * pro(src)[m (+) tap, ci]
 //
 // This is a GEMM whose reduction dimension is the pixel index (N*H*W: 1e5 at batch 128), so it is
-// split over workgroups along pixels; partial tiles meet in dw by fp32 atomic add (dw is zeroed once
-// per step together with the whole flat gradient buffer).  pro(src) -- GroupNorm apply, SiLU and the
-// train-mode dropout mask -- is RECOMPUTED while the halo tile is staged, exactly as the forward
-// kernel does (conv_mfma.hip), so the normalised / activated tensor is never stored for backward.
+// split over workgroups along pixels.  Every workgroup writes its partial tile to a scratch slab with
+// coalesced stores (lane = input channel) and a second kernel sums the slabs in a fixed order into dw
+// (deterministic; a first version met in dw by fp32 atomics and spent 75% of its time in them).
+// Workgroups that share pixels (same split, different tile) are placed on the same XCD.
+// pro(src) -- GroupNorm apply, SiLU and the train-mode dropout mask -- is RECOMPUTED while the halo
+// tile is staged, exactly as the forward kernel does (conv_mfma.hip), so the normalised / activated
+// tensor is never stored for backward.
 //
 // Workgroup (4 waves) = BCO x BCI x T accumulators: T = 9 taps -> 64 x 64 (each wave one 32x32 block
 // per tap, 144 accumulator registers); T = 1 -> 128 x 128 (each wave 2x2 blocks).  Per pixel chunk
@@ -31,10 +34,11 @@ struct WgParams {
   int stride, pad;
   int lTW, lTH, lPX;
   int tiles_x, tiles_per_img, chunks, chunks_per_split;
-  int co_tiles, ci_tiles;
+  int co_tiles, ci_tiles, splits;
   int transpose_out;
   float scale;
   float* dw;
+  float* scratch;
 };
 
 template <int KS, int CO_B, int CI_B>
@@ -48,8 +52,12 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(const WgParams p) {
   const int li = lane & 31, lh = lane >> 5;
   const int wco = wave >> 1, wci = wave & 1;
 
+  // XCD-aware order: the tiles of one pixel split are consecutive on ONE XCD (blocks are dispatched
+  // round-robin over the 8 XCDs), so a split's gradient rows / halo are fetched into one L2 only
   const int ntiles = p.co_tiles * p.ci_tiles;
-  const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
+  const int xcd = blockIdx.x & 7, lin = blockIdx.x >> 3;
+  const int tile = lin % ntiles, split = (lin / ntiles) * 8 + xcd;
+  if (split >= p.splits) return;
   const int co0 = (tile / p.ci_tiles) * BCO, ci0 = (tile % p.ci_tiles) * BCI;
   const int ch_begin = split * p.chunks_per_split;
   const int ch_end = min(p.chunks, ch_begin + p.chunks_per_split);
@@ -176,50 +184,100 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(const WgParams p) {
   }
 
   // ---- epilogue: lane owns input channel ci (column), 16 output channels (rows) per block ----
-  if (ch_begin >= ch_end) return;
+  if (p.splits == 1) {
 #pragma unroll
-  for (int b = 0; b < CI_B; ++b) {
-    const int ci = ci0 + wci * (CI_B * 32) + b * 32 + li;
-    if (ci >= p.cin_store) continue;
+    for (int b = 0; b < CI_B; ++b) {
+      const int ci = ci0 + wci * (CI_B * 32) + b * 32 + li;
+      if (ci >= p.cin_store) continue;
+#pragma unroll
+      for (int a = 0; a < CO_B; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + wco * (CO_B * 32) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (co >= p.Cout) continue;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const size_t idx = p.transpose_out ? (size_t)ci * p.Cout + co : ((size_t)co * p.cin_store + ci) * T + t;
+            p.dw[idx] += acc[t][a][b][r] * p.scale;
+          }
+        }
+    }
+    return;
+  }
+  // partial slab [split][tile][tap][BCO][BCI]: consecutive lanes -> consecutive ci (128-byte runs)
+  float* slab = p.scratch + ((size_t)split * ntiles + tile) * (size_t)(T * BCO * BCI);
+#pragma unroll
+  for (int t = 0; t < T; ++t)
 #pragma unroll
     for (int a = 0; a < CO_B; ++a)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wco * (CO_B * 32) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (co >= p.Cout) continue;
+      for (int b = 0; b < CI_B; ++b)
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const size_t idx = p.transpose_out ? (size_t)ci * p.Cout + co : ((size_t)co * p.cin_store + ci) * T + t;
-          unsafeAtomicAdd(p.dw + idx, acc[t][a][b][r] * p.scale);
+        for (int r = 0; r < 16; ++r) {
+          const int col = wco * (CO_B * 32) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          slab[((size_t)t * BCO + col) * BCI + wci * (CI_B * 32) + b * 32 + li] = acc[t][a][b][r];
         }
-      }
+}
+
+// dw[co, ci, tap] += scale * sum_splits slab[split][tile][tap][co_l][ci_l]; thread = one (tile, tap, co_l, ci_l)
+template <int T, int BCO, int BCI>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgParams p) {
+  const int ntiles = p.co_tiles * p.ci_tiles;
+  const size_t per_tile = (size_t)T * BCO * BCI;
+  const size_t total = per_tile * ntiles;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int tile = (int)(idx / per_tile);
+    const size_t rem = idx - (size_t)tile * per_tile;
+    const int ci_l = (int)(rem % BCI);
+    const int co_l = (int)((rem / BCI) % BCO);
+    const int t = (int)(rem / ((size_t)BCI * BCO));
+    const int co = (tile / p.ci_tiles) * BCO + co_l, ci = (tile % p.ci_tiles) * BCI + ci_l;
+    if (co >= p.Cout || ci >= p.cin_store) continue;
+    float s0 = 0.f, s1 = 0.f;
+    int sp = 0;
+    for (; sp + 1 < p.splits; sp += 2) {
+      s0 += p.scratch[(size_t)sp * total + idx];
+      s1 += p.scratch[(size_t)(sp + 1) * total + idx];
+    }
+    if (sp < p.splits) s0 += p.scratch[(size_t)sp * total + idx];
+    const size_t o = p.transpose_out ? (size_t)ci * p.Cout + co : ((size_t)co * p.cin_store + ci) * T + t;
+    p.dw[o] += (s0 + s1) * p.scale;
   }
 }
 
 template <int KS, int CO_B, int CI_B>
-int launch(const WgParams& p, int splits, int lds_bytes, hipStream_t st) {
+int launch(const WgParams& p, int lds_bytes, hipStream_t st) {
+  constexpr int BCO = 2 * CO_B * 32, BCI = 2 * CI_B * 32;
   auto kfn = wgrad_kernel<KS, CO_B, CI_B>;
   static bool attr_set = false;   // once per instantiation, before any stream capture
   if (!attr_set) {
     SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kfn, dim3(p.co_tiles * p.ci_tiles * splits), dim3(kThreads), lds_bytes, st, p);
+  const int ntiles = p.co_tiles * p.ci_tiles;
+  hipLaunchKernelGGL(kfn, dim3(ssde_cdiv(p.splits, 8) * 8 * ntiles), dim3(kThreads), lds_bytes, st, p);
   SSDE_LAUNCH_CHECK();
+  if (p.splits > 1) {
+    const size_t total = (size_t)KS * KS * BCO * BCI * ntiles;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((wgrad_reduce_kernel<KS * KS, BCO, BCI>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    SSDE_LAUNCH_CHECK();
+  }
   return SSDE_OK;
 }
 
 int pow2_floor(int v) { int q = 1; while (q * 2 <= v) q *= 2; return q; }
 
-}  // namespace
+struct WgPlan { WgParams p; int lds; int64_t slab_floats; int pref_splits; };
 
-extern "C" int ssde_conv_wgrad(const ssde_wgrad_args* a, void* stream) {
-  SSDE_REQUIRE(a && a->g && a->dw && a->src.p0, "wgrad: null args");
+int make_plan(const ssde_wgrad_args* a, WgPlan* pl) {
+  SSDE_REQUIRE(a && a->ksize != 0, "wgrad: null args");
   SSDE_REQUIRE(a->ksize == 3 || a->ksize == 1, "wgrad: ksize must be 1 or 3");
   SSDE_REQUIRE(a->stride == 1 || a->stride == 2, "wgrad: stride must be 1 or 2");
   const ssde_src& s = a->src;
   const int Ctot = s.c0 + s.c1;
-  SSDE_REQUIRE(s.c0 > 0 && s.c0 % 4 == 0 && s.c1 % 4 == 0 && (s.c1 == 0 || s.p1), "wgrad: source channels must be multiples of 4");
+  SSDE_REQUIRE(s.c0 > 0 && s.c0 % 4 == 0 && s.c1 % 4 == 0, "wgrad: source channels must be multiples of 4");
   SSDE_REQUIRE(a->cin_store > 0 && a->cin_store <= Ctot, "wgrad: cin_store %d outside 1..%d", a->cin_store, Ctot);
   SSDE_REQUIRE(a->g_ld % 4 == 0 && a->g_off % 4 == 0 && a->g_off + a->c_out <= a->g_ld + 3, "wgrad: bad g columns");
   SSDE_REQUIRE(a->n > 0 && a->h_out > 0 && a->w_out > 0 && a->c_out > 0, "wgrad: bad shape");
@@ -227,17 +285,14 @@ extern "C" int ssde_conv_wgrad(const ssde_wgrad_args* a, void* stream) {
   if (a->ksize == 1) SSDE_REQUIRE(a->h_in == a->h_out && a->w_in == a->w_out && a->stride == 1 && a->pad == 0, "wgrad: 1x1 geometry");
   else SSDE_REQUIRE((a->h_in + 2 * a->pad - 3) / a->stride + 1 >= a->h_out && (a->w_in + 2 * a->pad - 3) / a->stride + 1 >= a->w_out,
                     "wgrad: output larger than the convolution produces");
-  if (s.pro_mode == SSDE_PRO_GN || s.pro_mode == SSDE_PRO_GN_SILU) {
+  if (s.pro_mode == SSDE_PRO_GN || s.pro_mode == SSDE_PRO_GN_SILU)
     SSDE_REQUIRE(s.gn_groups > 0 && Ctot % s.gn_groups == 0 && (Ctot / s.gn_groups) % 4 == 0, "wgrad: GroupNorm channels-per-group %% 4");
-    SSDE_REQUIRE(s.gn_mean && s.gn_rstd && s.gn_gamma && s.gn_beta, "wgrad: GroupNorm pointers missing");
-  }
-  SSDE_REQUIRE(s.drop_thresh == 0 || s.drop_seed, "wgrad: dropout seed pointer missing");
-
-  WgParams p;
+  WgParams& p = pl->p;
   p.src = s; p.g = a->g; p.g_ld = a->g_ld; p.g_off = a->g_off;
   p.N = a->n; p.Hin = a->h_in; p.Win = a->w_in; p.Hout = a->h_out; p.Wout = a->w_out;
   p.Cout = a->c_out; p.Ctot = Ctot; p.cin_store = a->cin_store;
   p.stride = a->stride; p.pad = a->pad; p.transpose_out = a->transpose_out; p.scale = a->scale; p.dw = a->dw;
+  p.scratch = a->scratch;
   const int hw = a->h_out * a->w_out;
   int px;
   if (a->ksize == 1) px = 64;
@@ -255,22 +310,46 @@ extern "C" int ssde_conv_wgrad(const ssde_wgrad_args* a, void* stream) {
   p.co_tiles = ssde_cdiv(a->c_out, bco);
   p.ci_tiles = ssde_cdiv(a->cin_store, bci);
   const int ntiles = p.co_tiles * p.ci_tiles;
-  int splits = a->splits;
-  if (splits <= 0) {
-    // ~2 workgroups per CU, but never less than 2 chunks per workgroup (the epilogue's atomics must amortise)
-    splits = ssde_cdiv(512, ntiles);
-    const int max_splits = p.chunks >= 2 ? p.chunks / 2 : 1;
-    if (splits > max_splits) splits = max_splits;
-  }
-  if (splits > p.chunks) splits = p.chunks;
+  pl->slab_floats = (int64_t)a->ksize * a->ksize * bco * bci * ntiles;
+  // ~2 workgroups per CU; a split costs one slab write + read, so keep >= 2 chunks per workgroup
+  int splits = ssde_cdiv(512, ntiles);
+  const int max_splits = p.chunks >= 2 ? p.chunks / 2 : 1;
+  if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
+  pl->pref_splits = splits;
+  if (a->splits > 0) splits = a->splits;
+  if (splits > p.chunks) splits = p.chunks;
+  if (splits > 1 && a->scratch_floats < pl->slab_floats * splits) {
+    splits = (int)(a->scratch_floats / pl->slab_floats);     // fewer, longer workgroups when scratch is short
+    if (splits < 1) splits = 1;
+  }
   p.chunks_per_split = ssde_cdiv(p.chunks, splits);
-  splits = ssde_cdiv(p.chunks, p.chunks_per_split);
+  p.splits = ssde_cdiv(p.chunks, p.chunks_per_split);
   const int ks = a->ksize;
   const int halo = imgs * ((th - 1) * a->stride + ks) * ((tw - 1) * a->stride + ks);
-  const int lds = (px * bco + halo * bci) * 4;
-  SSDE_REQUIRE(lds <= 160 * 1024, "wgrad: %d bytes of LDS needed", lds);
+  pl->lds = (px * bco + halo * bci) * 4;
+  SSDE_REQUIRE(pl->lds <= 160 * 1024, "wgrad: %d bytes of LDS needed", pl->lds);
+  return SSDE_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t ssde_wgrad_scratch_floats(const ssde_wgrad_args* a) {
+  WgPlan pl;
+  if (int rc = make_plan(a, &pl)) return rc;
+  return pl.pref_splits > 1 ? pl.slab_floats * pl.pref_splits : 0;
+}
+
+extern "C" int ssde_conv_wgrad(const ssde_wgrad_args* a, void* stream) {
+  WgPlan pl;
+  if (int rc = make_plan(a, &pl)) return rc;
+  const ssde_src& s = a->src;
+  SSDE_REQUIRE(a->g && a->dw && s.p0 && (s.c1 == 0 || s.p1), "wgrad: null tensors");
+  if (s.pro_mode == SSDE_PRO_GN || s.pro_mode == SSDE_PRO_GN_SILU)
+    SSDE_REQUIRE(s.gn_mean && s.gn_rstd && s.gn_gamma && s.gn_beta, "wgrad: GroupNorm pointers missing");
+  SSDE_REQUIRE(s.drop_thresh == 0 || s.drop_seed, "wgrad: dropout seed pointer missing");
+  SSDE_REQUIRE(pl.p.splits == 1 || a->scratch, "wgrad: scratch missing");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (a->ksize == 3) return launch<3, 1, 1>(p, splits, lds, st);
-  return launch<1, 2, 2>(p, splits, lds, st);
+  if (a->ksize == 3) return launch<3, 1, 1>(pl.p, pl.lds, st);
+  return launch<1, 2, 2>(pl.p, pl.lds, st);
 }

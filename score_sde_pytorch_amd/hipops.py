@@ -193,8 +193,25 @@ def conv_wgrad(x, g, ksize, dw, stride=1, pad=1, x2=None, pro=L.PRO_NONE, gn=Non
     a.ksize, a.stride, a.pad = ksize, stride, pad
     a.cin_store = cin_store if cin_store is not None else ctot
     a.transpose_out, a.splits, a.scale, a.dw = int(transpose_out), splits, scale, _p(dw)
+    a.splits = 0
+    need = wgrad_scratch_floats(a)       # slabs of the library's preferred split
+    a.splits = splits
+    if splits > 1:                       # explicit split (tests): a slab is at most one padded copy of dw per tile grid
+        bt = 64 if ksize == 3 else 128
+        slab = ksize * ksize * (-(-a.c_out // bt) * bt) * (-(-a.cin_store // bt) * bt)
+        need = max(need, slab * splits)
+    scratch = torch.empty(max(int(need), 1), device=x.device)
+    a.scratch, a.scratch_floats = _p(scratch), scratch.numel()
     L.check(L.load().ssde_conv_wgrad(C.byref(a), _stream()), "ssde_conv_wgrad")
     return dw
+
+
+def wgrad_scratch_floats(a):
+    """Floats of scratch the library's preferred pixel split of this weight-gradient launch needs (host-side query)."""
+    r = int(L.load().ssde_wgrad_scratch_floats(C.byref(a)))
+    if r < 0:
+        L.check(r, "ssde_wgrad_scratch_floats")
+    return r
 
 
 def colsum(g, c=None, g_off=0, scale=1.0, per_sample=None, ps_off=0, total=None, total2=None):
@@ -205,14 +222,16 @@ def colsum(g, c=None, g_off=0, scale=1.0, per_sample=None, ps_off=0, total=None,
     a.g, a.g_ld, a.g_off, a.n, a.hw = _p(g), g.shape[-1], g_off, n, hw
     a.c = c if c is not None else g.shape[-1] - g_off
     a.scale = scale
-    scratch = None
     if per_sample is not None:
         a.per_sample, a.ps_ld, a.ps_off = _p(per_sample), per_sample.shape[-1], ps_off
-    else:
-        scratch = torch.empty(n * a.c, device=g.device)
-        a.scratch = _p(scratch)
+    scratch = torch.empty(n * (colsum_slices(hw) + 1) * a.c, device=g.device)
+    a.scratch = _p(scratch)
     a.total, a.total2 = _p(total), _p(total2)
     L.check(L.load().ssde_colsum(C.byref(a), _stream()), "ssde_colsum")
+
+
+def colsum_slices(hw):
+    return max(1, min(32, hw // 64))
 
 
 def gn_backward(x, dp, gn, pro, x2=None, dropout=None, slices=1, scale=1.0, acc=(False, False), want=(True, True)):
