@@ -89,7 +89,10 @@ typedef struct ssde_conv_args {
   float* dst;            /* [N, h_out, w_out, c_out]                       */
 } ssde_conv_args;
 
-enum { SSDE_TILE_AUTO = 0, SSDE_TILE_256x64 = 1, SSDE_TILE_128x64 = 2, SSDE_TILE_64x64 = 3, SSDE_TILE_256x32 = 4 };
+enum { SSDE_TILE_AUTO = 0, SSDE_TILE_256x64 = 1, SSDE_TILE_128x64 = 2, SSDE_TILE_64x64 = 3, SSDE_TILE_256x32 = 4,
+       /* Winograd F(2x2,3x3) kernel (3x3, stride 1, pad 1, even output, no aux): w_main must then be packed as
+        * [ceil(Cin/8)][ceil(Cout/64)][16 positions][4 channel pairs][64 couts, bit 4 ^= pair parity][2], G g G^T */
+       SSDE_TILE_WINOGRAD = 5 };
 
 /* ---- GroupNorm statistics: mean / rstd per (sample, group) -----------------
  * replaces the reduction half of nn.GroupNorm(min(C/4,32), C, eps=1e-6)

@@ -96,6 +96,7 @@ class TrainEngine(E.UNetEngine):
         self._G = {}
         self._lower_backward()
         self.program = self.b.finalize()
+        self.n_fwd = self.program.spec_start[self.n_fwd]      # spec count -> op count
         self.n_bwd = self.program.n - self.n_fwd
 
     # ------------------------------------------------------------------ helpers
@@ -247,9 +248,12 @@ class TrainEngine(E.UNetEngine):
             dst, resid = b.buf(n, h_in, w_in, ctot, name="dP"), None
         gsrc = _src(g, g_ld)
         if ksize == 3:
-            wd = self.weights.derived(wpacked, lambda w: E.pack_conv_weight(w.permute(1, 0, 2, 3).flip(2, 3)), "dgrad")
+            wino = stride == 1 and low.wino_ok(h_in, w_in, ctot, g_ld)
+            pack = E.pack_wino_weight if wino else E.pack_conv_weight
+            wd = self.weights.derived(wpacked, lambda w: pack(w.permute(1, 0, 2, 3).flip(2, 3)), "dgrad_wino" if wino else "dgrad")
             if stride == 1:
-                low.conv(dst, h_in, w_in, ctot, main=gsrc, w_main=wd, h_in=ho, w_in=wo, stride=1, pad=1, resid=resid, resid_post=1, scale=scale)
+                low.conv(dst, h_in, w_in, ctot, main=gsrc, w_main=wd, h_in=ho, w_in=wo, stride=1, pad=1, resid=resid,
+                         resid_post=1, scale=scale, wino=wino)
             else:
                 # transposed strided conv = zero-insertion (upfirdn, up=2, 1x1 kernel) + stride-1 conv with pad 2, cropped
                 assert stride == 2 and pad == 0

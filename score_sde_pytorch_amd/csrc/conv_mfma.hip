@@ -357,6 +357,7 @@ int make_plan(const ssde_conv_args* a, ConvPlan* pl) {
     if (a->w_out * a->h_out * a->n < kTiles[tile].bm && tile != SSDE_TILE_256x32) tile = SSDE_TILE_64x64;
   }
   SSDE_REQUIRE(tile >= 1 && tile <= 4, "conv: bad tile id %d", tile);
+  (void)SSDE_TILE_WINOGRAD;
   int lTW = 0, lTH = 0;
   if (pl->has3) {
     // the halo of the chosen tile must fit the per-thread staging plan (5 x 256 float4 items)
@@ -423,6 +424,7 @@ int launch_cfg(const ConvPlan& pl, hipStream_t st) {
 }  // namespace
 
 extern "C" int ssde_conv2d(const ssde_conv_args* a, void* stream) {
+  if (a && a->tile == SSDE_TILE_WINOGRAD) return ssde_conv_wino_launch(a, stream, nullptr);
   ConvPlan pl;
   if (int rc = make_plan(a, &pl)) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -437,6 +439,11 @@ extern "C" int ssde_conv2d(const ssde_conv_args* a, void* stream) {
 }
 
 extern "C" int ssde_conv_lds_bytes(const ssde_conv_args* a) {
+  if (a && a->tile == SSDE_TILE_WINOGRAD) {
+    int lds = 0;
+    if (int rc = ssde_conv_wino_launch(a, nullptr, &lds)) return rc;
+    return lds;
+  }
   ConvPlan pl;
   if (int rc = make_plan(a, &pl)) return rc;
   return pl.lds_bytes;

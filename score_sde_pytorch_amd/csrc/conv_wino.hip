@@ -1,0 +1,326 @@
+// 3x3 / stride 1 / pad 1 convolution by Winograd F(2x2, 3x3) on the exact-fp32 matrix pipe.
+//
+//   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A          (Lavin & Gray; the fp32 algorithm cuDNN / MIOpen
+//                                                          also pick for these layers in the reference)
+// Per 2x2 output tile and (ci, co) pair the 36 multiply-adds of the direct form become 16: the 3x3
+// layers are 90% of the network's FLOPs, so the matrix pipe -- the bound of the direct
+// kernel (conv_mfma.hip) -- does 2.25x less work.  Everything stays fp32; the transforms only add
+// and halve, so the result differs from the direct sum by fp32 rounding (tests: same tolerance).
+//
+// One workgroup (4 waves, one per SIMD, 256 accumulator registers per lane) owns 64 tiles (a 16x16
+// output patch, or 8x8 patches of 4 images, or 4x4 of 16) x 64 output channels x all 16 transform
+// positions.  Per 8-input-channel stage:
+//   raw halo (with the fused GroupNorm / SiLU / dropout prologue)  -> LDS, channel-pair major
+//   input transform B^T d B, one (tile, channel pair) per thread   -> LDS V[pos][pair][tile][2]
+//   host-transformed weights G g G^T, pre-arranged as the LDS image -> LDS U[pos][pair][cout][2]
+//   16 positions x (32 tiles x 32 couts per wave) on v_mfma_f32_16x16x4_f32: a lane's ds_read_b64 is the
+//   channel pair (2q, 2q+1), q = lane >> 4 = the MFMA k index, so one read feeds two MFMAs
+// V/U stages are double buffered; tile / cout index bit 4 is XOR-swizzled with the pair's parity so
+// the b64 fragment reads of a 32-lane group cover all 64 banks.  The accumulator layout of the 16x16
+// MFMA keeps all 16 positions of a (tile, cout) in ONE lane, so the output transform A^T M A is
+// register-local; the epilogue (bias, temb addend, residual, scale) is the direct kernel's.
+#include "ssde_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kStageFloats = 16 * 4 * 64 * 2;     // one V or U stage: [pos][pair][64][2]
+constexpr int kMaxRaw = 5;                        // raw float4 items per thread per stage
+
+struct WinoParams {
+  ssde_src src;
+  const float* wpk;        // [ceil(C/8)][n_tiles][16][4][64][2] (LDS image per stage)
+  int N, H, W, Cout;
+  int lTWt, lTHt;          // log2 tiles per patch row / column
+  int tiles_x, tiles_per_img, m_tiles, n_tiles;
+  const float* bias; const float* chan_add; int chan_add_ld;
+  const float* resid; int resid_post;
+  float scale;
+  float* dst;
+};
+
+__global__ __launch_bounds__(kThreads, 1) void conv_wino_kernel(const WinoParams p) {
+  SSDE_LDS(smem);
+  float* Vb = smem;                          // [2][kStageFloats]
+  float* Ub = smem + 2 * kStageFloats;       // [2][kStageFloats]
+  float* raw = smem + 4 * kStageFloats;      // [4 pairs][halo_px][2]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lq = lane >> 4;
+
+  // XCD-aware order (as conv_mfma.hip): the cout tiles of one pixel tile run on one XCD
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, l = bid >> 3;
+  const int nt = l % p.n_tiles;
+  const int mt = (l / p.n_tiles) * 8 + xcd;
+  if (mt >= p.m_tiles) return;
+
+  const int TWt = 1 << p.lTWt, THt = 1 << p.lTHt;       // tiles per patch row / column
+  const int IMGS = 64 >> (p.lTWt + p.lTHt);
+  const int HWd = 2 * TWt + 2, HH = 2 * THt + 2;
+  const int halo_px = IMGS * HH * HWd;
+  const int img0 = (mt / p.tiles_per_img) * IMGS;
+  const int trem = mt % p.tiles_per_img;
+  const int ty = trem / p.tiles_x, tx = trem % p.tiles_x;
+  const int n0 = nt * 64;
+
+  const ssde_src& s = p.src;
+  const int Ctot = s.c0 + s.c1;
+  const int nst = (Ctot + 7) >> 3;
+  const SsdePro pro = ssde_pro_decode(s);
+  const int cpg = pro.gn ? Ctot / s.gn_groups : 1;
+
+  // ---- per-thread raw staging plan: item = (halo pixel, channel half) ----
+  int goff[kMaxRaw], gimg[kMaxRaw];
+#pragma unroll
+  for (int it = 0; it < kMaxRaw; ++it) {
+    const int q = tid + it * kThreads;
+    goff[it] = -2; gimg[it] = 0;
+    if (q < halo_px * 2) {
+      const int hp = q >> 1;
+      const int il = hp / (HH * HWd);
+      const int rem = hp - il * (HH * HWd);
+      const int hy = rem / HWd, hx = rem - hy * HWd;
+      const int iy = ty * 2 * THt - 1 + hy, ix = tx * 2 * TWt - 1 + hx;
+      const int img = img0 + il;
+      const bool inb = img < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      goff[it] = inb ? (img * p.H + iy) * p.W + ix : -1;
+      gimg[it] = img;
+    }
+  }
+  // transform item: this thread's tile and channel pair
+  const int t_tile = tid & 63, t_pair = tid >> 6;
+  int t_base;
+  {
+    const int il = t_tile >> (p.lTWt + p.lTHt);
+    const int tr = (t_tile >> p.lTWt) & (THt - 1), tc = t_tile & (TWt - 1);
+    t_base = (il * HH + 2 * tr) * HWd + 2 * tc;
+  }
+  const int t_vcol = ((t_tile ^ ((t_pair & 1) << 4)) + t_pair * 64) * 2;
+
+  float4 rv[kMaxRaw];
+  float4 uv[8];
+  float mu[kMaxRaw], rs[kMaxRaw];
+  float4 gam = make_float4(1.f, 1.f, 1.f, 1.f), bet = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool chan_ok = false;
+  int c_cur = 0;
+
+  auto load_stage = [&](int st) {
+    const int c_base = st * 8;
+    c_cur = c_base;
+    const float* base; int C, cc;
+    if (c_base < s.c0) { base = s.p0; C = s.c0; cc = c_base; } else { base = s.p1; C = s.c1; cc = c_base - s.c0; }
+    const int half = tid & 1;
+    const int cthr = cc + half * 4;
+    chan_ok = cthr < C;
+#pragma unroll
+    for (int it = 0; it < kMaxRaw; ++it) {
+      rv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (goff[it] >= 0 && chan_ok) rv[it] = *reinterpret_cast<const float4*>(base + (size_t)goff[it] * C + cthr);
+    }
+    const float4* wsrc = reinterpret_cast<const float4*>(p.wpk + ((size_t)st * p.n_tiles + nt) * kStageFloats);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) uv[it] = wsrc[tid + it * kThreads];
+#pragma unroll
+    for (int it = 0; it < kMaxRaw; ++it) { mu[it] = 0.f; rs[it] = 1.f; }
+    if (pro.gn && (c_base + half * 4) < Ctot) {
+      gam = *reinterpret_cast<const float4*>(s.gn_gamma + c_base + half * 4);
+      bet = *reinterpret_cast<const float4*>(s.gn_beta + c_base + half * 4);
+      const int gidx = (c_base + half * 4) / cpg;
+#pragma unroll
+      for (int it = 0; it < kMaxRaw; ++it)
+        if (goff[it] >= 0) {
+          mu[it] = s.gn_mean[gimg[it] * s.gn_groups + gidx];
+          rs[it] = s.gn_rstd[gimg[it] * s.gn_groups + gidx];
+        }
+    }
+  };
+  // prologue + raw LDS store (channel-pair major), weights -> U stage
+  auto store_stage = [&](float* Un) {
+    const int half = tid & 1;
+#pragma unroll
+    for (int it = 0; it < kMaxRaw; ++it) {
+      if (goff[it] == -2) continue;
+      float4 v = rv[it];
+      if (goff[it] >= 0 && chan_ok)
+        v = ssde_pro_apply(v, mu[it], rs[it], gam, bet, (uint32_t)goff[it] * (uint32_t)Ctot + (uint32_t)(c_cur + half * 4), pro);
+      const int hp = (tid + it * kThreads) >> 1;
+      *reinterpret_cast<float2*>(raw + ((2 * half) * halo_px + hp) * 2) = make_float2(v.x, v.y);
+      *reinterpret_cast<float2*>(raw + ((2 * half + 1) * halo_px + hp) * 2) = make_float2(v.z, v.w);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) reinterpret_cast<float4*>(Un)[tid + it * kThreads] = uv[it];
+  };
+  // V = B^T d B for this thread's (tile, channel pair), both channels at once
+  auto transform = [&](float* Vn) {
+    const float* rp = raw + (t_pair * halo_px + t_base) * 2;
+    float2 d[4][4];
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+      for (int x = 0; x < 4; ++x) d[y][x] = *reinterpret_cast<const float2*>(rp + (y * HWd + x) * 2);
+    float2 r[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      r[0][x] = make_float2(d[0][x].x - d[2][x].x, d[0][x].y - d[2][x].y);
+      r[1][x] = make_float2(d[1][x].x + d[2][x].x, d[1][x].y + d[2][x].y);
+      r[2][x] = make_float2(d[2][x].x - d[1][x].x, d[2][x].y - d[1][x].y);
+      r[3][x] = make_float2(d[1][x].x - d[3][x].x, d[1][x].y - d[3][x].y);
+    }
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      const float2 v0 = make_float2(r[y][0].x - r[y][2].x, r[y][0].y - r[y][2].y);
+      const float2 v1 = make_float2(r[y][1].x + r[y][2].x, r[y][1].y + r[y][2].y);
+      const float2 v2 = make_float2(r[y][2].x - r[y][1].x, r[y][2].y - r[y][1].y);
+      const float2 v3 = make_float2(r[y][1].x - r[y][3].x, r[y][1].y - r[y][3].y);
+      *reinterpret_cast<float2*>(Vn + (y * 4 + 0) * 512 + t_vcol) = v0;
+      *reinterpret_cast<float2*>(Vn + (y * 4 + 1) * 512 + t_vcol) = v1;
+      *reinterpret_cast<float2*>(Vn + (y * 4 + 2) * 512 + t_vcol) = v2;
+      *reinterpret_cast<float2*>(Vn + (y * 4 + 3) * 512 + t_vcol) = v3;
+    }
+  };
+
+  f32x4 acc[16][2][2];
+#pragma unroll
+  for (int ps = 0; ps < 16; ++ps)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ps][a][b][r] = 0.f;
+
+  // fragment column offsets inside a [pos] slab of 512 floats: ((pair q) * 64 + (index ^ swizzle)) * 2
+  const int tb0 = (wave >> 1) * 32, cb0 = (wave & 1) * 32;
+  const int swz = (lq & 1) << 4;
+  int aoff[2], boff[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) aoff[a] = (lq * 64 + ((tb0 + a * 16 + li) ^ swz)) * 2;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) boff[b] = (lq * 64 + ((cb0 + b * 16 + li) ^ swz)) * 2;
+
+  // ---- pipeline prologue: stage 0 ----
+  load_stage(0);
+  store_stage(Ub);
+  __syncthreads();
+  transform(Vb);
+  __syncthreads();
+
+  for (int st = 0; st < nst; ++st) {
+    const float* Vc = Vb + (st & 1) * kStageFloats;
+    const float* Uc = Ub + (st & 1) * kStageFloats;
+    float* Vn = Vb + ((st + 1) & 1) * kStageFloats;
+    float* Un = Ub + ((st + 1) & 1) * kStageFloats;
+    const bool has_next = (st + 1) < nst;
+    if (has_next) load_stage(st + 1);
+#pragma unroll
+    for (int ps = 0; ps < 16; ++ps) {
+      float2 af[2], bf[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const float2*>(Vc + ps * 512 + aoff[a]);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const float2*>(Uc + ps * 512 + boff[b]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          acc[ps][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a].x, bf[b].x, acc[ps][a][b], 0, 0, 0);
+          acc[ps][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a].y, bf[b].y, acc[ps][a][b], 0, 0, 0);
+        }
+      if (ps == 7 && has_next) {        // mid-stage: the next stage's operands have landed
+        store_stage(Un);
+        __syncthreads();
+        transform(Vn);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- output transform Y = A^T M A (register local) + epilogue ----
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int j = n0 + cb0 + b * 16 + li;
+    if (j >= p.Cout) continue;
+    const float bj = p.bias ? p.bias[j] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tile = tb0 + a * 16 + 4 * lq + r;
+        const int il = tile >> (p.lTWt + p.lTHt);
+        const int tr = (tile >> p.lTWt) & (THt - 1), tc = tile & (TWt - 1);
+        const int img = img0 + il;
+        const int oy = (ty * THt + tr) * 2, ox = (tx * TWt + tc) * 2;
+        if (img >= p.N || oy >= p.H || ox >= p.W) continue;
+        float t0[4], t1[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          t0[x] = acc[0 + x][a][b][r] + acc[4 + x][a][b][r] + acc[8 + x][a][b][r];
+          t1[x] = acc[4 + x][a][b][r] - acc[8 + x][a][b][r] - acc[12 + x][a][b][r];
+        }
+        const float y[2][2] = {{t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3]}, {t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]}};
+        const float ca = p.chan_add ? p.chan_add[(size_t)img * p.chan_add_ld + j] : 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const size_t pix = ((size_t)img * p.H + oy + dy) * p.W + ox + dx;
+            float v = y[dy][dx] + bj + ca;
+            if (p.resid && !p.resid_post) v += p.resid[pix * p.Cout + j];
+            v *= p.scale;
+            if (p.resid && p.resid_post) v += p.resid[pix * p.Cout + j];
+            p.dst[pix * p.Cout + j] = v;
+          }
+      }
+  }
+}
+
+int pow2_floor(int v) { int q = 1; while (q * 2 <= v) q *= 2; return q; }
+
+}  // namespace
+
+// Launched by ssde_conv2d when a->tile == SSDE_TILE_WINOGRAD (the caller packs w_main for this kernel).
+int ssde_conv_wino_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
+  SSDE_REQUIRE(a && a->dst && a->main.p0 && a->w_main, "conv(winograd): null args");
+  SSDE_REQUIRE(a->ksize == 3 && a->stride == 1 && a->pad == 1, "conv(winograd): needs 3x3, stride 1, pad 1");
+  SSDE_REQUIRE(a->aux.p0 == nullptr, "conv(winograd): fused 1x1 source not supported (issue it as a second conv)");
+  SSDE_REQUIRE(a->h_in == a->h_out && a->w_in == a->w_out && a->h_out % 2 == 0 && a->w_out % 2 == 0 && a->h_out >= 2 && a->w_out >= 2,
+               "conv(winograd): even same-size output needed (got %dx%d)", a->h_out, a->w_out);
+  const ssde_src& s = a->main;
+  SSDE_REQUIRE(s.c0 > 0 && s.c0 % 4 == 0 && s.c1 % 4 == 0 && (s.c1 == 0 || (s.p1 && s.c0 % 8 == 0)),
+               "conv(winograd): channels must be multiples of 4 (concat boundary of 8)");
+  if (s.pro_mode == SSDE_PRO_GN || s.pro_mode == SSDE_PRO_GN_SILU) {
+    SSDE_REQUIRE(s.gn_groups > 0 && (s.c0 + s.c1) % s.gn_groups == 0 && ((s.c0 + s.c1) / s.gn_groups) % 4 == 0,
+                 "conv(winograd): GroupNorm needs channels-per-group %% 4 == 0");
+    SSDE_REQUIRE(s.gn_mean && s.gn_rstd && s.gn_gamma && s.gn_beta, "conv(winograd): GroupNorm pointers missing");
+  }
+  SSDE_REQUIRE(s.drop_thresh == 0 || s.drop_seed, "conv(winograd): dropout seed pointer missing");
+  WinoParams p;
+  p.src = s; p.wpk = a->w_main;
+  p.N = a->n; p.H = a->h_out; p.W = a->w_out; p.Cout = a->c_out;
+  const int twt = pow2_floor((a->w_out / 2) < 8 ? (a->w_out / 2) : 8);
+  int tht = 64 / twt; if (tht > a->h_out / 2) tht = a->h_out / 2;
+  tht = pow2_floor(tht);
+  const int imgs = 64 / (twt * tht);
+  p.lTWt = ssde_ilog2(twt); p.lTHt = ssde_ilog2(tht);
+  p.tiles_x = ssde_cdiv(a->w_out, 2 * twt);
+  p.tiles_per_img = p.tiles_x * ssde_cdiv(a->h_out, 2 * tht);
+  p.m_tiles = ssde_cdiv(a->n, imgs) * p.tiles_per_img;
+  p.n_tiles = ssde_cdiv(a->c_out, 64);
+  p.bias = a->bias; p.chan_add = a->chan_add; p.chan_add_ld = a->chan_add_ld;
+  p.resid = a->resid; p.resid_post = a->resid_post; p.scale = a->out_scale; p.dst = a->dst;
+  const int halo_px = imgs * (2 * tht + 2) * (2 * twt + 2);
+  SSDE_REQUIRE(halo_px * 2 <= kMaxRaw * kThreads, "conv(winograd): halo of %d pixels exceeds the staging plan", halo_px);
+  const int lds = (4 * kStageFloats + 4 * halo_px * 2) * 4;
+  if (lds_out) { *lds_out = lds; return SSDE_OK; }
+  static bool attr_set = false;   // once, before any stream capture
+  if (!attr_set) {
+    SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_wino_kernel, dim3(ssde_cdiv(p.m_tiles, 8) * 8 * p.n_tiles), dim3(kThreads), lds,
+                     static_cast<hipStream_t>(stream), p);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}

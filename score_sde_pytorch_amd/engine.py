@@ -68,6 +68,8 @@ def _ptr(value):
 
 def _fill(struct, fields):
     for k, v in fields.items():
+        if k.startswith("_"):
+            continue            # lowering-time annotations (e.g. the scratch of a split Winograd conv)
         cur = getattr(struct, k)
         if isinstance(v, dict):
             _fill(cur, v)
@@ -148,12 +150,34 @@ class ProgramBuilder:
                     free.append(b.tensor)
         self.blocks = blocks
         self.arena_bytes = sum(t.numel() for t in blocks) * _FLT
-        ops = []
-        for kind, fields, fclass, _ in self.specs:
-            args = _STRUCT[kind]()
-            _fill(args, fields)
-            ops.append(L.make_op(kind, args, fclass))
-        return Program(L.op_array(ops), [s[2] for s in self.specs], [s[3] for s in self.specs], self)
+        ops, classes, flops, starts = [], [], [], []
+        for kind, fields, fclass, fl in self.specs:
+            starts.append(len(ops))
+            for sub_fields, sub_class, sub_fl in _expand(kind, fields, fclass, fl):
+                args = _STRUCT[kind]()
+                _fill(args, sub_fields)
+                ops.append(L.make_op(kind, args, sub_class))
+                classes.append(sub_class)
+                flops.append(sub_fl)
+        prog = Program(L.op_array(ops), classes, flops, self)
+        prog.spec_start = starts + [len(ops)]      # op index of every lowering spec (a spec may expand to several ops)
+        return prog
+
+
+def _expand(kind, fields, fclass, fl):
+    """One lowering spec -> the C ops that execute it.  A fused (3x3 + 1x1 skip) convolution whose 3x3 part runs on
+    the Winograd kernel is issued as two launches: tmp = conv3x3 + bias + temb addend, then the 1x1 GEMM with tmp as
+    its residual; the spec stays ONE fused op for the backward lowering."""
+    if kind != L.OP_CONV or fields.get("_split_tmp") is None:
+        return [(fields, fclass, fl)]
+    px = fields["n"] * fields["h_out"] * fields["w_out"]
+    fl1 = 2.0 * px * (fields["aux"]["c0"] + fields["aux"]["c1"]) * fields["c_out"]
+    a = dict(fields)
+    a.update(aux=_NOSRC, w_aux=None, resid=None, resid_post=0, out_scale=1.0, dst=fields["_split_tmp"])
+    b = dict(fields)
+    b.update(main=_NOSRC, w_main=None, ksize=0, bias=None, chan_add=None, chan_add_ld=0, resid=fields["_split_tmp"],
+             resid_post=0, tile=L.TILE_AUTO)
+    return [(a, fclass, fl - fl1), (b, FC_CONV1, fl1)]
 
 
 class Program:
@@ -223,6 +247,27 @@ def pack_conv_weight(w):
     return full.reshape(cin8, 8, t, cpad).permute(0, 2, 3, 1).contiguous()
 
 
+_WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+
+
+def pack_wino_weight(w):
+    """[Cout, Cin, 3, 3] -> Winograd F(2x2,3x3) weights U = G g G^T arranged as the LDS image conv_wino.hip reads:
+    [ceil(Cin/8)][ceil(Cout/64)][16 positions][4 channel pairs][64 couts with bit 4 ^= pair parity][2]."""
+    cout, cin = w.shape[0], w.shape[1]
+    G = _WINO_G.to(w.device, torch.float32)
+    u = torch.einsum("ak,ockl,bl->ocab", G, w.detach().to(torch.float32), G)     # [Cout, Cin, 4, 4]
+    c8, nt = (cin + 7) // 8, (cout + 63) // 64
+    full = torch.zeros(nt * 64, c8 * 8, 16, dtype=torch.float32, device=w.device)
+    full[:cout, :cin] = u.reshape(cout, cin, 16)
+    full = full.reshape(nt, 64, c8, 4, 2, 16)                   # [nt, co, c8, pair, e, pos]
+    co = torch.arange(64, device=w.device)
+    out = torch.empty(c8, nt, 16, 4, 64, 2, dtype=torch.float32, device=w.device)
+    for q in range(4):
+        src = full[:, :, :, q]                                  # [nt, co, c8, e, pos]
+        out[:, :, :, q, co ^ ((q & 1) << 4)] = src.permute(2, 0, 4, 1, 3)   # -> [c8, nt, pos, co, e]
+    return out.contiguous()
+
+
 def pack_matrix(w):
     """[Cout, Cin] (nn.Linear / 1x1 conv orientation) -> [ceil(Cin/8)][roundup(Cout,64)][8]."""
     return pack_conv_weight(w.reshape(w.shape[0], w.shape[1], 1, 1))
@@ -252,8 +297,9 @@ class WeightStore:
         return packed
 
     # -- typed registrations -------------------------------------------------------------------
-    def conv3(self, param, cin_pad=None, cout_pad=None):
-        """[Cout, Cin, 3, 3] conv weight, optionally zero-padded to cin_pad / cout_pad channels."""
+    def conv3(self, param, cin_pad=None, cout_pad=None, wino=False):
+        """[Cout, Cin, 3, 3] conv weight, optionally zero-padded to cin_pad / cout_pad channels; wino: packed for the
+        Winograd kernel (G g G^T, conv_wino.hip) instead of the direct one."""
         def logical(w):
             w = w.to(torch.float32)
             if cin_pad and w.shape[1] < cin_pad:
@@ -263,7 +309,8 @@ class WeightStore:
             return w
         meta = dict(kind="conv3", sources=[param], logical=logical,
                     parts=[dict(param=param, row0=0, rows=param.shape[0], transpose=False)], cin_store=param.shape[1])
-        return self.add([param], lambda w: pack_conv_weight(logical(w)), meta)
+        pack = pack_wino_weight if wino else pack_conv_weight
+        return self.add([param], lambda w: pack(logical(w)), meta)
 
     def matrix(self, parts, cin_pad=None):
         """Rows-concatenated [Cout_i, Cin] matrices; parts = [(param, transpose)], transpose for NIN's [in, out]."""
@@ -372,7 +419,14 @@ class Lowering:
 
     def conv(self, dst, h_out, w_out, c_out, main=None, w_main=None, h_in=0, w_in=0, stride=1, pad=1,
              aux=None, w_aux=None, bias=None, chan_add=None, chan_add_ld=0, resid=None, scale=1.0, tile=L.TILE_AUTO,
-             resid_post=0):
+             resid_post=0, wino=False):
+        """wino=True: w_main is Winograd-packed (see wino_ok); a fused 1x1 source then runs as a second launch."""
+        split_tmp = None
+        if wino:
+            assert main is not None and stride == 1 and pad == 1 and (h_in, w_in) == (h_out, w_out)
+            tile = L.TILE_WINOGRAD
+            if aux is not None:
+                split_tmp = self.b.buf(self.n, h_out, w_out, c_out, name="wino_tmp")
         px = self.n * h_out * w_out
         flops = 0.0
         if main is not None:
@@ -383,8 +437,18 @@ class Lowering:
             main=main if main is not None else _NOSRC, aux=aux if aux is not None else _NOSRC,
             w_main=w_main, w_aux=w_aux, n=self.n, h_in=h_in, w_in=w_in, h_out=h_out, w_out=w_out, c_out=c_out,
             ksize=3 if main is not None else 0, stride=stride, pad=pad, tile=tile, bias=bias, chan_add=chan_add,
-            chan_add_ld=chan_add_ld, resid_post=resid_post, resid=resid, out_scale=float(scale), dst=dst),
+            chan_add_ld=chan_add_ld, resid_post=resid_post, resid=resid, out_scale=float(scale), dst=dst,
+            _split_tmp=split_tmp),
             FC_CONV3 if main is not None else FC_CONV1, flops)
+
+    @staticmethod
+    def wino_ok(h, w, c_out, c_in):
+        """Winograd F(2x2,3x3) pays when the matrix pipe is the bound: even outputs, enough channels to fill the
+        64-cout tile and the 8-channel stages.  SSDE_WINOGRAD=0 forces the direct (bitwise fmaf-chain) kernel."""
+        import os
+        if os.environ.get("SSDE_WINOGRAD", "1") == "0":
+            return False
+        return h % 2 == 0 and w % 2 == 0 and h >= 4 and w >= 4 and c_out >= 32 and c_in >= 8 and c_in % 8 == 0
 
     def upfirdn(self, src, n_ch, h_in, w_in, taps, up=1, down=1, pad=(0, 0), name="fir"):
         kh, kw = taps.shape
@@ -586,8 +650,8 @@ class UNetEngine:
         b.add(L.OP_TO_NCHW, dict(src=o, dst=self.out, n=n, c=self.channels, h=hh, w=ww, c_src=4, mode=mode, v=vec))
 
     # -- packed parameter helpers
-    def _w3(self, m, cin_pad=None, cout_pad=None):
-        return self.weights.conv3(m.weight, cin_pad, cout_pad)
+    def _w3(self, m, cin_pad=None, cout_pad=None, wino=False):
+        return self.weights.conv3(m.weight, cin_pad, cout_pad, wino=wino)
 
     def _w1(self, m, cin_pad=None):
         return self.weights.matrix([(m.weight, False)], cin_pad=cin_pad)
@@ -621,8 +685,10 @@ class UNetEngine:
             main0 = _src(t, c, t2, c2, pro=L.PRO_GN_SILU, gn=gn0)
             skip_t, skip_c, skip_t2, skip_c2 = t, c, t2, c2
         h1 = b.buf(n, hh, ww, cout, name="res_h1")
-        low.conv(h1, hh, ww, cout, main=main0, w_main=self._w3(m.Conv_0), h_in=hh, w_in=ww, bias=self._bias(m.Conv_0),
-                 chan_add=chan_add, chan_add_ld=ld)
+        wino0 = low.wino_ok(hh, ww, cout, main0["c0"] + main0["c1"])
+        wino1 = low.wino_ok(hh, ww, cout, cout)
+        low.conv(h1, hh, ww, cout, main=main0, w_main=self._w3(m.Conv_0, wino=wino0), h_in=hh, w_in=ww, bias=self._bias(m.Conv_0),
+                 chan_add=chan_add, chan_add_ld=ld, wino=wino0)
         gn1 = low.gn_stats(h1, cout, hh * ww, m.GroupNorm_1)
         out = b.buf(n, hh, ww, cout, name="res_out")
         self._n_res += 1
@@ -630,12 +696,12 @@ class UNetEngine:
         main1 = _src(h1, cout, pro=L.PRO_GN_SILU, gn=gn1, drop=drop)
         if hasattr(m, "Conv_2"):
             bsum = self.weights.vector([m.Conv_1.bias, m.Conv_2.bias], mode="sum")
-            low.conv(out, hh, ww, cout, main=main1, w_main=self._w3(m.Conv_1), h_in=hh, w_in=ww,
-                     aux=_src(skip_t, skip_c, skip_t2, skip_c2), w_aux=self._w1(m.Conv_2), bias=bsum, scale=scale)
+            low.conv(out, hh, ww, cout, main=main1, w_main=self._w3(m.Conv_1, wino=wino1), h_in=hh, w_in=ww,
+                     aux=_src(skip_t, skip_c, skip_t2, skip_c2), w_aux=self._w1(m.Conv_2), bias=bsum, scale=scale, wino=wino1)
         else:
             assert skip_t2 is None
-            low.conv(out, hh, ww, cout, main=main1, w_main=self._w3(m.Conv_1), h_in=hh, w_in=ww, bias=self._bias(m.Conv_1),
-                     resid=skip_t, scale=scale)
+            low.conv(out, hh, ww, cout, main=main1, w_main=self._w3(m.Conv_1, wino=wino1), h_in=hh, w_in=ww,
+                     bias=self._bias(m.Conv_1), resid=skip_t, scale=scale, wino=wino1)
         return out, cout
 
     # -- AttnBlockpp (layerspp.py:75-91)

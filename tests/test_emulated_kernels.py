@@ -90,3 +90,34 @@ def test_unet_forward_matches_reference_golden(name):
         eng = E.UNetEngine(model, x.shape[0], x.shape[2], x.shape[3], torch.device("cpu"))
         y = eng.forward(x, cond)
     assert rel_err(y, y_ref) < 1e-4
+
+
+@pytest.mark.parametrize("n,cin,cout,h", [(1, 8, 64, 16), (2, 32, 64, 8), (3, 16, 96, 4), (5, 24, 40, 8), (17, 8, 64, 4)])
+def test_conv3x3_winograd(ops, n, cin, cout, h):
+    """F(2x2,3x3) kernel (conv_wino.hip) against the plain fp32 convolution: same tolerance as the direct kernel"""
+    pass
+    from score_sde_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(n, cin, h, h, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
+    b = torch.randn(cout, generator=g)
+    y = ops.conv2d(nhwc(x), w, b, tile=L.TILE_WINOGRAD)
+    assert rel_err(nchw(y.cpu()), F.conv2d(x, w, b, padding=1)) < 2e-5
+
+
+def test_conv3x3_winograd_fused_prologue_epilogue(ops):
+    """GroupNorm+SiLU prologue over a concatenated source, bias, temb addend, residual and scale on the Winograd kernel"""
+    pass
+    from score_sde_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(7)
+    n, c0, c1, cout, h = 2, 32, 32, 64, 8
+    x1, x2 = torch.randn(n, c0, h, h, generator=g), torch.randn(n, c1, h, h, generator=g)
+    C, G = c0 + c1, 16
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    w, b = torch.randn(cout, C, 3, 3, generator=g) / np.sqrt(9 * C), torch.randn(cout, generator=g)
+    ca, res = torch.randn(n, cout, generator=g), torch.randn(n, cout, h, h, generator=g)
+    mean, rstd = ops.groupnorm_stats(nhwc(x1), G, 1e-6, x2=nhwc(x2))
+    y = ops.conv2d(nhwc(x1), w, b, x2=nhwc(x2), pro=L.PRO_GN_SILU, gn=(mean, rstd, gamma, beta, G),
+                   chan_add=ca, resid=nhwc(res), scale=0.7, tile=L.TILE_WINOGRAD)
+    ref = 0.7 * (F.conv2d(F.silu(F.group_norm(torch.cat([x1, x2], 1), G, gamma, beta, 1e-6)), w, b, padding=1) + ca[:, :, None, None] + res)
+    assert rel_err(nchw(y.cpu()), ref) < 2e-5

@@ -253,3 +253,34 @@ def test_randn_moments_and_streams():
     assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1.0) < 5e-3
     assert abs(float((a * b).mean())) < 5e-3  # streams uncorrelated
     assert abs(float((a ** 4).mean()) - 3.0) < 0.05
+
+
+@pytest.mark.parametrize("n,cin,cout,h", [(1, 8, 64, 16), (2, 32, 64, 8), (3, 16, 96, 4), (5, 24, 40, 8), (17, 8, 64, 4)])
+def test_conv3x3_winograd(n, cin, cout, h):
+    """F(2x2,3x3) kernel (conv_wino.hip) against the plain fp32 convolution: same tolerance as the direct kernel"""
+    ops = _ops()
+    from score_sde_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(n, cin, h, h, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
+    b = torch.randn(cout, generator=g)
+    y = ops.conv2d(nhwc(x).cuda(), w, b.cuda(), tile=L.TILE_WINOGRAD)
+    assert rel_err(nchw(y.cpu()), F.conv2d(x, w, b, padding=1)) < TOL_GEMM
+
+
+def test_conv3x3_winograd_fused_prologue_epilogue():
+    """GroupNorm+SiLU prologue over a concatenated source, bias, temb addend, residual and scale on the Winograd kernel"""
+    ops = _ops()
+    from score_sde_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(7)
+    n, c0, c1, cout, h = 2, 32, 32, 64, 8
+    x1, x2 = torch.randn(n, c0, h, h, generator=g), torch.randn(n, c1, h, h, generator=g)
+    C, G = c0 + c1, 16
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    w, b = torch.randn(cout, C, 3, 3, generator=g) / np.sqrt(9 * C), torch.randn(cout, generator=g)
+    ca, res = torch.randn(n, cout, generator=g), torch.randn(n, cout, h, h, generator=g)
+    mean, rstd = ops.groupnorm_stats(nhwc(x1).cuda(), G, 1e-6, x2=nhwc(x2).cuda())
+    y = ops.conv2d(nhwc(x1).cuda(), w, b.cuda(), x2=nhwc(x2).cuda(), pro=L.PRO_GN_SILU, gn=(mean, rstd, gamma.cuda(), beta.cuda(), G),
+                   chan_add=ca.cuda(), resid=nhwc(res).cuda(), scale=0.7, tile=L.TILE_WINOGRAD)
+    ref = 0.7 * (F.conv2d(F.silu(F.group_norm(torch.cat([x1, x2], 1), G, gamma, beta, 1e-6)), w, b, padding=1) + ca[:, :, None, None] + res)
+    assert rel_err(nchw(y.cpu()), ref) < TOL_GEMM
