@@ -7,9 +7,18 @@
 // kernel (conv_mfma.hip) -- does 2.25x less work.  Everything stays fp32; the transforms only add
 // and halve, so the result differs from the direct sum by fp32 rounding (tests: same tolerance).
 //
-// One workgroup (4 waves, one per SIMD, 256 accumulator registers per lane) owns 64 tiles (a 16x16
+// One workgroup (8 waves = two per SIMD, 128 accumulator registers per lane) owns 64 tiles (a 16x16
 // output patch, or 8x8 patches of 4 images, or 4x4 of 16) x 64 output channels x all 16 transform
-// positions.  Per 8-input-channel stage:
+// positions: waves 0-3 hold positions 0-7 (transform rows 0,1), waves 4-7 positions 8-15, each wave a
+// 32-tile x 32-cout block.  The two waves of a SIMD (w and w+4) PING-PONG: while one runs its 64 MFMAs
+// of the stage, the other does staging work for the next stage, then they swap (two barriers per
+// stage); a version in which every wave staged and computed in the same phase kept the matrix pipe
+// only 22% busy, because VALU/LDS/VMEM work of both waves coincided and nothing covered it.
+//   phase 1: waves 0-3 MFMA(stage k)   | waves 4-7 prologue + LDS stores of raw halo / weights (k+1)
+//   phase 2: waves 4-7 MFMA(stage k)   | waves 0-3 input transform raw -> V(k+1); 4-7 first issue the
+//                                         halo loads of stage k+2 (registers) and the LDS-DMA of the
+//                                         weights of stage k+1 (no registers), which fly under their MFMAs
+// Per 8-input-channel stage:
 //   raw halo (with the fused GroupNorm / SiLU / dropout prologue)  -> LDS, channel-pair major
 //   input transform B^T d B, one (tile, channel pair) per thread   -> LDS V[pos][pair][tile][2]
 //   host-transformed weights G g G^T, pre-arranged as the LDS image -> LDS U[pos][pair][cout][2]
@@ -17,17 +26,20 @@
 //   channel pair (2q, 2q+1), q = lane >> 4 = the MFMA k index, so one read feeds two MFMAs
 // V/U stages are double buffered; tile / cout index bit 4 is XOR-swizzled with the pair's parity so
 // the b64 fragment reads of a 32-lane group cover all 64 banks.  The accumulator layout of the 16x16
-// MFMA keeps all 16 positions of a (tile, cout) in ONE lane, so the output transform A^T M A is
-// register-local; the epilogue (bias, temb addend, residual, scale) is the direct kernel's.
+// MFMA keeps a wave's 8 positions of a (tile, cout) in ONE lane, so each wave applies its half of the
+// (linear) output transform A^T M A in registers; waves 4-7 hand their 2x2 partial to waves 0-3 through
+// LDS once per workgroup; the epilogue (bias, temb addend, residual, scale) is the direct kernel's.
 #include "ssde_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;
 constexpr int kStageFloats = 16 * 4 * 64 * 2;     // one V or U stage: [pos][pair][64][2]
-constexpr int kMaxRaw = 5;                        // raw float4 items per thread per stage
+constexpr int kStagers = 256;                     // waves 4-7 stage (load / prologue / LDS store)
+constexpr int kMaxRaw = 5;                        // raw float4 items per staging thread per stage
+constexpr int kUItems = kStageFloats / 4 / kStagers;   // weight float4 items per staging thread per stage
 
 struct WinoParams {
   ssde_src src;
@@ -41,7 +53,7 @@ struct WinoParams {
   float* dst;
 };
 
-__global__ __launch_bounds__(kThreads, 1) void conv_wino_kernel(const WinoParams p) {
+__global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams p) {
   SSDE_LDS(smem);
   float* Vb = smem;                          // [2][kStageFloats]
   float* Ub = smem + 2 * kStageFloats;       // [2][kStageFloats]
@@ -72,10 +84,11 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino_kernel(const WinoParams
   const int cpg = pro.gn ? Ctot / s.gn_groups : 1;
 
   // ---- per-thread raw staging plan: item = (halo pixel, channel half) ----
+  const int sid = tid & (kStagers - 1);          // index among the 256 staging threads (waves 4-7) / transform threads (0-3)
   int goff[kMaxRaw], gimg[kMaxRaw];
 #pragma unroll
   for (int it = 0; it < kMaxRaw; ++it) {
-    const int q = tid + it * kThreads;
+    const int q = sid + it * kStagers;
     goff[it] = -2; gimg[it] = 0;
     if (q < halo_px * 2) {
       const int hp = q >> 1;
@@ -89,8 +102,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino_kernel(const WinoParams
       gimg[it] = img;
     }
   }
-  // transform item: this thread's tile and channel pair
-  const int t_tile = tid & 63, t_pair = tid >> 6;
+  // transform item (waves 0-3): this thread's tile and channel pair
+  const int t_tile = sid & 63, t_pair = sid >> 6;
   int t_base;
   {
     const int il = t_tile >> (p.lTWt + p.lTHt);
@@ -100,7 +113,6 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino_kernel(const WinoParams
   const int t_vcol = ((t_tile ^ ((t_pair & 1) << 4)) + t_pair * 64) * 2;
 
   float4 rv[kMaxRaw];
-  float4 uv[8];
   float mu[kMaxRaw], rs[kMaxRaw];
   float4 gam = make_float4(1.f, 1.f, 1.f, 1.f), bet = make_float4(0.f, 0.f, 0.f, 0.f);
   bool chan_ok = false;
@@ -111,7 +123,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino_kernel(const WinoParams
     c_cur = c_base;
     const float* base; int C, cc;
     if (c_base < s.c0) { base = s.p0; C = s.c0; cc = c_base; } else { base = s.p1; C = s.c1; cc = c_base - s.c0; }
-    const int half = tid & 1;
+    const int half = sid & 1;
     const int cthr = cc + half * 4;
     chan_ok = cthr < C;
 #pragma unroll
@@ -119,9 +131,6 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino_kernel(const WinoParams
       rv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (goff[it] >= 0 && chan_ok) rv[it] = *reinterpret_cast<const float4*>(base + (size_t)goff[it] * C + cthr);
     }
-    const float4* wsrc = reinterpret_cast<const float4*>(p.wpk + ((size_t)st * p.n_tiles + nt) * kStageFloats);
-#pragma unroll
-    for (int it = 0; it < 8; ++it) uv[it] = wsrc[tid + it * kThreads];
 #pragma unroll
     for (int it = 0; it < kMaxRaw; ++it) { mu[it] = 0.f; rs[it] = 1.f; }
     if (pro.gn && (c_base + half * 4) < Ctot) {
@@ -136,21 +145,26 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino_kernel(const WinoParams
         }
     }
   };
-  // prologue + raw LDS store (channel-pair major), weights -> U stage
-  auto store_stage = [&](float* Un) {
-    const int half = tid & 1;
+  // weights of stage st: the host packed them as the LDS image, so they go global -> LDS by DMA
+  auto dma_weights = [&](int st, float* Un) {
+    const float4* wsrc = reinterpret_cast<const float4*>(p.wpk + ((size_t)st * p.n_tiles + nt) * kStageFloats);
+#pragma unroll
+    for (int it = 0; it < kUItems; ++it)
+      SSDE_GLDS16(wsrc + sid + it * kStagers, Un + (size_t)((sid & ~63) + it * kStagers) * 4);
+  };
+  // prologue + raw LDS store (channel-pair major)
+  auto store_stage = [&]() {
+    const int half = sid & 1;
 #pragma unroll
     for (int it = 0; it < kMaxRaw; ++it) {
       if (goff[it] == -2) continue;
       float4 v = rv[it];
       if (goff[it] >= 0 && chan_ok)
         v = ssde_pro_apply(v, mu[it], rs[it], gam, bet, (uint32_t)goff[it] * (uint32_t)Ctot + (uint32_t)(c_cur + half * 4), pro);
-      const int hp = (tid + it * kThreads) >> 1;
+      const int hp = (sid + it * kStagers) >> 1;
       *reinterpret_cast<float2*>(raw + ((2 * half) * halo_px + hp) * 2) = make_float2(v.x, v.y);
       *reinterpret_cast<float2*>(raw + ((2 * half + 1) * halo_px + hp) * 2) = make_float2(v.z, v.w);
     }
-#pragma unroll
-    for (int it = 0; it < 8; ++it) reinterpret_cast<float4*>(Un)[tid + it * kThreads] = uv[it];
   };
   // V = B^T d B for this thread's (tile, channel pair), both channels at once
   auto transform = [&](float* Vn) {
@@ -181,9 +195,9 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino_kernel(const WinoParams
     }
   };
 
-  f32x4 acc[16][2][2];
+  f32x4 acc[8][2][2];
 #pragma unroll
-  for (int ps = 0; ps < 16; ++ps)
+  for (int ps = 0; ps < 8; ++ps)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -192,30 +206,18 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino_kernel(const WinoParams
         for (int r = 0; r < 4; ++r) acc[ps][a][b][r] = 0.f;
 
   // fragment column offsets inside a [pos] slab of 512 floats: ((pair q) * 64 + (index ^ swizzle)) * 2
-  const int tb0 = (wave >> 1) * 32, cb0 = (wave & 1) * 32;
+  const int ph = wave >> 2;                                   // position half: transform rows 2*ph, 2*ph+1
+  const int tb0 = ((wave >> 1) & 1) * 32, cb0 = (wave & 1) * 32;
   const int swz = (lq & 1) << 4;
   int aoff[2], boff[2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a) aoff[a] = (lq * 64 + ((tb0 + a * 16 + li) ^ swz)) * 2;
+  for (int a = 0; a < 2; ++a) aoff[a] = ph * 8 * 512 + (lq * 64 + ((tb0 + a * 16 + li) ^ swz)) * 2;
 #pragma unroll
-  for (int b = 0; b < 2; ++b) boff[b] = (lq * 64 + ((cb0 + b * 16 + li) ^ swz)) * 2;
+  for (int b = 0; b < 2; ++b) boff[b] = ph * 8 * 512 + (lq * 64 + ((cb0 + b * 16 + li) ^ swz)) * 2;
 
-  // ---- pipeline prologue: stage 0 ----
-  load_stage(0);
-  store_stage(Ub);
-  __syncthreads();
-  transform(Vb);
-  __syncthreads();
-
-  for (int st = 0; st < nst; ++st) {
-    const float* Vc = Vb + (st & 1) * kStageFloats;
-    const float* Uc = Ub + (st & 1) * kStageFloats;
-    float* Vn = Vb + ((st + 1) & 1) * kStageFloats;
-    float* Un = Ub + ((st + 1) & 1) * kStageFloats;
-    const bool has_next = (st + 1) < nst;
-    if (has_next) load_stage(st + 1);
+  auto mfma_stage = [&](const float* Vc, const float* Uc) {
 #pragma unroll
-    for (int ps = 0; ps < 16; ++ps) {
+    for (int ps = 0; ps < 8; ++ps) {
       float2 af[2], bf[2];
 #pragma unroll
       for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const float2*>(Vc + ps * 512 + aoff[a]);
@@ -228,16 +230,74 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino_kernel(const WinoParams
           acc[ps][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a].x, bf[b].x, acc[ps][a][b], 0, 0, 0);
           acc[ps][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a].y, bf[b].y, acc[ps][a][b], 0, 0, 0);
         }
-      if (ps == 7 && has_next) {        // mid-stage: the next stage's operands have landed
-        store_stage(Un);
-        __syncthreads();
-        transform(Vn);
-      }
+    }
+  };
+
+  // ---- pipeline prologue: stage 0 staged, stage 1 in flight ----
+  if (ph == 1) { dma_weights(0, Ub); load_stage(0); store_stage(); }
+  __syncthreads();
+  if (ph == 0) transform(Vb);
+  else if (nst > 1) load_stage(1);
+  __syncthreads();
+
+  for (int st = 0; st < nst; ++st) {
+    const float* Vc = Vb + (st & 1) * kStageFloats;
+    const float* Uc = Ub + (st & 1) * kStageFloats;
+    float* Vn = Vb + ((st + 1) & 1) * kStageFloats;
+    float* Un = Ub + ((st + 1) & 1) * kStageFloats;
+    // phase 1: waves 0-3 on the matrix pipe; waves 4-7 apply the prologue and store stage st+1's raw halo
+    if (ph == 0) mfma_stage(Vc, Uc);
+    else if (st + 1 < nst) store_stage();
+    __syncthreads();
+    // phase 2: waves 4-7 on the matrix pipe (weights DMA of st+1 and halo loads of st+2 fly underneath); 0-3 transform
+    if (ph == 1) {
+      if (st + 1 < nst) dma_weights(st + 1, Un);
+      if (st + 2 < nst) load_stage(st + 2);
+      mfma_stage(Vc, Uc);
+    } else if (st + 1 < nst) {
+      transform(Vn);
     }
     __syncthreads();
   }
 
-  // ---- output transform Y = A^T M A (register local) + epilogue ----
+  // ---- output transform Y = A^T M A: this wave's two transform rows (register local) ----
+  // A^T = [[1,1,1,0],[0,1,-1,-1]]; rows py = 2*ph, 2*ph+1 contribute  At[dy][py] * sum_px At[dx][px] M[py][px]
+  float yp[2][2][4][4];     // [a][b][r][dy*2+dx]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t[2][2];
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy) {
+          t[yy][0] = acc[yy * 4 + 0][a][b][r] + acc[yy * 4 + 1][a][b][r] + acc[yy * 4 + 2][a][b][r];
+          t[yy][1] = acc[yy * 4 + 1][a][b][r] - acc[yy * 4 + 2][a][b][r] - acc[yy * 4 + 3][a][b][r];
+        }
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          // ph 0: rows 0,1 -> Y0 += t0 + t1, Y1 += t1 ; ph 1: rows 2,3 -> Y0 += t2, Y1 += -t2 - t3
+          yp[a][b][r][0 * 2 + dx] = ph == 0 ? t[0][dx] + t[1][dx] : t[0][dx];
+          yp[a][b][r][1 * 2 + dx] = ph == 0 ? t[1][dx] : -t[0][dx] - t[1][dx];
+        }
+      }
+  // waves 4-7 hand their partial 2x2 to waves 0-3 (same tile / cout blocks) through LDS: [wave & 3][a][b][r][lane][4]
+  float4* xch = reinterpret_cast<float4*>(smem);
+  if (ph == 1) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          xch[((((wave & 3) * 2 + a) * 2 + b) * 4 + r) * 64 + lane] =
+              make_float4(yp[a][b][r][0], yp[a][b][r][1], yp[a][b][r][2], yp[a][b][r][3]);
+  }
+  __syncthreads();
+  if (ph == 1) return;
+
+  // ---- epilogue (waves 0-3) ----
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const int j = n0 + cb0 + b * 16 + li;
@@ -253,13 +313,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv_wino_kernel(const WinoParams
         const int img = img0 + il;
         const int oy = (ty * THt + tr) * 2, ox = (tx * TWt + tc) * 2;
         if (img >= p.N || oy >= p.H || ox >= p.W) continue;
-        float t0[4], t1[4];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-          t0[x] = acc[0 + x][a][b][r] + acc[4 + x][a][b][r] + acc[8 + x][a][b][r];
-          t1[x] = acc[4 + x][a][b][r] - acc[8 + x][a][b][r] - acc[12 + x][a][b][r];
-        }
-        const float y[2][2] = {{t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3]}, {t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]}};
+        const float4 o = xch[(((wave * 2 + a) * 2 + b) * 4 + r) * 64 + lane];
+        const float y[2][2] = {{yp[a][b][r][0] + o.x, yp[a][b][r][1] + o.y}, {yp[a][b][r][2] + o.z, yp[a][b][r][3] + o.w}};
         const float ca = p.chan_add ? p.chan_add[(size_t)img * p.chan_add_ld + j] : 0.f;
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
@@ -311,7 +366,7 @@ int ssde_conv_wino_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
   p.bias = a->bias; p.chan_add = a->chan_add; p.chan_add_ld = a->chan_add_ld;
   p.resid = a->resid; p.resid_post = a->resid_post; p.scale = a->out_scale; p.dst = a->dst;
   const int halo_px = imgs * (2 * tht + 2) * (2 * twt + 2);
-  SSDE_REQUIRE(halo_px * 2 <= kMaxRaw * kThreads, "conv(winograd): halo of %d pixels exceeds the staging plan", halo_px);
+  SSDE_REQUIRE(halo_px * 2 <= kMaxRaw * kStagers, "conv(winograd): halo of %d pixels exceeds the staging plan", halo_px);
   const int lds = (4 * kStageFloats + 4 * halo_px * 2) * 4;
   if (lds_out) { *lds_out = lds; return SSDE_OK; }
   static bool attr_set = false;   // once, before any stream capture

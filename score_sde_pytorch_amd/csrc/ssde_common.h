@@ -42,6 +42,12 @@ static inline bool ssde_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 // float4 element type keeps the base 16-byte aligned for ds_read_b128.
 #define SSDE_LDS(var) HIP_DYNAMIC_SHARED(float4, var##_f4) float* var = reinterpret_cast<float*>(var##_f4)
 
+// Async global -> LDS copy of 16 bytes per lane with no VGPR round trip (global_load_lds_dwordx4): lane l's
+// bytes land at lds_wave_base + 16*l, so the destination is a wave-uniform base and the LDS image is
+// lane-linear.  Visible to other waves after the issuer's vmcnt wait + a workgroup barrier (__syncthreads).
+#define SSDE_GLDS16(gptr, lds_wave_base) \
+  __builtin_amdgcn_global_load_lds((gptr), (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
+
 #ifdef __HIPCC__
 // x * sigmoid(x); v_exp_f32 + v_rcp_f32 (each ~1 ulp)
 __device__ __forceinline__ float ssde_silu(float x) {

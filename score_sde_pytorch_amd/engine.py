@@ -441,14 +441,20 @@ class Lowering:
             _split_tmp=split_tmp),
             FC_CONV3 if main is not None else FC_CONV1, flops)
 
-    @staticmethod
-    def wino_ok(h, w, c_out, c_in):
+    def wino_ok(self, h, w, c_out, c_in):
         """Winograd F(2x2,3x3) pays when the matrix pipe is the bound: even outputs, enough channels to fill the
-        64-cout tile and the 8-channel stages.  SSDE_WINOGRAD=0 forces the direct (bitwise fmaf-chain) kernel."""
+        64-cout tile and the 8-channel stages, and enough 64-tile x 64-cout workgroups to cover the 256 CUs (measured:
+        x1.2-1.5 over the direct kernel from 8x8 up at batch 256, x0.5 at 4x4 where only 64 workgroups exist).
+        SSDE_WINOGRAD=0 forces the direct (bitwise fmaf-chain) kernel, =2 forces Winograd wherever it is legal."""
         import os
-        if os.environ.get("SSDE_WINOGRAD", "1") == "0":
+        mode = os.environ.get("SSDE_WINOGRAD", "1")
+        if mode == "0":
             return False
-        return h % 2 == 0 and w % 2 == 0 and h >= 4 and w >= 4 and c_out >= 32 and c_in >= 8 and c_in % 8 == 0
+        legal = h % 2 == 0 and w % 2 == 0 and h >= 4 and w >= 4 and c_out >= 32 and c_in >= 8 and c_in % 8 == 0
+        if not legal or mode == "2":
+            return legal
+        workgroups = -(-(self.n * h * w) // 256) * -(-c_out // 64)
+        return workgroups >= 192
 
     def upfirdn(self, src, n_ch, h_in, w_in, taps, up=1, down=1, pad=(0, 0), name="fir"):
         kh, kw = taps.shape

@@ -8,6 +8,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# Test batches are tiny, where the engine's size heuristic would always pick the direct convolution kernel:
+# force the Winograd kernel wherever it is legal so whole-network tests cover it (individual tests switch to
+# "0" = direct / "1" = heuristic with monkeypatch.setenv).
+os.environ.setdefault("SSDE_WINOGRAD", "2")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -132,6 +132,11 @@ static inline emu_f32x4 emu_mfma_16x16x4(float a, float b, emu_f32x4 c) {
 }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_16x16x4((a), (b), (c))
+// LDS-DMA: lane l's `size` bytes land at the wave-uniform LDS base + size * l (executed synchronously here)
+static inline void emu_global_load_lds(const void* g, __attribute__((address_space(3))) void* l, unsigned size, int off) {
+  memcpy((char*)(void*)l + off + (size_t)size * emu::cur->lane, g, size);
+}
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void*)(g), (l), (size), (off))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_barrier() emu::syncthreads()

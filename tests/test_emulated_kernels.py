@@ -77,6 +77,11 @@ CASES = {
 }
 
 
+def test_unet_forward_direct_kernel(monkeypatch):
+    monkeypatch.setenv("SSDE_WINOGRAD", "0")
+    test_unet_forward_matches_reference_golden("unet_small_ncsnpp")
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_unet_forward_matches_reference_golden(name):
     from score_sde_pytorch_amd.models import utils as mutils

@@ -33,6 +33,14 @@ def _model(cfg):
     return model.cuda().eval(), sd
 
 
+@pytest.mark.parametrize("name", ["unet_small_ncsnpp", "unet_small_ffhq", "unet_cifar_ncsnpp"])
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_forward_direct_kernel_and_size_heuristic(name, mode, monkeypatch):
+    """SSDE_WINOGRAD=0: every 3x3 on the direct (bitwise fmaf-chain) kernel; =1: the production size heuristic"""
+    monkeypatch.setenv("SSDE_WINOGRAD", mode)
+    test_forward_matches_reference_golden(name)
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_forward_matches_reference_golden(name):
     path = os.path.join(_util.GOLDEN, name + ".npz")

@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the convolution kernels at the BASELINE shapes (GPU only): direct MFMA kernel vs the
+Winograd kernel, and the weight-gradient kernel.  Prints algorithmic TFLOP/s (2*9*Cin*Cout*pixels)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from score_sde_pytorch_amd import hipops as ops, _lib as L  # noqa: E402
+from score_sde_pytorch_amd.engine import pack_conv_weight, pack_wino_weight  # noqa: E402
+
+
+def time_conv(n, cin, cout, h, tile, gn=False, reps=5):
+    dev = "cuda"
+    x = torch.randn(n, h, h, cin, device=dev)
+    w = torch.randn(cout, cin, 3, 3, device=dev) / np.sqrt(9 * cin)
+    a = L.ConvArgs()
+    gnt = None
+    if gn:
+        G = min(cin // 4, 32)
+        mean, rstd = ops.groupnorm_stats(x, G, 1e-6)
+        gnt = (mean, rstd, torch.ones(cin, device=dev), torch.zeros(cin, device=dev), G)
+    ops._fill_src(a.main, x, None, L.PRO_GN_SILU if gn else L.PRO_NONE, gnt)
+    wp = (pack_wino_weight if tile == L.TILE_WINOGRAD else pack_conv_weight)(w)
+    dst = torch.empty(n, h, h, cout, device=dev)
+    a.w_main, a.ksize, a.stride, a.pad, a.h_in, a.w_in = wp.data_ptr(), 3, 1, 1, h, h
+    a.n, a.h_out, a.w_out, a.c_out, a.out_scale, a.dst, a.tile = n, h, h, cout, 1.0, dst.data_ptr(), tile
+    lib = L.load()
+    st = ops._stream()
+    L.check(lib.ssde_conv2d(C.byref(a), st))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        L.check(lib.ssde_conv2d(C.byref(a), st))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    return 2.0 * 9 * cin * cout * n * h * h / ms / 1e9, ms
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    shapes = [(128, 128, 32), (256, 128, 32), (256, 256, 16), (512, 256, 16), (256, 256, 8), (256, 256, 4), (384, 128, 32)]
+    for cin, cout, h in shapes:
+        for gn in (False, True):
+            d, dms = time_conv(n, cin, cout, h, L.TILE_AUTO, gn)
+            wv, wms = time_conv(n, cin, cout, h, L.TILE_WINOGRAD, gn)
+            print("B=%d %4d->%4d @%2dx%-2d gn=%d  direct %6.1f TF/s (%.3f ms)   winograd %6.1f TF/s (%.3f ms)   x%.2f"
+                  % (n, cin, cout, h, h, gn, d, dms, wv, wms, dms / wms), flush=True)
