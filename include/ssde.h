@@ -299,6 +299,25 @@ typedef struct ssde_adam_args {
 } ssde_adam_args;
 
 typedef struct ssde_memset_args { void* dst; int64_t bytes; int32_t value; int32_t _pad0; } ssde_memset_args;
+
+/* ---- weight re-packing after an optimizer step ------------------------------------------------- *
+ * The kernels read weights in their own layouts (conv: [cin/8][tap][cout_pad][8]; Winograd: the LDS image of
+ * G g G^T; 1x1 / NIN / Linear: [cin/8][cout_pad][8]; input-gradient variants transposed + rotated), the
+ * parameters stay in the reference layouts (state_dict compatibility).  One launch per kind re-packs
+ * every weight of the model from a device-resident descriptor table. */
+enum { SSDE_PACK_CONV3 = 1, SSDE_PACK_WINO3 = 2, SSDE_PACK_MATRIX = 3, SSDE_PACK_VECTOR = 4 };
+typedef struct ssde_pack_desc {
+  const float* src;        /* parameter: conv [cout][cin][3][3]; matrix [cout][cin]; vector [n] */
+  const float* src2;       /* vector: optional second addend (Conv_1.bias + Conv_2.bias) */
+  float* dst;
+  int32_t kind;
+  int32_t cout, cin;       /* parameter dims */
+  int32_t cout_l, cin_l;   /* conv: output / input channels of the packed operand; matrix: padded row count of dst */
+  int32_t flags;           /* 1: conv = input-gradient weights (transposed, rotated 180 degrees); matrix = transposed */
+  int32_t r_off, c_off;    /* matrix / vector: destination row (element) and column offsets */
+  int64_t n;               /* conv: elements of dst; matrix / vector: elements of src */
+} ssde_pack_desc;
+typedef struct ssde_pack_args { const ssde_pack_desc* table; int32_t count; int32_t kind; int64_t max_n; } ssde_pack_args;
 typedef struct ssde_axpy_args {   /* dst = (acc ? dst : 0) + alpha * x, optional SiLU' gate: * silu'(gate) */
   const float* x; const float* gate; float* dst; int64_t numel; float alpha; int32_t acc;
 } ssde_axpy_args;
@@ -329,6 +348,7 @@ int ssde_sumsq_flat(const ssde_sumsq_flat_args* a, void* stream);
 int ssde_adam_clip_ema(const ssde_adam_args* a, void* stream);
 int ssde_memset(const ssde_memset_args* a, void* stream);
 int ssde_axpy(const ssde_axpy_args* a, void* stream);
+int ssde_pack_weights(const ssde_pack_args* a, void* stream);
 
 /* ---- programs: a whole U-Net forward / PC step as one call -------------------
  * A program is a flat array of tagged ops built once by the host (it replaces the
@@ -340,7 +360,7 @@ enum {
   SSDE_OP_LANGEVIN = 11, SSDE_OP_PREDICTOR = 12, SSDE_OP_FILL = 13, SSDE_OP_STEP_INC = 14,
   SSDE_OP_WGRAD = 15, SSDE_OP_COLSUM = 16, SSDE_OP_GN_BWD_REDUCE = 17, SSDE_OP_PROLOGUE_BWD = 18,
   SSDE_OP_ATTN_BWD = 19, SSDE_OP_PERTURB = 20, SSDE_OP_DSM_LOSS = 21, SSDE_OP_SUMSQ_FLAT = 22,
-  SSDE_OP_ADAM = 23, SSDE_OP_MEMSET = 24, SSDE_OP_AXPY = 25
+  SSDE_OP_ADAM = 23, SSDE_OP_MEMSET = 24, SSDE_OP_AXPY = 25, SSDE_OP_PACK = 26
 };
 typedef struct ssde_op {
   int32_t kind; int32_t flops_class;   /* flops_class: free tag echoed by timing */
@@ -353,6 +373,7 @@ typedef struct ssde_op {
     ssde_wgrad_args wgrad; ssde_colsum_args colsum; ssde_gn_bwd_reduce_args gn_bwd; ssde_prologue_bwd_args pro_bwd;
     ssde_attn_bwd_args attn_bwd; ssde_perturb_args perturb; ssde_dsm_loss_args dsm_loss;
     ssde_sumsq_flat_args sumsq_flat; ssde_adam_args adam; ssde_memset_args memset; ssde_axpy_args axpy;
+    ssde_pack_args pack;
   } u;
 } ssde_op;
 

@@ -15,7 +15,8 @@ PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_SILU = 0, 1, 2, 3
 TILE_AUTO, TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32, TILE_WINOGRAD = 0, 1, 2, 3, 4, 5
 (OP_CONV, OP_GN_STATS, OP_UPFIRDN, OP_ATTN, OP_EMBED, OP_TO_NHWC, OP_TO_NCHW, OP_BIAS_ACT, OP_SUMSQ,
  OP_RANDN, OP_LANGEVIN, OP_PREDICTOR, OP_FILL, OP_STEP_INC, OP_WGRAD, OP_COLSUM, OP_GN_BWD_REDUCE, OP_PROLOGUE_BWD,
- OP_ATTN_BWD, OP_PERTURB, OP_DSM_LOSS, OP_SUMSQ_FLAT, OP_ADAM, OP_MEMSET, OP_AXPY) = range(1, 26)
+ OP_ATTN_BWD, OP_PERTURB, OP_DSM_LOSS, OP_SUMSQ_FLAT, OP_ADAM, OP_MEMSET, OP_AXPY, OP_PACK) = range(1, 27)
+PACK_CONV3, PACK_WINO3, PACK_MATRIX, PACK_VECTOR = 1, 2, 3, 4
 
 _fp = C.c_void_p  # device pointers are passed as integers
 
@@ -159,6 +160,16 @@ class AxpyArgs(C.Structure):
     _fields_ = [("x", _fp), ("gate", _fp), ("dst", _fp), ("numel", C.c_int64), ("alpha", C.c_float), ("acc", C.c_int32)]
 
 
+class PackDesc(C.Structure):
+    _fields_ = [("src", _fp), ("src2", _fp), ("dst", _fp), ("kind", C.c_int32), ("cout", C.c_int32), ("cin", C.c_int32),
+                ("cout_l", C.c_int32), ("cin_l", C.c_int32), ("flags", C.c_int32), ("r_off", C.c_int32), ("c_off", C.c_int32),
+                ("n", C.c_int64)]
+
+
+class PackArgs(C.Structure):
+    _fields_ = [("table", _fp), ("count", C.c_int32), ("kind", C.c_int32), ("max_n", C.c_int64)]
+
+
 class _OpUnion(C.Union):
     _fields_ = [("conv", ConvArgs), ("gn", GnStatsArgs), ("fir", UpfirdnArgs), ("attn", AttnArgs),
                 ("embed", EmbedArgs), ("to_nhwc", ToNhwcArgs), ("to_nchw", ToNchwArgs), ("bias_act", BiasActArgs),
@@ -166,7 +177,8 @@ class _OpUnion(C.Union):
                 ("fill", FillArgs), ("step_inc", StepIncArgs),
                 ("wgrad", WgradArgs), ("colsum", ColsumArgs), ("gn_bwd", GnBwdReduceArgs), ("pro_bwd", PrologueBwdArgs),
                 ("attn_bwd", AttnBwdArgs), ("perturb", PerturbArgs), ("dsm_loss", DsmLossArgs),
-                ("sumsq_flat", SumsqFlatArgs), ("adam", AdamArgs), ("memset", MemsetArgs), ("axpy", AxpyArgs)]
+                ("sumsq_flat", SumsqFlatArgs), ("adam", AdamArgs), ("memset", MemsetArgs), ("axpy", AxpyArgs),
+                ("pack", PackArgs)]
 
 
 class Op(C.Structure):
@@ -178,7 +190,7 @@ _UNION_FIELD = {OP_CONV: "conv", OP_GN_STATS: "gn", OP_UPFIRDN: "fir", OP_ATTN: 
                 OP_RANDN: "randn", OP_LANGEVIN: "langevin", OP_PREDICTOR: "predictor", OP_FILL: "fill",
                 OP_STEP_INC: "step_inc", OP_WGRAD: "wgrad", OP_COLSUM: "colsum", OP_GN_BWD_REDUCE: "gn_bwd",
                 OP_PROLOGUE_BWD: "pro_bwd", OP_ATTN_BWD: "attn_bwd", OP_PERTURB: "perturb", OP_DSM_LOSS: "dsm_loss",
-                OP_SUMSQ_FLAT: "sumsq_flat", OP_ADAM: "adam", OP_MEMSET: "memset", OP_AXPY: "axpy"}
+                OP_SUMSQ_FLAT: "sumsq_flat", OP_ADAM: "adam", OP_MEMSET: "memset", OP_AXPY: "axpy", OP_PACK: "pack"}
 
 EXPORTS = ["ssde_conv2d", "ssde_groupnorm_stats", "ssde_upfirdn2d", "ssde_attention", "ssde_embed", "ssde_to_nhwc",
            "ssde_to_nchw", "ssde_fused_bias_act", "ssde_sumsq", "ssde_randn", "ssde_langevin_update",
@@ -187,7 +199,7 @@ EXPORTS = ["ssde_conv2d", "ssde_groupnorm_stats", "ssde_upfirdn2d", "ssde_attent
            "ssde_abi_version", "ssde_sizeof_op", "ssde_last_error", "ssde_conv_lds_bytes",
            "ssde_conv_wgrad", "ssde_colsum", "ssde_gn_bwd_reduce", "ssde_prologue_bwd", "ssde_attention_bwd",
            "ssde_perturb", "ssde_dsm_loss", "ssde_sumsq_flat", "ssde_adam_clip_ema", "ssde_memset", "ssde_axpy",
-           "ssde_wgrad_scratch_floats"]
+           "ssde_wgrad_scratch_floats", "ssde_pack_weights"]
 
 _lib = None
 
@@ -216,7 +228,7 @@ def bind(lib):
                       ("ssde_gn_bwd_reduce", GnBwdReduceArgs), ("ssde_prologue_bwd", PrologueBwdArgs),
                       ("ssde_attention_bwd", AttnBwdArgs), ("ssde_perturb", PerturbArgs), ("ssde_dsm_loss", DsmLossArgs),
                       ("ssde_sumsq_flat", SumsqFlatArgs), ("ssde_adam_clip_ema", AdamArgs), ("ssde_memset", MemsetArgs),
-                      ("ssde_axpy", AxpyArgs)]:
+                      ("ssde_axpy", AxpyArgs), ("ssde_pack_weights", PackArgs)]:
         getattr(lib, name).argtypes = [C.POINTER(typ), C.c_void_p]
     lib.ssde_conv_lds_bytes.argtypes = [C.POINTER(ConvArgs)]
     lib.ssde_wgrad_scratch_floats.argtypes = [C.POINTER(WgradArgs)]

@@ -465,3 +465,92 @@ extern "C" int ssde_axpy(const ssde_axpy_args* a, void* stream) {
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;
 }
+
+// ---- weight re-packing -----------------------------------------------------------------------------------
+namespace {
+
+// logical 3x3 weight of a packed operand: W[co][ci][ky][kx] (zero outside the parameter)
+__device__ __forceinline__ float pack_w3(const ssde_pack_desc& d, int co, int ci, int ky, int kx) {
+  if (d.flags & 1) {      // input-gradient weights: transposed + rotated by 180 degrees
+    if (ci >= d.cout || co >= d.cin) return 0.f;
+    return d.src[((size_t)(ci * d.cin + co) * 3 + (2 - ky)) * 3 + (2 - kx)];
+  }
+  if (co >= d.cout || ci >= d.cin) return 0.f;
+  return d.src[((size_t)(co * d.cin + ci) * 3 + ky) * 3 + kx];
+}
+
+// grid (x, entries): every workgroup row re-packs one table entry, destination-driven (coalesced stores)
+__global__ __launch_bounds__(256) void pack_conv3_kernel(const ssde_pack_desc* __restrict__ table) {
+  const ssde_pack_desc d = table[blockIdx.y];
+  const int cpad = (d.cout_l + 63) / 64 * 64;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < (size_t)d.n; idx += (size_t)gridDim.x * 256) {
+    const int e = (int)(idx & 7);
+    const int co = (int)((idx >> 3) % cpad);
+    const size_t r = (idx >> 3) / cpad;
+    const int tap = (int)(r % 9), c8 = (int)(r / 9);
+    d.dst[idx] = pack_w3(d, co, c8 * 8 + e, tap / 3, tap % 3);
+  }
+}
+
+// Winograd: U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], stored as conv_wino.hip's LDS image
+__global__ __launch_bounds__(256) void pack_wino3_kernel(const ssde_pack_desc* __restrict__ table) {
+  const ssde_pack_desc d = table[blockIdx.y];
+  const int ntl = (d.cout_l + 63) / 64;
+  const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < (size_t)d.n; idx += (size_t)gridDim.x * 256) {
+    const int e = (int)(idx & 1);
+    const int cs = (int)((idx >> 1) & 63);
+    const int q = (int)((idx >> 7) & 3);
+    const int pos = (int)((idx >> 9) & 15);
+    const size_t r = idx >> 13;
+    const int nt = (int)(r % ntl), c8 = (int)(r / ntl);
+    const int co = nt * 64 + (cs ^ ((q & 1) << 4));
+    const int ci = c8 * 8 + 2 * q + e;
+    const int pa = pos >> 2, pb = pos & 3;
+    float u = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float t = 0.f;
+#pragma unroll
+      for (int l = 0; l < 3; ++l) t += pack_w3(d, co, ci, k, l) * G[pb][l];
+      u += G[pa][k] * t;
+    }
+    d.dst[idx] = u;
+  }
+}
+
+// matrix parts (source-driven): dst[(col/8)*ld + row][col%8] = src[i][j]; flags&1 swaps the roles of i and j
+__global__ __launch_bounds__(256) void pack_matrix_kernel(const ssde_pack_desc* __restrict__ table) {
+  const ssde_pack_desc d = table[blockIdx.y];
+  const int ld = (d.cout_l + 63) / 64 * 64;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < (size_t)d.n; idx += (size_t)gridDim.x * 256) {
+    const int i = (int)(idx / d.cin), j = (int)(idx % d.cin);
+    const int row = ((d.flags & 1) ? j : i) + d.r_off, col = ((d.flags & 1) ? i : j) + d.c_off;
+    d.dst[((size_t)(col >> 3) * ld + row) * 8 + (col & 7)] = d.src[idx];
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_vector_kernel(const ssde_pack_desc* __restrict__ table) {
+  const ssde_pack_desc d = table[blockIdx.y];
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < (size_t)d.n; idx += (size_t)gridDim.x * 256)
+    d.dst[d.r_off + idx] = d.src[idx] + (d.src2 ? d.src2[idx] : 0.f);
+}
+
+}  // namespace
+
+extern "C" int ssde_pack_weights(const ssde_pack_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->table && a->count > 0 && a->max_n > 0, "pack_weights: bad args");
+  size_t bx = ((size_t)a->max_n + 255) / 256;
+  if (bx > 256) bx = 256;
+  const dim3 grid((unsigned)bx, (unsigned)a->count);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (a->kind) {
+    case SSDE_PACK_CONV3: hipLaunchKernelGGL(pack_conv3_kernel, grid, dim3(256), 0, st, a->table); break;
+    case SSDE_PACK_WINO3: hipLaunchKernelGGL(pack_wino3_kernel, grid, dim3(256), 0, st, a->table); break;
+    case SSDE_PACK_MATRIX: hipLaunchKernelGGL(pack_matrix_kernel, grid, dim3(256), 0, st, a->table); break;
+    case SSDE_PACK_VECTOR: hipLaunchKernelGGL(pack_vector_kernel, grid, dim3(256), 0, st, a->table); break;
+    default: ssde_set_error("pack_weights: unknown kind %d", a->kind); return SSDE_EINVAL;
+  }
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}

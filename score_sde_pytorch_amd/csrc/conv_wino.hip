@@ -14,10 +14,11 @@
 // of the stage, the other does staging work for the next stage, then they swap (two barriers per
 // stage); a version in which every wave staged and computed in the same phase kept the matrix pipe
 // only 22% busy, because VALU/LDS/VMEM work of both waves coincided and nothing covered it.
-//   phase 1: waves 0-3 MFMA(stage k)   | waves 4-7 prologue + LDS stores of raw halo / weights (k+1)
-//   phase 2: waves 4-7 MFMA(stage k)   | waves 0-3 input transform raw -> V(k+1); 4-7 first issue the
-//                                         halo loads of stage k+2 (registers) and the LDS-DMA of the
-//                                         weights of stage k+1 (no registers), which fly under their MFMAs
+//   phase 1: waves 0-3 MFMA(stage k)   | waves 4-7 prologue + LDS stores of the raw halo (k+1), then issue
+//                                         the halo loads of stage k+2 into registers
+//   phase 2: waves 4-7 MFMA(stage k)   | waves 0-3 LDS-DMA of the weights (k+1, no registers) and the
+//                                         input transform raw -> V(k+1)
+// so a wave's matrix phase is MFMAs and fragment reads only.
 // Per 8-input-channel stage:
 //   raw halo (with the fused GroupNorm / SiLU / dropout prologue)  -> LDS, channel-pair major
 //   input transform B^T d B, one (tile, channel pair) per thread   -> LDS V[pos][pair][tile][2]
@@ -215,29 +216,39 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
 #pragma unroll
   for (int b = 0; b < 2; ++b) boff[b] = ph * 8 * 512 + (lq * 64 + ((cb0 + b * 16 + li) ^ swz)) * 2;
 
+  // fragments of position ps+1 are read while the 8 MFMAs of position ps issue (two register sets)
   auto mfma_stage = [&](const float* Vc, const float* Uc) {
+    float2 af[2][2], bf[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) af[0][a] = *reinterpret_cast<const float2*>(Vc + aoff[a]);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) bf[0][b] = *reinterpret_cast<const float2*>(Uc + boff[b]);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
-      float2 af[2], bf[2];
+      const int cur = ps & 1;
+      if (ps + 1 < 8) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const float2*>(Vc + ps * 512 + aoff[a]);
+        for (int a = 0; a < 2; ++a) af[cur ^ 1][a] = *reinterpret_cast<const float2*>(Vc + (ps + 1) * 512 + aoff[a]);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) bf[b] = *reinterpret_cast<const float2*>(Uc + ps * 512 + boff[b]);
+        for (int b = 0; b < 2; ++b) bf[cur ^ 1][b] = *reinterpret_cast<const float2*>(Uc + (ps + 1) * 512 + boff[b]);
+      }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          acc[ps][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a].x, bf[b].x, acc[ps][a][b], 0, 0, 0);
-          acc[ps][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a].y, bf[b].y, acc[ps][a][b], 0, 0, 0);
+          acc[ps][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][a].x, bf[cur][b].x, acc[ps][a][b], 0, 0, 0);
+          acc[ps][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][a].y, bf[cur][b].y, acc[ps][a][b], 0, 0, 0);
         }
     }
+    __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- pipeline prologue: stage 0 staged, stage 1 in flight ----
-  if (ph == 1) { dma_weights(0, Ub); load_stage(0); store_stage(); }
+  if (ph == 1) { load_stage(0); store_stage(); if (nst > 1) load_stage(1); }
+  else dma_weights(0, Ub);
   __syncthreads();
   if (ph == 0) transform(Vb);
-  else if (nst > 1) load_stage(1);
   __syncthreads();
 
   for (int st = 0; st < nst; ++st) {
@@ -245,16 +256,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
     const float* Uc = Ub + (st & 1) * kStageFloats;
     float* Vn = Vb + ((st + 1) & 1) * kStageFloats;
     float* Un = Ub + ((st + 1) & 1) * kStageFloats;
-    // phase 1: waves 0-3 on the matrix pipe; waves 4-7 apply the prologue and store stage st+1's raw halo
-    if (ph == 0) mfma_stage(Vc, Uc);
-    else if (st + 1 < nst) store_stage();
-    __syncthreads();
-    // phase 2: waves 4-7 on the matrix pipe (weights DMA of st+1 and halo loads of st+2 fly underneath); 0-3 transform
-    if (ph == 1) {
-      if (st + 1 < nst) dma_weights(st + 1, Un);
-      if (st + 2 < nst) load_stage(st + 2);
+    // phase 1: waves 0-3 on the matrix pipe; waves 4-7 apply the prologue, store stage st+1's raw halo and
+    // put stage st+2's halo loads in flight
+    if (ph == 0) {
       mfma_stage(Vc, Uc);
     } else if (st + 1 < nst) {
+      store_stage();
+      if (st + 2 < nst) load_stage(st + 2);
+    }
+    __syncthreads();
+    // phase 2: waves 4-7 on the matrix pipe; waves 0-3 start the weight DMA of st+1 and transform its halo
+    if (ph == 1) {
+      mfma_stage(Vc, Uc);
+    } else if (st + 1 < nst) {
+      dma_weights(st + 1, Un);
       transform(Vn);
     }
     __syncthreads();

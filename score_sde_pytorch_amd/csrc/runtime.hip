@@ -43,6 +43,7 @@ static int run_one(const ssde_op& op, void* stream) {
     case SSDE_OP_ADAM: return ssde_adam_clip_ema(&op.u.adam, stream);
     case SSDE_OP_MEMSET: return ssde_memset(&op.u.memset, stream);
     case SSDE_OP_AXPY: return ssde_axpy(&op.u.axpy, stream);
+    case SSDE_OP_PACK: return ssde_pack_weights(&op.u.pack, stream);
   }
   ssde_set_error("program: unknown op kind %d", op.kind);
   return SSDE_EINVAL;

@@ -288,12 +288,15 @@ class WeightStore:
         self.entries = []   # [packed, sources, fn, stamp]
         self.meta = {}
 
-    def add(self, sources, fn, meta=None):
+    def add(self, sources, fn, meta=None, recipe=None):
+        """recipe: descriptors for the device-side re-pack (ssde_pack_weights); fn is the same packing in torch, used for
+        the first fill, for CPU dry lowering, and as the cross-check of the device kernels in the tests."""
         with torch.no_grad():
             packed = fn(*[s.detach() for s in sources]).to(self.device).contiguous()
-        self.entries.append([packed, list(sources), fn, self._stamp(sources)])
+        self.entries.append([packed, list(sources), fn, self._stamp(sources), recipe])
         if meta is not None:
             self.meta[id(packed)] = meta
+        self._tables = None
         return packed
 
     # -- typed registrations -------------------------------------------------------------------
@@ -307,10 +310,13 @@ class WeightStore:
             if cout_pad and w.shape[0] < cout_pad:
                 w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cout_pad - w.shape[0]))
             return w
-        meta = dict(kind="conv3", sources=[param], logical=logical,
+        cout_l, cin_l = max(param.shape[0], cout_pad or 0), max(param.shape[1], cin_pad or 0)
+        meta = dict(kind="conv3", sources=[param], logical=logical, dims=(cout_l, cin_l),
                     parts=[dict(param=param, row0=0, rows=param.shape[0], transpose=False)], cin_store=param.shape[1])
         pack = pack_wino_weight if wino else pack_conv_weight
-        return self.add([param], lambda w: pack(logical(w)), meta)
+        recipe = [dict(kind=L.PACK_WINO3 if wino else L.PACK_CONV3, src=param, cout=param.shape[0], cin=param.shape[1],
+                       cout_l=cout_l, cin_l=cin_l, flags=0, n="dst")]
+        return self.add([param], lambda w: pack(logical(w)), meta, recipe)
 
     def matrix(self, parts, cin_pad=None):
         """Rows-concatenated [Cout_i, Cin] matrices; parts = [(param, transpose)], transpose for NIN's [in, out]."""
@@ -332,8 +338,11 @@ class WeightStore:
             cin = p_.shape[0] if tr else int(np.prod(p_.shape[1:]))
             desc.append(dict(param=p_, row0=rows, rows=n_rows, transpose=tr))
             rows += n_rows
-        meta = dict(kind="matrix", sources=params, logical=logical, parts=desc, cin_store=cin)
-        return self.add(params, lambda *ws: pack_matrix(logical(*ws)), meta)
+        meta = dict(kind="matrix", sources=params, logical=logical, parts=desc, cin_store=cin,
+                    dims=(rows, max(cin, cin_pad or 0)))
+        recipe = [dict(kind=L.PACK_MATRIX, src=d["param"], cout=d["param"].shape[0], cin=int(np.prod(d["param"].shape[1:])),
+                       cout_l=rows, cin_l=0, flags=int(d["transpose"]), r_off=d["row0"], c_off=0, n="src") for d in desc]
+        return self.add(params, lambda *ws: pack_matrix(logical(*ws)), meta, recipe)
 
     def vector(self, params, mode="cat", pad_to=None):
         """Per-channel vectors: biases (concatenated, or summed when two convolutions share one epilogue), GroupNorm affine."""
@@ -347,27 +356,86 @@ class WeightStore:
         for p_ in params:
             desc.append(dict(param=p_, off=0 if mode == "sum" else off, n=p_.numel()))
             off += p_.numel()
-        return self.add(params, fn, dict(kind="vector", mode=mode, sources=list(params), parts=desc))
+        if mode == "sum":
+            assert len(params) == 2
+            recipe = [dict(kind=L.PACK_VECTOR, src=params[0], src2=params[1], r_off=0, n="src")]
+        else:
+            recipe = [dict(kind=L.PACK_VECTOR, src=d["param"], r_off=d["off"], n="src") for d in desc]
+        return self.add(params, fn, dict(kind="vector", mode=mode, sources=list(params), parts=desc), recipe)
 
     def derived(self, packed, fn, tag):
-        """A second packing of an existing entry's logical weight (input-gradient weights): fn(logical) -> packed."""
+        """The input-gradient packing of an existing entry's logical weight: fn(logical) -> packed, with tag
+        'dgrad' (direct conv / matrix) or 'dgrad_wino'."""
         meta = self.meta[id(packed)]
         key = (id(packed), tag)
         if key not in self.meta:
-            self.meta[key] = self.add(meta["sources"], lambda *ws: fn(meta["logical"](*ws)))
+            cout_l, cin_l = meta["dims"]
+            if meta["kind"] == "conv3":
+                p_ = meta["sources"][0]
+                recipe = [dict(kind=L.PACK_WINO3 if tag == "dgrad_wino" else L.PACK_CONV3, src=p_, cout=p_.shape[0], cin=p_.shape[1],
+                               cout_l=cin_l, cin_l=cout_l, flags=1, n="dst")]
+            else:
+                # D = M^T: part rows become column ranges; a transposed (NIN) part is read straight, a plain one swapped
+                recipe = [dict(kind=L.PACK_MATRIX, src=d["param"], cout=d["param"].shape[0], cin=int(np.prod(d["param"].shape[1:])),
+                               cout_l=cin_l, cin_l=0, flags=int(not d["transpose"]), r_off=0, c_off=d["row0"], n="src")
+                          for d in meta["parts"]]
+            self.meta[key] = self.add(meta["sources"], lambda *ws: fn(meta["logical"](*ws)), None, recipe)
         return self.meta[key]
+
+    # -- device-side re-pack -------------------------------------------------------------------------
+    def _build_tables(self):
+        descs = {}
+        for e in self.entries:
+            packed, recipe = e[0], e[4]
+            if recipe is None:
+                continue
+            for r in recipe:
+                d = L.PackDesc()
+                src = r["src"]
+                d.src, d.dst, d.kind = src.data_ptr(), packed.data_ptr(), r["kind"]
+                d.src2 = r["src2"].data_ptr() if r.get("src2") is not None else None
+                d.cout, d.cin = r.get("cout", 0), r.get("cin", 0)
+                d.cout_l, d.cin_l, d.flags = r.get("cout_l", 0), r.get("cin_l", 0), r.get("flags", 0)
+                d.r_off, d.c_off = r.get("r_off", 0), r.get("c_off", 0)
+                d.n = packed.numel() if r["n"] == "dst" else src.numel()
+                descs.setdefault(r["kind"], []).append(d)
+        tables = []
+        for kind, ds in sorted(descs.items()):
+            arr = (L.PackDesc * len(ds))(*ds)
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            args = L.PackArgs()
+            args.table, args.count, args.kind, args.max_n = raw.data_ptr(), len(ds), kind, max(int(x.n) for x in ds)
+            tables.append((args, raw))
+        stamp = tuple(s.data_ptr() for e in self.entries if e[4] is not None for s in e[1])
+        self._tables = (tables, stamp)
+
+    def device_refresh(self):
+        """Re-pack every entry that has a recipe with four launches (one per kind); returns False when nothing has one."""
+        from . import hipops
+        if getattr(self, "_tables", None) is None or \
+                self._tables[1] != tuple(s.data_ptr() for e in self.entries if e[4] is not None for s in e[1]):
+            self._build_tables()
+        lib = L.load()
+        for args, _ in self._tables[0]:
+            L.check(lib.ssde_pack_weights(C.byref(args), hipops._stream()), "ssde_pack_weights")
+        return bool(self._tables[0])
 
     @staticmethod
     def _stamp(sources):
         return tuple((s.data_ptr(), s._version) for s in sources)
 
-    def refresh(self, force=False):
+    def refresh(self, force=False, on_device=None):
+        """Bring packed copies up to date.  force=True (after the fused optimizer wrote the flat parameter buffer behind
+        torch's back) re-packs everything: with the device kernels when the library can run here, else in torch."""
+        if on_device is None:
+            on_device = self.device.type == "cuda" if isinstance(self.device, torch.device) else str(self.device).startswith("cuda")
+        done_on_device = force and on_device and self.device_refresh()
         for e in self.entries:
             st = self._stamp(e[1])
-            if force or st != e[3]:
+            if (force and not (done_on_device and e[4] is not None)) or st != e[3]:
                 with torch.no_grad():
                     e[0].copy_(e[2](*[s.detach() for s in e[1]]).to(self.device))
-                e[3] = st
+            e[3] = st
 
 
 # --------------------------------------------------------------------------- lowering helpers

@@ -363,3 +363,31 @@ def check_fused_step(dev, steps=3, sde_kind="vesde"):
     osd = opt.state_dict()
     assert len(osd["state"]) == len(names) and all(float(v["step"]) == steps for v in osd["state"].values())
     return float(loss)
+
+
+def check_device_repack(dev, kind="ncsnpp"):
+    """ssde_pack_weights (four launches for the whole model, driven by a device-resident descriptor table) against the
+    torch packers in engine.py, for every packed operand incl. Winograd and input-gradient variants."""
+    from score_sde_pytorch_amd.models import utils as mutils
+    from score_sde_pytorch_amd import backward as B
+    cfg = small_cfg(kind)
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    _util.load_seeded(model, seed=1)
+    model = model.to(dev)
+    R = cfg.data.image_size
+    eng = B.TrainEngine(model, 2, R, R, torch.device(dev), input_grad=True, dropout=False)
+    ws = eng.weights
+    eng.flat.data.add_(torch.randn(eng.flat.numel, generator=torch.Generator().manual_seed(5)).to(dev) * 0.1)
+    ws.refresh(force=True, on_device=False)
+    ref = [e[0].clone() for e in ws.entries]
+    for e in ws.entries:
+        if e[4] is not None:
+            e[0].fill_(7.0) if e[4][0]["kind"] in (1, 2) else e[0].zero_()   # matrix / vector kernels keep the zero padding
+    assert ws.device_refresh()
+    n = 0
+    for e, r in zip(ws.entries, ref):
+        if e[4] is not None:
+            assert float((e[0] - r).abs().max()) < 1e-6, (e[4][0]["kind"], e[4][0].get("flags"), tuple(e[0].shape))
+            n += 1
+    assert n >= len(ws.entries) - 2

@@ -45,3 +45,8 @@ def test_autograd_bridge(monkeypatch):
 @pytest.mark.parametrize("sde_kind", ["vesde", "subvpsde"])
 def test_fused_training_step(sde_kind):
     T.check_fused_step("cpu", steps=2, sde_kind=sde_kind)
+
+
+@pytest.mark.parametrize("kind", ["ncsnpp", "ffhq"])
+def test_device_weight_repack(kind):
+    T.check_device_repack("cpu", kind)

@@ -60,3 +60,8 @@ def test_step_fn_selects_fused_path_and_trains():
     assert float((model.all_modules[3].weight.detach() - p0).abs().max()) > 0
     le = float(eval_fn(state, batch))
     assert le == le and le > 0
+
+
+@pytest.mark.parametrize("kind", ["ncsnpp", "ffhq"])
+def test_device_weight_repack(kind):
+    T.check_device_repack("cuda", kind)
