@@ -160,7 +160,9 @@ typedef struct ssde_bias_act_args {
   int64_t numel; int32_t channels; int32_t inner;   /* bias index = (i / inner) % channels */
   int32_t act;                    /* 1 linear, 3 leaky relu */
   float alpha, scale;
-  int32_t _pad0;
+  int32_t grad;                   /* 0: forward; 1: first-order gradient mode, dst = src * (ref > 0 ? 1 : alpha) * scale
+                                     (op/fused_bias_act_kernel.cu:36-44, used by FusedLeakyReLUFunctionBackward) */
+  const float* ref;               /* grad == 1: the forward OUTPUT whose sign selects the slope */
 } ssde_bias_act_args;
 
 /* ---- predictor-corrector update (sampling.py:195-200, 262-282, 181-187) ----- */

@@ -73,7 +73,8 @@ class ToNchwArgs(C.Structure):
 
 class BiasActArgs(C.Structure):
     _fields_ = [("src", _fp), ("bias", _fp), ("dst", _fp), ("numel", C.c_int64), ("channels", C.c_int32),
-                ("inner", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float), ("scale", C.c_float), ("_pad0", C.c_int32)]
+                ("inner", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float), ("scale", C.c_float), ("grad", C.c_int32),
+                ("ref", _fp)]
 
 
 class SumsqArgs(C.Structure):

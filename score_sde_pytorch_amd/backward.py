@@ -38,7 +38,14 @@ class FlatParams:
     """All trainable parameters of a model as views into one flat fp32 buffer (+ a same-shaped gradient buffer)."""
 
     def __init__(self, model, device):
-        self.params = [p for p in model.parameters() if p.requires_grad]
+        params = [p for p in model.parameters() if p.requires_grad]
+        # parameters the kernels treat as ONE operand (the Dense_0 projections of all residual blocks form one GEMM,
+        # engine.py) are laid out back to back, so their gradient is one weight-gradient launch as well
+        groups = model.flat_param_groups() if hasattr(model, "flat_param_groups") else []
+        grouped = [p for g in groups for p in g]
+        seen = {id(p) for p in grouped}
+        self.params = grouped + [p for p in params if id(p) not in seen]
+        self.model_order = params            # model.parameters() order (what optimizers / EMA objects were built from)
         self.index, off = {}, 0
         for p in self.params:
             self.index[id(p)] = (off, p.numel())
@@ -67,6 +74,19 @@ class FlatParams:
     def grad_view(self, p):
         o, n = self.index[id(p)]
         return self.grad[o:o + n].view(p.shape)
+
+    def contiguous(self, params):
+        """True when `params` occupy one gap-free run of the flat buffers, in this order."""
+        for a, b in zip(params[:-1], params[1:]):
+            oa, na = self.index[id(a)]
+            if self.index[id(b)][0] != oa + na:
+                return False
+        return True
+
+    def grad_run(self, params):
+        o = self.index[id(params[0])][0]
+        n = sum(self.index[id(p)][1] for p in params)
+        return self.grad[o:o + n]
 
     def attach_grads(self):
         """Expose the flat gradient buffer through `p.grad` (views, no copies)."""
@@ -210,6 +230,13 @@ class TrainEngine(E.UNetEngine):
                                     ps_ld=ps_ld, ps_off=ps_off, total=None, total2=None,
                                     scratch=b.buf(n * (max(1, min(32, hw // 64)) + 1) * f["c_out"], name="colsum_scratch")), FC_BWD)
             return
+        if len(parts) > 1 and per is None and self.flat.contiguous([pt["param"] for pt in parts]):
+            # concatenated biases stored back to back (Dense_0 of every block): one launch for all of them
+            c = sum(pt["n"] for pt in parts)
+            b.add(L.OP_COLSUM, dict(g=g, g_ld=g_ld, g_off=parts[0]["off"], n=n, hw=hw, c=c, scale=float(scale), per_sample=None,
+                                    ps_ld=0, ps_off=0, total=self.flat.grad_run([pt["param"] for pt in parts]), total2=None,
+                                    scratch=b.buf(n * (max(1, min(32, hw // 64)) + 1) * c, name="colsum_scratch")), FC_BWD)
+            return
         for i, part in enumerate(parts):
             use_per = per if (i == 0 and len(parts) == 1) else None
             assert per is None or len(parts) == 1
@@ -227,12 +254,18 @@ class TrainEngine(E.UNetEngine):
             h_in, w_in, stride, pad = ho, wo, 1, 0
         meta = self.weights.meta[id(wpacked)]
         ctot = src["c0"] + src["c1"]
-        for part in meta["parts"]:
+        parts = meta["parts"]
+        if len(parts) > 1 and not any(pt["transpose"] for pt in parts) and self.flat.contiguous([pt["param"] for pt in parts]):
+            # row-concatenated [out_i, in] matrices stored back to back ARE the [sum out_i, in] matrix
+            whole = self.flat.grad_run([pt["param"] for pt in parts])
+            parts = [dict(param=None, row0=parts[0]["row0"], rows=sum(pt["rows"] for pt in parts), transpose=False, view=whole)]
+        for part in parts:
             flops = 2.0 * n * ho * wo * ksize * ksize * meta["cin_store"] * part["rows"]
             fields = dict(src=src, g=g, g_ld=g_ld, g_off=part["row0"], n=n, h_in=h_in, w_in=w_in, h_out=ho, w_out=wo,
                           c_out=part["rows"], ksize=ksize, stride=stride, pad=pad, cin_store=meta["cin_store"],
                           transpose_out=int(part["transpose"]), splits=0, scale=float(scale),
-                          dw=self.flat.grad_view(part["param"]), scratch=None, scratch_floats=0)
+                          dw=part["view"] if part.get("view") is not None else self.flat.grad_view(part["param"]),
+                          scratch=None, scratch_floats=0)
             need = self._wgrad_scratch(fields)
             if need > 0:
                 fields.update(scratch=b.buf(need, name="wgrad_slabs"), scratch_floats=need)

@@ -62,15 +62,25 @@ __global__ void colsum_slices_kernel(const float* __restrict__ part, int slices,
   per[(size_t)n * ld + off + j] = s;
 }
 
-// total[j] = sum_n per[n, off + j]  (fixed order: deterministic)
-__global__ void colsum_total_kernel(const float* __restrict__ per, int ld, int off, int n, int c,
-                                    float* __restrict__ t0, float* __restrict__ t1) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= c) return;
+// total[j] = sum_n per[n, off + j].  Block = 32 channels x 8 sample lanes (a serial loop over the samples is a chain
+// of dependent L2 latencies: 28 us for 128 samples); fixed summation order -> deterministic.
+__global__ __launch_bounds__(256) void colsum_total_kernel(const float* __restrict__ per, int ld, int off, int n, int c,
+                                                           float* __restrict__ t0, float* __restrict__ t1) {
+  SSDE_LDS(smem);                                        // [8][32]
+  const int jl = threadIdx.x & 31, nl = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + jl;
   float s = 0.f;
-  for (int i = 0; i < n; ++i) s += per[(size_t)i * ld + off + j];
-  t0[j] = s;
-  if (t1) t1[j] = s;
+  if (j < c)
+    for (int i = nl; i < n; i += 8) s += per[(size_t)i * ld + off + j];
+  smem[nl * 32 + jl] = s;
+  __syncthreads();
+  if (nl == 0 && j < c) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += smem[k * 32 + jl];
+    t0[j] = t;
+    if (t1) t1[j] = t;
+  }
 }
 
 // ---- GroupNorm backward: reduction -----------------------------------------------------------------
@@ -132,13 +142,15 @@ __global__ __launch_bounds__(kGbThreads) void gn_bwd_reduce_kernel(const GbParam
   }
 }
 
-// role A (blockIdx.y == 0): sums[n][g] = (mean_g dxh, mean_g dxh*xhat), dxh = du*gamma
-// role B (blockIdx.y == 1): dgamma[c], dbeta[c] = sum over samples and slices
-__global__ void gn_bwd_finalize_kernel(const GbParams p) {
+// role A (blockIdx.y == 0): sums[n][g] = (mean_g dxh, mean_g dxh*xhat), dxh = du*gamma; one thread per (n, g)
+// role B (blockIdx.y == 1): dgamma[c], dbeta[c] = sum over samples and slices; block = 32 channels x 8 (sample,slice)
+//                            lanes + an LDS tree (a serial loop over 128 samples x slices was 45 us of latency)
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const GbParams p) {
+  SSDE_LDS(smem);                                        // [2][8][32]
   const ssde_src& s = p.src;
   const int C = s.c0 + s.c1, G = s.gn_groups, cpg = C / G;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (blockIdx.y == 0) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.n * G) return;
     const int n = idx / G, g = idx % G;
     float A = 0.f, B = 0.f;
@@ -150,15 +162,26 @@ __global__ void gn_bwd_finalize_kernel(const GbParams p) {
     p.sums[idx * 2] = A * inv;
     p.sums[idx * 2 + 1] = B * inv;
   } else {
-    if (idx >= C) return;
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float dg = 0.f, db = 0.f;
-    for (int n = 0; n < p.n; ++n)
-      for (int sl = 0; sl < p.slices; ++sl) {
-        const float* o = p.scratch + (((size_t)n * p.slices + sl) * C + idx) * 2;
-        dg += o[0]; db += o[1];
+    if (c < C) {
+      const int rows = p.n * p.slices;
+      for (int r = rl; r < rows; r += 8) {
+        const float2 o = *reinterpret_cast<const float2*>(p.scratch + ((size_t)r * C + c) * 2);
+        dg += o.x; db += o.y;
       }
-    p.dgamma[idx] = dg;
-    p.dbeta[idx] = db;
+    }
+    smem[rl * 32 + cl] = dg;
+    smem[256 + rl * 32 + cl] = db;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+      float tg = 0.f, tb = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { tg += smem[k * 32 + cl]; tb += smem[256 + k * 32 + cl]; }
+      p.dgamma[c] = tg;
+      p.dbeta[c] = tb;
+    }
   }
 }
 
@@ -373,7 +396,7 @@ extern "C" int ssde_colsum(const ssde_colsum_args* a, void* stream) {
     SSDE_LAUNCH_CHECK();
   }
   if (a->total) {
-    hipLaunchKernelGGL(colsum_total_kernel, dim3(ssde_cdiv(a->c, 256)), dim3(256), 0, st, per, ld, off, a->n, a->c, a->total, a->total2);
+    hipLaunchKernelGGL(colsum_total_kernel, dim3(ssde_cdiv(a->c, 32)), dim3(256), 8 * 32 * 4, st, per, ld, off, a->n, a->c, a->total, a->total2);
     SSDE_LAUNCH_CHECK();
   }
   return SSDE_OK;
@@ -390,8 +413,8 @@ extern "C" int ssde_gn_bwd_reduce(const ssde_gn_bwd_reduce_args* a, void* stream
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(slices, a->n), dim3(kGbThreads), kGbThreads * 8 * 4, st, p);
   SSDE_LAUNCH_CHECK();
-  const int work = a->n * a->src.gn_groups > C ? a->n * a->src.gn_groups : C;
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(ssde_cdiv(work, 256), 2), dim3(256), 0, st, p);
+  const int bx_a = ssde_cdiv(a->n * a->src.gn_groups, 256), bx_b = ssde_cdiv(C, 32);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(bx_a > bx_b ? bx_a : bx_b, 2), dim3(256), 2 * 8 * 32 * 4, st, p);
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;
 }

@@ -69,11 +69,16 @@ __global__ void to_nchw_kernel(const float* __restrict__ src, float* __restrict_
 
 // ---- fused bias + activation (op/fused_bias_act_kernel.cu:18-49, forward only) ------
 __global__ void bias_act_kernel(const float* __restrict__ src, const float* __restrict__ bias, float* __restrict__ dst,
-                                size_t numel, int channels, int inner, int act, float alpha, float scale) {
+                                size_t numel, int channels, int inner, int act, float alpha, float scale, int grad,
+                                const float* __restrict__ ref) {
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < numel; idx += (size_t)gridDim.x * blockDim.x) {
     float x = src[idx];
     if (bias) x += bias[(idx / inner) % channels];
-    if (act == 3) x = x > 0.f ? x : x * alpha;
+    if (grad == 1) {                       // gradient mode: slope chosen by the sign of the forward output
+      if (act == 3) x = ref[idx] > 0.f ? x : x * alpha;
+    } else if (act == 3) {
+      x = x > 0.f ? x : x * alpha;
+    }
     dst[idx] = x * scale;
   }
 }
@@ -221,9 +226,10 @@ extern "C" int ssde_fused_bias_act(const ssde_bias_act_args* a, void* stream) {
   SSDE_REQUIRE(a && a->src && a->dst && a->numel >= 0, "fused_bias_act: bad args");
   SSDE_REQUIRE(a->act == 1 || a->act == 3, "fused_bias_act: act must be 1 (linear) or 3 (leaky relu)");
   SSDE_REQUIRE(!a->bias || (a->channels > 0 && a->inner > 0), "fused_bias_act: bad bias geometry");
+  SSDE_REQUIRE(a->grad == 0 || (a->grad == 1 && a->ref), "fused_bias_act: grad must be 0 or 1 (with ref)");
   if (a->numel == 0) return SSDE_OK;
   hipLaunchKernelGGL(bias_act_kernel, dim3(grid_for((size_t)a->numel)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     a->src, a->bias, a->dst, (size_t)a->numel, a->channels, a->inner, a->act, a->alpha, a->scale);
+                     a->src, a->bias, a->dst, (size_t)a->numel, a->channels, a->inner, a->act, a->alpha, a->scale, a->grad, a->ref);
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;
 }

@@ -150,13 +150,14 @@ def to_nchw(x, c=None, mode=0, v=None):
     return dst
 
 
-def fused_bias_act(x, bias=None, channels=1, inner=1, act=1, alpha=0.2, scale=1.0):
+def fused_bias_act(x, bias=None, channels=1, inner=1, act=1, alpha=0.2, scale=1.0, grad=0, ref=None):
     _need_cuda(x)
     x = x.contiguous()
     dst = torch.empty_like(x)
     a = L.BiasActArgs()
     a.src, a.bias, a.dst, a.numel, a.channels, a.inner, a.act, a.alpha, a.scale = \
         _p(x), _p(bias), _p(dst), x.numel(), channels, inner, act, alpha, scale
+    a.grad, a.ref = grad, _p(ref)
     L.check(L.load().ssde_fused_bias_act(C.byref(a), _stream()), "ssde_fused_bias_act")
     return dst
 

@@ -64,9 +64,9 @@ class ExponentialMovingAverage:
         if self._flat is not None and self._flat.numel() == flat.numel and self._flat.device == flat.data.device:
             return self._flat
         buf = torch.zeros(flat.numel, dtype=torch.float32, device=flat.data.device)
-        assert len(self.shadow_params) == len(flat.params)
+        assert len(self.shadow_params) == len(flat.model_order)
         new = []
-        for s, p in zip(self.shadow_params, flat.params):
+        for s, p in zip(self.shadow_params, flat.model_order):      # shadow parameters follow model.parameters() order
             o, n = flat.index[id(p)]
             buf[o:o + n].copy_(s.reshape(-1).to(buf.device, torch.float32))
             new.append(buf[o:o + n].view(p.shape))

@@ -277,6 +277,11 @@ class NCSNpp(nn.Module):
         self.all_modules = nn.ModuleList(mods)
         self._engines = {}
 
+    def flat_param_groups(self):
+        """Parameters the HIP programs use as one concatenated operand (backward.FlatParams stores them back to back)."""
+        dense = [m.Dense_0 for m in self.all_modules if getattr(m, "kind", "") == "res" and hasattr(m, "Dense_0")]
+        return [[d.weight for d in dense], [d.bias for d in dense]] if dense else []
+
     # ------------------------------------------------------------------ forward
     def _engine_for(self, x):
         from .. import engine as _engine

@@ -391,3 +391,33 @@ def check_device_repack(dev, kind="ncsnpp"):
             assert float((e[0] - r).abs().max()) < 1e-6, (e[4][0]["kind"], e[4][0].get("flags"), tuple(e[0].shape))
             n += 1
     assert n >= len(ws.entries) - 2
+
+
+def check_op_package(dev):
+    """score_sde_pytorch_amd.op: upfirdn2d / fused_leaky_relu (NCHW, autograd) vs the oracle's upfirdn2d_native
+    restatement and F.leaky_relu, forward and gradients."""
+    from oracle import unet_oracle
+    import score_sde_pytorch_amd.op as op
+    g = torch.Generator().manual_seed(21)
+    k = torch.from_numpy(unet_oracle.setup_fir_kernel([1, 3, 3, 1]))
+    for up, down, pad, c in [(2, 1, (2, 1), 6), (1, 2, (1, 1), 8), (1, 1, (2, 2), 3)]:
+        x = torch.randn(2, c, 8, 8, generator=g)
+        go = None
+        xr = x.clone().requires_grad_()
+        ref = unet_oracle.upfirdn2d(xr, k * (up ** 2), up=up, down=down, pad=pad)
+        go = torch.randn(ref.shape, generator=g)
+        ref.backward(go)
+        xd = x.to(dev).requires_grad_()
+        y = op.upfirdn2d(xd, (k * (up ** 2)).to(dev), up=up, down=down, pad=pad)
+        y.backward(go.to(dev))
+        assert rel_err(y.detach(), ref.detach()) < 2e-6 and rel_err(xd.grad, xr.grad) < 2e-6, (up, down, pad)
+    x = torch.randn(3, 5, 4, 4, generator=g)
+    b = torch.randn(5, generator=g)
+    xr, br = x.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = F.leaky_relu(xr + br[None, :, None, None], 0.2) * 2 ** 0.5
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    xd, bd = x.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    y = op.fused_leaky_relu(xd, bd)
+    y.backward(go.to(dev))
+    assert rel_err(y.detach(), ref.detach()) < 2e-6 and rel_err(xd.grad, xr.grad) < 2e-6 and rel_err(bd.grad, br.grad) < 2e-6

@@ -1,0 +1,81 @@
+"""Data-parallel training path on CPU: 2 ranks over `gloo`, each running the fused DSM step on its shard (kernels under
+the test-only emulator), against ONE process on the full batch.  Checks the single exchange of the design
+(DESIGN.md section 6): gradients pre-scaled by 1/world in the loss head + one SUM all-reduce of the flat gradient
+buffer == full-batch gradient, and the replicas stay bit-identical after the optimizer step.  Sampling shards by
+replication with no collective, so there is nothing to test there beyond per-rank seeds."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import emu
+import _util
+
+pytestmark = pytest.mark.skipif(not emu.available(), reason="emulator needs x86-64 + ROCm's clang++")
+
+
+def _build(world_batch):
+    from score_sde_pytorch_amd.models import utils as mutils, ema as ema_mod
+    from score_sde_pytorch_amd import losses, sde_lib
+    cfg = _util.small_config("ncsnpp")
+    cfg.optim.warmup = 0
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    _util.load_seeded(model, seed=1)
+    sde = sde_lib.VESDE(cfg.model.sigma_min, cfg.model.sigma_max, cfg.model.num_scales)
+    opt = losses.get_optimizer(cfg, model.parameters())
+    ema = ema_mod.ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate)
+    optimize_fn = losses.optimization_manager(cfg)
+    step_fn = losses.get_step_fn(sde, train=True, optimize_fn=optimize_fn)
+    state = dict(optimizer=opt, model=model, ema=ema, step=0)
+    g = torch.Generator().manual_seed(3)
+    batch = torch.rand(world_batch, 3, 16, 16, generator=g)
+    t = torch.rand(world_batch, generator=g) * (1 - 1e-5) + 1e-5
+    z = torch.randn(world_batch, 3, 16, 16, generator=g)
+    return cfg, model, state, step_fn, optimize_fn, batch, t, z
+
+
+def _one_step(state, step_fn, optimize_fn, batch, t, z):
+    fs = step_fn.fused_for(state, batch)
+    loss = fs.loss_and_grads(batch, t=t, z=z).clone()
+    grads_local = fs.flat.grad.clone()
+    fs.optimizer_step(state["optimizer"], state["ema"], state["step"], optimize_fn.ssde_hyper)
+    return float(loss), grads_local, fs.flat.grad.clone(), fs.flat.data.clone()
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from score_sde_pytorch_amd import parallel
+    parallel.init_from_env(backend="gloo")
+    assert parallel.world_size() == world
+    _, model, state, step_fn, optimize_fn, batch, t, z = _build(4)
+    with emu.emulated():
+        parallel.broadcast_parameters(model)
+        sl = slice(rank * 2, rank * 2 + 2)
+        assert torch.equal(parallel.shard_batch(batch), batch[sl])
+        loss, g_local, g_sum, params = _one_step(state, step_fn, optimize_fn, batch[sl].clone(), t[sl].clone(), z[sl].clone())
+    torch.save(dict(loss=loss, g_sum=g_sum, params=params), os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_matches_full_batch(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in (0, 1))
+    # replicas agree bit for bit after the exchange and the update
+    assert torch.equal(r0["g_sum"], r1["g_sum"]) and torch.equal(r0["params"], r1["params"])
+    # one process, full batch
+    _, model, state, step_fn, optimize_fn, batch, t, z = _build(4)
+    with emu.emulated():
+        loss, g_full, _, params = _one_step(state, step_fn, optimize_fn, batch, t, z)
+    assert abs(0.5 * (r0["loss"] + r1["loss"]) - loss) / abs(loss) < 1e-6
+    scale = float(g_full.abs().max())
+    assert float((r0["g_sum"] - g_full).abs().max()) / scale < 2e-5
+    assert float((r0["params"] - params).abs().max()) / float(params.abs().max()) < 1e-5

