@@ -14,11 +14,13 @@
 // of the stage, the other does staging work for the next stage, then they swap (two barriers per
 // stage); a version in which every wave staged and computed in the same phase kept the matrix pipe
 // only 22% busy, because VALU/LDS/VMEM work of both waves coincided and nothing covered it.
-//   phase 1: waves 0-3 MFMA(stage k)   | waves 4-7 prologue + LDS stores of the raw halo (k+1), then issue
-//                                         the halo loads of stage k+2 into registers
-//   phase 2: waves 4-7 MFMA(stage k)   | waves 0-3 LDS-DMA of the weights (k+1, no registers) and the
-//                                         input transform raw -> V(k+1)
-// so a wave's matrix phase is MFMAs and fragment reads only.
+//   phase 1: waves 0-3 start the LDS-DMA of the weights (k+1), then MFMA(stage k)
+//            waves 4-7 prologue + LDS stores of the raw halo (k+1)
+//   phase 2: waves 4-7 issue the halo loads of stage k+2 into registers, then MFMA(stage k)
+//            waves 0-3 input transform raw -> V(k+1), then wait for their DMA
+// Every asynchronous load is issued a full phase (>= 2048 matrix cycles) before it is needed and the barriers
+// order LDS only (SSDE_LDS_BARRIER): with __syncthreads() the compiler drained vmcnt(0) -- an HBM latency --
+// at both barriers of every stage and the matrix pipe was 47% busy.
 // Per 8-input-channel stage:
 //   raw halo (with the fused GroupNorm / SiLU / dropout prologue)  -> LDS, channel-pair major
 //   input transform B^T d B, one (tile, channel pair) per thread   -> LDS V[pos][pair][tile][2]
@@ -223,6 +225,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
     for (int a = 0; a < 2; ++a) af[0][a] = *reinterpret_cast<const float2*>(Vc + aoff[a]);
 #pragma unroll
     for (int b = 0; b < 2; ++b) bf[0][b] = *reinterpret_cast<const float2*>(Uc + boff[b]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // position 0's reads form their own group (see below)
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
@@ -240,40 +243,48 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
           acc[ps][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][a].x, bf[cur][b].x, acc[ps][a][b], 0, 0, 0);
           acc[ps][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][a].y, bf[cur][b].y, acc[ps][a][b], 0, 0, 0);
         }
+      // pin the issue order: the 4 fragment reads of position ps+1 go out BEFORE the 8 MFMAs of position ps, so their
+      // LDS latency is covered by 256 matrix cycles (left alone, hipcc sinks the reads below the MFMAs and waits on them)
+      if (ps + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
     }
     __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- pipeline prologue: stage 0 staged, stage 1 in flight ----
-  if (ph == 1) { load_stage(0); store_stage(); if (nst > 1) load_stage(1); }
+  if (ph == 1) { load_stage(0); store_stage(); }
   else dma_weights(0, Ub);
-  __syncthreads();
-  if (ph == 0) transform(Vb);
-  __syncthreads();
+  SSDE_LDS_BARRIER();
+  if (ph == 0) { transform(Vb); SSDE_WAIT_VMCNT(0); }
+  else if (nst > 1) load_stage(1);
+  SSDE_LDS_BARRIER();
 
   for (int st = 0; st < nst; ++st) {
     const float* Vc = Vb + (st & 1) * kStageFloats;
     const float* Uc = Ub + (st & 1) * kStageFloats;
     float* Vn = Vb + ((st + 1) & 1) * kStageFloats;
     float* Un = Ub + ((st + 1) & 1) * kStageFloats;
-    // phase 1: waves 0-3 on the matrix pipe; waves 4-7 apply the prologue, store stage st+1's raw halo and
-    // put stage st+2's halo loads in flight
+    // phase 1: waves 0-3 start the weight DMA of st+1 and run the matrix pipe; waves 4-7 apply the prologue to the
+    // halo of st+1 (loaded during their previous matrix phase) and store it
     if (ph == 0) {
+      if (st + 1 < nst) dma_weights(st + 1, Un);
       mfma_stage(Vc, Uc);
     } else if (st + 1 < nst) {
       store_stage();
-      if (st + 2 < nst) load_stage(st + 2);
     }
-    __syncthreads();
-    // phase 2: waves 4-7 on the matrix pipe; waves 0-3 start the weight DMA of st+1 and transform its halo
+    SSDE_LDS_BARRIER();
+    // phase 2: waves 4-7 put the halo loads of st+2 in flight and run the matrix pipe; waves 0-3 transform st+1 and
+    // make sure their DMA has landed before the barrier that publishes U(st+1)
     if (ph == 1) {
+      if (st + 2 < nst) load_stage(st + 2);
       mfma_stage(Vc, Uc);
     } else if (st + 1 < nst) {
-      dma_weights(st + 1, Un);
       transform(Vn);
+      SSDE_WAIT_VMCNT(0);
     }
-    __syncthreads();
+    SSDE_LDS_BARRIER();
   }
+  __syncthreads();
 
   // ---- output transform Y = A^T M A: this wave's two transform rows (register local) ----
   // A^T = [[1,1,1,0],[0,1,-1,-1]]; rows py = 2*ph, 2*ph+1 contribute  At[dy][py] * sum_px At[dx][px] M[py][px]

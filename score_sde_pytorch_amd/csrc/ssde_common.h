@@ -48,6 +48,21 @@ static inline bool ssde_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 #define SSDE_GLDS16(gptr, lds_wave_base) \
   __builtin_amdgcn_global_load_lds((gptr), (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which hipcc lowers
+// to s_waitcnt vmcnt(0) whenever an LDS-DMA (or any global load) is in flight: a full memory latency exposed at every
+// barrier.  This form waits for the wave's own LDS operations (lgkmcnt(0)), pins the compiler's ordering of memory
+// accesses around it, and leaves VMEM in flight; a wave that must publish LDS-DMA'd data calls SSDE_WAIT_VMCNT(n)
+// before the barrier its readers pass (cdna_hip_programming.md 5: "issuer's counted vmcnt + a barrier").
+// s_waitcnt simm16 (gfx9): vmcnt = [15:14|3:0], expcnt = [6:4], lgkmcnt = [11:8]; all-ones = no wait.
+#define SSDE_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt((((n) & 0xF) | (((n) >> 4) << 14)) | 0x0F70)
+#define SSDE_LDS_BARRIER()                       \
+  do {                                           \
+    asm volatile("" ::: "memory");               \
+    __builtin_amdgcn_s_waitcnt(0xC07F);          \
+    __builtin_amdgcn_s_barrier();                \
+    asm volatile("" ::: "memory");               \
+  } while (0)
+
 #ifdef __HIPCC__
 // x * sigmoid(x); v_exp_f32 + v_rcp_f32 (each ~1 ulp)
 __device__ __forceinline__ float ssde_silu(float x) {

@@ -138,6 +138,7 @@ static inline void emu_global_load_lds(const void* g, __attribute__((address_spa
 }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void*)(g), (l), (size), (off))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_barrier() emu::syncthreads()
 
