@@ -257,35 +257,32 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvKParam
     conv_phase<1, 32, BM, BN, TM, TN, (BM * 8) / kThreads>(p.aux, p.w_aux, g, 1, 0, g.Hout, g.Wout,
                                                           img0, ty, tx, n0, wm0, wn0, acc, smem);
 
-  // ---- epilogue: lane owns output channel j; 16 rows per 32x32 block ----
+  // ---- epilogue: accumulators -> LDS tile [BM pixels][BN + 4] -> coalesced float4 stores (ssde_store_tile) ----
   const int lane = threadIdx.x & 63;
   const int li = lane & 31, lh = lane >> 5;
   const int TW = 1 << g.lTW, TH = 1 << g.lTH;
+  constexpr int LDT = BN + 4;
+  __syncthreads();                       // every wave is done with the operand stages
 #pragma unroll
-  for (int b = 0; b < TN; ++b) {
-    const int j = n0 + wn0 + b * 32 + li;
-    if (j >= g.Cout) continue;
-    const float bj = p.bias ? p.bias[j] : 0.f;
+  for (int b = 0; b < TN; ++b)
 #pragma unroll
-    for (int a = 0; a < TM; ++a) {
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int c = m & (TW - 1);
-        const int rr = (m >> g.lTW) & (TH - 1);
-        const int img = img0 + (m >> (g.lTW + g.lTH));
-        const int oy = ty * TH + rr, ox = tx * TW + c;
-        if (img >= g.N || oy >= g.Hout || ox >= g.Wout) continue;
-        const size_t pix = ((size_t)img * g.Hout + oy) * g.Wout + ox;
-        float v = acc[a][b][r] + bj;
-        if (p.chan_add) v += p.chan_add[(size_t)img * p.chan_add_ld + j];
-        if (p.resid && !p.resid_post) v += p.resid[pix * g.Cout + j];
-        v *= p.scale;
-        if (p.resid && p.resid_post) v += p.resid[pix * g.Cout + j];
-        p.dst[pix * g.Cout + j] = v;
+        smem[m * LDT + wn0 + b * 32 + li] = acc[a][b][r];
       }
-    }
-  }
+  __syncthreads();
+  SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, g.Cout};
+  ssde_store_tile(smem, BM, LDT, BN, n0, e, kThreads, [&](int m, size_t& pix, int& img) {
+    const int c = m & (TW - 1);
+    const int rr = (m >> g.lTW) & (TH - 1);
+    img = img0 + (m >> (g.lTW + g.lTH));
+    const int oy = ty * TH + rr, ox = tx * TW + c;
+    if (img >= g.N || oy >= g.Hout || ox >= g.Wout) return false;
+    pix = ((size_t)img * g.Hout + oy) * g.Wout + ox;
+    return true;
+  });
 }
 
 struct TileCfg { int bm, bn; };
@@ -396,7 +393,8 @@ int make_plan(const ssde_conv_args* a, ConvPlan* pl) {
     const int l1 = (bm * 36 + bn * 36) * 4;
     if (l1 > lds) lds = l1;
   }
-  pl->lds_bytes = lds;
+  const int epi_bytes = bm * (bn + 4) * 4;          // the epilogue parks the output tile in LDS
+  pl->lds_bytes = lds > epi_bytes ? lds : epi_bytes;
   pl->tile = tile;
   pl->grid = ssde_cdiv(g.m_tiles, 8) * 8 * g.n_tiles;
   return SSDE_OK;
@@ -408,9 +406,12 @@ int launch_cfg(const ConvPlan& pl, hipStream_t st) {
 #define SSDE_CONV_LAUNCH(H3, H1)                                                                     \
   do {                                                                                               \
     auto kfn = conv_mfma_kernel<WM, WN, TM, TN, H3, H1>;                                             \
-    if (pl.lds_bytes > 64 * 1024)                                                                    \
+    static bool attr_set = false; /* once per instantiation, before any stream capture */            \
+    if (!attr_set) {                                                                                 \
       SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                         \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, pl.lds_bytes)); \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));   \
+      attr_set = true;                                                                               \
+    }                                                                                                \
     hipLaunchKernelGGL(kfn, grid, block, pl.lds_bytes, st, pl.kp);                                   \
   } while (0)
   if (pl.has3 && pl.has1) SSDE_CONV_LAUNCH(true, true);

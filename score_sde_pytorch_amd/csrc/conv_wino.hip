@@ -321,40 +321,38 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
               make_float4(yp[a][b][r][0], yp[a][b][r][1], yp[a][b][r][2], yp[a][b][r][3]);
   }
   __syncthreads();
-  if (ph == 1) return;
-
-  // ---- epilogue (waves 0-3) ----
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int j = n0 + cb0 + b * 16 + li;
-    if (j >= p.Cout) continue;
-    const float bj = p.bias ? p.bias[j] : 0.f;
+  // waves 0-3 complete Y and park it in LDS as [256 local pixels = tile * 4 + dy * 2 + dx][64 couts + 4] (above the
+  // 64 KB exchange area); then all 8 waves store it with coalesced float4s (ssde_store_tile)
+  constexpr int LDT = 68;
+  float* outs = smem + 16384;
+  if (ph == 0) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int tile = tb0 + a * 16 + 4 * lq + r;
-        const int il = tile >> (p.lTWt + p.lTHt);
-        const int tr = (tile >> p.lTWt) & (THt - 1), tc = tile & (TWt - 1);
-        const int img = img0 + il;
-        const int oy = (ty * THt + tr) * 2, ox = (tx * TWt + tc) * 2;
-        if (img >= p.N || oy >= p.H || ox >= p.W) continue;
-        const float4 o = xch[(((wave * 2 + a) * 2 + b) * 4 + r) * 64 + lane];
-        const float y[2][2] = {{yp[a][b][r][0] + o.x, yp[a][b][r][1] + o.y}, {yp[a][b][r][2] + o.z, yp[a][b][r][3] + o.w}};
-        const float ca = p.chan_add ? p.chan_add[(size_t)img * p.chan_add_ld + j] : 0.f;
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx) {
-            const size_t pix = ((size_t)img * p.H + oy + dy) * p.W + ox + dx;
-            float v = y[dy][dx] + bj + ca;
-            if (p.resid && !p.resid_post) v += p.resid[pix * p.Cout + j];
-            v *= p.scale;
-            if (p.resid && p.resid_post) v += p.resid[pix * p.Cout + j];
-            p.dst[pix * p.Cout + j] = v;
-          }
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int tile = tb0 + a * 16 + 4 * lq + r;
+          const float4 o = xch[(((wave * 2 + a) * 2 + b) * 4 + r) * 64 + lane];
+          float* dstp = outs + (tile * 4) * LDT + cb0 + b * 16 + li;
+          dstp[0 * LDT] = yp[a][b][r][0] + o.x;
+          dstp[1 * LDT] = yp[a][b][r][1] + o.y;
+          dstp[2 * LDT] = yp[a][b][r][2] + o.z;
+          dstp[3 * LDT] = yp[a][b][r][3] + o.w;
+        }
   }
+  __syncthreads();
+  SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, p.Cout};
+  ssde_store_tile(outs, 256, LDT, 64, n0, e, kThreads, [&](int row, size_t& pix, int& img) {
+    const int tile = row >> 2, dy = (row >> 1) & 1, dx = row & 1;
+    const int il = tile >> (p.lTWt + p.lTHt);
+    const int tr = (tile >> p.lTWt) & (THt - 1), tc = tile & (TWt - 1);
+    img = img0 + il;
+    const int oy = (ty * THt + tr) * 2 + dy, ox = (tx * TWt + tc) * 2 + dx;
+    if (img >= p.N || oy >= p.H || ox >= p.W) return false;
+    pix = ((size_t)img * p.H + oy) * p.W + ox;
+    return true;
+  });
 }
 
 int pow2_floor(int v) { int q = 1; while (q * 2 <= v) q *= 2; return q; }

@@ -115,6 +115,56 @@ __device__ __forceinline__ float4 ssde_pro_apply(float4 v, float mu, float rs, c
   return v;
 }
 
+// ---- coalesced epilogue ---------------------------------------------------------------------------------------
+// The MFMA accumulator layout gives a lane one output channel of scattered pixels (4-byte stores in 64..128-byte
+// runs: store-ISSUE bound -- for K <= 256 the epilogue took as long as the main loop).  Instead the workgroup parks
+// its output tile in LDS as [rows = local pixels][ld] and every thread moves float4s along channels: 16-byte
+// stores / residual loads, a whole NHWC pixel row per 16 lanes.
+struct SsdeEpi {
+  const float* bias; const float* chan_add; int chan_add_ld;
+  const float* resid; int resid_post; float scale; float* dst; int Cout;
+};
+// pixfn(row, pix, img) -> false when the row is outside the tensor.  ncols must be a multiple of 4.
+template <class PixFn>
+__device__ __forceinline__ void ssde_store_tile(const float* tile, int rows, int ld, int ncols, int n0, const SsdeEpi& e,
+                                                int nthreads, PixFn pixfn) {
+  const int c4n = ncols >> 2;
+  for (int q = threadIdx.x; q < rows * c4n; q += nthreads) {
+    const int row = q / c4n, c = (q - row * c4n) * 4;
+    const int j = n0 + c;
+    if (j >= e.Cout) continue;
+    size_t pix; int img;
+    if (!pixfn(row, pix, img)) continue;
+    const float4 t = *reinterpret_cast<const float4*>(tile + row * ld + c);
+    float v[4] = {t.x, t.y, t.z, t.w};
+    if (j + 4 <= e.Cout && (e.Cout & 3) == 0) {
+      if (e.bias) { const float4 b = *reinterpret_cast<const float4*>(e.bias + j); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+      if (e.chan_add) {
+        const float4 a = *reinterpret_cast<const float4*>(e.chan_add + (size_t)img * e.chan_add_ld + j);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+      }
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e.resid) r = *reinterpret_cast<const float4*>(e.resid + pix * e.Cout + j);
+      if (e.resid && !e.resid_post) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] *= e.scale;
+      if (e.resid && e.resid_post) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+      *reinterpret_cast<float4*>(e.dst + pix * e.Cout + j) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      for (int k = 0; k < 4 && j + k < e.Cout; ++k) {
+        float x = v[k];
+        if (e.bias) x += e.bias[j + k];
+        if (e.chan_add) x += e.chan_add[(size_t)img * e.chan_add_ld + j + k];
+        const float r = e.resid ? e.resid[pix * e.Cout + j + k] : 0.f;
+        if (e.resid && !e.resid_post) x += r;
+        x *= e.scale;
+        if (e.resid && e.resid_post) x += r;
+        e.dst[pix * e.Cout + j + k] = x;
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ float ssde_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
