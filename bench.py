@@ -225,9 +225,28 @@ def main():
                         ("groupnorm_stats", E.FC_GN), ("upfirdn", E.FC_FIR), ("other", E.FC_OTHER)]:
             m = cls == c
             by_class[name] = {"launches": int(m.sum()), "ms": float(ms[m].sum()), "gflop": float(fl[m].sum()) / 1e9}
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure is the
+        # per-launch average of the committed rocprofv3 passes over this same command (tools/profile_gpu.sh ->
+        # profiles/*_profile_summary.json: (2*FETCH_SIZE + WRITE_SIZE) * 1024, MI355X_MICROARCH.md HBM section)
+        traffic, mfma_busy = None, None
+        try:
+            import glob
+            summ = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_profile_summary.json")))[-1]
+            with open(summ) as f:
+                prof = json.load(f)
+            traffic = prof["hbm_traffic"]["conv_wino_kernel"]["hbm_bytes_per_launch"]
+            out["config"]["pmc_source"] = os.path.basename(summ)
+        except Exception:
+            pass
+        wino = os.environ.get("SSDE_WINOGRAD", "1") != "0"
         out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                           "kernel": "conv_mfma_kernel (3x3 + fused 1x1 skip), %d launches per U-Net evaluation" % int(conv3.sum()),
+                           "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                           "kernel": ("conv_wino_kernel (Winograd F(2x2,3x3), fp32 MFMA) + conv_mfma_kernel for the layers it does not "
+                                      "take: the %d 3x3 launches of one U-Net evaluation" if wino else
+                                      "conv_mfma_kernel (direct 3x3): the %d 3x3 launches of one U-Net evaluation") % int(conv3.sum()),
+                           "note": "achieved = algorithmic (direct-form) FLOPs / HIP-event time; Winograd executes 2.25x fewer "
+                                   "MFMA FLOPs than that, so frac is against the direct-form fp32 peak and can exceed the "
+                                   "matrix-pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES in profiles/)",
                            "unet_eval_ms_eager_events": float(ms.sum()), "by_class": by_class}
         if args.dump_ops:
             rows = []
