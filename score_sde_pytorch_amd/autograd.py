@@ -28,18 +28,20 @@ class _UNetFunction(torch.autograd.Function):
             raise RuntimeError("score_sde_pytorch_amd: backward through a NCSNpp forward whose activations were "
                                "overwritten by a later forward of the same shape (one live graph per engine)")
         eng.backward(gy.contiguous())
-        grads = tuple(eng.flat.grad_view(p).clone() for p in eng.flat.params)
+        n_params = len(ctx.needs_input_grad) - 4
+        grads = tuple(eng.flat.grad_view(p).clone() for p in eng.flat.params) if eng.param_grads else (None,) * n_params
         gx = eng.gx_view().clone() if ctx.need_x else None
         return (None, None, gx, None) + grads
 
 
 def unet_apply(model, x, cond):
-    key = ("train", x.device.index, x.shape[0], x.shape[2], x.shape[3], bool(model.training), bool(x.requires_grad))
+    param_grads = any(p.requires_grad for p in B.trainable_params(model))
+    key = ("train", x.device.index, x.shape[0], x.shape[2], x.shape[3], bool(model.training), bool(x.requires_grad), param_grads)
     eng = model._engines.get(key)
     if eng is None:
         eng = B.TrainEngine(model, x.shape[0], x.shape[2], x.shape[3], x.device, dropout=model.training,
-                            input_grad=x.requires_grad)
+                            input_grad=x.requires_grad, param_grads=param_grads)
         model._engines[key] = eng
     model._dropout_calls = getattr(model, "_dropout_calls", 0) + 1
     seed = (int(torch.initial_seed()) * 1000003 + model._dropout_calls) & 0x7FFFFFFF
-    return _UNetFunction.apply(eng, seed, x, cond, *eng.flat.params)
+    return _UNetFunction.apply(eng, seed, x, cond, *(eng.flat.params if param_grads else ()))

@@ -34,11 +34,21 @@ from .engine import _src
 FC_WGRAD, FC_BWD = 6, 7
 
 
+def trainable_params(model):
+    """Parameters that are trainable by design, in model.parameters() order: everything but the frozen Fourier
+    frequencies (layerspp.py:38 `requires_grad=False`).  Independent of requires_grad flags a caller may toggle
+    temporarily (likelihood.py freezes everything while it differentiates w.r.t. the input)."""
+    frozen = {id(p) for m in model.modules() if getattr(m, "kind", "") == "fourier" for p in m.parameters(recurse=False)}
+    return [p for p in model.parameters() if id(p) not in frozen]
+
+
 class FlatParams:
     """All trainable parameters of a model as views into one flat fp32 buffer (+ a same-shaped gradient buffer)."""
 
     def __init__(self, model, device):
-        params = [p for p in model.parameters() if p.requires_grad]
+        # trainable-by-design parameters (the frozen Fourier frequencies are not): independent of requires_grad flags a
+        # caller may toggle temporarily (likelihood.py freezes everything while it differentiates w.r.t. the input)
+        params = trainable_params(model)
         # parameters the kernels treat as ONE operand (the Dense_0 projections of all residual blocks form one GEMM,
         # engine.py) are laid out back to back, so their gradient is one weight-gradient launch as well
         groups = model.flat_param_groups() if hasattr(model, "flat_param_groups") else []
@@ -61,7 +71,7 @@ class FlatParams:
         self.device = device
 
     def owns(self, model):
-        ps = [p for p in model.parameters() if p.requires_grad]
+        ps = trainable_params(model)
         if len(ps) != len(self.params):
             return False
         base = self.data.data_ptr()
@@ -105,7 +115,11 @@ def flat_params_of(model, device):
 class TrainEngine(E.UNetEngine):
     """Forward (train mode) + backward program of NCSNpp at a fixed (batch, H, W)."""
 
-    def __init__(self, model, batch, height, width, device, vp_score=False, input_grad=False, dropout=True):
+    def __init__(self, model, batch, height, width, device, vp_score=False, input_grad=False, dropout=True,
+                 param_grads=True):
+        # param_grads=False: only d out / d x is needed (likelihood.py's Hutchinson divergence): the backward program
+        # carries no weight-gradient / bias-gradient kernels (a third of its FLOPs)
+        self.param_grads = param_grads
         self.flat = flat_params_of(model, device)
         super().__init__(model, batch, height, width, device, vp_score=vp_score, train=bool(dropout), input_grad=input_grad,
                          finalize=False)
@@ -147,7 +161,8 @@ class TrainEngine(E.UNetEngine):
         if not self.input_grad:
             self._nograd.add(id(self._x0))
         fwd = list(b.specs[: self.n_fwd])
-        b.add(L.OP_MEMSET, dict(dst=self.flat.grad, bytes=self.flat.numel * 4, value=0), FC_BWD)
+        if self.param_grads:
+            b.add(L.OP_MEMSET, dict(dst=self.flat.grad, bytes=self.flat.numel * 4, value=0), FC_BWD)
         handlers = {L.OP_CONV: self._bwd_conv, L.OP_UPFIRDN: self._bwd_fir, L.OP_ATTN: self._bwd_attn,
                     L.OP_TO_NCHW: self._bwd_to_nchw, L.OP_TO_NHWC: self._bwd_to_nhwc}
         for kind, f, _, _ in reversed(fwd):
@@ -186,14 +201,16 @@ class TrainEngine(E.UNetEngine):
         e0 = self._gentry(src["p0"]) if self._needs(src["p0"]) else None
         e1 = self._gentry(src["p1"]) if self._needs(src["p1"]) else None
         sums = None
-        if src["pro_mode"] in (L.PRO_GN, L.PRO_GN_SILU):
+        if src["pro_mode"] in (L.PRO_GN, L.PRO_GN_SILU) and (e0 is not None or e1 is not None or self.param_grads):
             groups = src["gn_groups"]
             sums = b.buf(n, groups, 2, name="gn_bwd_sums")
             slices = max(1, min(int(math.ceil(256 / n)), hw // 64)) if hw >= 128 else 1
             scratch = b.buf(n * slices * ctot * 2, name="gn_bwd_scratch")
             b.add(L.OP_GN_BWD_REDUCE, dict(src=src, dp=dP, n=n, hw=hw, sums=sums,
-                                           dgamma=self.flat.grad_view(self._param_of(src["gn_gamma"])),
-                                           dbeta=self.flat.grad_view(self._param_of(src["gn_beta"])),
+                                           dgamma=self.flat.grad_view(self._param_of(src["gn_gamma"])) if self.param_grads
+                                           else b.buf(ctot, name="dgamma_unused"),
+                                           dbeta=self.flat.grad_view(self._param_of(src["gn_beta"])) if self.param_grads
+                                           else b.buf(ctot, name="dbeta_unused"),
                                            scratch=scratch, slices=slices), FC_BWD)
         if e0 is None and e1 is None:
             return
@@ -207,6 +224,15 @@ class TrainEngine(E.UNetEngine):
 
     def _bwd_bias(self, f, g, g_ld, n, hw, scale):
         b = self.b
+        if not self.param_grads:
+            if f["chan_add"] is not None:      # only the temb addend's gradient (it feeds d/dx of nothing, but keeps the tape uniform)
+                tbuf, off = f["chan_add"]
+                e = self._gentry(tbuf)
+                e[1] = True
+                b.add(L.OP_COLSUM, dict(g=g, g_ld=g_ld, g_off=0, n=n, hw=hw, c=f["c_out"], scale=float(scale), per_sample=e[0],
+                                        ps_ld=f["chan_add_ld"], ps_off=off, total=None, total2=None,
+                                        scratch=b.buf(n * (max(1, min(32, hw // 64)) + 1) * f["c_out"], name="colsum_scratch")), FC_BWD)
+            return
         per, ps_ld, ps_off = None, 0, 0
         if f["chan_add"] is not None:
             tbuf, off = f["chan_add"]
@@ -254,7 +280,7 @@ class TrainEngine(E.UNetEngine):
             h_in, w_in, stride, pad = ho, wo, 1, 0
         meta = self.weights.meta[id(wpacked)]
         ctot = src["c0"] + src["c1"]
-        parts = meta["parts"]
+        parts = meta["parts"] if self.param_grads else []
         if len(parts) > 1 and not any(pt["transpose"] for pt in parts) and self.flat.contiguous([pt["param"] for pt in parts]):
             # row-concatenated [out_i, in] matrices stored back to back ARE the [sum out_i, in] matrix
             whole = self.flat.grad_run([pt["param"] for pt in parts])

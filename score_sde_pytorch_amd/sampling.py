@@ -306,11 +306,12 @@ def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_step
 
 def get_ode_sampler(sde, shape, inverse_scaler, denoise=False, rtol=1e-5, atol=1e-5, method='RK45', eps=1e-3,
                     device='cuda'):
-    """Probability-flow ODE sampler driven by scipy's adaptive RK45 (sampling.py:414-485).
+    """Probability-flow ODE sampler with adaptive RK45 (sampling.py:414-485).
 
-    The drift evaluation (one U-Net forward per function evaluation) runs as a HIP program; the
-    integrator itself still lives on the host as in the reference (SURVEY 8f-1 lists the on-device
-    Dormand-Prince driver as the next row)."""
+    The drift evaluation (one U-Net forward per function evaluation) runs as a HIP program.  With method='RK45' on a
+    GPU tensor the integrator is ode.solve_rk45 -- scipy's RK45 algorithm with the fp64 state resident on the device
+    (no per-evaluation host round trip, models/utils.py:181-188); other methods, or SSDE_HOST_ODE=1, use
+    scipy.integrate.solve_ivp on the host exactly as the reference does."""
 
     def denoise_update_fn(model, x):
         score_fn = get_score_fn(sde, model, train=False, continuous=True)
@@ -331,10 +332,20 @@ def get_ode_sampler(sde, shape, inverse_scaler, denoise=False, rtol=1e-5, atol=1
                 vec_t = torch.ones(shape[0], device=xt.device) * t
                 return to_flattened_numpy(drift_fn(model, xt, vec_t))
 
-            sol = integrate.solve_ivp(ode_func, (sde.T, eps), to_flattened_numpy(x), rtol=rtol, atol=atol, method=method)
-            x = torch.tensor(sol.y[:, -1]).reshape(shape).to(device).type(torch.float32)
+            import os
+            if method == 'RK45' and x.is_cuda and os.environ.get("SSDE_HOST_ODE", "0") != "1":
+                from . import ode
+
+                def dev_func(t, y):
+                    vec_t = torch.ones(shape[0], device=y.device) * t
+                    return drift_fn(model, y.to(torch.float32), vec_t).to(torch.float64)
+                y, nfev = ode.solve_rk45(dev_func, (sde.T, eps), x, rtol=rtol, atol=atol)
+                x = y.to(torch.float32)
+            else:
+                sol = integrate.solve_ivp(ode_func, (sde.T, eps), to_flattened_numpy(x), rtol=rtol, atol=atol, method=method)
+                x, nfev = torch.tensor(sol.y[:, -1]).reshape(shape).to(device).type(torch.float32), sol.nfev
             if denoise:
                 x = denoise_update_fn(model, x)
-            return inverse_scaler(x), sol.nfev
+            return inverse_scaler(x), nfev
 
     return ode_sampler

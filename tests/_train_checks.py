@@ -421,3 +421,75 @@ def check_op_package(dev):
     y = op.fused_leaky_relu(xd, bd)
     y.backward(go.to(dev))
     assert rel_err(y.detach(), ref.detach()) < 2e-6 and rel_err(xd.grad, xr.grad) < 2e-6 and rel_err(bd.grad, br.grad) < 2e-6
+
+
+def check_input_gradient_only(dev):
+    """TrainEngine(param_grads=False): d out / d x without any weight-gradient kernel, vs oracle autograd."""
+    from score_sde_pytorch_amd.models import utils as mutils
+    from score_sde_pytorch_amd import backward as B, _lib as L
+    cfg = small_cfg("ddpmpp")
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    sd = {k: v.clone() for k, v in _util.load_seeded(model, seed=1).items()}
+    sd["sigmas"] = model.sigmas.clone()
+    model = model.to(dev)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 3, 16, 16, generator=g)
+    cond = torch.tensor([120.0, 800.0])
+    gout = torch.randn(2, 3, 16, 16, generator=g)
+    _, gx_ref, _ = oracle_grads(cfg, sd, x, cond, gout)
+    eng = B.TrainEngine(model, 2, 16, 16, torch.device(dev), input_grad=True, dropout=False, param_grads=False)
+    kinds = [int(eng.program.ops[i].kind) for i in range(eng.program.n)]
+    assert L.OP_WGRAD not in kinds and L.OP_MEMSET not in kinds
+    eng.forward_train(x.to(dev), cond.to(dev))
+    eng.backward(gout.to(dev))
+    assert rel_err(eng.gx_view(), gx_ref) < TOL_GRAD
+
+
+def check_likelihood(dev):
+    """likelihood.get_likelihood_fn on a small sub-VP DDPM++ net: bits/dim, latent and NFE against the same
+    algorithm driven by the CPU oracle's score (torch autograd for the divergence)."""
+    from scipy import integrate
+    from score_sde_pytorch_amd.models import utils as mutils
+    from score_sde_pytorch_amd import likelihood, sde_lib
+    from oracle import unet_oracle
+    cfg = small_cfg("ddpmpp")
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    sd = {k: v.clone() for k, v in _util.load_seeded(model, seed=1).items()}
+    sd["sigmas"] = model.sigmas.clone()
+    model = model.to(dev).eval()
+    sde = sde_lib.subVPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales)
+    g = torch.Generator().manual_seed(5)
+    data = torch.rand(2, 3, 16, 16, generator=g) * 2 - 1
+    inv = lambda v: (v + 1.) / 2.  # noqa: E731
+    torch.manual_seed(77)
+    bpd, z, nfe = likelihood.get_likelihood_fn(sde, inv, rtol=1e-4, atol=1e-4)(model, data.to(dev))
+    # the same integration with the oracle
+    torch.manual_seed(77)
+    shape = data.shape
+    epsilon = torch.randint_like(data, low=0, high=2).float() * 2 - 1.
+
+    def score(x, t):
+        std = sde.marginal_prob(torch.zeros_like(x), t)[1]
+        return -unet_oracle.ncsnpp_forward(cfg, sd, x, t * 999) / std[:, None, None, None]
+
+    def drift(x, t):
+        return sde.reverse(score, probability_flow=True).sde(x, t)[0]
+
+    def ode_func(t, y):
+        x = torch.from_numpy(y[:-2].reshape(shape)).float()
+        vt = torch.ones(2) * t
+        with torch.enable_grad():
+            x.requires_grad_(True)
+            d = drift(x, vt)
+            gfe = torch.autograd.grad(torch.sum(d * epsilon), x)[0]
+        div = torch.sum(gfe * epsilon, dim=(1, 2, 3))
+        return np.concatenate([d.detach().numpy().reshape(-1), div.numpy().reshape(-1)])
+    init = np.concatenate([data.numpy().reshape(-1), np.zeros(2)])
+    sol = integrate.solve_ivp(ode_func, (1e-5, sde.T), init, rtol=1e-4, atol=1e-4, method="RK45")
+    zr = torch.from_numpy(sol.y[:-2, -1].reshape(shape)).float()
+    dl = torch.from_numpy(sol.y[-2:, -1]).float()
+    bpd_ref = -(sde.prior_logp(zr) + dl) / np.log(2) / np.prod(shape[1:]) + (7. - inv(-1.))
+    assert abs(nfe - sol.nfev) <= 12, (nfe, sol.nfev)
+    assert rel_err(z, zr) < 2e-3 and float((bpd.cpu() - bpd_ref).abs().max()) < 2e-3, (bpd, bpd_ref)

@@ -65,3 +65,7 @@ def test_op_package(monkeypatch):
     monkeypatch.setattr(op, "fused_leaky_relu", lambda input, bias, negative_slope=0.2, scale=2 ** 0.5:
                         op.FusedLeakyReLUFunction.apply(input, bias, negative_slope, scale))
     T.check_op_package("cpu")
+
+
+def test_input_gradient_only_program():
+    T.check_input_gradient_only("cpu")

@@ -198,3 +198,19 @@ def test_ema_matches_reference_formula():
     assert torch.allclose(p[0].detach(), torch.full((4,), 3.0))
     with pytest.raises(ValueError):
         ExponentialMovingAverage(p, decay=1.5)
+
+
+def test_on_device_rk45_reproduces_scipy():
+    """ode.solve_rk45 is scipy's RK45 (same initial step, error norm, step control): identical nfev, result to rounding"""
+    import math
+    from scipy import integrate
+    from score_sde_pytorch_amd import ode
+    A = np.array([[-0.5, 2.0, 0.0], [-2.0, -0.5, 0.3], [0.0, -0.3, -1.0]])
+    At = torch.from_numpy(A)
+    b = np.array([1.0, 0.0, 0.5])
+    y0 = np.array([1.0, -0.5, 2.0])
+    for span in [(0.0, 5.0), (1.0, 1e-3)]:
+        sol = integrate.solve_ivp(lambda t, y: A @ y + math.sin(3 * t) * b, span, y0, rtol=1e-5, atol=1e-5, method="RK45")
+        y, nfev = ode.solve_rk45(lambda t, y: At @ y + math.sin(3 * t) * torch.from_numpy(b), span, torch.from_numpy(y0), 1e-5, 1e-5)
+        assert nfev == sol.nfev
+        assert float(np.abs(sol.y[:, -1] - y.numpy()).max()) < 1e-12

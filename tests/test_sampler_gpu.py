@@ -135,3 +135,24 @@ def test_vp_euler_maruyama_fused_matches_oracle():
     ref = sampler_oracle.pc_sample(cfg, sd, "subvpsde", dict(beta_min=0.1, beta_max=20, N=N), x_T, noises, snr=0.16,
                                    eps=1e-3, denoise=True, predictor="euler_maruyama", corrector="none")
     assert rel_err(out, ref["samples"]) < 2e-4
+
+
+def test_ode_sampler_on_device_matches_host_scipy(monkeypatch):
+    """get_ode_sampler: the on-device RK45 driver and the reference's host scipy loop give the same samples and NFE"""
+    import _util
+    from score_sde_pytorch_amd import sde_lib, sampling
+    from score_sde_pytorch_amd.models import utils as mutils
+    cfg = _util.small_config("ddpmpp")
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    _util.load_seeded(model, seed=1)
+    model = model.cuda().eval()
+    sde = sde_lib.subVPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales)
+    shape = (2, 3, 16, 16)
+    z = torch.randn(*shape, generator=torch.Generator().manual_seed(1)).cuda()
+    smp = sampling.get_ode_sampler(sde, shape, lambda v: v, rtol=1e-4, atol=1e-4, eps=1e-3, device="cuda")
+    x_dev, nfe_dev = smp(model, z=z.clone())
+    monkeypatch.setenv("SSDE_HOST_ODE", "1")
+    x_host, nfe_host = smp(model, z=z.clone())
+    assert abs(nfe_dev - nfe_host) <= 12 and torch.isfinite(x_dev).all()
+    assert _util.rel_err(x_dev, x_host) < 2e-3

@@ -75,3 +75,11 @@ def test_op_package_refuses_cpu():
     import score_sde_pytorch_amd.op as op
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         op.upfirdn2d(torch.zeros(1, 4, 4, 4), torch.ones(2, 2))
+
+
+def test_input_gradient_only_program():
+    T.check_input_gradient_only("cuda")
+
+
+def test_likelihood_bits_per_dim():
+    T.check_likelihood("cuda")
