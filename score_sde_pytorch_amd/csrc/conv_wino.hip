@@ -105,12 +105,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
       gimg[it] = img;
     }
   }
-  // element offsets of the items inside the current source tensor (32-bit: a tensor is < 2^31 floats); recomputed only
-  // when the channel walk crosses from p0 to p1
-  unsigned eoff[kMaxRaw];
-  int cur_C = s.c0;
-#pragma unroll
-  for (int it = 0; it < kMaxRaw; ++it) eoff[it] = goff[it] >= 0 ? (unsigned)goff[it] * (unsigned)s.c0 : 0u;
   // transform item (waves 0-3): this thread's tile and channel pair
   const int t_tile = sid & 63, t_pair = sid >> 6;
   int t_base;
@@ -132,19 +126,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
     c_cur = c_base;
     const float* base; int C, cc;
     if (c_base < s.c0) { base = s.p0; C = s.c0; cc = c_base; } else { base = s.p1; C = s.c1; cc = c_base - s.c0; }
-    if (C != cur_C) {
-      cur_C = C;
-#pragma unroll
-      for (int it = 0; it < kMaxRaw; ++it) eoff[it] = goff[it] >= 0 ? (unsigned)goff[it] * (unsigned)C : 0u;
-    }
     const int half = sid & 1;
     const int cthr = cc + half * 4;
     chan_ok = cthr < C;
-    const float* bthr = base + cthr;            // wave-uniform base + 32-bit per-lane offset: no 64-bit VALU address math
 #pragma unroll
     for (int it = 0; it < kMaxRaw; ++it) {
       rv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (goff[it] >= 0 && chan_ok) rv[it] = *reinterpret_cast<const float4*>(bthr + eoff[it]);
+      if (goff[it] >= 0 && chan_ok) rv[it] = *reinterpret_cast<const float4*>(base + (size_t)goff[it] * C + cthr);
     }
 #pragma unroll
     for (int it = 0; it < kMaxRaw; ++it) { mu[it] = 0.f; rs[it] = 1.f; }

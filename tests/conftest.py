@@ -15,6 +15,9 @@ os.environ.setdefault("SSDE_WINOGRAD", "2")
 
 
 def pytest_configure(config):
+    # the CPU oracle (small torch ops) crawls when oneDNN fans out over the 256 hardware threads of the GPU box
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
