@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--dump-ops", type=str, default="")
     ap.add_argument("--no-train", action="store_true", help="skip the DSM training-step measurement")
+    ap.add_argument("--workload", default="cifar10", choices=["cifar10", "ffhq256"],
+                    help="cifar10 = BASELINE configs[1] (the headline line); ffhq256 = configs[3] (NCSN++ 256x256, N=2000, batch 16/GPU)")
     ap.add_argument("--train-batch", type=int, default=128)
     ap.add_argument("--train-steps", type=int, default=0, help="timed training steps (0: same as --steps, capped at 10)")
     ap.add_argument("--dump-train-ops", type=str, default="")
@@ -156,7 +158,15 @@ def main():
     from score_sde_pytorch_amd import sde_lib, sampling, engine as E
     from score_sde_pytorch_amd.models import utils as mutils
 
-    cfg = _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous")
+    if args.workload == "ffhq256":
+        cfg = _util.cfgs.get_config("ve/ffhq_256_ncsnpp_continuous")
+        if args.batch == 256:
+            args.batch = 16
+        if args.sde_steps == 1000:
+            args.sde_steps = 2000
+        args.no_train = args.no_cpu_baseline = True
+    else:
+        cfg = _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous")
     torch.manual_seed(0)
     model = mutils.get_model("ncsnpp")(cfg)
     sd = _util.load_seeded(model, seed=1)
@@ -198,8 +208,10 @@ def main():
         "metric": "pc_sampler_images_per_sec", "value": images_per_sec, "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs/ve/cifar10_ncsnpp_continuous PC sampler (reverse_diffusion+langevin), "
-                               "batch %d/GPU, N=%d, 32x32; 1 step = 1 PC iteration = 2 U-Net evaluations" % (B, args.sde_steps),
+        "config": {"workload": "configs/ve/%s PC sampler (reverse_diffusion+langevin), "
+                               "batch %d/GPU, N=%d, %dx%d; 1 step = 1 PC iteration = 2 U-Net evaluations"
+                               % ("ffhq_256_ncsnpp_continuous" if args.workload == "ffhq256" else "cifar10_ncsnpp_continuous",
+                                  B, args.sde_steps, R, R),
                    "batch_per_gpu": B, "sde_steps": args.sde_steps, "nfe_per_step": eng.nfe_per_step(),
                    "path": eng.last_path, "state_finite": finite,
                    "unet_gflop_per_image": eng.unet.flops_per_forward() / B / 1e9,

@@ -89,3 +89,18 @@ def test_cpu_tensor_fails_loudly():
     model = mutils.get_model("ncsnpp")(cfg)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model(torch.rand(1, 3, 16, 16), torch.ones(1))
+
+
+def test_forward_ffhq256_full_architecture():
+    """BASELINE configs[3]: the 65.6 M-parameter 256x256 NCSN++ (output-skip pyramid, input-skip Combine), batch 1, vs the CPU oracle"""
+    from oracle import unet_oracle
+    cfg = _util.cfgs.get_config("ve/ffhq_256_ncsnpp_continuous")
+    model, sd = _model(cfg)
+    sd = dict(sd); sd["sigmas"] = model.sigmas.cpu()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 3, 256, 256, generator=g) * 3
+    sig = torch.tensor([2.5])
+    with torch.no_grad():
+        y = model(x.cuda(), sig.cuda())
+        ref = unet_oracle.ncsnpp_forward(cfg, sd, x, sig)
+    assert rel_err(y, ref) < TOL_FWD
