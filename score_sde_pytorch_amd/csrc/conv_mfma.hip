@@ -114,24 +114,30 @@ __device__ __forceinline__ void conv_phase(const ssde_src& s, const float* __res
   constexpr int B_ITEMS = T * BN * F4;
   constexpr int B_ITERS = (B_ITEMS + kThreads - 1) / kThreads;
 
-  for (int ch = 0; ch < nchunks; ++ch) {
+  // ---- staging registers of the stage in flight ----
+  float4 av[MAXI];
+  float4 bv[B_ITERS];
+  float mu[MAXI], rs[MAXI];
+  float4 gam = make_float4(1.f, 1.f, 1.f, 1.f), bet = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool chan_ok = false;
+  int c_stage = 0;
+
+  // global loads of stage `ch` into registers (activation halo, weights, GroupNorm parameters)
+  auto load_stage = [&](int ch) {
     const int c_base = ch * BKC;
+    c_stage = c_base;
     const float* base;
     int C, cc;
     if (c_base < s.c0) { base = s.p0; C = s.c0; cc = c_base; }
     else               { base = s.p1; C = s.c1; cc = c_base - s.c0; }
     const int cthr = cc + f4 * 4;
-    const bool chan_ok = cthr < C;
-
-    // issue all global loads of the stage first
-    float4 av[MAXI];
+    chan_ok = cthr < C;
 #pragma unroll
     for (int it = 0; it < MAXI; ++it) {
       av[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (goff[it] >= 0 && chan_ok)
         av[it] = *reinterpret_cast<const float4*>(base + (size_t)goff[it] * C + cthr);
     }
-    float4 bv[B_ITERS];
 #pragma unroll
     for (int it = 0; it < B_ITERS; ++it) {
       const int q = tid + it * kThreads;
@@ -147,8 +153,6 @@ __device__ __forceinline__ void conv_phase(const ssde_src& s, const float* __res
               wpk + ((size_t)(cin8 * T + tap) * g.CoutPad + n0 + j) * 8 + f * 4);
       }
     }
-    float4 gam = make_float4(1.f, 1.f, 1.f, 1.f), bet = make_float4(0.f, 0.f, 0.f, 0.f);
-    float mu[MAXI], rs[MAXI];
 #pragma unroll
     for (int it = 0; it < MAXI; ++it) { mu[it] = 0.f; rs[it] = 1.f; }
     if (pro.gn && (c_base + f4 * 4) < Ctot) {
@@ -156,28 +160,24 @@ __device__ __forceinline__ void conv_phase(const ssde_src& s, const float* __res
       bet = *reinterpret_cast<const float4*>(s.gn_beta + c_base + f4 * 4);
       const int gidx = (c_base + f4 * 4) / cpg;
 #pragma unroll
-      for (int it = 0; it < MAXI; ++it) {
-        mu[it] = 0.f; rs[it] = 1.f;
+      for (int it = 0; it < MAXI; ++it)
         if (goff[it] >= 0) {
           mu[it] = s.gn_mean[gimg[it] * s.gn_groups + gidx];
           rs[it] = s.gn_rstd[gimg[it] * s.gn_groups + gidx];
         }
-      }
     }
-
-    __syncthreads();   // previous stage's fragment reads are done
-
-    // ---- A: prologue transform (GroupNorm apply, SiLU, dropout) + LDS store ----
+  };
+  // prologue transform (GroupNorm apply, SiLU, dropout) + LDS stores of the staged registers
+  auto store_stage = [&]() {
 #pragma unroll
     for (int it = 0; it < MAXI; ++it) {
       if (goff[it] == -2) continue;
       float4 v = av[it];
       if (goff[it] >= 0 && chan_ok)
-        v = ssde_pro_apply(v, mu[it], rs[it], gam, bet, (uint32_t)goff[it] * (uint32_t)Ctot + (uint32_t)(c_base + f4 * 4), pro);
+        v = ssde_pro_apply(v, mu[it], rs[it], gam, bet, (uint32_t)goff[it] * (uint32_t)Ctot + (uint32_t)(c_stage + f4 * 4), pro);
       const int q = tid + it * kThreads;
       *reinterpret_cast<float4*>(As + (q / F4) * LDA + f4 * 4) = v;
     }
-    // ---- B: LDS store ----
 #pragma unroll
     for (int it = 0; it < B_ITERS; ++it) {
       const int q = tid + it * kThreads;
@@ -189,8 +189,16 @@ __device__ __forceinline__ void conv_phase(const ssde_src& s, const float* __res
         *reinterpret_cast<float4*>(Bs + (tap * BN + j) * LDA + cb * 8 + f * 4) = bv[it];
       }
     }
-    __syncthreads();
+  };
 
+  // software pipeline: the global loads of stage ch+1 are in flight while stage ch runs on the matrix pipe
+  load_stage(0);
+  __syncthreads();       // the previous phase's fragment reads are done
+  store_stage();
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const bool has_next = ch + 1 < nchunks;
+    if (has_next) load_stage(ch + 1);
     // ---- MFMA: every tap re-uses the staged halo ----
 #pragma unroll
     for (int tap = 0; tap < T; ++tap) {
@@ -213,6 +221,11 @@ __device__ __forceinline__ void conv_phase(const ssde_src& s, const float* __res
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
           }
       }
+    }
+    if (has_next) {
+      __syncthreads();   // every wave is done reading this stage
+      store_stage();
+      __syncthreads();
     }
   }
 }
