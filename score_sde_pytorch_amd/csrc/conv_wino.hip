@@ -8,7 +8,7 @@
 // and halve, so the result differs from the direct sum by fp32 rounding (tests: same tolerance).
 //
 // One workgroup (8 waves = two per SIMD, 128 accumulator registers per lane) owns 64 tiles (a 16x16
-// output patch, or 8x8 patches of 4 images, or 4x4 of 16) x 64 output channels x all 16 transform
+// output patch, or 8x8 patches of 4 images; 4x4 images go to the direct kernel) x 64 output channels x all 16 transform
 // positions: waves 0-3 hold positions 0-7 (transform rows 0,1), waves 4-7 positions 8-15, each wave a
 // 32-tile x 32-cout block.  The two waves of a SIMD (w and w+4) PING-PONG: while one runs its 64 MFMAs
 // of the stage, the other does staging work for the next stage, then they swap (two barriers per
@@ -41,7 +41,7 @@ namespace {
 constexpr int kThreads = 512;
 constexpr int kStageFloats = 16 * 4 * 64 * 2;     // one V or U stage: [pos][pair][64][2]
 constexpr int kStagers = 256;                     // waves 4-7 stage (load / prologue / LDS store)
-constexpr int kMaxRaw = 5;                        // raw float4 items per staging thread per stage
+constexpr int kMaxRaw = 4;                        // raw float4 items per staging thread per stage (halo <= 512 pixels)
 constexpr int kUItems = kStageFloats / 4 / kStagers;   // weight float4 items per staging thread per stage
 
 struct WinoParams {
@@ -149,11 +149,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
     }
   };
   // weights of stage st: the host packed them as the LDS image, so they go global -> LDS by DMA
+  // (a straight 32 KB copy: each of the 4 issuing waves moves a contiguous 8 KB with 8 instructions that differ only in
+  // the immediate offset -4096 .. +3072, applied by the hardware to the global and the LDS address alike)
   auto dma_weights = [&](int st, float* Un) {
-    const float4* wsrc = reinterpret_cast<const float4*>(p.wpk + ((size_t)st * p.n_tiles + nt) * kStageFloats);
-#pragma unroll
-    for (int it = 0; it < kUItems; ++it)
-      SSDE_GLDS16(wsrc + sid + it * kStagers, Un + (size_t)((sid & ~63) + it * kStagers) * 4);
+    static_assert(kUItems == 8, "the immediate-offset run below is written for 8 x 1 KiB per wave");
+    const int wv = (sid >> 6);
+    const float* gsrc = p.wpk + ((size_t)st * p.n_tiles + nt) * kStageFloats + (size_t)wv * 2048 + 1024 + lane * 4;
+    float* ldst = Un + wv * 2048 + 1024;
+    SSDE_GLDS16_OFF(gsrc, ldst, -4096);
+    SSDE_GLDS16_OFF(gsrc, ldst, -3072);
+    SSDE_GLDS16_OFF(gsrc, ldst, -2048);
+    SSDE_GLDS16_OFF(gsrc, ldst, -1024);
+    SSDE_GLDS16_OFF(gsrc, ldst, 0);
+    SSDE_GLDS16_OFF(gsrc, ldst, 1024);
+    SSDE_GLDS16_OFF(gsrc, ldst, 2048);
+    SSDE_GLDS16_OFF(gsrc, ldst, 3072);
   };
   // prologue + raw LDS store (channel-pair major)
   auto store_stage = [&]() {
@@ -364,8 +374,8 @@ int ssde_conv_wino_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
   SSDE_REQUIRE(a && a->dst && a->main.p0 && a->w_main, "conv(winograd): null args");
   SSDE_REQUIRE(a->ksize == 3 && a->stride == 1 && a->pad == 1, "conv(winograd): needs 3x3, stride 1, pad 1");
   SSDE_REQUIRE(a->aux.p0 == nullptr, "conv(winograd): fused 1x1 source not supported (issue it as a second conv)");
-  SSDE_REQUIRE(a->h_in == a->h_out && a->w_in == a->w_out && a->h_out % 2 == 0 && a->w_out % 2 == 0 && a->h_out >= 2 && a->w_out >= 2,
-               "conv(winograd): even same-size output needed (got %dx%d)", a->h_out, a->w_out);
+  SSDE_REQUIRE(a->h_in == a->h_out && a->w_in == a->w_out && a->h_out % 2 == 0 && a->w_out % 2 == 0 && a->h_out >= 8 && a->w_out >= 8,
+               "conv(winograd): even same-size output of at least 8x8 needed (got %dx%d)", a->h_out, a->w_out);
   const ssde_src& s = a->main;
   SSDE_REQUIRE(s.c0 > 0 && s.c0 % 4 == 0 && s.c1 % 4 == 0 && (s.c1 == 0 || (s.p1 && s.c0 % 8 == 0)),
                "conv(winograd): channels must be multiples of 4 (concat boundary of 8)");

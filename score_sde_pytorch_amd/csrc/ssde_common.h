@@ -47,6 +47,10 @@ static inline bool ssde_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 // lane-linear.  Visible to other waves after the issuer's vmcnt wait + a workgroup barrier (__syncthreads).
 #define SSDE_GLDS16(gptr, lds_wave_base) \
   __builtin_amdgcn_global_load_lds((gptr), (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
+// same with the instruction's 13-bit signed immediate offset, which the hardware adds to BOTH the global and the LDS
+// address: a run of copies with equal strides on both sides needs one M0 / one address setup
+#define SSDE_GLDS16_OFF(gptr, lds_wave_base, imm) \
+  __builtin_amdgcn_global_load_lds((gptr), (__attribute__((address_space(3))) void*)(lds_wave_base), 16, (imm), 0)
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which hipcc lowers
 // to s_waitcnt vmcnt(0) whenever an LDS-DMA (or any global load) is in flight: a full memory latency exposed at every

@@ -518,7 +518,7 @@ class Lowering:
         mode = os.environ.get("SSDE_WINOGRAD", "1")
         if mode == "0":
             return False
-        legal = h % 2 == 0 and w % 2 == 0 and h >= 4 and w >= 4 and c_out >= 32 and c_in >= 8 and c_in % 8 == 0
+        legal = h % 2 == 0 and w % 2 == 0 and h >= 8 and w >= 8 and c_out >= 32 and c_in >= 8 and c_in % 8 == 0
         if not legal or mode == "2":
             return legal
         workgroups = -(-(self.n * h * w) // 256) * -(-c_out // 64)

@@ -134,7 +134,7 @@ static inline emu_f32x4 emu_mfma_16x16x4(float a, float b, emu_f32x4 c) {
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_16x16x4((a), (b), (c))
 // LDS-DMA: lane l's `size` bytes land at the wave-uniform LDS base + size * l (executed synchronously here)
 static inline void emu_global_load_lds(const void* g, __attribute__((address_space(3))) void* l, unsigned size, int off) {
-  memcpy((char*)(void*)l + off + (size_t)size * emu::cur->lane, g, size);
+  memcpy((char*)(void*)l + off + (size_t)size * emu::cur->lane, (const char*)g + off, size);   // imm offset: both sides
 }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void*)(g), (l), (size), (off))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

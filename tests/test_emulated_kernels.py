@@ -97,7 +97,7 @@ def test_unet_forward_matches_reference_golden(name):
     assert rel_err(y, y_ref) < 1e-4
 
 
-@pytest.mark.parametrize("n,cin,cout,h", [(1, 8, 64, 16), (2, 32, 64, 8), (3, 16, 96, 4), (5, 24, 40, 8), (17, 8, 64, 4)])
+@pytest.mark.parametrize("n,cin,cout,h", [(1, 8, 64, 16), (2, 32, 64, 8), (3, 16, 96, 8), (5, 24, 40, 8), (9, 8, 64, 8), (1, 64, 128, 32)])
 def test_conv3x3_winograd(ops, n, cin, cout, h):
     """F(2x2,3x3) kernel (conv_wino.hip) against the plain fp32 convolution: same tolerance as the direct kernel"""
     pass

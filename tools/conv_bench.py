@@ -45,7 +45,7 @@ def time_conv(n, cin, cout, h, tile, gn=False, reps=5):
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    shapes = [(128, 128, 32), (256, 128, 32), (256, 256, 16), (512, 256, 16), (256, 256, 8), (256, 256, 4), (384, 128, 32)]
+    shapes = [(128, 128, 32), (256, 128, 32), (256, 256, 16), (512, 256, 16), (256, 256, 8), (384, 128, 32)]
     for cin, cout, h in shapes:
         for gn in (False, True):
             d, dms = time_conv(n, cin, cout, h, L.TILE_AUTO, gn)
