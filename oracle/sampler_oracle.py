@@ -48,6 +48,7 @@ class _VP:
         self.beta_0, self.beta_1, self.N, self.T, self.sub = beta_min, beta_max, N, 1, sub
         self.discrete_betas = torch.linspace(beta_min / N, beta_max / N, N)                          # sde_lib.py:125
         self.alphas = 1. - self.discrete_betas
+        self.sqrt_1m_alphas_cumprod = torch.sqrt(1. - torch.cumprod(self.alphas, dim=0))            # sde_lib.py:127-129
 
     def sde(self, x, t):                                                                             # sde_lib.py:135-139, 184-189
         beta_t = self.beta_0 + t * (self.beta_1 - self.beta_0)
@@ -64,6 +65,15 @@ class _VP:
         return torch.exp(_b(lmc)) * x, torch.sqrt(1. - torch.exp(2. * lmc))
 
 
+    def discretize(self, x, t):
+        if self.sub:                                                                                 # sde_lib.py:52-69 (Euler-Maruyama default)
+            dt = 1 / self.N
+            drift, diffusion = self.sde(x, t)
+            return drift * dt, diffusion * torch.sqrt(torch.tensor(dt))
+        idx = (t * (self.N - 1) / self.T).long()                                                     # sde_lib.py:155-163 (DDPM)
+        return _b(torch.sqrt(self.alphas[idx])) * x - x, torch.sqrt(self.discrete_betas[idx])
+
+
 def make_sde(kind, **kw):
     kind = kind.lower()
     if kind == "vesde":
@@ -76,19 +86,27 @@ def make_sde(kind, **kw):
 
 
 def score_fn(cfg, sd, sde, x, t, continuous=True):
-    """models/utils.py:129-178 (continuous models)."""
-    assert continuous
+    """models/utils.py:129-178: continuous models, and the discrete (DDPM / SMLD) label conventions."""
     if isinstance(sde, _VP):
-        labels = t * 999
-        out = unet_oracle.ncsnpp_forward(cfg, sd, x, labels)
-        std = sde.marginal_prob(torch.zeros_like(x), t)[1]
+        if continuous or sde.sub:                                                                    # :147-153
+            labels = t * 999
+            out = unet_oracle.ncsnpp_forward(cfg, sd, x, labels)
+            std = sde.marginal_prob(torch.zeros_like(x), t)[1]
+        else:                                                                                        # :154-158
+            labels = t * (sde.N - 1)
+            out = unet_oracle.ncsnpp_forward(cfg, sd, x, labels)
+            std = sde.sqrt_1m_alphas_cumprod[labels.long()]
         return -out / _b(std)
-    labels = sde.marginal_prob(torch.zeros_like(x), t)[1]
+    if continuous:                                                                                   # :165-166
+        labels = sde.marginal_prob(torch.zeros_like(x), t)[1]
+    else:                                                                                            # :168-171
+        labels = torch.round((sde.T - t) * (sde.N - 1)).long()
     return unet_oracle.ncsnpp_forward(cfg, sd, x, labels)
 
 
 def pc_sample(cfg, sd, sde_kind, sde_kwargs, x_T, noises, snr, n_steps=1, eps=1e-3, denoise=True,
-              predictor="reverse_diffusion", corrector="langevin", max_steps=None):
+              predictor="reverse_diffusion", corrector="langevin", max_steps=None, continuous=True,
+              probability_flow=False):
     """sampling.py:390-409 with noise injected: noises[i, 0] feeds the corrector, noises[i, 1] the predictor."""
     sde = make_sde(sde_kind, **sde_kwargs)
     B = x_T.shape[0]
@@ -103,7 +121,7 @@ def pc_sample(cfg, sd, sde_kind, sde_kwargs, x_T, noises, snr, n_steps=1, eps=1e
             if corrector == "langevin":                                                   # sampling.py:262-282
                 alpha = torch.ones_like(t) if isinstance(sde, _VE) else sde.alphas[(t * (sde.N - 1) / sde.T).long()]
                 for _ in range(n_steps):
-                    grad = score_fn(cfg, sd, sde, x, t)
+                    grad = score_fn(cfg, sd, sde, x, t, continuous)
                     z = noises[i, 0]
                     score_norms.append(float(torch.norm(grad.reshape(B, -1), dim=-1).mean()))
                     gnorm = torch.norm(grad.reshape(B, -1), dim=-1).mean()
@@ -111,21 +129,47 @@ def pc_sample(cfg, sd, sde_kind, sde_kwargs, x_T, noises, snr, n_steps=1, eps=1e
                     step = (snr * znorm / gnorm) ** 2 * 2 * alpha
                     x_mean = x + _b(step) * grad
                     x = x_mean + _b(torch.sqrt(step * 2)) * z
+            elif corrector == "ald":                                                      # sampling.py:300-319
+                alpha = torch.ones_like(t) if isinstance(sde, _VE) else sde.alphas[(t * (sde.N - 1) / sde.T).long()]
+                std = sde.marginal_prob(x, t)[1]
+                for _ in range(n_steps):
+                    grad = score_fn(cfg, sd, sde, x, t, continuous)
+                    score_norms.append(float(torch.norm(grad.reshape(B, -1), dim=-1).mean()))
+                    step = (snr * std) ** 2 * 2 * alpha
+                    x_mean = x + _b(step) * grad
+                    x = x_mean + noises[i, 0] * _b(torch.sqrt(step * 2))
+            elif corrector != "none":
+                raise ValueError(corrector)
             if predictor == "reverse_diffusion":                                          # sampling.py:195-200
                 f, G = sde.discretize(x, t)
-                s = score_fn(cfg, sd, sde, x, t)
+                s = score_fn(cfg, sd, sde, x, t, continuous)
                 score_norms.append(float(torch.norm(s.reshape(B, -1), dim=-1).mean()))
-                rev_f = f - _b(G) ** 2 * s                                                # sde_lib.py:105
+                rev_f = f - _b(G) ** 2 * s * (0.5 if probability_flow else 1.)            # sde_lib.py:105
+                rev_G = torch.zeros_like(G) if probability_flow else G                    # sde_lib.py:106
                 x_mean = x - rev_f
-                x = x_mean + _b(G) * noises[i, 1]
+                x = x_mean + _b(rev_G) * noises[i, 1]
             elif predictor == "euler_maruyama":                                           # sampling.py:181-187
                 dt = -1. / sde.N
                 drift, diffusion = sde.sde(x, t)
-                s = score_fn(cfg, sd, sde, x, t)
+                s = score_fn(cfg, sd, sde, x, t, continuous)
                 score_norms.append(float(torch.norm(s.reshape(B, -1), dim=-1).mean()))
                 drift = drift - _b(diffusion) ** 2 * s                                    # sde_lib.py:96
                 x_mean = x + drift * dt
                 x = x_mean + _b(diffusion) * np.sqrt(-dt) * noises[i, 1]
+            elif predictor == "ancestral_sampling":                                       # sampling.py:213-239
+                idx = (t * (sde.N - 1) / sde.T).long()
+                s = score_fn(cfg, sd, sde, x, t, continuous)
+                score_norms.append(float(torch.norm(s.reshape(B, -1), dim=-1).mean()))
+                if isinstance(sde, _VE):
+                    sigma = sde.discrete_sigmas[idx]
+                    adj = torch.where(idx == 0, torch.zeros_like(t), sde.discrete_sigmas[idx - 1])
+                    x_mean = x + s * _b(sigma ** 2 - adj ** 2)
+                    std = torch.sqrt((adj ** 2 * (sigma ** 2 - adj ** 2)) / (sigma ** 2))
+                    x = x_mean + _b(std) * noises[i, 1]
+                else:
+                    beta = sde.discrete_betas[idx]
+                    x_mean = (x + _b(beta) * s) / _b(torch.sqrt(1. - beta))
+                    x = x_mean + _b(torch.sqrt(beta)) * noises[i, 1]
             elif predictor != "none":
                 raise ValueError(predictor)
             x_steps.append(x.clone())

@@ -29,7 +29,7 @@ from . import engine as E
 from . import sde_lib
 
 
-def plan_fused(sde, predictor, corrector, model, continuous, x):
+def plan_fused(sde, predictor, corrector, model, continuous, x, probability_flow=False):
     """Return a lowering plan when (sde, predictor, corrector, model) are all stock, else None."""
     from . import sampling as S
     from .models.ncsnpp import NCSNpp
@@ -38,12 +38,15 @@ def plan_fused(sde, predictor, corrector, model, continuous, x):
     if type(sde) not in (sde_lib.VESDE, sde_lib.VPSDE, sde_lib.subVPSDE):
         return None
     pred = {None: "none", S.NonePredictor: "none", S.ReverseDiffusionPredictor: "reverse_diffusion",
-            S.EulerMaruyamaPredictor: "euler_maruyama"}.get(predictor, "?")
-    corr = {None: "none", S.NoneCorrector: "none", S.LangevinCorrector: "langevin"}.get(corrector, "?")
+            S.EulerMaruyamaPredictor: "euler_maruyama", S.AncestralSamplingPredictor: "ancestral_sampling"}.get(predictor, "?")
+    corr = {None: "none", S.NoneCorrector: "none", S.LangevinCorrector: "langevin",
+            S.AnnealedLangevinDynamics: "ald"}.get(corrector, "?")
     if pred == "?" or corr == "?":
         return None
-    if corr == "langevin" and type(sde) is sde_lib.subVPSDE:
+    if corr in ("langevin", "ald") and type(sde) is sde_lib.subVPSDE:
         return None    # the reference raises AttributeError (subVPSDE has no `alphas`); keep that behaviour
+    if pred == "ancestral_sampling" and (type(sde) is sde_lib.subVPSDE or probability_flow):
+        return None    # NotImplementedError / AssertionError from the predictor's constructor (sampling.py:206-210)
     vp_like = type(sde) in (sde_lib.VPSDE, sde_lib.subVPSDE)
     if vp_like and model.config.model.scale_by_sigma:
         return None
@@ -86,8 +89,27 @@ def step_tables(sde, plan, eps, probability_flow):
         b = -(diffusion ** 2) * half * dt
         c = torch.zeros_like(diffusion) if probability_flow else diffusion * np.sqrt(-dt)
         tabs["coef"] = torch.stack([a, b, c], dim=1)
-    if plan["corrector"] == "langevin" and plan["vp_like"]:                # sampling.py:267-269
+    elif plan["predictor"] == "ancestral_sampling":                        # sampling.py:213-239
+        idx = (ts * (N - 1) / sde.T).long()
+        if plan["vp_like"]:
+            beta = sde.discrete_betas[idx]
+            a = 1.0 / torch.sqrt(1. - beta)
+            b = beta / torch.sqrt(1. - beta)
+            c = torch.sqrt(beta)
+        else:
+            sigma = sde.discrete_sigmas[idx]
+            adj = torch.where(idx == 0, torch.zeros_like(ts), sde.discrete_sigmas[idx - 1])
+            a = torch.ones_like(sigma)
+            b = sigma ** 2 - adj ** 2
+            c = torch.sqrt((adj ** 2 * (sigma ** 2 - adj ** 2)) / (sigma ** 2))
+        tabs["coef"] = torch.stack([a, b, c], dim=1)
+    if plan["corrector"] in ("langevin", "ald") and plan["vp_like"]:       # sampling.py:267-269, 306-309
         tabs["alpha"] = sde.alphas[(ts * (N - 1) / sde.T).long()]
+    if plan["corrector"] == "ald":                                         # sampling.py:311,316: step = (snr * std)^2 * 2 alpha
+        # the Langevin kernel forms (snr * mean||z|| / mean||g||)^2 * 2 alpha from per-sample squared norms; feeding it
+        # ||z||^2 := std^2 and ||g||^2 := 1 makes it evaluate the annealed step without a second kernel
+        tabs["ald_std2"] = sde.marginal_prob(zeros, ts)[1] ** 2
+        tabs["ald_one"] = torch.ones(N)
     return {k: v.to(torch.float32).contiguous() for k, v in tabs.items()}
 
 
@@ -133,12 +155,16 @@ class FusedPCSampler:
         emit(L.OP_FILL, L.FillArgs, dst=self.unet.cond.tensor, tab=self.tabs["label"], step_ptr=self.step, n=self.B)
         if self.plan["vp_like"]:
             emit(L.OP_FILL, L.FillArgs, dst=self.unet.std.tensor, tab=self.tabs["std"], step_ptr=self.step, n=self.B)
-        if self.plan["corrector"] == "langevin":
+        if self.plan["corrector"] == "ald":
+            emit(L.OP_FILL, L.FillArgs, dst=self.gss, tab=self.tabs["ald_one"], step_ptr=self.step, n=self.B)
+            emit(L.OP_FILL, L.FillArgs, dst=self.zss, tab=self.tabs["ald_std2"], step_ptr=self.step, n=self.B)
+        if self.plan["corrector"] in ("langevin", "ald"):
             for k in range(self.n_steps):
                 emit_unet()
                 if with_rng:
                     emit(L.OP_RANDN, L.RandnArgs, dst=self.z_c, numel=self.B * self.per, seed=seed, step_ptr=self.step, stream_id=k)
-                emit(L.OP_SUMSQ, L.SumsqArgs, a=score, b=self.z_c, out_a=self.gss, out_b=self.zss, n=self.B, per=self.per)
+                if self.plan["corrector"] == "langevin":
+                    emit(L.OP_SUMSQ, L.SumsqArgs, a=score, b=self.z_c, out_a=self.gss, out_b=self.zss, n=self.B, per=self.per)
                 emit(L.OP_LANGEVIN, L.LangevinArgs, x=self.x, x_mean=self.x_mean, grad=score, noise=self.z_c,
                      grad_sumsq=self.gss, noise_sumsq=self.zss, alpha_tab=self.tabs.get("alpha"), step_ptr=self.step,
                      n=self.B, per=self.per, snr=self.snr)
@@ -158,7 +184,7 @@ class FusedPCSampler:
         return self._programs[key]
 
     def nfe_per_step(self):
-        return (self.n_steps if self.plan["corrector"] == "langevin" else 0) + (1 if self.plan["predictor"] != "none" else 0)
+        return (self.n_steps if self.plan["corrector"] != "none" else 0) + (1 if self.plan["predictor"] != "none" else 0)
 
     # -------------------------------------------------------------- execution
     def reset(self, x):

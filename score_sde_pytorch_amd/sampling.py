@@ -269,7 +269,7 @@ def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_step
         from . import pc_engine
         with torch.no_grad():
             x = (sde.prior_sampling(shape) if x_init is None else x_init).to(device)
-            plan = pc_engine.plan_fused(sde, predictor, corrector, model, continuous, x)
+            plan = pc_engine.plan_fused(sde, predictor, corrector, model, continuous, x, probability_flow)
             if plan is not None:
                 key = id(model)
                 eng = fused_cache.get(key)

@@ -79,6 +79,12 @@ def rel_err(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+def pc_variant_inputs(name, batch, n_steps, size, sigma_max):
+    """x_T and injected noises of one entry of tests/golden/pc_small_variants.npz (oracle/gen_golden_variants.py)"""
+    import zlib
+    return pc_case_inputs(batch, n_steps, sigma_max, size, seed=zlib.crc32(name.encode()) & 0xffff)
+
+
 def pc_case_inputs(batch=8, n_steps=10, sigma_max=50.0, size=32, seed=7):
     """x_T and injected noises of the PC-sampler golden case (BASELINE config #1); shared by
     oracle/gen_golden.py and the tests so the fixture need not store them."""
@@ -86,3 +92,22 @@ def pc_case_inputs(batch=8, n_steps=10, sigma_max=50.0, size=32, seed=7):
     x_T = torch.randn(batch, 3, size, size, generator=g) * sigma_max
     noises = torch.randn(n_steps, 2, batch, 3, size, size, generator=g)
     return x_T, noises
+
+
+# entries of tests/golden/pc_small_variants.npz (made by oracle/gen_golden_variants.py from the reference sampler):
+# name -> (small-config kind, sde kind, sde kwargs, predictor, corrector, n_steps, continuous, probability_flow, denoise, eps)
+PC_VARIANT_BATCH, PC_VARIANT_SIZE = 4, 16
+# (the VP entries use beta_max=3: at N=6 the DDPM betas of beta_max=20 exceed 1 and sqrt(1-beta) is NaN)
+PC_VARIANTS = {
+    "ve_ancestral_ald": ("ncsnpp", "vesde", dict(sigma_min=0.01, sigma_max=50, N=6), "ancestral_sampling", "ald", 2, True, False, True, 1e-5),
+    "ve_rd_none": ("ncsnpp", "vesde", dict(sigma_min=0.01, sigma_max=50, N=6), "reverse_diffusion", "none", 1, True, False, False, 1e-5),
+    "ve_none_langevin": ("ncsnpp", "vesde", dict(sigma_min=0.01, sigma_max=50, N=6), "none", "langevin", 2, True, False, True, 1e-5),
+    # (euler_maruyama with probability_flow=True raises TypeError in the reference: RSDE.sde returns a float diffusion,
+    #  sde_lib.py:99 vs sampling.py:186 -- not a usable combination, so no entry)
+    "ve_em_langevin": ("ncsnpp", "vesde", dict(sigma_min=0.01, sigma_max=50, N=6), "euler_maruyama", "langevin", 1, True, False, True, 1e-5),
+    "vp_ancestral_ald_discrete": ("ddpmpp", "vpsde", dict(beta_min=0.1, beta_max=3, N=6), "ancestral_sampling", "ald", 1, False, False, True, 1e-3),
+    "vp_em_langevin": ("ddpmpp", "vpsde", dict(beta_min=0.1, beta_max=3, N=6), "euler_maruyama", "langevin", 1, True, False, True, 1e-3),
+    "vp_rd_langevin_discrete": ("ddpmpp", "vpsde", dict(beta_min=0.1, beta_max=3, N=6), "reverse_diffusion", "langevin", 1, False, False, False, 1e-3),
+    "subvp_em_none": ("ddpmpp", "subvpsde", dict(beta_min=0.1, beta_max=20, N=6), "euler_maruyama", "none", 1, True, False, True, 1e-3),
+    "subvp_rd_none_pflow": ("ddpmpp", "subvpsde", dict(beta_min=0.1, beta_max=20, N=6), "reverse_diffusion", "none", 1, True, True, True, 1e-3),
+}

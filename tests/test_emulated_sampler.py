@@ -1,0 +1,39 @@
+"""The fused PC step program (pc_engine.FusedPCSampler: U-Net program + FILL / SUMSQ / LANGEVIN / PREDICTOR ops of the
+C ABI) run under the CPU emulator of the HIP sources, against the samples of the REFERENCE sampler
+(tests/golden/pc_small_variants.npz).  The same cases run on the MI355X in tests/test_sampler_gpu.py."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import _util
+from _util import rel_err
+from emu import emulated, available
+
+pytestmark = pytest.mark.skipif(not available(), reason="g++ not available for the kernel emulator")
+
+
+@pytest.mark.parametrize("name", ["ve_ancestral_ald", "vp_ancestral_ald_discrete", "vp_em_langevin", "subvp_rd_none_pflow"])
+def test_fused_step_program_variants(name):
+    from score_sde_pytorch_amd import sde_lib, sampling, pc_engine
+    from score_sde_pytorch_amd.models import utils as mutils
+    gold = np.load(os.path.join(_util.GOLDEN, "pc_small_variants.npz"))
+    kind, sde_kind, kw, pred, corr, n_steps, continuous, pflow, denoise, eps = _util.PC_VARIANTS[name]
+    cfg = _util.small_config(kind)
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg).eval()
+    _util.load_seeded(model, seed=1)
+    sde = {"vesde": sde_lib.VESDE, "vpsde": sde_lib.VPSDE, "subvpsde": sde_lib.subVPSDE}[sde_kind](**kw)
+    B, R = _util.PC_VARIANT_BATCH, _util.PC_VARIANT_SIZE
+    x_T, noises = _util.pc_variant_inputs(name, B, kw["N"], R, kw.get("sigma_max", 1.0))
+    with emulated():
+        plan = pc_engine.plan_fused(sde, sampling.get_predictor(pred), sampling.get_corrector(corr), model, continuous,
+                                    types.SimpleNamespace(is_cuda=True), pflow)   # only the device kind of x is inspected
+        assert plan is not None and plan["predictor"] == pred and plan["corrector"] == corr
+        eng = pc_engine.FusedPCSampler(model, sde, plan, (B, 3, R, R), snr=0.16, n_steps=n_steps, probability_flow=pflow,
+                                       eps=eps, device=torch.device("cpu"))
+        x, x_mean = eng.run(x_T, noises=noises)
+    out = x_mean if denoise else x
+    assert rel_err(out, torch.from_numpy(gold[name])) < 2e-4

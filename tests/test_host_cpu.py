@@ -130,6 +130,20 @@ def test_step_tables_follow_reference_formulas():
     plan = dict(predictor="euler_maruyama", corrector="none", vp_like=True, continuous=True)
     tabs = pc_engine.step_tables(sde_lib.subVPSDE(0.1, 20, N=N), plan, 1e-3, probability_flow=True)
     assert float(tabs["coef"][:, 2].abs().max()) == 0.0                      # ODE: no noise
+    # ancestral sampling (sampling.py:213-239) and annealed Langevin dynamics (:300-319)
+    plan = dict(predictor="ancestral_sampling", corrector="ald", vp_like=False, continuous=True)
+    tabs = pc_engine.step_tables(sde, plan, eps, probability_flow=False)
+    idx = (ts * (N - 1)).long()
+    sig = sde.discrete_sigmas[idx]
+    adj = torch.where(idx == 0, torch.zeros(N), sde.discrete_sigmas[idx - 1])
+    assert torch.equal(tabs["coef"][:, 1], sig ** 2 - adj ** 2) and float(tabs["coef"][-1, 2]) == 0.0
+    assert torch.equal(tabs["ald_std2"], sde.marginal_prob(torch.zeros(N, 1, 1, 1), ts)[1] ** 2) and "alpha" not in tabs
+    vp3 = sde_lib.VPSDE(0.1, 3, N=N)
+    plan = dict(predictor="ancestral_sampling", corrector="ald", vp_like=True, continuous=False)
+    tabs = pc_engine.step_tables(vp3, plan, 1e-3, probability_flow=False)
+    beta = vp3.discrete_betas[(torch.linspace(1, 1e-3, N) * (N - 1)).long()]
+    assert torch.allclose(tabs["coef"][:, 0] ** 2 * (1 - beta), torch.ones(N)) and torch.equal(tabs["coef"][:, 2], torch.sqrt(beta))
+    assert torch.equal(tabs["label"], torch.linspace(1, 1e-3, N) * (N - 1))  # discrete DDPM labels (models/utils.py:154-156)
 
 
 @pytest.mark.parametrize("name,batch,gflop_per_img", [("ve/cifar10_ncsnpp_continuous", 256, 21.76),

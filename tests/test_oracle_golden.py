@@ -63,6 +63,21 @@ def test_pc_sampler_oracle_prefix_reproduces_reference():
     assert abs(out["score_norms"][0] - gold["score_norms"][0]) / gold["score_norms"][0] < 2e-6
 
 
+@pytest.mark.parametrize("name", list(_util.PC_VARIANTS))
+def test_pc_sampler_oracle_variants_reproduce_reference(name):
+    """every stock predictor / corrector / SDE combination the fused sampler lowers, against the samples the REFERENCE
+    produced for it (tests/golden/pc_small_variants.npz, oracle/gen_golden_variants.py)"""
+    from oracle import sampler_oracle
+    gold = np.load(os.path.join(_util.GOLDEN, "pc_small_variants.npz"))
+    kind, sde_kind, kw, pred, corr, n_steps, continuous, pflow, denoise, eps = _util.PC_VARIANTS[name]
+    cfg = _util.small_config(kind)
+    sd = _sd_for(cfg)
+    x_T, noises = _util.pc_variant_inputs(name, _util.PC_VARIANT_BATCH, kw["N"], _util.PC_VARIANT_SIZE, kw.get("sigma_max", 1.0))
+    out = sampler_oracle.pc_sample(cfg, sd, sde_kind, kw, x_T, noises, snr=0.16, n_steps=n_steps, eps=eps, denoise=denoise,
+                                   predictor=pred, corrector=corr, continuous=continuous, probability_flow=pflow)
+    assert rel_err(out["samples"], torch.from_numpy(gold[name])) < 1e-4
+
+
 def test_oracle_upfirdn_edge_cases():
     """ragged / degenerate shapes of upfirdn2d: 1x1 input, odd sizes, all three FIR modes keep their shape law"""
     from oracle import unet_oracle as uo

@@ -137,6 +137,61 @@ def test_vp_euler_maruyama_fused_matches_oracle():
     assert rel_err(out, ref["samples"]) < 2e-4
 
 
+def _variant(name):
+    from score_sde_pytorch_amd import sde_lib, sampling
+    from score_sde_pytorch_amd.models import utils as mutils
+    kind, sde_kind, kw, pred, corr, n_steps, continuous, pflow, denoise, eps = _util.PC_VARIANTS[name]
+    cfg = _util.small_config(kind)
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    _util.load_seeded(model, seed=1)
+    model = model.cuda().eval()
+    sde = {"vesde": sde_lib.VESDE, "vpsde": sde_lib.VPSDE, "subvpsde": sde_lib.subVPSDE}[sde_kind](**kw)
+    B, R = _util.PC_VARIANT_BATCH, _util.PC_VARIANT_SIZE
+    x_T, noises = _util.pc_variant_inputs(name, B, kw["N"], R, kw.get("sigma_max", 1.0))
+    mk = lambda p, c: sampling.get_pc_sampler(sde, (B, 3, R, R), p, c, lambda v: v, snr=0.16, n_steps=n_steps,
+                                              probability_flow=pflow, continuous=continuous, denoise=denoise, eps=eps,
+                                              device="cuda")
+    return model, mk, sampling.get_predictor(pred), sampling.get_corrector(corr), x_T, noises
+
+
+@pytest.mark.parametrize("name", list(_util.PC_VARIANTS))
+def test_fused_variants_match_reference_samples(name):
+    """ancestral / Euler-Maruyama / reverse-diffusion / none x ald / langevin / none on VE, VP (continuous and discrete
+    labels) and sub-VP: the fused step program against the REFERENCE sampler's output (pc_small_variants.npz)"""
+    gold = np.load(os.path.join(_util.GOLDEN, "pc_small_variants.npz"))
+    model, mk, pred, corr, x_T, noises = _variant(name)
+    sampler = mk(pred, corr)
+    out, nfe = sampler(model, x_init=x_T, noises=noises)
+    assert sampler.last_path == "fused-eager"
+    assert rel_err(out, torch.from_numpy(gold[name])) < 2e-4
+
+
+@pytest.mark.parametrize("name", ["ve_ancestral_ald", "vp_ancestral_ald_discrete"])
+def test_generic_path_variants_match_reference_samples(name):
+    """the same combinations through user subclasses (generic loop calling update_fn with our score_fn)"""
+    gold = np.load(os.path.join(_util.GOLDEN, "pc_small_variants.npz"))
+    model, mk, pred, corr, x_T, noises = _variant(name)
+    sampler = mk(type("MyPredictor", (pred,), {}), type("MyCorrector", (corr,), {}))
+    out, nfe = sampler(model, x_init=x_T, noises=noises)
+    assert sampler.last_path == "generic"
+    assert rel_err(out, torch.from_numpy(gold[name])) < 2e-4
+
+
+def test_unusable_combinations_keep_reference_errors():
+    from score_sde_pytorch_amd import sde_lib, sampling
+    model, mk, pred, corr, x_T, noises = _variant("subvp_em_none")
+    sub = sde_lib.subVPSDE(0.1, 20, N=4)
+    bad = sampling.get_pc_sampler(sub, (4, 3, 16, 16), sampling.AncestralSamplingPredictor, sampling.NoneCorrector,
+                                  lambda v: v, snr=0.16, continuous=True, device="cuda")
+    with pytest.raises(NotImplementedError):
+        bad(model, x_init=x_T)
+    bad = sampling.get_pc_sampler(sub, (4, 3, 16, 16), sampling.NonePredictor, sampling.LangevinCorrector,
+                                  lambda v: v, snr=0.16, continuous=True, device="cuda")
+    with pytest.raises(AttributeError):
+        bad(model, x_init=x_T)
+
+
 def test_ode_sampler_on_device_matches_host_scipy(monkeypatch):
     """get_ode_sampler: the on-device RK45 driver and the reference's host scipy loop give the same samples and NFE"""
     import _util
