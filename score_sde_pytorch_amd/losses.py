@@ -123,6 +123,9 @@ def get_smld_loss_fn(vesde, train, reduce_mean=False):
         losses = reduce_op(losses.reshape(losses.shape[0], -1), dim=-1) * sigmas ** 2
         return torch.mean(losses)
 
+    # (score - target)^2 sigma^2 with target = -z / sigma is (score sigma + z)^2: the DSM head with std = sigma[labels]
+    loss_fn.ssde_spec = dict(kind="smld", sde=vesde, train=train, reduce_mean=reduce_mean, continuous=False,
+                             likelihood_weighting=False, eps=0.0)
     return loss_fn
 
 
@@ -144,6 +147,9 @@ def get_ddpm_loss_fn(vpsde, train, reduce_mean=True):
         losses = reduce_op(losses.reshape(losses.shape[0], -1), dim=-1)
         return torch.mean(losses)
 
+    # (eps_theta - z)^2 is (score std + z)^2 for the VP score head score = -eps_theta / std, std = sqrt(1 - alpha_bar)[labels]
+    loss_fn.ssde_spec = dict(kind="ddpm", sde=vpsde, train=train, reduce_mean=reduce_mean, continuous=False,
+                             likelihood_weighting=False, eps=0.0)
     return loss_fn
 
 
@@ -219,13 +225,24 @@ class FusedTrainStep:
     def perturb_inputs(self, batch, t, z):
         """Per-sample coefficients with the SDE's own [B]-sized expressions; the per-pixel work is the perturb kernel."""
         sde, spec = self.spec["sde"], self.spec
-        ones = torch.ones(self.n, 1, 1, 1, device=self.device)
-        mean1, std = sde.marginal_prob(ones, t)                     # mean is linear in x: mean = a[n] * x
-        self.a.copy_(mean1.reshape(self.n))
+        if spec["kind"] == "smld":                                  # losses.py:111-118; t holds the integer noise levels
+            std = torch.flip(sde.discrete_sigmas, dims=(0,)).to(self.device)[t]
+            self.a.fill_(1.0)
+            labels = t.to(torch.float32)
+            if self.eng.sig is not self.eng.cond:                   # positional models gather sigma for scale_by_sigma
+                self.eng.sig.tensor[: self.n].copy_(self.model.sigmas.to(torch.float32)[t])
+        elif spec["kind"] == "ddpm":                                # losses.py:135-141
+            std = sde.sqrt_1m_alphas_cumprod.to(self.device)[t]
+            self.a.copy_(sde.sqrt_alphas_cumprod.to(self.device)[t])
+            labels = t.to(torch.float32)
+        else:
+            ones = torch.ones(self.n, 1, 1, 1, device=self.device)
+            mean1, std = sde.marginal_prob(ones, t)                 # mean is linear in x: mean = a[n] * x
+            self.a.copy_(mean1.reshape(self.n))
+            if spec["likelihood_weighting"]:
+                self.g2.copy_(sde.sde(torch.zeros(self.n, 1, 1, 1, device=self.device), t)[1] ** 2)
+            labels = t * 999 if self.vp_like else std               # models/utils.py:147-166 (continuous)
         self.s.copy_(std)
-        if spec["likelihood_weighting"]:
-            self.g2.copy_(sde.sde(torch.zeros(self.n, 1, 1, 1, device=self.device), t)[1] ** 2)
-        labels = t * 999 if self.vp_like else std                   # models/utils.py:147-166 (continuous)
         self.eng.cond.tensor[: self.n].copy_(labels)
         if self.vp_like:
             self.eng.std.tensor[: self.n].copy_(std)
@@ -235,7 +252,9 @@ class FusedTrainStep:
     def loss_and_grads(self, batch, t=None, z=None, seed=None):
         """Forward + loss (+ backward when built for training); returns the device scalar loss."""
         spec = self.spec
-        if t is None:
+        if t is None and spec["kind"] in ("smld", "ddpm"):
+            t = torch.randint(0, spec["sde"].N, (batch.shape[0],), device=batch.device)                         # losses.py:116,136
+        elif t is None:
             t = torch.rand(batch.shape[0], device=batch.device) * (spec["sde"].T - spec["eps"]) + spec["eps"]   # losses.py:84
         if z is None:
             z = torch.randn_like(batch)                                                                         # losses.py:85

@@ -298,7 +298,11 @@ def check_fused_step(dev, steps=3, sde_kind="vesde"):
     from score_sde_pytorch_amd.models import utils as mutils, ema as ema_mod
     from score_sde_pytorch_amd import losses, sde_lib
     from oracle import unet_oracle
-    cfg = small_cfg("ncsnpp" if sde_kind == "vesde" else "ddpmpp")
+    cfg = small_cfg("ncsnpp" if sde_kind in ("vesde", "smld") else "ddpmpp")
+    if sde_kind == "smld":      # the discrete NCSN++ configs (configs/ve/cifar10_ncsnpp.py): positional labels, sigma gather
+        cfg.model.embedding_type, cfg.model.num_scales, cfg.training.continuous = "positional", 24, False
+    if sde_kind == "ddpm":      # configs/vp/cifar10_ddpmpp.py
+        cfg.model.num_scales, cfg.training.continuous = 24, False
     cfg.optim.warmup = 2
     torch.manual_seed(0)
     model = mutils.get_model("ncsnpp")(cfg)
@@ -306,10 +310,13 @@ def check_fused_step(dev, steps=3, sde_kind="vesde"):
     sd["sigmas"] = model.sigmas.clone()
     model = model.to(dev)
     names = [n for n, p in model.named_parameters() if p.requires_grad]
-    if sde_kind == "vesde":
+    if sde_kind in ("vesde", "smld"):
         sde = sde_lib.VESDE(cfg.model.sigma_min, cfg.model.sigma_max, cfg.model.num_scales)
+    elif sde_kind == "ddpm":
+        sde = sde_lib.VPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales)
     else:
         sde = sde_lib.subVPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales)
+    discrete = sde_kind in ("smld", "ddpm")
     R, Bn = cfg.data.image_size, 3
     g = torch.Generator().manual_seed(3)
     ref_params = {k: sd[k].clone().requires_grad_() for k in names}
@@ -318,7 +325,7 @@ def check_fused_step(dev, steps=3, sde_kind="vesde"):
     opt = losses.get_optimizer(cfg, model.parameters())
     ema = ema_mod.ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate)
     optimize_fn = losses.optimization_manager(cfg)
-    step_fn = losses.get_step_fn(sde, train=True, optimize_fn=optimize_fn, reduce_mean=False, continuous=True,
+    step_fn = losses.get_step_fn(sde, train=True, optimize_fn=optimize_fn, reduce_mean=False, continuous=not discrete,
                                  likelihood_weighting=False)
     state = dict(optimizer=opt, model=model, ema=ema, step=0)
     fs = step_fn.fused_for(state, torch.zeros(Bn, 3, R, R, device=dev))
@@ -328,13 +335,26 @@ def check_fused_step(dev, steps=3, sde_kind="vesde"):
         z = torch.randn(Bn, 3, R, R, generator=g)
         full = dict(sd)
         full.update(ref_params)
-        mean, std = sde.marginal_prob(batch, t)
-        xt = mean + std[:, None, None, None] * z
-        if sde_kind == "vesde":
-            score = unet_oracle.ncsnpp_forward(cfg, full, xt, std)
+        if sde_kind == "smld":                                                   # losses.py:111-124
+            t = torch.randint(0, sde.N, (Bn,), generator=g)
+            sigmas = torch.flip(sde.discrete_sigmas, dims=(0,))[t]
+            noise = z * sigmas[:, None, None, None]
+            score = unet_oracle.ncsnpp_forward(cfg, full, noise + batch, t)
+            target = -noise / (sigmas ** 2)[:, None, None, None]
+            ref_loss = (0.5 * torch.square(score - target).reshape(Bn, -1).sum(-1) * sigmas ** 2).mean()
+        elif sde_kind == "ddpm":                                                 # losses.py:135-147
+            t = torch.randint(0, sde.N, (Bn,), generator=g)
+            xt = sde.sqrt_alphas_cumprod[t, None, None, None] * batch + sde.sqrt_1m_alphas_cumprod[t, None, None, None] * z
+            eps_theta = unet_oracle.ncsnpp_forward(cfg, full, xt, t)
+            ref_loss = (0.5 * torch.square(eps_theta - z).reshape(Bn, -1).sum(-1)).mean()
         else:
-            score = -unet_oracle.ncsnpp_forward(cfg, full, xt, t * 999) / std[:, None, None, None]
-        ref_loss = (0.5 * torch.square(score * std[:, None, None, None] + z).reshape(Bn, -1).sum(-1)).mean()
+            mean, std = sde.marginal_prob(batch, t)
+            xt = mean + std[:, None, None, None] * z
+            if sde_kind == "vesde":
+                score = unet_oracle.ncsnpp_forward(cfg, full, xt, std)
+            else:
+                score = -unet_oracle.ncsnpp_forward(cfg, full, xt, t * 999) / std[:, None, None, None]
+            ref_loss = (0.5 * torch.square(score * std[:, None, None, None] + z).reshape(Bn, -1).sum(-1)).mean()
         ref_opt.zero_grad()
         ref_loss.backward()
         for gp in ref_opt.param_groups:

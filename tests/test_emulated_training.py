@@ -42,7 +42,7 @@ def test_autograd_bridge(monkeypatch):
     monkeypatch.setattr(ncsnpp.NCSNpp, "forward", orig)
 
 
-@pytest.mark.parametrize("sde_kind", ["vesde", "subvpsde"])
+@pytest.mark.parametrize("sde_kind", ["vesde", "subvpsde", "smld", "ddpm"])
 def test_fused_training_step(sde_kind):
     T.check_fused_step("cpu", steps=2, sde_kind=sde_kind)
 

@@ -32,7 +32,7 @@ def test_autograd_bridge():
     T.check_autograd_bridge("cuda")
 
 
-@pytest.mark.parametrize("sde_kind", ["vesde", "subvpsde"])
+@pytest.mark.parametrize("sde_kind", ["vesde", "subvpsde", "smld", "ddpm"])
 def test_fused_training_step(sde_kind):
     T.check_fused_step("cuda", steps=3, sde_kind=sde_kind)
 
