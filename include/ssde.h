@@ -190,6 +190,20 @@ typedef struct ssde_fill_args {   /* dst[i] = tab[*step_ptr] (vec_t / labels of 
   float* dst; const float* tab; const int32_t* step_ptr; int32_t n; int32_t _pad0;
 } ssde_fill_args;
 typedef struct ssde_step_inc_args { int32_t* step_ptr; int32_t delta; int32_t _pad0; } ssde_step_inc_args;
+typedef struct ssde_project_args {
+  /* data-consistency projection of controllable generation, applied in place to the NCHW sampler state after a
+   * corrector / predictor update (controllable_generation.py:44-52 inpainting, :136-144 colorization):
+   *   y      = A x                                   A = identity, or the colour decoupling M when use_matrix
+   *   known  = m D + s z                             (m, s) = coef[2*(*step_ptr) .. +1]: sde.marginal_prob's mean
+   *                                                  coefficient and std at this step; D = data in A's space
+   *   x      = A^-1 (y (1 - mask) + known mask)
+   *   x_mean = A^-1 ((A x)(1 - mask) + m D mask)     with the NEW x, as the reference computes it */
+  float* x; float* x_mean; const float* data; const float* mask; const float* noise;
+  const float* coef; const int32_t* step_ptr;
+  int32_t n, c, hw;               /* state is [n, c, hw]; use_matrix needs c == 3 */
+  int32_t use_matrix;
+  float M[9], invM[9];            /* row-major [i][j]: y_j = sum_i x_i M[i][j]  (einsum 'bihw,ij->bjhw', :108-113) */
+} ssde_project_args;
 
 
 /* =============================== training path ====================================
@@ -339,6 +353,7 @@ int ssde_langevin_update(const ssde_langevin_args* a, void* stream);
 int ssde_predictor_update(const ssde_predictor_args* a, void* stream);
 int ssde_fill_from_table(const ssde_fill_args* a, void* stream);
 int ssde_step_inc(const ssde_step_inc_args* a, void* stream);
+int ssde_project_update(const ssde_project_args* a, void* stream);
 int ssde_conv_wgrad(const ssde_wgrad_args* a, void* stream);
 int ssde_colsum(const ssde_colsum_args* a, void* stream);
 int ssde_gn_bwd_reduce(const ssde_gn_bwd_reduce_args* a, void* stream);
@@ -362,7 +377,7 @@ enum {
   SSDE_OP_LANGEVIN = 11, SSDE_OP_PREDICTOR = 12, SSDE_OP_FILL = 13, SSDE_OP_STEP_INC = 14,
   SSDE_OP_WGRAD = 15, SSDE_OP_COLSUM = 16, SSDE_OP_GN_BWD_REDUCE = 17, SSDE_OP_PROLOGUE_BWD = 18,
   SSDE_OP_ATTN_BWD = 19, SSDE_OP_PERTURB = 20, SSDE_OP_DSM_LOSS = 21, SSDE_OP_SUMSQ_FLAT = 22,
-  SSDE_OP_ADAM = 23, SSDE_OP_MEMSET = 24, SSDE_OP_AXPY = 25, SSDE_OP_PACK = 26
+  SSDE_OP_ADAM = 23, SSDE_OP_MEMSET = 24, SSDE_OP_AXPY = 25, SSDE_OP_PACK = 26, SSDE_OP_PROJECT = 27
 };
 typedef struct ssde_op {
   int32_t kind; int32_t flops_class;   /* flops_class: free tag echoed by timing */
@@ -375,7 +390,7 @@ typedef struct ssde_op {
     ssde_wgrad_args wgrad; ssde_colsum_args colsum; ssde_gn_bwd_reduce_args gn_bwd; ssde_prologue_bwd_args pro_bwd;
     ssde_attn_bwd_args attn_bwd; ssde_perturb_args perturb; ssde_dsm_loss_args dsm_loss;
     ssde_sumsq_flat_args sumsq_flat; ssde_adam_args adam; ssde_memset_args memset; ssde_axpy_args axpy;
-    ssde_pack_args pack;
+    ssde_pack_args pack; ssde_project_args project;
   } u;
 } ssde_op;
 

@@ -106,8 +106,10 @@ def score_fn(cfg, sd, sde, x, t, continuous=True):
 
 def pc_sample(cfg, sd, sde_kind, sde_kwargs, x_T, noises, snr, n_steps=1, eps=1e-3, denoise=True,
               predictor="reverse_diffusion", corrector="langevin", max_steps=None, continuous=True,
-              probability_flow=False):
-    """sampling.py:390-409 with noise injected: noises[i, 0] feeds the corrector, noises[i, 1] the predictor."""
+              probability_flow=False, project=None):
+    """sampling.py:390-409 with noise injected: noises[i, 0] feeds the corrector, noises[i, 1] the predictor.
+    `project(sde, x, t, z) -> (x, x_mean)`, when given, runs after the corrector (noise noises[i, 2]) and after the
+    predictor (noises[i, 3]): the data-consistency step of controllable_generation.py:44-52 / 136-144."""
     sde = make_sde(sde_kind, **sde_kwargs)
     B = x_T.shape[0]
     x = x_T.clone()
@@ -140,6 +142,8 @@ def pc_sample(cfg, sd, sde_kind, sde_kwargs, x_T, noises, snr, n_steps=1, eps=1e
                     x = x_mean + noises[i, 0] * _b(torch.sqrt(step * 2))
             elif corrector != "none":
                 raise ValueError(corrector)
+            if project is not None:
+                x, x_mean = project(sde, x, t, noises[i, 2])
             if predictor == "reverse_diffusion":                                          # sampling.py:195-200
                 f, G = sde.discretize(x, t)
                 s = score_fn(cfg, sd, sde, x, t, continuous)
@@ -172,8 +176,42 @@ def pc_sample(cfg, sd, sde_kind, sde_kwargs, x_T, noises, snr, n_steps=1, eps=1e
                     x = x_mean + _b(torch.sqrt(beta)) * noises[i, 1]
             elif predictor != "none":
                 raise ValueError(predictor)
+            if project is not None:
+                x, x_mean = project(sde, x, t, noises[i, 3])
             x_steps.append(x.clone())
     return dict(samples=(x_mean if denoise else x), x_steps=x_steps, score_norms=score_norms)
+
+
+_COLOR_M = torch.tensor([[5.7735014e-01, -8.1649649e-01, 4.7008697e-08],                              # controllable_generation.py:103-105
+                         [5.7735026e-01, 4.0824834e-01, 7.0710671e-01],
+                         [5.7735026e-01, 4.0824822e-01, -7.0710683e-01]])
+
+
+def inpaint(cfg, sd, sde_kind, sde_kwargs, data, mask, prior, noises, **kw):
+    """controllable_generation.py:42-81 (get_pc_inpainter) with injected prior / noises."""
+    def project(sde, x, t, z):                                                                        # :44-52
+        mean, std = sde.marginal_prob(data, t)
+        known = mean + z * _b(std)
+        x = x * (1. - mask) + known * mask
+        return x, x * (1. - mask) + mean * mask
+    x0 = data * mask + prior * (1. - mask)                                                            # :74
+    return pc_sample(cfg, sd, sde_kind, sde_kwargs, x0, noises, project=project, **kw)
+
+
+def colorize(cfg, sd, sde_kind, sde_kwargs, gray, prior, noises, **kw):
+    """controllable_generation.py:103-178 (get_pc_colorizer) with injected prior / noises."""
+    M, invM = _COLOR_M, torch.inverse(_COLOR_M)
+    dec = lambda v: torch.einsum('bihw,ij->bjhw', v, M)
+    cpl = lambda v: torch.einsum('bihw,ij->bjhw', v, invM)
+    mask = torch.cat([torch.ones_like(gray[:, :1]), torch.zeros_like(gray[:, 1:])], dim=1)            # :148-151
+
+    def project(sde, x, t, z):                                                                        # :136-144
+        mean, std = sde.marginal_prob(dec(gray), t)
+        known = mean + z * _b(std)
+        x = cpl(dec(x) * (1. - mask) + known * mask)
+        return x, cpl(dec(x) * (1. - mask) + mean * mask)
+    x0 = cpl(dec(gray) * mask + dec(prior * (1. - mask)))                                             # :170-172
+    return pc_sample(cfg, sd, sde_kind, sde_kwargs, x0, noises, project=project, **kw)
 
 
 def dsm_loss(cfg, sd, sde_kind, sde_kwargs, batch, t, z, reduce_mean=False, likelihood_weighting=False):

@@ -15,7 +15,7 @@ PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_SILU = 0, 1, 2, 3
 TILE_AUTO, TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32, TILE_WINOGRAD = 0, 1, 2, 3, 4, 5
 (OP_CONV, OP_GN_STATS, OP_UPFIRDN, OP_ATTN, OP_EMBED, OP_TO_NHWC, OP_TO_NCHW, OP_BIAS_ACT, OP_SUMSQ,
  OP_RANDN, OP_LANGEVIN, OP_PREDICTOR, OP_FILL, OP_STEP_INC, OP_WGRAD, OP_COLSUM, OP_GN_BWD_REDUCE, OP_PROLOGUE_BWD,
- OP_ATTN_BWD, OP_PERTURB, OP_DSM_LOSS, OP_SUMSQ_FLAT, OP_ADAM, OP_MEMSET, OP_AXPY, OP_PACK) = range(1, 27)
+ OP_ATTN_BWD, OP_PERTURB, OP_DSM_LOSS, OP_SUMSQ_FLAT, OP_ADAM, OP_MEMSET, OP_AXPY, OP_PACK, OP_PROJECT) = range(1, 28)
 PACK_CONV3, PACK_WINO3, PACK_MATRIX, PACK_VECTOR = 1, 2, 3, 4
 
 _fp = C.c_void_p  # device pointers are passed as integers
@@ -105,6 +105,12 @@ class StepIncArgs(C.Structure):
     _fields_ = [("step_ptr", _fp), ("delta", C.c_int32), ("_pad0", C.c_int32)]
 
 
+class ProjectArgs(C.Structure):
+    _fields_ = [("x", _fp), ("x_mean", _fp), ("data", _fp), ("mask", _fp), ("noise", _fp), ("coef", _fp), ("step_ptr", _fp),
+                ("n", C.c_int32), ("c", C.c_int32), ("hw", C.c_int32), ("use_matrix", C.c_int32),
+                ("M", C.c_float * 9), ("invM", C.c_float * 9)]
+
+
 class WgradArgs(C.Structure):
     _fields_ = [("src", Src), ("g", _fp), ("g_ld", C.c_int32), ("g_off", C.c_int32),
                 ("n", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32), ("h_out", C.c_int32), ("w_out", C.c_int32),
@@ -179,7 +185,7 @@ class _OpUnion(C.Union):
                 ("wgrad", WgradArgs), ("colsum", ColsumArgs), ("gn_bwd", GnBwdReduceArgs), ("pro_bwd", PrologueBwdArgs),
                 ("attn_bwd", AttnBwdArgs), ("perturb", PerturbArgs), ("dsm_loss", DsmLossArgs),
                 ("sumsq_flat", SumsqFlatArgs), ("adam", AdamArgs), ("memset", MemsetArgs), ("axpy", AxpyArgs),
-                ("pack", PackArgs)]
+                ("pack", PackArgs), ("project", ProjectArgs)]
 
 
 class Op(C.Structure):
@@ -191,7 +197,7 @@ _UNION_FIELD = {OP_CONV: "conv", OP_GN_STATS: "gn", OP_UPFIRDN: "fir", OP_ATTN: 
                 OP_RANDN: "randn", OP_LANGEVIN: "langevin", OP_PREDICTOR: "predictor", OP_FILL: "fill",
                 OP_STEP_INC: "step_inc", OP_WGRAD: "wgrad", OP_COLSUM: "colsum", OP_GN_BWD_REDUCE: "gn_bwd",
                 OP_PROLOGUE_BWD: "pro_bwd", OP_ATTN_BWD: "attn_bwd", OP_PERTURB: "perturb", OP_DSM_LOSS: "dsm_loss",
-                OP_SUMSQ_FLAT: "sumsq_flat", OP_ADAM: "adam", OP_MEMSET: "memset", OP_AXPY: "axpy", OP_PACK: "pack"}
+                OP_SUMSQ_FLAT: "sumsq_flat", OP_ADAM: "adam", OP_MEMSET: "memset", OP_AXPY: "axpy", OP_PACK: "pack", OP_PROJECT: "project"}
 
 EXPORTS = ["ssde_conv2d", "ssde_groupnorm_stats", "ssde_upfirdn2d", "ssde_attention", "ssde_embed", "ssde_to_nhwc",
            "ssde_to_nchw", "ssde_fused_bias_act", "ssde_sumsq", "ssde_randn", "ssde_langevin_update",
@@ -200,7 +206,7 @@ EXPORTS = ["ssde_conv2d", "ssde_groupnorm_stats", "ssde_upfirdn2d", "ssde_attent
            "ssde_abi_version", "ssde_sizeof_op", "ssde_last_error", "ssde_conv_lds_bytes",
            "ssde_conv_wgrad", "ssde_colsum", "ssde_gn_bwd_reduce", "ssde_prologue_bwd", "ssde_attention_bwd",
            "ssde_perturb", "ssde_dsm_loss", "ssde_sumsq_flat", "ssde_adam_clip_ema", "ssde_memset", "ssde_axpy",
-           "ssde_wgrad_scratch_floats", "ssde_pack_weights"]
+           "ssde_wgrad_scratch_floats", "ssde_pack_weights", "ssde_project_update"]
 
 _lib = None
 
@@ -229,7 +235,7 @@ def bind(lib):
                       ("ssde_gn_bwd_reduce", GnBwdReduceArgs), ("ssde_prologue_bwd", PrologueBwdArgs),
                       ("ssde_attention_bwd", AttnBwdArgs), ("ssde_perturb", PerturbArgs), ("ssde_dsm_loss", DsmLossArgs),
                       ("ssde_sumsq_flat", SumsqFlatArgs), ("ssde_adam_clip_ema", AdamArgs), ("ssde_memset", MemsetArgs),
-                      ("ssde_axpy", AxpyArgs), ("ssde_pack_weights", PackArgs)]:
+                      ("ssde_axpy", AxpyArgs), ("ssde_pack_weights", PackArgs), ("ssde_project_update", ProjectArgs)]:
         getattr(lib, name).argtypes = [C.POINTER(typ), C.c_void_p]
     lib.ssde_conv_lds_bytes.argtypes = [C.POINTER(ConvArgs)]
     lib.ssde_wgrad_scratch_floats.argtypes = [C.POINTER(WgradArgs)]

@@ -177,6 +177,62 @@ __global__ __launch_bounds__(256) void predictor_kernel(float* __restrict__ x, f
   }
 }
 
+// ---- controllable-generation projection (controllable_generation.py:44-52, 136-144) ------
+// Elementwise form (inpainting): x = x (1 - mask) + (m D + z s) mask ; x_mean = x (1 - mask) + m D mask.
+__global__ __launch_bounds__(256) void project_kernel(float* __restrict__ x, float* __restrict__ x_mean,
+                                                      const float* __restrict__ data, const float* __restrict__ mask,
+                                                      const float* __restrict__ z, const float* __restrict__ coef,
+                                                      const int* __restrict__ step_ptr, size_t numel) {
+  const int st = step_ptr ? *step_ptr : 0;
+  const float m = coef[2 * st], s = coef[2 * st + 1];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (size_t)gridDim.x * blockDim.x) {
+    const float mk = mask[i], inv = __fsub_rn(1.0f, mk);
+    const float mean = (m == 1.0f) ? data[i] : __fmul_rn(m, data[i]);
+    const float known = __fadd_rn(mean, __fmul_rn(z[i], s));
+    const float xn = __fadd_rn(__fmul_rn(x[i], inv), __fmul_rn(known, mk));
+    x[i] = xn;
+    x_mean[i] = __fadd_rn(__fmul_rn(xn, inv), __fmul_rn(mean, mk));
+  }
+}
+
+// Colour-space form (colorization): one thread per pixel, the three channels pass through M / M^-1 in registers.
+struct SsdeMat3 { float m[9]; };
+__device__ __forceinline__ void mat3_apply(const SsdeMat3& a, const float (&v)[3], float (&o)[3]) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) o[j] = fmaf(v[2], a.m[6 + j], fmaf(v[1], a.m[3 + j], __fmul_rn(v[0], a.m[j])));
+}
+__global__ __launch_bounds__(256) void project_color_kernel(float* __restrict__ x, float* __restrict__ x_mean,
+                                                            const float* __restrict__ data, const float* __restrict__ mask,
+                                                            const float* __restrict__ z, const float* __restrict__ coef,
+                                                            const int* __restrict__ step_ptr, int n, int hw,
+                                                            SsdeMat3 M, SsdeMat3 invM) {
+  const int st = step_ptr ? *step_ptr : 0;
+  const float m = coef[2 * st], s = coef[2 * st + 1];
+  const size_t pixels = (size_t)n * hw;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += (size_t)gridDim.x * blockDim.x) {
+    const size_t base = (p / hw) * 3 * (size_t)hw + (p % hw);
+    float xv[3], y[3], mean[3], mk[3], yn[3], xn[3], y2[3], ym[3], xm[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) xv[c] = x[base + (size_t)c * hw];
+    mat3_apply(M, xv, y);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const size_t i = base + (size_t)c * hw;
+      mk[c] = mask[i];
+      mean[c] = (m == 1.0f) ? data[i] : __fmul_rn(m, data[i]);
+      const float known = __fadd_rn(mean[c], __fmul_rn(z[i], s));
+      yn[c] = __fadd_rn(__fmul_rn(y[c], __fsub_rn(1.0f, mk[c])), __fmul_rn(known, mk[c]));
+    }
+    mat3_apply(invM, yn, xn);
+    mat3_apply(M, xn, y2);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ym[c] = __fadd_rn(__fmul_rn(y2[c], __fsub_rn(1.0f, mk[c])), __fmul_rn(mean[c], mk[c]));
+    mat3_apply(invM, ym, xm);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { x[base + (size_t)c * hw] = xn[c]; x_mean[base + (size_t)c * hw] = xm[c]; }
+  }
+}
+
 __global__ void fill_kernel(float* __restrict__ dst, const float* __restrict__ tab, const int* __restrict__ step_ptr, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = tab[step_ptr ? *step_ptr : 0];
@@ -275,6 +331,23 @@ extern "C" int ssde_fill_from_table(const ssde_fill_args* a, void* stream) {
   SSDE_REQUIRE(a && a->dst && a->tab && a->n > 0, "fill: bad args");
   hipLaunchKernelGGL(fill_kernel, dim3(ssde_cdiv(a->n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      a->dst, a->tab, a->step_ptr, a->n);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}
+
+extern "C" int ssde_project_update(const ssde_project_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->x && a->x_mean && a->data && a->mask && a->noise && a->coef, "project: null args");
+  SSDE_REQUIRE(a->n > 0 && a->c > 0 && a->hw > 0, "project: bad shape");
+  if (a->use_matrix) {
+    SSDE_REQUIRE(a->c == 3, "project: the colour-space form needs 3 channels (got %d)", a->c);
+    SsdeMat3 M, invM;
+    for (int i = 0; i < 9; ++i) { M.m[i] = a->M[i]; invM.m[i] = a->invM[i]; }
+    hipLaunchKernelGGL(project_color_kernel, dim3(grid_for((size_t)a->n * a->hw)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       a->x, a->x_mean, a->data, a->mask, a->noise, a->coef, a->step_ptr, a->n, a->hw, M, invM);
+  } else {
+    hipLaunchKernelGGL(project_kernel, dim3(grid_for((size_t)a->n * a->c * a->hw)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       a->x, a->x_mean, a->data, a->mask, a->noise, a->coef, a->step_ptr, (size_t)a->n * a->c * a->hw);
+  }
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;
 }

@@ -29,6 +29,7 @@ static int run_one(const ssde_op& op, void* stream) {
     case SSDE_OP_SUMSQ: return ssde_sumsq(&op.u.sumsq, stream);
     case SSDE_OP_RANDN: return ssde_randn(&op.u.randn, stream);
     case SSDE_OP_LANGEVIN: return ssde_langevin_update(&op.u.langevin, stream);
+    case SSDE_OP_PROJECT: return ssde_project_update(&op.u.project, stream);
     case SSDE_OP_PREDICTOR: return ssde_predictor_update(&op.u.predictor, stream);
     case SSDE_OP_FILL: return ssde_fill_from_table(&op.u.fill, stream);
     case SSDE_OP_STEP_INC: return ssde_step_inc(&op.u.step_inc, stream);

@@ -13,6 +13,9 @@ predictors / correctors / SDEs:
     PREDICTOR x_mean = a x + b score ; x = x_mean + c z   (sampling.py:181-187 / 195-200)
     STEP_INC
 
+Controllable generation (controllable_generation.py:44-52, 136-144) adds, after the corrector block and after the
+predictor block,    RANDN z ; PROJECT x, x_mean <- data-consistency projection (ssde_project_update).
+
 Every per-step scalar (sigma_i, G_i, alpha_i, std_i, dt terms) is precomputed on the host with
 the same fp32 torch expressions the reference evaluates, stored in device tables, and indexed by
 a device-resident step counter -- the captured graph is replayed with identical arguments.
@@ -114,7 +117,7 @@ def step_tables(sde, plan, eps, probability_flow):
 
 
 class FusedPCSampler:
-    def __init__(self, model, sde, plan, shape, snr, n_steps, probability_flow, eps, device):
+    def __init__(self, model, sde, plan, shape, snr, n_steps, probability_flow, eps, device, projection=None):
         if n_steps > 8:
             raise NotImplementedError("fused PC sampler supports n_steps <= 8 corrector steps")
         self.model, self.sde, self.plan, self.shape = model, sde, plan, tuple(shape)
@@ -132,6 +135,16 @@ class FusedPCSampler:
         self.zss = torch.zeros(B, device=device)
         self.step = torch.zeros(1, dtype=torch.int32, device=device)
         self.snr, self.B, self.per = float(snr), B, per
+        # projection: None, or dict(M=[9 floats] | None, invM=...) -- the inpainting / colorization data-consistency step
+        self.projection = projection
+        if projection is not None:
+            ts = tabs["t"]
+            mean1, std = sde.marginal_prob(torch.ones(sde.N, 1, 1, 1), ts)         # mean is linear in the data
+            self.tabs["proj"] = torch.stack([mean1.reshape(-1), std], dim=1).to(torch.float32).contiguous().to(device)
+            self.proj_data = torch.zeros(B * per, device=device)
+            self.proj_mask = torch.zeros(B * per, device=device)
+            self.z_pc = torch.zeros(B * per, device=device)
+            self.z_pp = torch.zeros(B * per, device=device)
         self._programs = {}
         self.last_path = None
         self._stream = None
@@ -145,8 +158,21 @@ class FusedPCSampler:
         def emit(kind, struct_cls, **fields):
             a = struct_cls()
             for k, v in fields.items():
+                if isinstance(v, (list, tuple)):
+                    v = (C.c_float * len(v))(*v)
                 setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
             ops.append(L.make_op(kind, a)); classes.append(E.FC_OTHER); flops.append(0.0)
+
+        def emit_projection(noise, stream_id):
+            pj = self.projection
+            if pj is None:
+                return
+            if with_rng:
+                emit(L.OP_RANDN, L.RandnArgs, dst=noise, numel=self.B * self.per, seed=seed, step_ptr=self.step, stream_id=stream_id)
+            Cc = self.shape[1]
+            emit(L.OP_PROJECT, L.ProjectArgs, x=self.x, x_mean=self.x_mean, data=self.proj_data, mask=self.proj_mask, noise=noise,
+                 coef=self.tabs["proj"], step_ptr=self.step, n=self.B, c=Cc, hw=self.per // Cc,
+                 use_matrix=int(pj.get("M") is not None), M=list(pj.get("M") or [0.0] * 9), invM=list(pj.get("invM") or [0.0] * 9))
 
         def emit_unet():
             ops.extend(unet_ops); classes.extend(unet_cls); flops.extend(unet_fl)
@@ -168,12 +194,14 @@ class FusedPCSampler:
                 emit(L.OP_LANGEVIN, L.LangevinArgs, x=self.x, x_mean=self.x_mean, grad=score, noise=self.z_c,
                      grad_sumsq=self.gss, noise_sumsq=self.zss, alpha_tab=self.tabs.get("alpha"), step_ptr=self.step,
                      n=self.B, per=self.per, snr=self.snr)
+        emit_projection(self.z_pc if self.projection is not None else None, 9)
         if self.plan["predictor"] != "none":
             emit_unet()
             if with_rng:
                 emit(L.OP_RANDN, L.RandnArgs, dst=self.z_p, numel=self.B * self.per, seed=seed, step_ptr=self.step, stream_id=8)
             emit(L.OP_PREDICTOR, L.PredictorArgs, x=self.x, x_mean=self.x_mean, score=score, noise=self.z_p,
                  coef=self.tabs["coef"], step_ptr=self.step, numel=self.B * self.per)
+        emit_projection(self.z_pp if self.projection is not None else None, 10)
         emit(L.OP_STEP_INC, L.StepIncArgs, step_ptr=self.step, delta=1)
         return E.Program(L.op_array(ops), classes, flops, self)
 
@@ -187,6 +215,11 @@ class FusedPCSampler:
         return (self.n_steps if self.plan["corrector"] != "none" else 0) + (1 if self.plan["predictor"] != "none" else 0)
 
     # -------------------------------------------------------------- execution
+    def set_projection_inputs(self, data, mask):
+        """`data` (already in the projection's space) and the 0/1 `mask` of known entries, both shaped like the state."""
+        self.proj_data.copy_(data.reshape(-1).to(torch.float32))
+        self.proj_mask.copy_(mask.reshape(-1).to(torch.float32))
+
     def reset(self, x):
         self.x.copy_(x.reshape(-1).to(torch.float32))
         self.x_mean.copy_(self.x)
@@ -203,6 +236,9 @@ class FusedPCSampler:
             for i in range(steps):
                 self.z_c.copy_(nz[i, 0].reshape(-1))
                 self.z_p.copy_(nz[i, 1].reshape(-1))
+                if self.projection is not None:
+                    self.z_pc.copy_(nz[i, 2].reshape(-1))
+                    self.z_pp.copy_(nz[i, 3].reshape(-1))
                 prog.run()
             self.last_path = "fused-eager"
         else:

@@ -111,3 +111,27 @@ PC_VARIANTS = {
     "subvp_em_none": ("ddpmpp", "subvpsde", dict(beta_min=0.1, beta_max=20, N=6), "euler_maruyama", "none", 1, True, False, True, 1e-3),
     "subvp_rd_none_pflow": ("ddpmpp", "subvpsde", dict(beta_min=0.1, beta_max=20, N=6), "reverse_diffusion", "none", 1, True, True, True, 1e-3),
 }
+
+
+# entries of tests/golden/controllable_small.npz (oracle/gen_golden_controllable.py, from the reference's
+# controllable_generation.py): name -> (task, variant of PC_VARIANTS supplying model / sde / predictor / corrector)
+CONTROLLABLE_CASES = {
+    "inpaint_ve_rd_langevin": ("inpaint", "ve_em_langevin", "reverse_diffusion", "langevin"),
+    "inpaint_vp_ancestral_none": ("inpaint", "vp_ancestral_ald_discrete", "ancestral_sampling", "none"),
+    "colorize_ve_rd_langevin": ("colorize", "ve_em_langevin", "reverse_diffusion", "langevin"),
+    "colorize_subvp_em_none": ("colorize", "subvp_em_none", "euler_maruyama", "none"),
+}
+
+
+def controllable_inputs(name, batch, n_steps, size, sigma_max):
+    """data (or grey-scale image), mask, prior sample and the four noise streams of a controllable-generation case"""
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0xffff)
+    data = torch.rand(batch, 3, size, size, generator=g)
+    if name.startswith("colorize"):
+        data = data.mean(dim=1, keepdim=True).repeat(1, 3, 1, 1)
+    mask = torch.ones(batch, 3, size, size)
+    mask[:, :, :, size // 2:] = 0.                     # right half unknown (the notebook's inpainting mask)
+    prior = torch.randn(batch, 3, size, size, generator=g) * sigma_max
+    noises = torch.randn(n_steps, 4, batch, 3, size, size, generator=g)
+    return data, mask, prior, noises

@@ -37,3 +37,35 @@ def test_fused_step_program_variants(name):
         x, x_mean = eng.run(x_T, noises=noises)
     out = x_mean if denoise else x
     assert rel_err(out, torch.from_numpy(gold[name])) < 2e-4
+
+
+@pytest.mark.parametrize("name", ["inpaint_vp_ancestral_none", "colorize_ve_rd_langevin"])
+def test_fused_controllable_generation(name, monkeypatch):
+    """get_pc_inpainter / get_pc_colorizer: the step program with ssde_project_update after the corrector and the
+    predictor blocks, against the REFERENCE's controllable_generation.py output (controllable_small.npz)"""
+    from score_sde_pytorch_amd import sde_lib, sampling, pc_engine, controllable_generation as cg
+    from score_sde_pytorch_amd.models import utils as mutils
+    gold = np.load(os.path.join(_util.GOLDEN, "controllable_small.npz"))
+    task, variant, pred, corr = _util.CONTROLLABLE_CASES[name]
+    kind, sde_kind, kw, _, _, _, continuous, _, _, eps = _util.PC_VARIANTS[variant]
+    cfg = _util.small_config(kind)
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg).eval()
+    _util.load_seeded(model, seed=1)
+    sde = {"vesde": sde_lib.VESDE, "vpsde": sde_lib.VPSDE, "subvpsde": sde_lib.subVPSDE}[sde_kind](**kw)
+    data, mask, prior, noises = _util.controllable_inputs(name, _util.PC_VARIANT_BATCH, kw["N"], _util.PC_VARIANT_SIZE,
+                                                          kw.get("sigma_max", 1.0))
+    real_plan = pc_engine.plan_fused
+    monkeypatch.setattr(pc_engine, "plan_fused",         # host tensors are only acceptable under the emulator
+                        lambda sde_, p, c, m, cont, x, pf=False: real_plan(sde_, p, c, m, cont, types.SimpleNamespace(is_cuda=True), pf))
+    args = (sde, sampling.get_predictor(pred), sampling.get_corrector(corr), lambda v: v)
+    kws = dict(snr=0.16, n_steps=1, probability_flow=False, continuous=continuous, denoise=True, eps=eps)
+    with emulated():
+        if task == "inpaint":
+            fn = cg.get_pc_inpainter(*args, **kws)
+            out = fn(model, data, mask, prior=prior, noises=noises)
+        else:
+            fn = cg.get_pc_colorizer(*args, **kws)
+            out = fn(model, data, prior=prior, noises=noises)
+    assert fn.last_path == "fused-eager"
+    assert rel_err(out, torch.from_numpy(gold[name])) < 2e-4

@@ -78,6 +78,25 @@ def test_pc_sampler_oracle_variants_reproduce_reference(name):
     assert rel_err(out["samples"], torch.from_numpy(gold[name])) < 1e-4
 
 
+@pytest.mark.parametrize("name", list(_util.CONTROLLABLE_CASES))
+def test_controllable_generation_oracle_reproduces_reference(name):
+    """inpainting / colorization (controllable_generation.py) against the REFERENCE's output (controllable_small.npz)"""
+    from oracle import sampler_oracle
+    gold = np.load(os.path.join(_util.GOLDEN, "controllable_small.npz"))
+    task, variant, pred, corr = _util.CONTROLLABLE_CASES[name]
+    kind, sde_kind, kw, _, _, _, continuous, _, _, eps = _util.PC_VARIANTS[variant]
+    cfg = _util.small_config(kind)
+    sd = _sd_for(cfg)
+    data, mask, prior, noises = _util.controllable_inputs(name, _util.PC_VARIANT_BATCH, kw["N"], _util.PC_VARIANT_SIZE,
+                                                          kw.get("sigma_max", 1.0))
+    okw = dict(snr=0.16, n_steps=1, eps=eps, denoise=True, predictor=pred, corrector=corr, continuous=continuous)
+    if task == "inpaint":
+        out = sampler_oracle.inpaint(cfg, sd, sde_kind, kw, data, mask, prior, noises, **okw)
+    else:
+        out = sampler_oracle.colorize(cfg, sd, sde_kind, kw, data, prior, noises, **okw)
+    assert rel_err(out["samples"], torch.from_numpy(gold[name])) < 1e-4
+
+
 def test_oracle_upfirdn_edge_cases():
     """ragged / degenerate shapes of upfirdn2d: 1x1 input, odd sizes, all three FIR modes keep their shape law"""
     from oracle import unet_oracle as uo
