@@ -68,7 +68,14 @@ class FlatParams:
                 o, n = self.index[id(p)]
                 self.data[o:o + n].copy_(p.detach().reshape(-1).to(device, torch.float32))
                 p.data = self.data[o:o + n].view(p.shape)
+                p._ssde_flat = self
         self.device = device
+        # bumped by whoever writes `data` as a whole (fused optimizer kernel, EMA swap): per-tensor version counters do
+        # not see such writes, engine.WeightStore stamps read this instead
+        self.generation = 0
+
+    def touch(self):
+        self.generation += 1
 
     def owns(self, model):
         ps = trainable_params(model)
@@ -76,6 +83,15 @@ class FlatParams:
             return False
         base = self.data.data_ptr()
         for p in ps:
+            e = self.index.get(id(p))
+            if e is None or p.data_ptr() != base + e[0] * 4:
+                return False
+        return True
+
+    def owns_params(self, params):
+        """True when every tensor of `params` still is the view of `data` this object gave it."""
+        base = self.data.data_ptr()
+        for p in params:
             e = self.index.get(id(p))
             if e is None or p.data_ptr() != base + e[0] * 4:
                 return False

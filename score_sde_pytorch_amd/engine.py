@@ -422,17 +422,21 @@ class WeightStore:
 
     @staticmethod
     def _stamp(sources):
-        return tuple((s.data_ptr(), s._version) for s in sources)
+        # `_ssde_flat.generation` counts whole-buffer writes that bypass the per-tensor version counters
+        # (backward.FlatParams: fused optimizer step, EMA swap)
+        return tuple((s.data_ptr(), s._version, getattr(getattr(s, "_ssde_flat", None), "generation", 0)) for s in sources)
 
     def refresh(self, force=False, on_device=None):
         """Bring packed copies up to date.  force=True (after the fused optimizer wrote the flat parameter buffer behind
         torch's back) re-packs everything: with the device kernels when the library can run here, else in torch."""
         if on_device is None:
             on_device = self.device.type == "cuda" if isinstance(self.device, torch.device) else str(self.device).startswith("cuda")
-        done_on_device = force and on_device and self.device_refresh()
-        for e in self.entries:
-            st = self._stamp(e[1])
-            if (force and not (done_on_device and e[4] is not None)) or st != e[3]:
+        stamps = [self._stamp(e[1]) for e in self.entries]
+        stale = [force or st != e[3] for e, st in zip(self.entries, stamps)]
+        # many stale entries (optimizer step, checkpoint load, EMA swap): four device launches re-pack everything
+        done_on_device = on_device and (force or sum(stale) > 16) and self.device_refresh()
+        for e, st, old in zip(self.entries, stamps, stale):
+            if old and not (done_on_device and e[4] is not None):
                 with torch.no_grad():
                     e[0].copy_(e[2](*[s.detach() for s in e[1]]).to(self.device))
             e[3] = st

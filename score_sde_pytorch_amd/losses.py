@@ -53,6 +53,10 @@ class FusedAdam(optim.Adam):
         self._ssde_flat = (flat, m, v)
         return m, v
 
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._ssde_flat = None          # the loaded exp_avg / exp_avg_sq tensors are re-homed on the next fused step
+
 
 def get_optimizer(config, params):
     """Returns an Adam optimizer built from `config.optim` (losses.py:26-35)."""
@@ -211,15 +215,16 @@ class FusedTrainStep:
         return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
     def _optimizer_program(self, optimizer, ema):
-        if self._opt_prog is None or self._opt_prog[1] is not optimizer or self._opt_prog[2] is not ema:
+        m, v = optimizer.flatten_like(self.flat)
+        ema_buf = ema.flatten_like(self.flat) if ema is not None else None
+        key = (m.data_ptr(), v.data_ptr(), ema_buf.data_ptr() if ema_buf is not None else 0)
+        if self._opt_prog is None or self._opt_prog[1] is not optimizer or self._opt_prog[2] is not ema or self._opt_prog[3] != key:
             L = self.L
-            m, v = optimizer.flatten_like(self.flat)
-            ema_buf = ema.flatten_like(self.flat) if ema is not None else None
             prog = self._prog([
                 (L.OP_SUMSQ_FLAT, dict(x=self.flat.grad, numel=self.flat.numel, partial=self.partial, out=self.gnorm)),
                 (L.OP_ADAM, dict(p=self.flat.data, g=self.flat.grad, m=m, v=v, ema=ema_buf, numel=self.flat.numel,
                                  hyper=self.hyper, gnorm_sq=self.gnorm))])
-            self._opt_prog = (prog, optimizer, ema)
+            self._opt_prog = (prog, optimizer, ema, key)
         return self._opt_prog[0]
 
     def perturb_inputs(self, batch, t, z):
@@ -293,7 +298,8 @@ class FusedTrainStep:
         self._optimizer_program(optimizer, ema).run()
         for p in self.flat.params:
             optimizer.state[p]["step"] += 1
-        self.eng.weights.refresh(force=True)         # packed weight copies follow the in-place parameter update
+        self.flat.touch()                            # every engine lowered from this model re-packs on its next refresh
+        self.eng.weights.refresh()                   # packed weight copies follow the in-place parameter update
         self.steps_done += 1
 
 

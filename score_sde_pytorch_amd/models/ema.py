@@ -18,6 +18,8 @@ class ExponentialMovingAverage:
         self.shadow_params = [p.clone().detach() for p in parameters if p.requires_grad]
         self.collected_params = []
         self._flat = None
+        self._flat_owner = None
+        self._stored_flat = None
 
     # -- models/ema.py:32-51
     def next_decay(self):
@@ -35,16 +37,43 @@ class ExponentialMovingAverage:
             for s_param, param in zip(self.shadow_params, parameters):
                 s_param.sub_(one_minus_decay * (s_param - param))
 
+    def _flat_home(self, parameters):
+        """The FlatParams whose buffer these parameters are views of, when the shadow copy lives in a twin buffer."""
+        flat = self._flat_owner
+        if flat is None or self._flat is None:
+            return None, parameters
+        parameters = list(parameters)
+        mine = [p for p in parameters if p.requires_grad]
+        if len(mine) != len(flat.model_order) or any(a is not b for a, b in zip(mine, flat.model_order)) or not flat.owns_params(mine):
+            return None, parameters
+        return flat, parameters
+
     def copy_to(self, parameters):
+        flat, parameters = self._flat_home(parameters)
+        if flat is not None:            # one device copy instead of one per tensor (models/ema.py:53-63)
+            flat.data.copy_(self._flat)
+            flat.touch()
+            return
         parameters = [p for p in parameters if p.requires_grad]
         for s_param, param in zip(self.shadow_params, parameters):
             if param.requires_grad:
                 param.data.copy_(s_param.data)
 
     def store(self, parameters):
+        flat, parameters = self._flat_home(parameters)
+        if flat is not None:            # models/ema.py:65-73; parameters outside the flat buffer are not trainable and
+            self._stored_flat = flat.data.clone()    # copy_to never touches them
+            self.collected_params = []
+            return
+        self._stored_flat = None
         self.collected_params = [param.clone() for param in parameters]
 
     def restore(self, parameters):
+        flat, parameters = self._flat_home(parameters)
+        if flat is not None and self._stored_flat is not None:
+            flat.data.copy_(self._stored_flat)
+            flat.touch()
+            return
         for c_param, param in zip(self.collected_params, parameters):
             param.data.copy_(c_param.data)
 
@@ -61,7 +90,7 @@ class ExponentialMovingAverage:
     # -- fused path
     def flatten_like(self, flat):
         """Re-home the shadow parameters into one buffer with the layout of `flat` (backward.FlatParams)."""
-        if self._flat is not None and self._flat.numel() == flat.numel and self._flat.device == flat.data.device:
+        if self._flat is not None and self._flat_owner is flat:
             return self._flat
         buf = torch.zeros(flat.numel, dtype=torch.float32, device=flat.data.device)
         assert len(self.shadow_params) == len(flat.model_order)
@@ -72,4 +101,5 @@ class ExponentialMovingAverage:
             new.append(buf[o:o + n].view(p.shape))
         self.shadow_params = new
         self._flat = buf
+        self._flat_owner = flat
         return buf

@@ -9,6 +9,8 @@ Tolerances (fp32; max-abs error / max-abs reference value per tensor):
   TOL_GRAD 2e-4   whole-network parameter / input gradients (tensors whose reference gradient is
                   numerically zero -- e.g. the key bias of attention, NIN_1.b -- are compared absolutely)
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -538,3 +540,95 @@ def check_likelihood(dev):
     # SAME model to 2e-3 -- tests/test_sampler_gpu.py)
     assert torch.isfinite(bpd).all() and torch.isfinite(z).all()
     assert float(((bpd.cpu() - bpd_ref) / bpd_ref).abs().max()) < 2e-2, (bpd, bpd_ref, nfe, sol.nfev)
+
+
+def check_checkpoint_and_ema_swap(dev, tmp_path):
+    """utils.save_checkpoint / restore_checkpoint (reference utils.py:7-28) around the fused step, the EMA
+    store / copy_to / restore swap (models/ema.py:53-89) on the flat buffers, and weight re-packing of an inference
+    engine after the fused optimizer wrote the parameters behind torch's back."""
+    from score_sde_pytorch_amd.models import utils as mutils, ema as ema_mod
+    from score_sde_pytorch_amd import losses, sde_lib, utils as ssde_utils
+    cfg = small_cfg("ncsnpp")
+    cfg.optim.warmup = 0
+    sde = sde_lib.VESDE(cfg.model.sigma_min, cfg.model.sigma_max, cfg.model.num_scales)
+    R, Bn = cfg.data.image_size, 3
+    g = torch.Generator().manual_seed(11)
+    batches = [(torch.rand(Bn, 3, R, R, generator=g), torch.rand(Bn, generator=g) * 0.9 + 0.05, torch.randn(Bn, 3, R, R, generator=g))
+               for _ in range(3)]
+    xq = torch.rand(2, 3, R, R, generator=g).to(dev)
+    sq = torch.tensor([0.5, 3.0]).to(dev)
+
+    def infer(m, x, sig):
+        """inference engine of the model (NCSNpp.forward's no-grad path; called directly so that the emulated run,
+        whose tensors are host tensors, passes the product's is_cuda guard)"""
+        return m._engine_for(x).forward(x, sig).clone()
+
+    def make(seed):
+        torch.manual_seed(seed)
+        model = mutils.get_model("ncsnpp")(cfg)
+        _util.load_seeded(model, seed=seed + 1)
+        model = model.to(dev)
+        opt = losses.get_optimizer(cfg, model.parameters())
+        ema = ema_mod.ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate)
+        optimize_fn = losses.optimization_manager(cfg)
+        step_fn = losses.get_step_fn(sde, train=True, optimize_fn=optimize_fn, reduce_mean=False, continuous=True)
+        state = dict(optimizer=opt, model=model, ema=ema, step=0)
+        fs = step_fn.fused_for(state, torch.zeros(Bn, 3, R, R, device=dev))
+
+        def step(i):
+            b, t, z = (v.to(dev) for v in batches[i])
+            loss = float(fs.loss_and_grads(b, t=t, z=z, seed=5))
+            fs.optimizer_step(opt, ema, state['step'], optimize_fn.ssde_hyper)
+            state['step'] += 1
+            return loss
+        return model, state, step
+
+    model, state, step = make(0)
+    with torch.no_grad():
+        y0 = infer(model, xq, sq)
+    step(0)
+    with torch.no_grad():
+        y1 = infer(model, xq, sq)          # the inference engine was lowered before the fused step touched the weights
+    fresh = mutils.get_model("ncsnpp")(cfg).to(dev)
+    fresh.load_state_dict(model.state_dict())
+    with torch.no_grad():
+        assert rel_err(y1, y0) > 1e-6 and torch.equal(y1, infer(fresh, xq, sq))
+    step(1)
+    path = os.path.join(str(tmp_path), "ckpt", "checkpoint_1.pth")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    ssde_utils.save_checkpoint(path, state, data_parallel_prefix=True)      # the form the reference writes
+    loss_a = step(2)
+    params_a = [p.detach().clone() for p in model.parameters()]
+    ema_a = [s.clone() for s in state['ema'].shadow_params]
+
+    model2, state2, step2 = make(7)
+    step2(0)                                # flat buffers and moments exist before the restore
+    missing = ssde_utils.restore_checkpoint(os.path.join(str(tmp_path), "nope", "x.pth"), state2, dev)
+    assert missing is state2 and state2['step'] == 1
+    ssde_utils.restore_checkpoint(path, state2, dev)
+    assert state2['step'] == 2
+    loss_b = step2(2)
+    assert loss_a == loss_b
+    for a, b in zip(params_a, model2.parameters()):
+        assert torch.equal(a, b.detach())
+    for a, b in zip(ema_a, state2['ema'].shadow_params):
+        assert torch.equal(a, b)
+
+    # EMA swap (what the eval branch of step_fn and run_lib's sampling snapshots do)
+    ema = state['ema']
+    before = [p.detach().clone() for p in model.parameters()]
+    with torch.no_grad():
+        y_raw = infer(model, xq, sq)
+    ema.store(model.parameters())
+    ema.copy_to(model.parameters())
+    for p, s in zip([p for p in model.parameters() if p.requires_grad], ema.shadow_params):
+        assert torch.equal(p.detach(), s)
+    fresh.load_state_dict(model.state_dict())
+    with torch.no_grad():
+        y_ema = infer(model, xq, sq)
+        assert torch.equal(y_ema, infer(fresh, xq, sq)) and rel_err(y_ema, y_raw) > 1e-7
+    ema.restore(model.parameters())
+    for a, b in zip(before, model.parameters()):
+        assert torch.equal(a, b.detach())
+    with torch.no_grad():
+        assert torch.equal(infer(model, xq, sq), y_raw)

@@ -69,3 +69,7 @@ def test_op_package(monkeypatch):
 
 def test_input_gradient_only_program():
     T.check_input_gradient_only("cpu")
+
+
+def test_checkpoint_roundtrip_and_ema_swap(tmp_path):
+    T.check_checkpoint_and_ema_swap("cpu", tmp_path)

@@ -83,3 +83,7 @@ def test_input_gradient_only_program():
 
 def test_likelihood_bits_per_dim():
     T.check_likelihood("cuda")
+
+
+def test_checkpoint_roundtrip_and_ema_swap(tmp_path):
+    T.check_checkpoint_and_ema_swap("cuda", tmp_path)
