@@ -33,6 +33,7 @@
 // (linear) output transform A^T M A in registers; waves 4-7 hand their 2x2 partial to waves 0-3 through
 // LDS once per workgroup; the epilogue (bias, temb addend, residual, scale) is the direct kernel's.
 #include "ssde_common.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -56,6 +57,7 @@ struct WinoParams {
   float* dst;
 };
 
+template <bool kGn>      // GroupNorm prologue: compile-time, so that the staging loads below are straight-line code
 __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams p) {
   SSDE_LDS(smem);
   float* Vb = smem;                          // [2][kStageFloats]
@@ -83,8 +85,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
   const ssde_src& s = p.src;
   const int Ctot = s.c0 + s.c1;
   const int nst = (Ctot + 7) >> 3;
-  const SsdePro pro = ssde_pro_decode(s);
-  const int cpg = pro.gn ? Ctot / s.gn_groups : 1;
+  SsdePro pro = ssde_pro_decode(s);
+  pro.gn = kGn;
+  const int cpg = kGn ? Ctot / s.gn_groups : 1;
 
   // ---- per-thread raw staging plan: item = (halo pixel, channel half) ----
   const int sid = tid & (kStagers - 1);          // index among the 256 staging threads (waves 4-7) / transform threads (0-3)
@@ -121,49 +124,68 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
   bool chan_ok = false;
   int c_cur = 0;
 
-  auto load_stage = [&](int st) {
-    const int c_base = st * 8;
-    c_cur = c_base;
-    const float* base; int C, cc;
-    if (c_base < s.c0) { base = s.p0; C = s.c0; cc = c_base; } else { base = s.p1; C = s.c1; cc = c_base - s.c0; }
+  // The loads of a stage are BRANCH-FREE (items outside the image / halo / channel range read a clamped, valid address
+  // and are zeroed in store_stage) and cut into 8 PIECES that mfma_stage issues between the MFMAs of its 8 positions:
+  // as exec-masked blocks in front of the matrix phase they cost ~870 cycles of every stage.
+  const float* ld_bp = nullptr; int ld_C = 0, ld_cg = 0;
+  auto load_piece = [&](int st, int k) {
     const int half = sid & 1;
-    const int cthr = cc + half * 4;
-    chan_ok = cthr < C;
-#pragma unroll
-    for (int it = 0; it < kMaxRaw; ++it) {
-      rv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (goff[it] >= 0 && chan_ok) rv[it] = *reinterpret_cast<const float4*>(base + (size_t)goff[it] * C + cthr);
+    if (k == 0) {
+      const int c_base = st * 8;
+      c_cur = c_base;
+      const bool second = c_base >= s.c0;
+      const float* base = second ? s.p1 : s.p0;
+      ld_C = second ? s.c1 : s.c0;
+      const int cthr = (second ? c_base - s.c0 : c_base) + half * 4;
+      chan_ok = cthr < ld_C;
+      ld_bp = base + (chan_ok ? cthr : 0);
+      ld_cg = (c_base + half * 4) < Ctot ? c_base + half * 4 : 0;
     }
+    // GroupNorm parameters first (two pieces), the halo float4s after them: the LAST load is issued at position 5 at the
+    // latest, >= 500 matrix cycles before the barrier behind which store_stage consumes all of them
+    constexpr int kFirstRaw = kGn ? 2 : 0;
+    if (kGn && k < 2) {
+      if (k == 0) {
+        gam = *reinterpret_cast<const float4*>(s.gn_gamma + ld_cg);
+        bet = *reinterpret_cast<const float4*>(s.gn_beta + ld_cg);
+      }
 #pragma unroll
-    for (int it = 0; it < kMaxRaw; ++it) { mu[it] = 0.f; rs[it] = 1.f; }
-    if (pro.gn && (c_base + half * 4) < Ctot) {
-      gam = *reinterpret_cast<const float4*>(s.gn_gamma + c_base + half * 4);
-      bet = *reinterpret_cast<const float4*>(s.gn_beta + c_base + half * 4);
-      const int gidx = (c_base + half * 4) / cpg;
-#pragma unroll
-      for (int it = 0; it < kMaxRaw; ++it)
-        if (goff[it] >= 0) {
-          mu[it] = s.gn_mean[gimg[it] * s.gn_groups + gidx];
-          rs[it] = s.gn_rstd[gimg[it] * s.gn_groups + gidx];
-        }
+      for (int it = 2 * k; it < 2 * k + 2; ++it) {
+        const int gi = (goff[it] >= 0 ? gimg[it] : 0) * s.gn_groups + ld_cg / cpg;
+        mu[it] = s.gn_mean[gi];
+        rs[it] = s.gn_rstd[gi];
+      }
+    } else if (k >= kFirstRaw && k < kFirstRaw + 4) {
+      const int it = k - kFirstRaw;
+      rv[it] = *reinterpret_cast<const float4*>(ld_bp + (size_t)(goff[it] >= 0 ? goff[it] : 0) * ld_C);
     }
+  };
+  auto load_stage = [&](int st) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) load_piece(st, k);
   };
   // weights of stage st: the host packed them as the LDS image, so they go global -> LDS by DMA
   // (a straight 32 KB copy: each of the 4 issuing waves moves a contiguous 8 KB with 8 instructions that differ only in
   // the immediate offset -4096 .. +3072, applied by the hardware to the global and the LDS address alike)
-  auto dma_weights = [&](int st, float* Un) {
-    static_assert(kUItems == 8, "the immediate-offset run below is written for 8 x 1 KiB per wave");
+  static_assert(kUItems == 8, "the immediate-offset pieces below are written for 8 x 1 KiB per wave");
+  auto dma_piece = [&](int st, float* Un, int k) {
     const int wv = (sid >> 6);
     const float* gsrc = p.wpk + ((size_t)st * p.n_tiles + nt) * kStageFloats + (size_t)wv * 2048 + 1024 + lane * 4;
     float* ldst = Un + wv * 2048 + 1024;
-    SSDE_GLDS16_OFF(gsrc, ldst, -4096);
-    SSDE_GLDS16_OFF(gsrc, ldst, -3072);
-    SSDE_GLDS16_OFF(gsrc, ldst, -2048);
-    SSDE_GLDS16_OFF(gsrc, ldst, -1024);
-    SSDE_GLDS16_OFF(gsrc, ldst, 0);
-    SSDE_GLDS16_OFF(gsrc, ldst, 1024);
-    SSDE_GLDS16_OFF(gsrc, ldst, 2048);
-    SSDE_GLDS16_OFF(gsrc, ldst, 3072);
+    switch (k) {
+      case 0: SSDE_GLDS16_OFF(gsrc, ldst, -4096); break;
+      case 1: SSDE_GLDS16_OFF(gsrc, ldst, -3072); break;
+      case 2: SSDE_GLDS16_OFF(gsrc, ldst, -2048); break;
+      case 3: SSDE_GLDS16_OFF(gsrc, ldst, -1024); break;
+      case 4: SSDE_GLDS16_OFF(gsrc, ldst, 0); break;
+      case 5: SSDE_GLDS16_OFF(gsrc, ldst, 1024); break;
+      case 6: SSDE_GLDS16_OFF(gsrc, ldst, 2048); break;
+      default: SSDE_GLDS16_OFF(gsrc, ldst, 3072); break;
+    }
+  };
+  auto dma_weights = [&](int st, float* Un) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dma_piece(st, Un, k);
   };
   // prologue + raw LDS store (channel-pair major)
   auto store_stage = [&]() {
@@ -171,9 +193,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
 #pragma unroll
     for (int it = 0; it < kMaxRaw; ++it) {
       if (goff[it] == -2) continue;
-      float4 v = rv[it];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (goff[it] >= 0 && chan_ok)
-        v = ssde_pro_apply(v, mu[it], rs[it], gam, bet, (uint32_t)goff[it] * (uint32_t)Ctot + (uint32_t)(c_cur + half * 4), pro);
+        v = ssde_pro_apply(rv[it], mu[it], rs[it], gam, bet, (uint32_t)goff[it] * (uint32_t)Ctot + (uint32_t)(c_cur + half * 4), pro);
       const int hp = (sid + it * kStagers) >> 1;
       *reinterpret_cast<float2*>(raw + ((2 * half) * halo_px + hp) * 2) = make_float2(v.x, v.y);
       *reinterpret_cast<float2*>(raw + ((2 * half + 1) * halo_px + hp) * 2) = make_float2(v.z, v.w);
@@ -229,13 +251,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
   for (int b = 0; b < 2; ++b) boff[b] = ph * 8 * 512 + (lq * 64 + ((cb0 + b * 16 + li) ^ swz)) * 2;
 
   // fragments of position ps+1 are read while the 8 MFMAs of position ps issue (two register sets)
-  auto mfma_stage = [&](const float* Vc, const float* Uc) {
+  // `piece(ps)`: a slice of this wave's asynchronous issue work for a later stage (weight DMA / halo loads), placed
+  // between the two MFMA quartets of position ps so that its VALU / VMEM issue slots hide under the matrix pipe.
+  // sched_barrier(0) closes every position: nothing moves across, the pieces cannot be hoisted in front of the MFMAs.
+  auto mfma_stage = [&](const float* Vc, const float* Uc, auto&& piece) {
     float2 af[2][2], bf[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) af[0][a] = *reinterpret_cast<const float2*>(Vc + aoff[a]);
 #pragma unroll
     for (int b = 0; b < 2; ++b) bf[0][b] = *reinterpret_cast<const float2*>(Uc + boff[b]);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // position 0's reads form their own group (see below)
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
@@ -246,27 +271,37 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
 #pragma unroll
         for (int b = 0; b < 2; ++b) bf[cur ^ 1][b] = *reinterpret_cast<const float2*>(Uc + (ps + 1) * 512 + boff[b]);
       }
+      // first the even channel of the pair for all four (tile, cout) blocks, then the odd one: a block's second MFMA
+      // depends on its first, four independent MFMAs and the piece sit in between
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < 2; ++b)
           acc[ps][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][a].x, bf[cur][b].x, acc[ps][a][b], 0, 0, 0);
+      piece(ps);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
           acc[ps][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][a].y, bf[cur][b].y, acc[ps][a][b], 0, 0, 0);
-        }
-      // pin the issue order: the 4 fragment reads of position ps+1 go out BEFORE the 8 MFMAs of position ps, so their
-      // LDS latency is covered by 256 matrix cycles (left alone, hipcc sinks the reads below the MFMAs and waits on them)
+      // issue order inside the position: the 4 fragment reads of position ps+1 first (their LDS latency is covered by
+      // 256 matrix cycles; left alone, hipcc sinks them below the MFMAs and waits), 4 MFMAs, the piece, 4 MFMAs
       if (ps + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x026, 24, 0);    // VALU | SALU | VMEM read of the piece
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- pipeline prologue: stage 0 staged, stage 1 in flight ----
+  const int last = nst - 1;
   if (ph == 1) { load_stage(0); store_stage(); }
   else dma_weights(0, Ub);
   SSDE_LDS_BARRIER();
   if (ph == 0) { transform(Vb); SSDE_WAIT_VMCNT(0); }
-  else if (nst > 1) load_stage(1);
+  else load_stage(min(1, last));
   SSDE_LDS_BARRIER();
 
   for (int st = 0; st < nst; ++st) {
@@ -276,9 +311,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
     float* Un = Ub + ((st + 1) & 1) * kStageFloats;
     // phase 1: waves 0-3 start the weight DMA of st+1 and run the matrix pipe; waves 4-7 apply the prologue to the
     // halo of st+1 (loaded during their previous matrix phase) and store it
+    // (past the last stage both issue a redundant copy of it instead of branching: the issue code stays in the
+    // basic block of the MFMAs; the stray DMA lands in the idle U buffer and is waited for before the epilogue)
     if (ph == 0) {
-      if (st + 1 < nst) dma_weights(st + 1, Un);
-      mfma_stage(Vc, Uc);
+      const int sn = min(st + 1, last);
+      mfma_stage(Vc, Uc, [&](int k) { dma_piece(sn, Un, k); });
     } else if (st + 1 < nst) {
       store_stage();
     }
@@ -286,10 +323,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
     // phase 2: waves 4-7 put the halo loads of st+2 in flight and run the matrix pipe; waves 0-3 transform st+1 and
     // make sure their DMA has landed before the barrier that publishes U(st+1)
     if (ph == 1) {
-      if (st + 2 < nst) load_stage(st + 2);
-      mfma_stage(Vc, Uc);
-    } else if (st + 1 < nst) {
-      transform(Vn);
+      const int sn = min(st + 2, last);
+      mfma_stage(Vc, Uc, [&](int k) { load_piece(sn, k); });
+    } else {
+      if (st + 1 < nst) transform(Vn);
       SSDE_WAIT_VMCNT(0);
     }
     SSDE_LDS_BARRIER();
@@ -405,11 +442,14 @@ int ssde_conv_wino_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
   if (lds_out) { *lds_out = lds; return SSDE_OK; }
   static bool attr_set = false;   // once, before any stream capture
   if (!attr_set) {
-    SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_wino_kernel, dim3(ssde_cdiv(p.m_tiles, 8) * 8 * p.n_tiles), dim3(kThreads), lds,
-                     static_cast<hipStream_t>(stream), p);
+  const bool gn = a->main.pro_mode == SSDE_PRO_GN || a->main.pro_mode == SSDE_PRO_GN_SILU;
+  const dim3 grid(ssde_cdiv(p.m_tiles, 8) * 8 * p.n_tiles);
+  if (gn) hipLaunchKernelGGL(conv_wino_kernel<true>, grid, dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL(conv_wino_kernel<false>, grid, dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;
 }

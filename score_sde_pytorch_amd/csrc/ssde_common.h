@@ -43,14 +43,21 @@ static inline bool ssde_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 #define SSDE_LDS(var) HIP_DYNAMIC_SHARED(float4, var##_f4) float* var = reinterpret_cast<float*>(var##_f4)
 
 // Async global -> LDS copy of 16 bytes per lane with no VGPR round trip (global_load_lds_dwordx4): lane l's
-// bytes land at lds_wave_base + 16*l, so the destination is a wave-uniform base and the LDS image is
-// lane-linear.  Visible to other waves after the issuer's vmcnt wait + a workgroup barrier (__syncthreads).
-#define SSDE_GLDS16(gptr, lds_wave_base) \
-  __builtin_amdgcn_global_load_lds((gptr), (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
-// same with the instruction's 13-bit signed immediate offset, which the hardware adds to BOTH the global and the LDS
-// address: a run of copies with equal strides on both sides needs one M0 / one address setup
-#define SSDE_GLDS16_OFF(gptr, lds_wave_base, imm) \
-  __builtin_amdgcn_global_load_lds((gptr), (__attribute__((address_space(3))) void*)(lds_wave_base), 16, (imm), 0)
+// bytes land at lds_wave_base + imm + 16*l (M0 holds the wave-uniform LDS base; the 13-bit signed immediate is added
+// to BOTH the global and the LDS address, so a run of copies with equal strides on both sides needs one address setup).
+// Issued through inline assembly on purpose: the compiler builtin (__builtin_amdgcn_global_load_lds) is modelled as
+// an LDS write, and hipcc then puts s_waitcnt vmcnt(0) in front of the next ds_read of ANY LDS address -- the issuing
+// wave sat out the whole copy latency before its first MFMA.  The asm form is opaque: ordering is the caller's job
+// (the data is visible to other waves after the issuer's SSDE_WAIT_VMCNT + a workgroup barrier).
+#ifndef SSDE_GLDS16_OFF
+#define SSDE_GLDS16_OFF(gptr, lds_wave_base, imm)                                                                        \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%2"                               \
+               :                                                                                                          \
+               : "s"(__builtin_amdgcn_readfirstlane(                                                                      \
+                     (int)(uintptr_t)(__attribute__((address_space(3))) void*)(lds_wave_base))),                          \
+                 "v"(gptr), "n"(imm)                                                                                      \
+               :)
+#endif
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which hipcc lowers
 // to s_waitcnt vmcnt(0) whenever an LDS-DMA (or any global load) is in flight: a full memory latency exposed at every
@@ -68,13 +75,16 @@ static inline bool ssde_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
   } while (0)
 
 #ifdef __HIPCC__
-// x * sigmoid(x); v_exp_f32 + v_rcp_f32 (each ~1 ulp)
+// x * sigmoid(x) = x * rcp(1 + exp2(-x log2 e)): v_mul + v_exp_f32 + v_add + v_rcp_f32 + v_mul, each ~1 ulp.
+// (__frcp_rn is the correctly rounded reciprocal: hipcc expands it to the 12-instruction IEEE division sequence, and
+//  on gfx950 VALU cycles are not hidden behind fp32 MFMAs of another wave -- tools/microbench/mfma_valu_overlap.hip --
+//  so in the staging prologues that sequence cost ~10% of a Winograd stage.)
 __device__ __forceinline__ float ssde_silu(float x) {
-  return x * __frcp_rn(1.0f + __expf(-x));
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 // d silu(u) / du = sig * (1 + u * (1 - sig))
 __device__ __forceinline__ float ssde_silu_grad(float u) {
-  const float sg = __frcp_rn(1.0f + __expf(-u));
+  const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
   return sg * (1.0f + u * (1.0f - sg));
 }
 

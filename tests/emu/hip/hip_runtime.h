@@ -137,9 +137,12 @@ static inline void emu_global_load_lds(const void* g, __attribute__((address_spa
   memcpy((char*)(void*)l + off + (size_t)size * emu::cur->lane, (const char*)g + off, size);   // imm offset: both sides
 }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void*)(g), (l), (size), (off))
+// the product issues the copy through inline assembly (ssde_common.h); the emulator substitutes its model of the instruction
+#define SSDE_GLDS16_OFF(gptr, lds_wave_base, imm) emu_global_load_lds((const void*)(gptr), (__attribute__((address_space(3))) void*)(lds_wave_base), 16, (imm))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
+#define __builtin_amdgcn_sched_barrier(a) ((void)0)
 #define __builtin_amdgcn_s_barrier() emu::syncthreads()
 
 // ---- device math ----
@@ -147,6 +150,7 @@ static inline void emu_global_load_lds(const void* g, __attribute__((address_spa
 #define __expf(x) expf(x)
 #define __logf(x) logf(x)
 static inline float __frcp_rn(float x) { return 1.0f / x; }
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 static inline float __fsqrt_rn(float x) { return sqrtf(x); }
 static inline float __frsqrt_rn(float x) { return 1.0f / sqrtf(x); }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

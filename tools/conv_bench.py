@@ -20,11 +20,11 @@ def time_conv(n, cin, cout, h, tile, gn=False, reps=5):
     w = torch.randn(cout, cin, 3, 3, device=dev) / np.sqrt(9 * cin)
     a = L.ConvArgs()
     gnt = None
-    if gn:
+    if int(gn) in (1, 2):
         G = min(cin // 4, 32)
         mean, rstd = ops.groupnorm_stats(x, G, 1e-6)
         gnt = (mean, rstd, torch.ones(cin, device=dev), torch.zeros(cin, device=dev), G)
-    ops._fill_src(a.main, x, None, L.PRO_GN_SILU if gn else L.PRO_NONE, gnt)
+    ops._fill_src(a.main, x, None, {0: L.PRO_NONE, 1: L.PRO_GN_SILU, 2: L.PRO_GN, 3: L.PRO_SILU}[int(gn)], gnt)
     wp = (pack_wino_weight if tile == L.TILE_WINOGRAD else pack_conv_weight)(w)
     dst = torch.empty(n, h, h, cout, device=dev)
     a.w_main, a.ksize, a.stride, a.pad, a.h_in, a.w_in = wp.data_ptr(), 3, 1, 1, h, h
@@ -47,7 +47,7 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     shapes = [(128, 128, 32), (256, 128, 32), (256, 256, 16), (512, 256, 16), (256, 256, 8), (384, 128, 32)]
     for cin, cout, h in shapes:
-        for gn in (False, True):
+        for gn in ((0, 1, 2, 3) if os.environ.get("CONV_BENCH_PROLOGUES") else (0, 1)):   # 1 GN+SiLU, 2 GN, 3 SiLU
             d, dms = time_conv(n, cin, cout, h, L.TILE_AUTO, gn)
             wv, wms = time_conv(n, cin, cout, h, L.TILE_WINOGRAD, gn)
             print("B=%d %4d->%4d @%2dx%-2d gn=%d  direct %6.1f TF/s (%.3f ms)   winograd %6.1f TF/s (%.3f ms)   x%.2f"
