@@ -1,0 +1,251 @@
+// 1x1 convolutions / NIN / Linear layers as a plain fp32 GEMM on the matrix pipe (ddpm_conv1x1 models/layers.py:100-105,
+// NIN layers.py:546-555, nn.Linear at ncsnpp.py:86-91 and layerspp.py:227,263, and the input-gradients of all of them):
+//
+//   out[m, j] = scale * ( sum_k pro(src)[m, k] * W[k, j] + bias[j] + chan_add[img(m), j] (+ resid[m, j]) ) (+ resid[m, j])
+//
+// m runs over the N*H*W pixels (NHWC rows are contiguous, so the pixel operand is a row-major [M, K] matrix and no
+// spatial tiling is needed), the source may be a virtual concat (p0 | p1) with the usual GroupNorm / SiLU / dropout
+// prologue.  The general kernel (conv_mfma.hip) runs these layers as its "aux" phase with 64-wide output tiles and a
+// single LDS stage: the pixel operand is re-read Cout/64 times and every 32-channel chunk costs two barriers -- 60-85
+// TF/s at the BASELINE shapes.  Here:
+//   workgroup = 4 waves = 128 pixels x 128 output channels, each wave a 64 x 64 block (2 x 2 v_mfma_f32_32x32x2_f32 tiles,
+//   64 accumulator registers); K advances 32 channels per stage through DOUBLE-BUFFERED LDS, one barrier per stage:
+//   the global loads of stage s+1 are issued before the 64 MFMAs of stage s (4096 matrix cycles = 1.7 us, an L2 / HBM
+//   latency; with 16-channel stages the kernel was load-latency bound) and parked in LDS after them.
+//   Both operands sit K-major in LDS with a row pitch of 34 floats: a lane's ds_read_b64 is the channel pair
+//   (4t + 2h, 4t + 2h + 1) of its row (h = lane >> 5 = the MFMA k index), one read feeds two MFMAs, and the 32 rows of a
+//   half-wave cover all 64 banks (34 i mod 64 hits every even bank once).
+//   Workgroups that share a pixel tile are consecutive on ONE XCD (blocks are dealt round-robin to the 8 XCDs), so the
+//   second output-channel tile finds the pixel rows in that XCD's L2.
+// The epilogue is the shared coalesced one (ssde_store_tile): accumulators -> LDS tile -> float4 rows.
+#include "ssde_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int BM = 128, BN = 128, BK = 16, LDK = 18;
+constexpr int kStage = (BM + BN) * LDK;           // floats per LDS stage (A rows then B rows)
+
+struct GemmParams {
+  ssde_src src;
+  const float* wpk;        // [ceil(K/8)][CoutPad][8]
+  int M, HW, K, Cout, CoutPad, m_tiles, n_tiles;
+  const float* bias; const float* chan_add; int chan_add_ld;
+  const float* resid; int resid_post;
+  float scale;
+  float* dst;
+};
+
+template <bool kGn>
+__global__ __launch_bounds__(kThreads, 4) void gemm1x1_kernel(const GemmParams p) {
+  SSDE_LDS(smem);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int xcd = blockIdx.x & 7, lin = blockIdx.x >> 3;
+  const int nt = lin % p.n_tiles, mt = (lin / p.n_tiles) * 8 + xcd;
+  if (mt >= p.m_tiles) return;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const ssde_src& s = p.src;
+  SsdePro pro = ssde_pro_decode(s);
+  pro.gn = kGn;
+  const int Ctot = s.c0 + s.c1;
+  const int cpg = kGn ? Ctot / s.gn_groups : 1;
+  const int nst = (p.K + BK - 1) / BK;
+  const int ncin8 = (p.K + 7) >> 3;
+
+  // ---- staging plan: thread = (rows r0 = tid >> 3 + 32 i, channel quad f = tid & 7) of both operands ----
+  constexpr int NI = 2, RS = 64;
+  const int f = tid & 3, r0 = tid >> 2;
+  int arow[NI], aimg[NI];
+  bool aok[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int m = m0 + r0 + i * RS;
+    aok[i] = m < p.M;
+    arow[i] = aok[i] ? m : 0;
+    aimg[i] = arow[i] / p.HW;
+  }
+  bool bok[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) bok[i] = (n0 + r0 + i * RS) < p.CoutPad;
+  const float* bptr = p.wpk + ((size_t)n0 + r0) * 8 + (f & 1) * 4;      // + 8-channel chunk * CoutPad * 8
+
+  float4 av[NI], bv[NI];
+  float mu[NI], rs[NI];
+  float4 gam = make_float4(1.f, 1.f, 1.f, 1.f), bet = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool k_ok = false;
+  int c_cur = 0;
+
+  // branch-free global loads of stage st (rows / channels outside the problem read a clamped address and are zeroed below)
+  auto load_stage = [&](int st) {
+    const int c_base = st * BK;
+    const bool second = c_base >= s.c0;
+    const float* base = second ? s.p1 : s.p0;
+    const int C = second ? s.c1 : s.c0;
+    const int cthr = (second ? c_base - s.c0 : c_base) + f * 4;
+    c_cur = c_base + f * 4;
+    k_ok = c_cur < p.K;
+    const float* ap = base + (k_ok ? cthr : 0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) av[i] = *reinterpret_cast<const float4*>(ap + (size_t)arow[i] * C);
+    const int cin8 = min(st * 2 + (f >> 1), ncin8 - 1);
+    const float* bp = bptr + (size_t)cin8 * p.CoutPad * 8;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) bv[i] = *reinterpret_cast<const float4*>(bp + (bok[i] ? i * RS * 8 : 0));
+    if (kGn) {
+      const int cg = k_ok ? c_cur : 0;
+      gam = *reinterpret_cast<const float4*>(s.gn_gamma + cg);
+      bet = *reinterpret_cast<const float4*>(s.gn_beta + cg);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int gi = aimg[i] * s.gn_groups + cg / cpg;
+        mu[i] = s.gn_mean[gi];
+        rs[i] = s.gn_rstd[gi];
+      }
+    }
+  };
+  auto store_stage = [&](int st, float* buf) {
+    const int cin8 = st * 2 + (f >> 1);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (aok[i] && k_ok)
+        v = ssde_pro_apply(av[i], mu[i], rs[i], gam, bet, (uint32_t)arow[i] * (uint32_t)Ctot + (uint32_t)c_cur, pro);
+      float* d = buf + (r0 + i * RS) * LDK + f * 4;
+      *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+      *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+      float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bok[i] && cin8 < ncin8) w = bv[i];
+      float* e = buf + (BM + r0 + i * RS) * LDK + f * 4;
+      *reinterpret_cast<float2*>(e) = make_float2(w.x, w.y);
+      *reinterpret_cast<float2*>(e + 2) = make_float2(w.z, w.w);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  int aoff[2], boff[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) aoff[a] = (wm0 + a * 32 + li) * LDK + 2 * lh;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) boff[b] = (BM + wn0 + b * 32 + li) * LDK + 2 * lh;
+
+  load_stage(0);
+  store_stage(0, smem);
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    const float* cur = smem + (st & 1) * kStage;
+    const bool has_next = st + 1 < nst;
+    if (has_next) load_stage(st + 1);
+    float2 af[2][2], bf[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) af[0][a] = *reinterpret_cast<const float2*>(cur + aoff[a]);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) bf[0][b] = *reinterpret_cast<const float2*>(cur + boff[b]);
+#pragma unroll
+    for (int t = 0; t < BK / 4; ++t) {
+      const int c = t & 1;
+      if (t + 1 < BK / 4) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) af[c ^ 1][a] = *reinterpret_cast<const float2*>(cur + aoff[a] + (t + 1) * 4);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) bf[c ^ 1][b] = *reinterpret_cast<const float2*>(cur + boff[b] + (t + 1) * 4);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][a].x, bf[c][b].x, acc[a][b], 0, 0, 0);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][a].y, bf[c][b].y, acc[a][b], 0, 0, 0);
+      // the fragment reads of step t+1 go out before the 8 MFMAs of step t (512 matrix cycles cover their latency)
+      if (t + 1 < BK / 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    }
+    if (has_next) store_stage(st + 1, smem + ((st + 1) & 1) * kStage);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS tile [64][BN + 4] -> coalesced float4 rows, the two 64-row halves in turn
+  // (a half tile is 33 KB: with the 37 KB of operand stages four workgroups fit a CU and cover each other's pipeline
+  // fill and epilogue; the loops are short -- K = 128 .. 512 -- so those fixed costs matter)
+  constexpr int LDT = BN + 4;
+  SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, p.Cout};
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if ((wave >> 1) == half) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            smem[m * LDT + wn0 + b * 32 + li] = acc[a][b][r];
+          }
+    }
+    __syncthreads();
+    ssde_store_tile(smem, 64, LDT, BN, n0, e, kThreads, [&](int row, size_t& pix, int& img) {
+      const int m = m0 + half * 64 + row;
+      if (m >= p.M) return false;
+      pix = (size_t)m;
+      img = m / p.HW;
+      return true;
+    });
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+// Used by ssde_conv2d for 1x1-only launches it judges large enough (conv_mfma.hip); shapes it does not take stay on the
+// general kernel.
+bool ssde_conv1x1_wants(const ssde_conv_args* a) {
+  if (a->ksize != 0 || a->aux.p0 == nullptr || a->tile != SSDE_TILE_AUTO) return false;
+  const long long M = (long long)a->n * a->h_out * a->w_out;
+  return a->c_out >= 96 && M >= 128 && M < (1ll << 31);
+}
+
+int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
+  const ssde_src& s = a->aux;
+  SSDE_REQUIRE(s.c0 % 4 == 0 && s.c1 % 4 == 0, "conv1x1: channels must be multiples of 4 (got %d,%d)", s.c0, s.c1);
+  SSDE_REQUIRE(s.c1 == 0 || (s.p1 != nullptr && s.c0 % 32 == 0), "conv1x1: concat boundary must be a multiple of 32");
+  const bool gn = s.pro_mode == SSDE_PRO_GN || s.pro_mode == SSDE_PRO_GN_SILU;
+  if (gn) {
+    SSDE_REQUIRE(s.gn_groups > 0 && (s.c0 + s.c1) % s.gn_groups == 0 && ((s.c0 + s.c1) / s.gn_groups) % 4 == 0,
+                 "conv1x1: GroupNorm needs channels-per-group %% 4 == 0");
+    SSDE_REQUIRE(s.gn_mean && s.gn_rstd && s.gn_gamma && s.gn_beta, "conv1x1: GroupNorm pointers missing");
+  }
+  SSDE_REQUIRE(a->w_aux && a->dst, "conv1x1: null weights / destination");
+  GemmParams p;
+  p.src = s; p.wpk = a->w_aux;
+  p.M = a->n * a->h_out * a->w_out; p.HW = a->h_out * a->w_out; p.K = s.c0 + s.c1;
+  p.Cout = a->c_out; p.CoutPad = ssde_cdiv(a->c_out, 64) * 64;
+  p.m_tiles = ssde_cdiv(p.M, BM); p.n_tiles = ssde_cdiv(a->c_out, BN);
+  p.bias = a->bias; p.chan_add = a->chan_add; p.chan_add_ld = a->chan_add_ld;
+  p.resid = a->resid; p.resid_post = a->resid_post; p.scale = a->out_scale; p.dst = a->dst;
+  const int lds_ops = 2 * kStage * 4, lds_epi = 64 * (BN + 4) * 4;
+  const int lds = lds_ops > lds_epi ? lds_ops : lds_epi;
+  if (lds_out) { *lds_out = lds; return SSDE_OK; }
+  static bool attr_set = false;   // once, before any stream capture
+  if (!attr_set) {
+    SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm1x1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm1x1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const dim3 grid(ssde_cdiv(p.m_tiles, 8) * 8 * p.n_tiles);
+  if (gn) hipLaunchKernelGGL(gemm1x1_kernel<true>, grid, dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL(gemm1x1_kernel<false>, grid, dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}

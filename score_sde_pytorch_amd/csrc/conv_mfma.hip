@@ -439,6 +439,7 @@ int launch_cfg(const ConvPlan& pl, hipStream_t st) {
 
 extern "C" int ssde_conv2d(const ssde_conv_args* a, void* stream) {
   if (a && a->tile == SSDE_TILE_WINOGRAD) return ssde_conv_wino_launch(a, stream, nullptr);
+  if (a && a->dst && ssde_conv1x1_wants(a)) return ssde_conv1x1_launch(a, stream, nullptr);   // 1x1-only: GEMM kernel (conv1x1.hip)
   ConvPlan pl;
   if (int rc = make_plan(a, &pl)) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -456,6 +457,11 @@ extern "C" int ssde_conv_lds_bytes(const ssde_conv_args* a) {
   if (a && a->tile == SSDE_TILE_WINOGRAD) {
     int lds = 0;
     if (int rc = ssde_conv_wino_launch(a, nullptr, &lds)) return rc;
+    return lds;
+  }
+  if (a && a->dst && ssde_conv1x1_wants(a)) {
+    int lds = 0;
+    if (int rc = ssde_conv1x1_launch(a, nullptr, &lds)) return rc;
     return lds;
   }
   ConvPlan pl;

@@ -592,7 +592,8 @@ def check_checkpoint_and_ema_swap(dev, tmp_path):
     fresh = mutils.get_model("ncsnpp")(cfg).to(dev)
     fresh.load_state_dict(model.state_dict())
     with torch.no_grad():
-        assert rel_err(y1, y0) > 1e-6 and rel_err(y1, infer(fresh, xq, sq)) < 1e-6    # (device vs torch weight packing: rounding)
+        assert rel_err(y1, y0) > 1e-6
+        assert rel_err(y1, infer(fresh, xq, sq)) < 2e-5    # (device vs torch packing of the Winograd weights: rounding)
     step(1)
     path = os.path.join(str(tmp_path), "ckpt", "checkpoint_1.pth")
     os.makedirs(os.path.dirname(path), exist_ok=True)
@@ -626,7 +627,7 @@ def check_checkpoint_and_ema_swap(dev, tmp_path):
     fresh.load_state_dict(model.state_dict())
     with torch.no_grad():
         y_ema = infer(model, xq, sq)
-        assert rel_err(y_ema, infer(fresh, xq, sq)) < 1e-6 and rel_err(y_ema, y_raw) > 1e-7
+        assert rel_err(y_ema, infer(fresh, xq, sq)) < 2e-5 and rel_err(y_ema, y_raw) > 1e-7
     ema.restore(model.parameters())
     for a, b in zip(before, model.parameters()):
         assert torch.equal(a, b.detach())

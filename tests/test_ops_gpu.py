@@ -284,3 +284,39 @@ def test_conv3x3_winograd_fused_prologue_epilogue():
                    chan_add=ca.cuda(), resid=nhwc(res).cuda(), scale=0.7, tile=L.TILE_WINOGRAD)
     ref = 0.7 * (F.conv2d(F.silu(F.group_norm(torch.cat([x1, x2], 1), G, gamma, beta, 1e-6)), w, b, padding=1) + ca[:, :, None, None] + res)
     assert rel_err(nchw(y.cpu()), ref) < TOL_GEMM
+
+
+# (n, h, cin1, cin2, cout, prologue, extras): shapes that take the GEMM kernel of conv1x1.hip (M >= 128, Cout >= 96),
+# with ragged M / K / Cout tails, a virtual concat, every prologue and the whole epilogue
+GEMM1X1_CASES = [(2, 8, 64, 0, 128, 0, False), (3, 8, 40, 0, 96, 0, True), (1, 16, 32, 24, 200, 2, True),
+                 (5, 6, 8, 0, 130, 3, False), (2, 16, 64, 32, 256, 1, True)]
+
+
+@pytest.mark.parametrize("n,h,c1,c2,cout,pro,extras", GEMM1X1_CASES)
+def test_conv1x1_gemm_kernel(n, h, c1, c2, cout, pro, extras):
+    ops = _ops()
+    g = torch.Generator().manual_seed(n * 1000 + cout)
+    xa = torch.randn(n, c1, h, h, generator=g)
+    xb = torch.randn(n, c2, h, h, generator=g) if c2 else None
+    cat = xa if xb is None else torch.cat([xa, xb], 1)
+    k = c1 + c2
+    w = torch.randn(cout, k, generator=g) / np.sqrt(k)
+    gn, act = None, cat
+    if pro in (1, 2):
+        G = k // 4 if k // 4 <= 32 else 32
+        while k % G or (k // G) % 4:
+            G -= 1
+        gam, bet = 1 + 0.1 * torch.randn(k, generator=g), 0.1 * torch.randn(k, generator=g)
+        mean, rstd = ops.groupnorm_stats(nhwc(xa).cuda(), G, x2=None if xb is None else nhwc(xb).cuda())
+        gn = (mean, rstd, gam.cuda(), bet.cuda(), G)
+        act = F.group_norm(cat, G, gam, bet, 1e-6)
+    if pro in (2, 3):
+        act = F.silu(act)
+    kw = {}
+    ref = F.conv2d(act, w[:, :, None, None])
+    if extras:
+        bias, tproj, res = torch.randn(cout, generator=g), torch.randn(n, cout, generator=g), torch.randn(n, cout, h, h, generator=g)
+        kw = dict(bias=bias.cuda(), chan_add=tproj.cuda(), resid=nhwc(res).cuda(), scale=float(1 / np.sqrt(2)))
+        ref = (ref + bias[None, :, None, None] + tproj[:, :, None, None] + res) / np.sqrt(2)
+    y = ops.conv2d(aux=nhwc(xa).cuda(), aux2=None if xb is None else nhwc(xb).cuda(), aux_weight=w, aux_pro=pro, aux_gn=gn, **kw)
+    assert rel_err(nchw(y.cpu()), ref) < TOL_GEMM
