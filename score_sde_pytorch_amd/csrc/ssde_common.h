@@ -15,6 +15,9 @@ void ssde_set_error(const char* fmt, ...);
 int ssde_conv_wino_launch(const ssde_conv_args* a, void* stream, int* lds_out);
 bool ssde_conv1x1_wants(const ssde_conv_args* a);                                    // conv1x1.hip
 int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out);
+bool ssde_wgrad_wino_wants(const ssde_wgrad_args* a);                                // wgrad_wino.hip
+int64_t ssde_wgrad_wino_scratch_floats(const ssde_wgrad_args* a);
+int ssde_wgrad_wino_launch(const ssde_wgrad_args* a, void* stream);
 
 #define SSDE_REQUIRE(cond, ...)            \
   do {                                     \

@@ -161,3 +161,44 @@ def test_conv1x1_gemm_kernel(ops, n, h, c1, c2, cout, pro, extras):
         ref = (ref + bias[None, :, None, None] + tproj[:, :, None, None] + res) / np.sqrt(2)
     y = ops.conv2d(aux=(nhwc(xa)), aux2=None if xb is None else (nhwc(xb)), aux_weight=w, aux_pro=pro, aux_gn=gn, **kw)
     assert rel_err(nchw(y.cpu()), ref) < 2e-5
+
+
+# (n, h, w, cin1, cin2, cout, prologue, dropout): shapes that take the Winograd weight-gradient kernel (wgrad_wino.hip:
+# 3x3 / stride 1 / pad 1, h % 4 == 0, w % 8 == 0, channels % 64 == 0), with a virtual concat, every prologue, dropout
+WGRAD_WINO_CASES = [(1, 8, 8, 64, 0, 64, 0, 0.0), (2, 8, 16, 64, 0, 128, 3, 0.0), (3, 4, 8, 64, 64, 64, 2, 0.0),
+                    (1, 16, 16, 128, 0, 64, 1, 0.0), (2, 8, 8, 64, 0, 64, 2, 0.25)]
+
+
+@pytest.mark.parametrize("n,h,w,c1,c2,cout,pro,drop", WGRAD_WINO_CASES)
+def test_wgrad_winograd_kernel(ops, n, h, w, c1, c2, cout, pro, drop):
+    g = torch.Generator().manual_seed(n * 100 + cout + c1)
+    xa = torch.randn(n, c1, h, w, generator=g)
+    xb = torch.randn(n, c2, h, w, generator=g) if c2 else None
+    cat = xa if xb is None else torch.cat([xa, xb], 1)
+    k = c1 + c2
+    gy = torch.randn(n, cout, h, w, generator=g)
+    gn, act = None, cat
+    if pro in (1, 2):
+        G = min(32, k // 4)
+        gam, bet = 1 + 0.1 * torch.randn(k, generator=g), 0.1 * torch.randn(k, generator=g)
+        mean, rstd = ops.groupnorm_stats((nhwc(xa)), G, x2=None if xb is None else (nhwc(xb)))
+        gn = (mean, rstd, (gam), (bet), G)
+        act = F.group_norm(cat, G, gam, bet, 1e-6)
+    if pro in (2, 3):
+        act = F.silu(act)
+    dropout = None
+    if drop > 0:
+        seed = (torch.tensor([1234], dtype=torch.int32))
+        dropout = (drop, seed, 77)
+    wt = torch.zeros(cout, k, 3, 3, requires_grad=True)
+    dw = (torch.zeros(cout, k, 3, 3))
+    kw = dict(x2=None if xb is None else (nhwc(xb)), pro=pro, gn=gn, scale=0.5, dropout=dropout)
+    ops.conv_wgrad((nhwc(xa)), (nhwc(gy)), 3, dw, stride=1, pad=1, **kw)
+    if drop > 0:        # the mask is a hash of the element index: reference = the direct kernel, which keeps the launch
+        # when cin_store < Ctot (its own parity with autograd incl. dropout is tests/_train_checks.check_backward_ops)
+        dw2 = (torch.zeros(cout, k - 4, 3, 3))
+        ops.conv_wgrad((nhwc(xa)), (nhwc(gy)), 3, dw2, stride=1, pad=1, cin_store=k - 4, **kw)
+        assert rel_err(dw.cpu()[:, : k - 4], dw2.cpu()) < 2e-5
+        return
+    F.conv2d(act.clone().requires_grad_(False), wt, padding=1).backward(gy)
+    assert rel_err(dw.cpu(), 0.5 * wt.grad) < 2e-5
