@@ -56,11 +56,15 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_wino_kernel(const WwParams 
   const int li = lane & 15, lq = lane >> 4;
   const int ph = wave >> 2;
 
-  // XCD-aware order: the (co, ci) blocks of one chunk range run on ONE XCD and share its L2
+  // XCD-aware order: blocks are dealt round-robin to the 8 XCDs, and a workgroup needs a whole CU (155 KB of LDS), so
+  // every XCD must get the SAME number (<= 32) of workgroups: XCD x takes the x-th run of ceil(total / 8) consecutive
+  // (split, tile) pairs -- the (co, ci) blocks of one chunk range sit on one XCD (at most two) and share its L2.
+  // (Dealing whole splits to XCDs left 5 XCDs with 36 workgroups for 32 CUs at 12 blocks per split: two rounds.)
   const int ntiles = p.co_tiles * p.ci_tiles;
-  const int xcd = blockIdx.x & 7, lin = blockIdx.x >> 3;
-  const int tile = lin % ntiles, split = (lin / ntiles) * 8 + xcd;
-  if (split >= p.splits) return;
+  const int total = p.splits * ntiles, per_xcd = (total + 7) >> 3;
+  const int j = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (j >= total) return;
+  const int tile = j % ntiles, split = j / ntiles;
   const int co0 = (tile / p.ci_tiles) * 64, ci0 = (tile % p.ci_tiles) * 64;
   const int ch_begin = split * p.chunks_per_split;
   const int nst = min(p.chunks, ch_begin + p.chunks_per_split) - ch_begin;
@@ -373,8 +377,9 @@ static int ww_plan(const ssde_wgrad_args* a, WwParams* p) {
   p->chunks = a->n * p->cx * p->cy;
   p->co_tiles = a->c_out / 64; p->ci_tiles = p->Ctot / 64;
   const int ntiles = p->co_tiles * p->ci_tiles;
-  // one workgroup fills a CU (155 KB of LDS): aim at one round of 256, with at least 4 stages each
-  int splits = ssde_cdiv(256, ntiles);
+  // one workgroup fills a CU (155 KB of LDS): aim at ONE round of at most 256 workgroups (257 would take as long as
+  // 512), with at least 4 stages each
+  int splits = 256 / ntiles;
   const int max_splits = p->chunks >= 4 ? p->chunks / 4 : 1;
   if (splits > max_splits) splits = max_splits;
   if (a->splits > 0) splits = a->splits;
@@ -423,7 +428,7 @@ int ssde_wgrad_wino_launch(const ssde_wgrad_args* a, void* stream) {
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int ntiles = p.co_tiles * p.ci_tiles;
-  const dim3 grid(ssde_cdiv(p.splits, 8) * 8 * ntiles);
+  const dim3 grid(ssde_cdiv(p.splits * ntiles, 8) * 8);
   if (gn) hipLaunchKernelGGL(wgrad_wino_kernel<true>, grid, dim3(kThreads), lds, st, p);
   else hipLaunchKernelGGL(wgrad_wino_kernel<false>, grid, dim3(kThreads), lds, st, p);
   SSDE_LAUNCH_CHECK();
