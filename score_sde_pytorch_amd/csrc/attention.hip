@@ -48,21 +48,34 @@ __device__ __forceinline__ void gemm_nt(const float* __restrict__ A, int a_valid
   const int li = lane & 31, lh = lane >> 5;
   const int kb = wave * 64;
   zero_acc(acc);
+  // The 32-channel chunk c0+32 is fetched into registers while the MFMAs of chunk c0 run (as fixed-count, branch-free
+  // loads: rows past the valid range read a clamped address and are zeroed); it is parked in LDS behind the barrier.
+  const int f = tid & 7, r0 = tid >> 3;                   // item (row r0 + 32 it, channel quad f)
+  float4 ra[2], rb[8];
+  auto load_chunk = [&](int c0) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = r0 + it * 32;
+      const float4 v = *reinterpret_cast<const float4*>(A + (size_t)max(min(row, a_valid - 1), 0) * lda + c0 + f * 4);
+      ra[it] = row < a_valid ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = r0 + it * 32;
+      const float4 v = *reinterpret_cast<const float4*>(B + (size_t)max(min(row, b_valid - 1), 0) * ldb + c0 + f * 4);
+      rb[it] = row < b_valid ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  load_chunk(0);
   for (int c0 = 0; c0 < C; c0 += 32) {
     __syncthreads();
-    for (int q = tid; q < kQB * 8; q += 256) {
-      const int row = q >> 3, f = q & 7;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < a_valid) v = *reinterpret_cast<const float4*>(A + (size_t)row * lda + c0 + f * 4);
-      *reinterpret_cast<float4*>(Qs + row * kLDC + f * 4) = v;
-    }
-    for (int q = tid; q < Lk * 8; q += 256) {
-      const int row = q >> 3, f = q & 7;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < b_valid) v = *reinterpret_cast<const float4*>(B + (size_t)row * ldb + c0 + f * 4);
-      *reinterpret_cast<float4*>(Ks + row * kLDC + f * 4) = v;
-    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) *reinterpret_cast<float4*>(Qs + (r0 + it * 32) * kLDC + f * 4) = ra[it];
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+      if (r0 + it * 32 < Lk) *reinterpret_cast<float4*>(Ks + (r0 + it * 32) * kLDC + f * 4) = rb[it];
     __syncthreads();
+    if (c0 + 32 < C) load_chunk(c0 + 32);
     if (kb < Lk) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
@@ -95,16 +108,36 @@ __device__ __forceinline__ void gemm_pv(const float* Ps, int Lp, const float* __
     const int Cw = min(256, C - cp);
     const int cb = wave * 64;
     zero_acc(acc);
+    // 32-token chunk of V: up to 8 float4 per thread, prefetched into registers during the MFMAs of the previous chunk
+    const int f4n = Cw >> 2;
+    int vrow[8], vf[8];
+    {
+      int row = tid / f4n, ff = tid - row * f4n;
+      const int dr = 256 / f4n, df = 256 - dr * f4n;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        vrow[it] = row; vf[it] = ff;
+        row += dr; ff += df;
+        if (ff >= f4n) { ff -= f4n; ++row; }
+      }
+    }
+    float4 rv[8];
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int tok = k0 + vrow[it];
+        const float4 v = *reinterpret_cast<const float4*>(Bm + (size_t)max(min(tok, b_valid - 1), 0) * ldb + cp + vf[it] * 4);
+        rv[it] = (vrow[it] < 32 && tok < b_valid) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    load_chunk(0);
     for (int k0 = 0; k0 < Lp; k0 += 32) {
       __syncthreads();
-      const int f4n = Cw >> 2;
-      for (int q = tid; q < 32 * f4n; q += 256) {
-        const int row = q / f4n, f = q - row * f4n;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k0 + row < b_valid) v = *reinterpret_cast<const float4*>(Bm + (size_t)(k0 + row) * ldb + cp + f * 4);
-        *reinterpret_cast<float4*>(Vs + row * kLDP + f * 4) = v;
-      }
+#pragma unroll
+      for (int it = 0; it < 8; ++it)
+        if (vrow[it] < 32) *reinterpret_cast<float4*>(Vs + vrow[it] * kLDP + vf[it] * 4) = rv[it];
       __syncthreads();
+      if (k0 + 32 < Lp) load_chunk(k0 + 32);
       if (cb < Cw) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
