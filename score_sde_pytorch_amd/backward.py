@@ -419,6 +419,69 @@ class TrainEngine(E.UNetEngine):
     def run_backward(self):
         self.program.run_range(self.n_fwd, self.n_bwd)
 
+    # ------------------------------------------------------------------ gradient buckets (data-parallel overlap)
+    def grad_buckets(self, bucket_floats=8 << 20):
+        """[(lo, hi, op_end)] from the END of the flat gradient buffer to its start: the slice [lo, hi) is final once the
+        backward ops before index `op_end` have run.  The backward walks the network in reverse while the flat buffer
+        is laid out in forward order, so the tail of the buffer completes first; `op_end` is found by scanning every
+        pointer field of every backward op for addresses inside the flat gradient (a slice is final after the LAST op
+        that holds a pointer at or beyond its start -- conservative for ops that write runs of several parameters)."""
+        if getattr(self, "_buckets", None) is not None and self._buckets[0] == bucket_floats:
+            return self._buckets[1]
+        import ctypes as C
+        base, end = self.flat.grad.data_ptr(), self.flat.grad.data_ptr() + self.flat.numel * 4
+
+        def pointers(struct):
+            for name, typ in struct._fields_:
+                v = getattr(struct, name)
+                if isinstance(v, C.Structure):
+                    yield from pointers(v)
+                elif typ is C.c_void_p and v:
+                    yield v
+        touch = []                                   # (float offset, op index) of every reference into flat.grad
+        for i in range(self.n_fwd, self.program.n):
+            op = self.program.ops[i]
+            if op.kind == L.OP_MEMSET:
+                continue                             # the zero-fill at the head of the backward program
+            for ptr in pointers(getattr(op.u, L._UNION_FIELD[op.kind])):
+                if base <= ptr < end:
+                    touch.append(((ptr - base) // 4, i))
+        # bucket boundaries at parameter starts; the grouped parameters at the head of the buffer (written as one run by a
+        # single kernel) stay in one bucket
+        groups = self.model.flat_param_groups() if hasattr(self.model, "flat_param_groups") else []
+        grouped_end = 0
+        for g in groups:
+            for p in g:
+                o, n = self.flat.index[id(p)]
+                grouped_end = max(grouped_end, o + n)
+        starts = sorted(o for o, _ in self.flat.index.values())
+        bounds, hi = [], self.flat.numel
+        for o in reversed(starts):
+            if o < grouped_end:
+                break
+            if hi - o >= bucket_floats:
+                bounds.append((o, hi)); hi = o
+        if hi > 0:
+            bounds.append((0, hi))
+        buckets = []
+        for lo, hi_ in bounds:
+            last = max([i for off, i in touch if off >= lo], default=self.n_fwd - 1)
+            buckets.append((lo, hi_, last + 1))
+        self._buckets = (bucket_floats, buckets)
+        return buckets
+
+    def run_backward_bucketed(self, on_ready, bucket_floats=8 << 20):
+        """Backward program in segments; `on_ready(lo, hi)` is called as soon as the ops that finalise flat.grad[lo:hi]
+        are ENQUEUED (stream order makes a collective issued there wait for exactly those ops)."""
+        cur = self.n_fwd
+        for lo, hi, op_end in self.grad_buckets(bucket_floats):
+            if op_end > cur:
+                self.program.run_range(cur, op_end - cur)
+                cur = op_end
+            on_ready(lo, hi)
+        if cur < self.program.n:
+            self.program.run_range(cur, self.program.n - cur)
+
     def forward_train(self, x, cond, seed=0):
         if tuple(x.shape) != (self.n, self.channels, self.h, self.w):
             raise ValueError("engine built for %s, got %s" % ((self.n, self.channels, self.h, self.w), tuple(x.shape)))

@@ -270,14 +270,29 @@ class FusedTrainStep:
         self._head[0].run()
         eng.run_forward()
         self._head[1].run()
+        self._pending = []
         if spec["train"]:
-            eng.run_backward()
+            if self._world() > 1:
+                # data parallel: ~32 MB buckets of the flat gradient are all-reduced (RCCL, its own stream) as soon as the
+                # backward ops that finalise them are enqueued, overlapping the rest of the backward program
+                import torch.distributed as dist
+                import os
+                bucket = int(float(os.environ.get("SSDE_GRAD_BUCKET_MB", "32")) * 262144)
+                eng.run_backward_bucketed(
+                    lambda lo, hi: self._pending.append(dist.all_reduce(self.flat.grad[lo:hi], async_op=True)), bucket)
+            else:
+                eng.run_backward()
         return self.loss
 
     def optimizer_step(self, optimizer, ema, step, hyper):
         import torch.distributed as dist
-        if self._world() > 1:
-            dist.all_reduce(self.flat.grad)          # gradients were pre-scaled by 1/world in the loss head
+        if self._world() > 1:                        # gradients were pre-scaled by 1/world in the loss head
+            if getattr(self, "_pending", None):
+                for work in self._pending:           # bucketed all-reduces started during the backward program
+                    work.wait()
+                self._pending = []
+            else:
+                dist.all_reduce(self.flat.grad)
         group = optimizer.param_groups[0]
         lr = hyper["lr"]
         if hyper["warmup"] > 0:

@@ -48,6 +48,7 @@ def _one_step(state, step_fn, optimize_fn, batch, t, z):
 
 def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ["SSDE_GRAD_BUCKET_MB"] = "0.05"       # ~13k floats: the small test model splits into many buckets
     from score_sde_pytorch_amd import parallel
     parallel.init_from_env(backend="gloo")
     assert parallel.world_size() == world
@@ -79,3 +80,34 @@ def test_two_rank_gradient_allreduce_matches_full_batch(tmp_path):
     scale = float(g_full.abs().max())
     assert float((r0["g_sum"] - g_full).abs().max()) / scale < 2e-5
     assert float((r0["params"] - params).abs().max()) / float(params.abs().max()) < 1e-5
+
+
+def test_gradient_buckets_are_final_when_announced():
+    """TrainEngine.run_backward_bucketed: at the moment a bucket is announced (the point where its all-reduce is issued)
+    the slice already holds its final value, the buckets tile the flat buffer from its end to its start, and the segmented
+    run equals the one-shot backward."""
+    from score_sde_pytorch_amd import backward as B
+    from score_sde_pytorch_amd.models import utils as mutils
+    cfg = _util.small_config("ncsnpp", image_size=16, ch_mult=(1, 2), attn=(8,))
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    _util.load_seeded(model, seed=1)
+    g = torch.Generator().manual_seed(1)
+    x, sig, gout = torch.randn(2, 3, 16, 16, generator=g), torch.tensor([0.7, 3.0]), torch.randn(2, 3, 16, 16, generator=g)
+    with emu.emulated():
+        eng = B.TrainEngine(model, 2, 16, 16, torch.device("cpu"), dropout=False)
+        eng.forward_train(x, sig)
+        eng.backward(gout)
+        ref = eng.flat.grad.clone()
+        buckets = eng.grad_buckets(10000)
+        assert len(buckets) > 3 and buckets[0][1] == eng.flat.numel and buckets[-1][0] == 0
+        assert all(a[0] == b[1] for a, b in zip(buckets[:-1], buckets[1:]))            # contiguous, end -> start
+        assert all(a[2] <= b[2] for a, b in zip(buckets[:-1], buckets[1:]))            # announced in program order
+        eng.forward_train(x, sig)
+        eng.gout.tensor[: gout.numel()].copy_(gout.reshape(-1))
+        seen = []
+        eng.run_backward_bucketed(lambda lo, hi: seen.append((lo, hi, eng.flat.grad[lo:hi].clone())), 10000)
+        assert [(lo, hi) for lo, hi, _ in seen] == [(lo, hi) for lo, hi, _ in buckets]
+        for lo, hi, snap in seen:
+            assert torch.equal(snap, ref[lo:hi]), (lo, hi)
+        assert torch.equal(eng.flat.grad, ref)
