@@ -515,30 +515,48 @@ __global__ __launch_bounds__(256) void pack_conv3_kernel(const ssde_pack_desc* _
   }
 }
 
-// Winograd: U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], stored as conv_wino.hip's LDS image
+// Winograd: U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], stored as conv_wino.hip's LDS image.
+// One thread = one (cout, channel pair): it reads the two 3x3 filters once (the first version was one thread per OUTPUT
+// element: every filter was re-read 16 times with a 9 KB lane stride and the kernel ran at 0.9 ms per training step)
+// and writes the pair's 16 positions as float2 -- consecutive lanes = consecutive couts = 512-byte runs.
 __global__ __launch_bounds__(256) void pack_wino3_kernel(const ssde_pack_desc* __restrict__ table) {
   const ssde_pack_desc d = table[blockIdx.y];
   const int ntl = (d.cout_l + 63) / 64;
   const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < (size_t)d.n; idx += (size_t)gridDim.x * 256) {
-    const int e = (int)(idx & 1);
-    const int cs = (int)((idx >> 1) & 63);
-    const int q = (int)((idx >> 7) & 3);
-    const int pos = (int)((idx >> 9) & 15);
-    const size_t r = idx >> 13;
+  const size_t items = (size_t)d.n >> 5;                  // 16 positions x 2 channels per item
+  for (size_t it = (size_t)blockIdx.x * 256 + threadIdx.x; it < items; it += (size_t)gridDim.x * 256) {
+    const int cs = (int)(it & 63);
+    const int q = (int)((it >> 6) & 3);
+    const size_t r = it >> 8;
     const int nt = (int)(r % ntl), c8 = (int)(r / ntl);
     const int co = nt * 64 + (cs ^ ((q & 1) << 4));
-    const int ci = c8 * 8 + 2 * q + e;
-    const int pa = pos >> 2, pb = pos & 3;
-    float u = 0.f;
+    float u[2][16];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      float t = 0.f;
+    for (int e = 0; e < 2; ++e) {
+      const int ci = c8 * 8 + 2 * q + e;
+      float w[3][3];
 #pragma unroll
-      for (int l = 0; l < 3; ++l) t += pack_w3(d, co, ci, k, l) * G[pb][l];
-      u += G[pa][k] * t;
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int l = 0; l < 3; ++l) w[k][l] = pack_w3(d, co, ci, k, l);
+#pragma unroll
+      for (int pa = 0; pa < 4; ++pa)
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+          float acc = 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            float t = 0.f;
+#pragma unroll
+            for (int l = 0; l < 3; ++l) t += w[k][l] * G[pb][l];
+            acc += G[pa][k] * t;
+          }
+          u[e][pa * 4 + pb] = acc;
+        }
     }
-    d.dst[idx] = u;
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos)
+      *reinterpret_cast<float2*>(d.dst + ((((r * 16 + pos) * 4 + q) * 64 + cs) << 1)) = make_float2(u[0][pos], u[1][pos]);
   }
 }
 
