@@ -54,6 +54,8 @@ static inline bool ssde_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 // an LDS write, and hipcc then puts s_waitcnt vmcnt(0) in front of the next ds_read of ANY LDS address -- the issuing
 // wave sat out the whole copy latency before its first MFMA.  The asm form is opaque: ordering is the caller's job
 // (the data is visible to other waves after the issuer's SSDE_WAIT_VMCNT + a workgroup barrier).
+// M0 is written without a clobber (hipcc rejects "m0" as reserved): on gfx9+ nothing else in these kernels uses M0 (LDS
+// instructions need no M0 initialisation; no s_movrel / s_sendmsg / LDS-direct), checked in the ISA of conv_wino.hip.
 #ifndef SSDE_GLDS16_OFF
 #define SSDE_GLDS16_OFF(gptr, lds_wave_base, imm)                                                                        \
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%2"                               \
