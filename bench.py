@@ -51,8 +51,9 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--dump-ops", type=str, default="")
     ap.add_argument("--no-train", action="store_true", help="skip the DSM training-step measurement")
-    ap.add_argument("--workload", default="cifar10", choices=["cifar10", "ffhq256"],
-                    help="cifar10 = BASELINE configs[1] (the headline line); ffhq256 = configs[3] (NCSN++ 256x256, N=2000, batch 16/GPU)")
+    ap.add_argument("--workload", default="cifar10", choices=["cifar10", "ffhq256", "subvp_ode"],
+                    help="cifar10 = BASELINE configs[1] (the headline line); ffhq256 = configs[3] (NCSN++ 256x256, N=2000, batch "
+                         "16/GPU); subvp_ode = configs[4] (DDPM++ sub-VP, probability-flow ODE sampler with RK45; 1 step = 1 solve)")
     ap.add_argument("--train-batch", type=int, default=128)
     ap.add_argument("--train-steps", type=int, default=0, help="timed training steps (0: same as --steps, capped at 10)")
     ap.add_argument("--dump-train-ops", type=str, default="")
@@ -137,6 +138,57 @@ def bench_train(args, cfg, dev, dist, world, rank, sync_all):
     return out
 
 
+def bench_ode(args, dev, dist, world, rank):
+    """BASELINE configs[4]: CIFAR-10 DDPM++ sub-VP, probability-flow ODE sampler (sampling.py:414-485: RK45, rtol = atol =
+    1e-5, eps 1e-3) on the device-resident integrator.  One step = one full solve of a batch; the number of function
+    evaluations is adaptive and is reported (random-init weights of the architecture: the NFE of a trained net differs)."""
+    import _util
+    from score_sde_pytorch_amd import sde_lib, sampling
+    from score_sde_pytorch_amd.models import utils as mutils
+    cfg = _util.cfgs.get_config("subvp/cifar10_ddpmpp_continuous")
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    _util.load_seeded(model, seed=1)
+    model = model.to(dev).eval()
+    B, R = args.batch, cfg.data.image_size
+    sde = sde_lib.subVPSDE(beta_min=cfg.model.beta_min, beta_max=cfg.model.beta_max, N=cfg.model.num_scales)
+    sampler = sampling.get_ode_sampler(sde, (B, 3, R, R), lambda v: v, denoise=cfg.sampling.noise_removal, rtol=1e-5, atol=1e-5,
+                                       method="RK45", eps=1e-3, device=dev)
+    torch.manual_seed(1234 + rank)
+    steps, warm = max(1, min(args.steps, 3)), max(1, min(args.warmup, 1))
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+    for _ in range(warm):
+        sampler(model, z=sde.prior_sampling((B, 3, R, R)).to(dev))
+    sync_all()
+    t0 = time.perf_counter()
+    nfes = []
+    for _ in range(steps):
+        x, nfe = sampler(model, z=sde.prior_sampling((B, 3, R, R)).to(dev))
+        nfes.append(int(nfe))
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    out = {"metric": "ode_sampler_images_per_sec", "value": world * B * steps / dt, "unit": "images/s", "n_gpus": world, "steps": steps,
+           "warmup": warm, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 (f64 integrator state)", "data": "synthetic",
+           "config": {"workload": "configs/subvp/cifar10_ddpmpp_continuous probability-flow ODE sampler (RK45 rtol=atol=1e-5, eps=1e-3), "
+                                  "batch %d/GPU, 32x32; 1 step = 1 solve" % B,
+                      "batch_per_gpu": B, "nfe_per_solve": nfes, "state_finite": bool(torch.isfinite(x).all()),
+                      "ms_per_nfe": dt / max(sum(nfes), 1) * 1e3, "parallelism": "replicas x%d (no collectives)" % world}}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,6 +210,8 @@ def main():
     from score_sde_pytorch_amd import sde_lib, sampling, engine as E
     from score_sde_pytorch_amd.models import utils as mutils
 
+    if args.workload == "subvp_ode":
+        return bench_ode(args, dev, dist, world, rank)
     if args.workload == "ffhq256":
         cfg = _util.cfgs.get_config("ve/ffhq_256_ncsnpp_continuous")
         if args.batch == 256:
