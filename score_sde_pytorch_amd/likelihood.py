@@ -3,30 +3,29 @@ likelihood.py:26-113: `get_div_fn`, `get_likelihood_fn`, same arguments and retu
 
 The drift and its vector-Jacobian product run on the HIP forward / backward programs through the autograd bridge
 (autograd.py).  Only d drift / d x is needed, so the parameters are frozen for the duration of a call: the backward
-program is then lowered without its weight-gradient kernels (backward.TrainEngine(param_grads=False)).  With
-method='RK45' on GPU data the integrator is ode.solve_rk45 (scipy's RK45 algorithm, fp64 state resident on the device);
-other methods, or SSDE_HOST_ODE=1, run scipy.integrate.solve_ivp on the host exactly as the reference does.
+program is then lowered without its weight-gradient kernels (backward.TrainEngine(param_grads=False)).
+The augmented state [x (B*D values) | accumulated log-density change (B values)] is one fp64 tensor; with method='RK45'
+on GPU data it is integrated by ode.solve_rk45 (scipy's RK45 algorithm, state resident on the device), otherwise -- or
+with SSDE_HOST_ODE=1 -- by scipy.integrate.solve_ivp on the host, as the reference does (ode.solve_host).
 """
-import os
 import contextlib
+import math
 
-import numpy as np
 import torch
-from scipy import integrate
 
+from . import ode
 from .models import utils as mutils
 
 
 def get_div_fn(fn):
-    """Divergence of `fn` by the Hutchinson-Skilling trace estimator (likelihood.py:26-37)."""
+    """div fn(x, t) estimated as eps^T (d fn / d x) eps (Hutchinson-Skilling, likelihood.py:26-37): one vector-Jacobian
+    product with the probe as the cotangent."""
 
     def div_fn(x, t, eps):
+        xg = x.detach().requires_grad_(True)
         with torch.enable_grad():
-            x.requires_grad_(True)
-            fn_eps = torch.sum(fn(x, t) * eps)
-            grad_fn_eps = torch.autograd.grad(fn_eps, x)[0]
-        x.requires_grad_(False)
-        return torch.sum(grad_fn_eps * eps, dim=tuple(range(1, len(x.shape))))
+            (vjp,) = torch.autograd.grad(fn(xg, t), xg, grad_outputs=eps)
+        return (vjp * eps).flatten(1).sum(dim=1)
 
     return div_fn
 
@@ -43,60 +42,40 @@ def _frozen(model):
             p.requires_grad_(f)
 
 
+def _probe(data, kind):
+    if kind == 'Rademacher':
+        return torch.randint_like(data, low=0, high=2).float() * 2 - 1.
+    if kind == 'Gaussian':
+        return torch.randn_like(data)
+    raise NotImplementedError(f"Hutchinson type {kind} unknown.")
+
+
 def get_likelihood_fn(sde, inverse_scaler, hutchinson_type='Rademacher', rtol=1e-5, atol=1e-5, method='RK45', eps=1e-5):
     """Returns likelihood_fn(model, data) -> (bpd [B], z, nfe)  (likelihood.py:40-113)."""
 
-    def drift_fn(model, x, t):
-        score_fn = mutils.get_score_fn(sde, model, train=False, continuous=True)
-        rsde = sde.reverse(score_fn, probability_flow=True)     # the probability-flow ODE is a special reverse SDE
-        return rsde.sde(x, t)[0]
-
-    def div_fn(model, x, t, noise):
-        return get_div_fn(lambda xx, tt: drift_fn(model, xx, tt))(x, t, noise)
-
     def likelihood_fn(model, data):
+        batch, dims = data.shape[0], data[0].numel()
         with torch.no_grad(), _frozen(model):
-            shape = data.shape
-            if hutchinson_type == 'Gaussian':
-                epsilon = torch.randn_like(data)
-            elif hutchinson_type == 'Rademacher':
-                epsilon = torch.randint_like(data, low=0, high=2).float() * 2 - 1.
-            else:
-                raise NotImplementedError(f"Hutchinson type {hutchinson_type} unknown.")
+            probe = _probe(data, hutchinson_type)
+            score_fn = mutils.get_score_fn(sde, model, train=False, continuous=True)
+            flow = sde.reverse(score_fn, probability_flow=True)          # the probability-flow ODE as a reverse SDE
 
-            def ode_func(t, x):
-                sample = mutils.from_flattened_numpy(x[:-shape[0]], shape).to(data.device).type(torch.float32)
-                vec_t = torch.ones(sample.shape[0], device=sample.device) * t
-                drift = mutils.to_flattened_numpy(drift_fn(model, sample, vec_t))
-                logp_grad = mutils.to_flattened_numpy(div_fn(model, sample, vec_t, epsilon))
-                return np.concatenate([drift, logp_grad], axis=0)
+            def drift(x, t):
+                return flow.sde(x, t)[0]
+            divergence = get_div_fn(drift)
 
-            if method == 'RK45' and data.is_cuda and os.environ.get("SSDE_HOST_ODE", "0") != "1":
-                from . import ode
+            def rhs(t, y):                                                # d/dt [x, delta log p] = [drift, div drift]
+                x = y[: batch * dims].reshape(data.shape).to(torch.float32)
+                vec_t = torch.full((batch,), float(t), device=x.device)
+                return torch.cat([drift(x, vec_t).reshape(-1), divergence(x, vec_t, probe)]).to(torch.float64)
 
-                def dev_func(t, y):
-                    sample = y[:-shape[0]].reshape(shape).to(torch.float32)
-                    vec_t = torch.ones(shape[0], device=sample.device) * t
-                    drift = drift_fn(model, sample, vec_t).reshape(-1)
-                    logp_grad = div_fn(model, sample, vec_t, epsilon).reshape(-1)
-                    return torch.cat([drift, logp_grad]).to(torch.float64)
-                init = torch.cat([data.reshape(-1).to(torch.float64), torch.zeros(shape[0], dtype=torch.float64, device=data.device)])
-                yT, nfe = ode.solve_rk45(dev_func, (eps, sde.T), init, rtol=rtol, atol=atol)
-                z = yT[:-shape[0]].reshape(shape).to(torch.float32)
-                delta_logp = yT[-shape[0]:].to(torch.float32)
-            else:
-                init = np.concatenate([mutils.to_flattened_numpy(data), np.zeros((shape[0],))], axis=0)
-                solution = integrate.solve_ivp(ode_func, (eps, sde.T), init, rtol=rtol, atol=atol, method=method)
-                nfe = solution.nfev
-                zp = solution.y[:, -1]
-                z = mutils.from_flattened_numpy(zp[:-shape[0]], shape).to(data.device).type(torch.float32)
-                delta_logp = mutils.from_flattened_numpy(zp[-shape[0]:], (shape[0],)).to(data.device).type(torch.float32)
-            prior_logp = sde.prior_logp(z)
-            bpd = -(prior_logp + delta_logp) / np.log(2)
-            N = np.prod(shape[1:])
-            bpd = bpd / N
-            offset = 7. - inverse_scaler(-1.)       # the reference's conversion of log-likelihoods to bits/dim
-            bpd = bpd + offset
+            y0 = torch.cat([data.reshape(-1), data.new_zeros(batch)]).to(torch.float64)
+            y1, nfe = ode.integrate_ode(rhs, (eps, sde.T), y0, rtol, atol, method)
+            z = y1[: batch * dims].reshape(data.shape).to(torch.float32)
+            delta_logp = y1[batch * dims:].to(torch.float32)
+            nats = -(sde.prior_logp(z) + delta_logp)
+            # bits per dimension, shifted for the [0, 255] pixel scale of the data (the reference's offset, likelihood.py:107-111)
+            bpd = nats / (math.log(2.) * dims) + (7. - inverse_scaler(-1.))
             return bpd, z, nfe
 
     return likelihood_fn

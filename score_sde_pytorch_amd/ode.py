@@ -86,3 +86,28 @@ def solve_rk45(fun, t_span, y0, rtol=1e-5, atol=1e-5):
             rejected = True
         t, y, f = t_new, y_new, f_new
     return y, nfev
+
+
+def solve_host(fun, t_span, y0, rtol=1e-5, atol=1e-5, method="RK45"):
+    """The reference's integrator, scipy.integrate.solve_ivp on the host, around the same tensor right-hand side as
+    solve_rk45: `fun(t, y)` takes / returns an fp64 tensor on y0's device; every evaluation crosses to numpy and back
+    (what models/utils.py:181-188 does in the reference).  Used for methods other than RK45 and with SSDE_HOST_ODE=1."""
+    import numpy as np
+    from scipy import integrate
+    dev = y0.device
+
+    def rhs(t, y_np):
+        y = torch.from_numpy(np.ascontiguousarray(y_np)).to(dev)
+        return fun(float(t), y).detach().to("cpu", torch.float64).numpy()
+    sol = integrate.solve_ivp(rhs, (float(t_span[0]), float(t_span[1])), y0.detach().to("cpu", torch.float64).numpy().reshape(-1),
+                              rtol=rtol, atol=atol, method=method)
+    return torch.from_numpy(sol.y[:, -1].copy()).to(dev), int(sol.nfev)
+
+
+def integrate_ode(fun, t_span, y0, rtol, atol, method):
+    """Device RK45 when the state lives on the GPU and nothing asks for the host path, else scipy on the host."""
+    import os
+    if method == "RK45" and y0.is_cuda and os.environ.get("SSDE_HOST_ODE", "0") != "1":
+        return solve_rk45(fun, t_span, y0, rtol=rtol, atol=atol)
+    return solve_host(fun, t_span, y0, rtol=rtol, atol=atol, method=method)
+

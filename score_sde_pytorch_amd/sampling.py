@@ -21,11 +21,10 @@ import functools
 
 import numpy as np
 import torch
-from scipy import integrate
 
 from . import sde_lib
 from .models import utils as mutils
-from .models.utils import from_flattened_numpy, to_flattened_numpy, get_score_fn
+from .models.utils import get_score_fn
 
 _CORRECTORS = {}
 _PREDICTORS = {}
@@ -324,26 +323,15 @@ def get_ode_sampler(sde, shape, inverse_scaler, denoise=False, rtol=1e-5, atol=1
         return sde.reverse(score_fn, probability_flow=True).sde(x, t)[0]
 
     def ode_sampler(model, z=None):
+        from . import ode
         with torch.no_grad():
             x = sde.prior_sampling(shape).to(device) if z is None else z
 
-            def ode_func(t, flat):
-                xt = from_flattened_numpy(flat, shape).to(device).type(torch.float32)
-                vec_t = torch.ones(shape[0], device=xt.device) * t
-                return to_flattened_numpy(drift_fn(model, xt, vec_t))
-
-            import os
-            if method == 'RK45' and x.is_cuda and os.environ.get("SSDE_HOST_ODE", "0") != "1":
-                from . import ode
-
-                def dev_func(t, y):
-                    vec_t = torch.ones(shape[0], device=y.device) * t
-                    return drift_fn(model, y.to(torch.float32), vec_t).to(torch.float64)
-                y, nfev = ode.solve_rk45(dev_func, (sde.T, eps), x, rtol=rtol, atol=atol)
-                x = y.to(torch.float32)
-            else:
-                sol = integrate.solve_ivp(ode_func, (sde.T, eps), to_flattened_numpy(x), rtol=rtol, atol=atol, method=method)
-                x, nfev = torch.tensor(sol.y[:, -1]).reshape(shape).to(device).type(torch.float32), sol.nfev
+            def rhs(t, y):
+                xt = y.reshape(shape).to(torch.float32)
+                return drift_fn(model, xt, torch.full((shape[0],), float(t), device=xt.device)).reshape(-1).to(torch.float64)
+            y, nfev = ode.integrate_ode(rhs, (sde.T, eps), x.reshape(-1).to(torch.float64), rtol, atol, method)
+            x = y.reshape(shape).to(torch.float32)
             if denoise:
                 x = denoise_update_fn(model, x)
             return inverse_scaler(x), nfev
