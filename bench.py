@@ -15,11 +15,19 @@ Weights: deterministic random init of the full architecture (every tensor re-ran
 data: synthetic prior noise.  fp32 end to end (dtype "f32"), as the reference.
 
 The JSON line also carries
-  roofline     -- the dominant kernel (conv_mfma: every 3x3 / fused 3x3+1x1 convolution launch of one
-                  U-Net evaluation): algorithmic FLOPs / HIP-event time on the launch stream, against
-                  the 157.3 TFLOP/s fp32 MFMA peak;
-  cpu_baseline -- the CPU oracle (a torch-CPU port of the reference path, oracle/) timed on this host
-                  for a bounded sample (rank 0, N=1 only).
+  roofline     -- the dominant kernel class (the 3x3 convolution launches of one U-Net evaluation, HIP events on the
+                  launch stream).  `frac` = EXECUTED matrix FLOP/s over the 157.3 TFLOP/s fp32 MFMA peak: a launch on
+                  the Winograd F(2x2,3x3) kernel executes 1/2.25 of its direct-form FLOPs, so it is counted at that
+                  (this is the matrix-pipe utilisation SQ_VALU_MFMA_BUSY_CYCLES shows in profiles/);
+                  `frac_algorithmic` = direct-form FLOP/s over the same peak (can exceed 1).  `by_class` adds the
+                  fraction of every other kernel class against ITS roofline: 1x1 GEMMs and attention against the
+                  MFMA peak, GroupNorm statistics / FIR resampling / PC-update kernels against 8 TB/s HBM with the
+                  algorithmic bytes of the op list;
+  cpu_baseline -- the CPU oracle (a torch-CPU port of the reference path, oracle/) timed on this host for a bounded
+                  sample (rank 0, N=1 only): K PC iterations at the config batch, and a DSM training step;
+  extra        -- compact results of the other BASELINE configs measured in the same run: `ffhq256` (configs[3]),
+                  `subvp_ode` (configs[4]); `train` (configs[2]) is a top-level key;
+  rccl_ranks   -- world size confirmed by an actual 1-element all-reduce over RCCL (N > 1).
 """
 import argparse
 import json
@@ -35,6 +43,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_HBM_TBS = 8.0              # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured float4 copy)
+WINOGRAD_FLOP_RATIO = 2.25      # F(2x2,3x3): 16 instead of 36 multiply-adds per 2x2 output tile and (ci, co)
 
 
 def parse():
@@ -47,8 +57,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-batch", type=int, default=256, help="batch of the CPU-oracle sampler sample (config batch)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0: min(64, all))")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="CPU-work budget per baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the compact ffhq256 / subvp_ode measurements")
     ap.add_argument("--dump-ops", type=str, default="")
     ap.add_argument("--no-train", action="store_true", help="skip the DSM training-step measurement")
     ap.add_argument("--workload", default="cifar10", choices=["cifar10", "ffhq256", "subvp_ode"],
@@ -189,6 +201,237 @@ def bench_ode(args, dev, dist, world, rank):
         dist.destroy_process_group()
 
 
+def _sync_factory(dev, dist):
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+    return sync_all
+
+
+def _max_over_ranks(dt, dev, dist):
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def op_bytes(op):
+    """Algorithmic (compulsory) HBM bytes of one HBM-bound op of the program, from its arguments (fp32):
+    GroupNorm statistics = one read of the tensor; FIR = input + output; randn = one write; squared norms = two reads;
+    Langevin / predictor update = 3 reads (x, score, z) + 2 writes (x, x_mean)."""
+    from score_sde_pytorch_amd import _lib as L
+    k = int(op.kind)
+    if k == L.OP_GN_STATS:
+        a = op.u.gn
+        return 4.0 * a.n * a.hw * (a.c0 + a.c1)
+    if k == L.OP_UPFIRDN:
+        a = op.u.fir
+        return 4.0 * a.n * a.c * (a.h_in * a.w_in + a.h_out * a.w_out)
+    if k == L.OP_RANDN:
+        return 4.0 * op.u.randn.numel
+    if k == L.OP_SUMSQ:
+        return 8.0 * op.u.sumsq.n * op.u.sumsq.per
+    if k == L.OP_LANGEVIN:
+        return 20.0 * op.u.langevin.n * op.u.langevin.per
+    if k == L.OP_PREDICTOR:
+        return 20.0 * op.u.predictor.numel
+    return 0.0
+
+
+def conv_bytes(c):
+    """Algorithmic bytes of a convolution launch: input(s) + output + packed weights (+ residual) in fp32."""
+    px_in = c.n * (c.h_in * c.w_in if c.ksize else c.h_out * c.w_out)
+    px_out = c.n * c.h_out * c.w_out
+    cin3, cin1 = c.main.c0 + c.main.c1, c.aux.c0 + c.aux.c1
+    b = 4.0 * (px_in * cin3 + px_out * cin1 + px_out * c.c_out)
+    b += 4.0 * c.c_out * (9 * cin3 + cin1)
+    if c.resid:
+        b += 4.0 * px_out * c.c_out
+    return b
+
+
+def roofline_of(prog, E, L, reps=3):
+    """Per-op HIP-event times of a program -> the roofline object of the bench line."""
+    acc = np.zeros(prog.n)
+    prog.run_timed()
+    for _ in range(reps):
+        acc += np.array(prog.run_timed())
+    ms = acc / reps
+    cls = np.array(prog.classes)
+    fl = np.array(prog.flops)
+    wino = np.array([int(prog.ops[i].kind) == L.OP_CONV and prog.ops[i].u.conv.tile == L.TILE_WINOGRAD for i in range(prog.n)])
+    executed = np.where(wino, fl / WINOGRAD_FLOP_RATIO, fl)
+    nbytes = np.array([op_bytes(prog.ops[i]) for i in range(prog.n)])
+    conv3 = cls == E.FC_CONV3
+    t3 = float(ms[conv3].sum()) * 1e-3
+    achieved_exec = float(executed[conv3].sum()) / t3 / 1e12
+    achieved_alg = float(fl[conv3].sum()) / t3 / 1e12
+    by_class = {}
+    for name, c, bound in [("conv3x3_fused", E.FC_CONV3, "mfma"), ("conv1x1_gemm", E.FC_CONV1, "mfma"), ("attention", E.FC_ATTN, "mfma"),
+                           ("groupnorm_stats", E.FC_GN, "hbm"), ("upfirdn", E.FC_FIR, "hbm"), ("other", E.FC_OTHER, None)]:
+        m = cls == c
+        t = float(ms[m].sum()) * 1e-3
+        row = {"launches": int(m.sum()), "ms": t * 1e3, "gflop": float(fl[m].sum()) / 1e9}
+        if bound == "mfma" and t > 0:
+            row.update(bound="mfma", executed_tflops=float(executed[m].sum()) / t / 1e12,
+                       frac=float(executed[m].sum()) / t / 1e12 / PEAK_FP32_MFMA_TFLOPS)
+        elif bound == "hbm" and t > 0:
+            row.update(bound="hbm", algorithmic_gb=float(nbytes[m].sum()) / 1e9, achieved_tbs=float(nbytes[m].sum()) / t / 1e12,
+                       frac=float(nbytes[m].sum()) / t / 1e12 / PEAK_HBM_TBS)
+        by_class[name] = row
+    # PC-update kernels (rocRAND noise, norms, Langevin and predictor updates): HBM-bound, grouped by op kind
+    upd = np.array([int(prog.ops[i].kind) in (L.OP_RANDN, L.OP_SUMSQ, L.OP_LANGEVIN, L.OP_PREDICTOR) for i in range(prog.n)])
+    if upd.any():
+        t = float(ms[upd].sum()) * 1e-3
+        by_class["pc_update"] = {"launches": int(upd.sum()), "ms": t * 1e3, "bound": "hbm", "algorithmic_gb": float(nbytes[upd].sum()) / 1e9,
+                                 "achieved_tbs": float(nbytes[upd].sum()) / t / 1e12,
+                                 "frac": float(nbytes[upd].sum()) / t / 1e12 / PEAK_HBM_TBS}
+    wl = [i for i in range(prog.n) if wino[i]]
+    alg_bytes_wino = float(np.mean([conv_bytes(prog.ops[i].u.conv) for i in wl])) if wl else None
+    return dict(ms=ms, cls=cls, fl=fl, wino=wino, executed=executed, conv3=conv3, by_class=by_class,
+                achieved_exec=achieved_exec, achieved_alg=achieved_alg, alg_bytes_wino=alg_bytes_wino)
+
+
+def bench_pc(args, cfg_name, B, N, dev, dist, world, rank, steps, warmup, detail):
+    """PC sampler of a VE NCSN++ config: one hipGraph replay per iteration; returns (result dict, engine, model, sd, cfg)."""
+    import _util
+    from score_sde_pytorch_amd import sde_lib, sampling, engine as E, _lib as L
+    from score_sde_pytorch_amd.models import utils as mutils
+    cfg = _util.cfgs.get_config(cfg_name)
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    sd = _util.load_seeded(model, seed=1)
+    model = model.to(dev).eval()
+    R = cfg.data.image_size
+    sde = sde_lib.VESDE(cfg.model.sigma_min, cfg.model.sigma_max, N=N)
+    sampler = sampling.get_pc_sampler(sde, (B, 3, R, R), sampling.get_predictor(cfg.sampling.predictor),
+                                      sampling.get_corrector(cfg.sampling.corrector), lambda v: v, snr=cfg.sampling.snr,
+                                      n_steps=cfg.sampling.n_steps_each, probability_flow=False, continuous=True,
+                                      denoise=True, eps=1e-5, device=dev)
+    torch.manual_seed(1234 + rank)
+    x_T = sde.prior_sampling((B, 3, R, R))
+    sampler(model, x_init=x_T, max_steps=0)     # builds the engine, loads the state, draws this rank's Philox seed word
+    eng = sampler.engine
+    prog = eng.step_program(with_rng=True)
+    use_graph = not args.no_graph
+    sync_all = _sync_factory(dev, dist)
+    eng.run_steps(prog, warmup, use_graph)
+    sync_all()
+    t0 = time.perf_counter()
+    eng.run_steps(prog, steps, use_graph)
+    sync_all()
+    dt = _max_over_ranks(time.perf_counter() - t0, dev, dist)
+    ms_per_step = dt / steps * 1e3
+    res = {"value": world * B / (N * ms_per_step * 1e-3), "unit": "images/s", "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup,
+           "workload": "configs/%s PC sampler (reverse_diffusion+langevin), batch %d/GPU, N=%d, %dx%d; 1 step = 1 PC iteration = "
+                       "2 U-Net evaluations" % (cfg_name, B, N, R, R),
+           "batch_per_gpu": B, "sde_steps": N, "nfe_per_step": eng.nfe_per_step(), "path": eng.last_path,
+           "state_finite": bool(torch.isfinite(eng.x).all()), "unet_gflop_per_image": eng.unet.flops_per_forward() / B / 1e9,
+           "end_to_end_tflops": eng.nfe_per_step() * eng.unet.flops_per_forward() / (ms_per_step * 1e-3) / 1e12,
+           "direct_form_ceiling_images_per_sec": world * B / (N * eng.nfe_per_step() * eng.unet.flops_per_forward() / (PEAK_FP32_MFMA_TFLOPS * 1e12))}
+    if detail and rank == 0 and not args.no_roofline:
+        roof = roofline_of(eng.unet.program, E, L)                 # classes of ONE U-Net evaluation
+        upd = roofline_of(prog, E, L, reps=2)["by_class"].get("pc_update")   # update kernels of one whole PC iteration
+        if upd:
+            roof["by_class"]["pc_update"] = upd
+        res["_roof"] = roof
+    return res, eng, model, sd, cfg
+
+
+def bench_ode_compact(args, dev, dist, world, rank):
+    """BASELINE configs[4] inside the default run: ONE solve of a batch (RK45 rtol = atol = 1e-5, eps 1e-3) after a few warm-up
+    evaluations of the right-hand side (engine lowering, graph of the integrator's stage kernels)."""
+    import _util
+    from score_sde_pytorch_amd import sde_lib, sampling
+    from score_sde_pytorch_amd.models import utils as mutils
+    cfg = _util.cfgs.get_config("subvp/cifar10_ddpmpp_continuous")
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    _util.load_seeded(model, seed=1)
+    model = model.to(dev).eval()
+    B, R = 256, cfg.data.image_size
+    sde = sde_lib.subVPSDE(beta_min=cfg.model.beta_min, beta_max=cfg.model.beta_max, N=cfg.model.num_scales)
+    sampler = sampling.get_ode_sampler(sde, (B, 3, R, R), lambda v: v, denoise=cfg.sampling.noise_removal, rtol=1e-5, atol=1e-5,
+                                       method="RK45", eps=1e-3, device=dev)
+    warm = sampling.get_ode_sampler(sde, (B, 3, R, R), lambda v: v, denoise=False, rtol=1e-1, atol=1e-1, method="RK45", eps=0.9,
+                                    device=dev)
+    torch.manual_seed(1234 + rank)
+    warm(model, z=sde.prior_sampling((B, 3, R, R)).to(dev))
+    sync_all = _sync_factory(dev, dist)
+    sync_all()
+    t0 = time.perf_counter()
+    x, nfe = sampler(model, z=sde.prior_sampling((B, 3, R, R)).to(dev))
+    sync_all()
+    dt = _max_over_ranks(time.perf_counter() - t0, dev, dist)
+    return {"metric": "ode_sampler_images_per_sec", "value": world * B / dt, "unit": "images/s", "solves": 1, "nfe": int(nfe),
+            "ms_per_nfe": dt / max(int(nfe), 1) * 1e3, "seconds_per_solve": dt, "batch_per_gpu": B, "state_finite": bool(torch.isfinite(x).all()),
+            "workload": "configs/subvp/cifar10_ddpmpp_continuous probability-flow ODE sampler (RK45 rtol=atol=1e-5, eps=1e-3), batch %d/GPU; "
+                        "random-init weights (the NFE of a trained network differs)" % B}
+
+
+def cpu_baseline(args, cfg, model, sd, R, N):
+    """The CPU oracle (torch-CPU port of the reference path, the same ATen ops the reference runs on CPU) on this box's host
+    cores: K whole PC iterations at the config batch (up to K=5, bounded by --cpu-seconds), extrapolated to N
+    iterations; and DSM training steps (forward + autograd backward + clip + Adam + EMA) at the largest batch the budget allows."""
+    from oracle import sampler_oracle, unet_oracle
+    total = os.cpu_count() or 1
+    cores = max(1, min(args.cpu_threads or 64, total))
+    torch.set_num_threads(cores)
+    full_sd = {k: v.detach().cpu() for k, v in sd.items()}
+    full_sd["sigmas"] = model.sigmas.cpu()
+    g = torch.Generator().manual_seed(3)
+    kw = dict(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=N)
+
+    def cpu_iters(cb, steps):
+        x0 = torch.randn(cb, 3, R, R, generator=g) * cfg.model.sigma_max
+        nz = torch.randn(steps, 2, cb, 3, R, R, generator=g)
+        t0 = time.perf_counter()
+        sampler_oracle.pc_sample(cfg, full_sd, "vesde", kw, x0, nz, snr=cfg.sampling.snr, eps=1e-5, max_steps=steps)
+        return time.perf_counter() - t0
+    t_probe = cpu_iters(4, 1) / 4                              # warm-up + per-image cost of one iteration
+    cb = int(max(4, min(args.cpu_batch, args.cpu_seconds / max(t_probe, 1e-4))))
+    t1 = cpu_iters(cb, 1)
+    k = int(max(1, min(5, (args.cpu_seconds - t1) // max(t1, 1e-3) + 1)))
+    t_k = t1 if k == 1 else cpu_iters(cb, k)
+    out = {"value": cb / (N / k * t_k), "unit": "images/s", "cores": cores, "host_cores_total": total, "kind": "port",
+           "sample": "K=%d PC iteration(s) (%d U-Net evaluations) at batch %d with the torch-CPU oracle (oracle/sampler_oracle.py) "
+                     "on %d of %d host threads: %.2f s; extrapolated img/s = B / ((N/K) * t_K) with N=%d"
+                     % (k, 2 * k, cb, cores, total, t_k, N)}
+    # ---- DSM training step on the CPU: oracle forward under autograd, reference optimizer sequence (losses.py:41-50)
+    sd_req = {n: (v.clone().requires_grad_() if (v.dtype == torch.float32 and n != "sigmas") else v) for n, v in full_sd.items()}
+    params = [v for v in sd_req.values() if torch.is_tensor(v) and v.requires_grad]
+    opt = torch.optim.Adam(params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8)
+    ema = [p.detach().clone() for p in params]
+
+    def train_step(tb):
+        batch = torch.rand(tb, 3, R, R, generator=g)
+        t = torch.rand(tb, generator=g) * (1 - 1e-5) + 1e-5
+        z = torch.randn(tb, 3, R, R, generator=g)
+        t0 = time.perf_counter()
+        std = cfg.model.sigma_min * (cfg.model.sigma_max / cfg.model.sigma_min) ** t
+        score = unet_oracle.ncsnpp_forward(cfg, sd_req, batch + std[:, None, None, None] * z, std)
+        loss = torch.mean(0.5 * torch.sum((score * std[:, None, None, None] + z).reshape(tb, -1) ** 2, dim=-1))
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        with torch.no_grad():
+            for e, p in zip(ema, params):
+                e.sub_(0.001 * (e - p))
+        return time.perf_counter() - t0
+    t_probe = train_step(4) / 4
+    tb = int(max(4, min(128, (args.cpu_seconds / 4) / max(t_probe, 1e-4))))
+    n_timed = 3 if t_probe * tb * 4 <= 2 * args.cpu_seconds else 1      # BASELINE.md 3: 1 warm-up + 3 timed; 1 on a slow host
+    ts = [train_step(tb) for _ in range(1 + n_timed)][1:]
+    out["train"] = {"value": float(np.mean(ts)) * 128.0 / tb, "unit": "s/step at batch 128 (linear in batch)", "measured_s_per_step": float(np.mean(ts)),
+                    "measured_batch": tb, "cores": cores,
+                    "sample": "1 warm-up + %d timed DSM steps (oracle forward, torch autograd backward, clip + Adam + EMA) at batch %d" % (n_timed, tb)}
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -201,120 +444,80 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)                          # an actual collective over RCCL: every rank contributes 1
+        rccl_ranks = int(round(float(one.item())))
+        assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, world)
 
     import _util
-    from score_sde_pytorch_amd import sde_lib, sampling, engine as E
-    from score_sde_pytorch_amd.models import utils as mutils
+    from score_sde_pytorch_amd import engine as E, _lib as L
 
     if args.workload == "subvp_ode":
         return bench_ode(args, dev, dist, world, rank)
     if args.workload == "ffhq256":
-        cfg = _util.cfgs.get_config("ve/ffhq_256_ncsnpp_continuous")
+        cfg_name = "ve/ffhq_256_ncsnpp_continuous"
         if args.batch == 256:
             args.batch = 16
         if args.sde_steps == 1000:
             args.sde_steps = 2000
-        args.no_train = args.no_cpu_baseline = True
+        args.no_train = args.no_cpu_baseline = args.no_extras = True
     else:
-        cfg = _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous")
-    torch.manual_seed(0)
-    model = mutils.get_model("ncsnpp")(cfg)
-    sd = _util.load_seeded(model, seed=1)
-    model = model.to(dev).eval()
+        cfg_name = "ve/cifar10_ncsnpp_continuous"
+    sync_all = _sync_factory(dev, dist)
+    res, eng, model, sd, cfg = bench_pc(args, cfg_name, args.batch, args.sde_steps, dev, dist, world, rank, args.steps, args.warmup, True)
     B, R = args.batch, cfg.data.image_size
-    sde = sde_lib.VESDE(cfg.model.sigma_min, cfg.model.sigma_max, N=args.sde_steps)
-    sampler = sampling.get_pc_sampler(sde, (B, 3, R, R), sampling.get_predictor(cfg.sampling.predictor),
-                                      sampling.get_corrector(cfg.sampling.corrector), lambda v: v, snr=cfg.sampling.snr,
-                                      n_steps=cfg.sampling.n_steps_each, probability_flow=False, continuous=True,
-                                      denoise=True, eps=1e-5, device=dev)
-    torch.manual_seed(1234 + rank)
-    x_T = sde.prior_sampling((B, 3, R, R))
-    sampler(model, x_init=x_T, max_steps=0, seed=rank)     # builds the engine, loads the state
-    eng = sampler.engine
-    prog = eng.step_program(with_rng=True, seed=rank)
-    use_graph = not args.no_graph
-
-    def sync_all():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    eng.run_steps(prog, args.warmup, use_graph)
-    sync_all()
-    t0 = time.perf_counter()
-    eng.run_steps(prog, args.steps, use_graph)
-    sync_all()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = dt / args.steps * 1e3
-    finite = bool(torch.isfinite(eng.x).all())
-    images_per_sec = world * B / (args.sde_steps * ms_per_step * 1e-3)
-
+    roof = res.pop("_roof", None)
     out = {
-        "metric": "pc_sampler_images_per_sec", "value": images_per_sec, "unit": "images/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "metric": "pc_sampler_images_per_sec", "value": res["value"], "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs/ve/%s PC sampler (reverse_diffusion+langevin), "
-                               "batch %d/GPU, N=%d, %dx%d; 1 step = 1 PC iteration = 2 U-Net evaluations"
-                               % ("ffhq_256_ncsnpp_continuous" if args.workload == "ffhq256" else "cifar10_ncsnpp_continuous",
-                                  B, args.sde_steps, R, R),
-                   "batch_per_gpu": B, "sde_steps": args.sde_steps, "nfe_per_step": eng.nfe_per_step(),
-                   "path": eng.last_path, "state_finite": finite,
-                   "unet_gflop_per_image": eng.unet.flops_per_forward() / B / 1e9,
+        "rccl_ranks": rccl_ranks,
+        "config": {"workload": res["workload"], "batch_per_gpu": B, "sde_steps": args.sde_steps, "nfe_per_step": res["nfe_per_step"],
+                   "path": res["path"], "state_finite": res["state_finite"], "unet_gflop_per_image": res["unet_gflop_per_image"],
+                   "end_to_end_tflops": res["end_to_end_tflops"],
+                   "direct_form_ceiling_images_per_sec": res["direct_form_ceiling_images_per_sec"],
                    "parallelism": "replicas x%d (no collectives)" % world},
     }
 
-    if rank == 0 and not args.no_roofline:
-        # dominant kernel = conv_mfma launches of one U-Net evaluation, HIP events on the launch stream
-        up = eng.unet.program
-        reps = 3
-        acc = np.zeros(up.n)
-        up.run_timed()
-        for _ in range(reps):
-            acc += np.array(up.run_timed())
-        ms = acc / reps
-        cls = np.array(up.classes)
-        fl = np.array(up.flops)
-        conv3 = cls == E.FC_CONV3
-        t_conv3 = float(ms[conv3].sum()) * 1e-3
-        achieved = float(fl[conv3].sum()) / t_conv3 / 1e12
-        by_class = {}
-        for name, c in [("conv3x3_fused", E.FC_CONV3), ("conv1x1_gemm", E.FC_CONV1), ("attention", E.FC_ATTN),
-                        ("groupnorm_stats", E.FC_GN), ("upfirdn", E.FC_FIR), ("other", E.FC_OTHER)]:
-            m = cls == c
-            by_class[name] = {"launches": int(m.sum()), "ms": float(ms[m].sum()), "gflop": float(fl[m].sum()) / 1e9}
+    if roof is not None:
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure is the
-        # per-launch average of the committed rocprofv3 passes over this same command (tools/profile_gpu.sh ->
-        # profiles/*_profile_summary.json: (2*FETCH_SIZE + WRITE_SIZE) * 1024, MI355X_MICROARCH.md HBM section)
-        traffic, mfma_busy = None, None
+        # per-launch average of the committed rocprofv3 passes over THIS command with --no-train (tools/profile_gpu.sh ->
+        # profiles/*_profile_summary.json: (2*FETCH_SIZE + WRITE_SIZE) * 1024, MI355X_MICROARCH.md HBM section), next to the
+        # algorithmic bytes (inputs + output + weights + residual) of the same launches
+        traffic = mfma_busy = None
         try:
             import glob
             summ = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_profile_summary.json")))[-1]
             with open(summ) as f:
                 prof = json.load(f)
             traffic = prof["hbm_traffic"]["conv_wino_kernel"]["hbm_bytes_per_launch"]
+            m = prof.get("mfma", {}).get("conv_wino_kernel", {})
+            if m.get("SQ_VALU_MFMA_BUSY_CYCLES") and m.get("GRBM_GUI_ACTIVE"):
+                mfma_busy = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * m["GRBM_GUI_ACTIVE"])
             out["config"]["pmc_source"] = os.path.basename(summ)
         except Exception:
             pass
-        wino = os.environ.get("SSDE_WINOGRAD", "1") != "0"
-        out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                           "kernel": ("conv_wino_kernel (Winograd F(2x2,3x3), fp32 MFMA) + conv_mfma_kernel for the layers it does not "
-                                      "take: the %d 3x3 launches of one U-Net evaluation" if wino else
-                                      "conv_mfma_kernel (direct 3x3): the %d 3x3 launches of one U-Net evaluation") % int(conv3.sum()),
-                           "note": "achieved = algorithmic (direct-form) FLOPs / HIP-event time; Winograd executes 2.25x fewer "
-                                   "MFMA FLOPs than that, so frac is against the direct-form fp32 peak and can exceed the "
-                                   "matrix-pipe utilisation (SQ_VALU_MFMA_BUSY_CYCLES in profiles/)",
-                           "unet_eval_ms_eager_events": float(ms.sum()), "by_class": by_class}
+        n3 = int(roof["conv3"].sum())
+        n3w = int((roof["conv3"] & roof["wino"]).sum())
+        out["roofline"] = {
+            "bound": "mfma", "achieved": roof["achieved_exec"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": roof["achieved_exec"] / PEAK_FP32_MFMA_TFLOPS,
+            "achieved_algorithmic": roof["achieved_alg"], "frac_algorithmic": roof["achieved_alg"] / PEAK_FP32_MFMA_TFLOPS,
+            "traffic": traffic, "traffic_algorithmic": roof["alg_bytes_wino"], "mfma_busy_pmc": mfma_busy,
+            "kernel": "the %d 3x3 convolution launches of one U-Net evaluation: %d on conv_wino_kernel (Winograd F(2x2,3x3), fp32 MFMA), "
+                      "%d on conv_mfma_kernel (direct)" % (n3, n3w, n3 - n3w),
+            "note": "achieved = EXECUTED matrix FLOPs (Winograd launches at 1/2.25 of their direct-form FLOPs) / HIP-event time of "
+                    "those launches; achieved_algorithmic = direct-form FLOPs / the same time; traffic(_algorithmic) = bytes per "
+                    "conv_wino_kernel launch (PMC / op list)",
+            "unet_eval_ms_eager_events": float(roof["ms"].sum()),
+            "by_class": roof["by_class"]}
         if args.dump_ops:
+            up, ms, cls, fl = eng.unet.program, roof["ms"], roof["cls"], roof["fl"]
             rows = []
             for i in range(up.n):
                 op = up.ops[i]
@@ -322,44 +525,31 @@ def main():
                 if op.kind == 1:
                     c = op.u.conv
                     row.update(h=c.h_out, w=c.w_out, cout=c.c_out, cin=c.main.c0 + c.main.c1, caux=c.aux.c0 + c.aux.c1,
-                               ks=c.ksize, stride=c.stride, pro=c.main.pro_mode)
+                               ks=c.ksize, stride=c.stride, pro=c.main.pro_mode, tile=c.tile)
                     row["tflops"] = row["gflop"] / max(row["ms"], 1e-9)
                 rows.append(row)
             with open(args.dump_ops, "w") as f:
                 json.dump(rows, f)
-        out["config"]["end_to_end_tflops"] = eng.nfe_per_step() * eng.unet.flops_per_forward() / (ms_per_step * 1e-3) / 1e12
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import sampler_oracle
-        # bounded sample: oneDNN scales badly past a few dozen threads on small convolutions (a 256-thread run
-        # of this sample took minutes), so the port is timed on a fixed, stated number of host threads
-        cores = max(1, min(args.cpu_threads, os.cpu_count()))
-        torch.set_num_threads(cores)
-        full_sd = {k: v.cpu() for k, v in sd.items()}
-        full_sd["sigmas"] = model.sigmas.cpu()
-        g = torch.Generator().manual_seed(3)
-        kw = dict(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=args.sde_steps)
+        out["cpu_baseline"] = cpu_baseline(args, cfg, model, sd, R, args.sde_steps)
 
-        def cpu_iter(cb, steps):
-            x0 = torch.randn(cb, 3, R, R, generator=g) * cfg.model.sigma_max
-            nz = torch.randn(steps, 2, cb, 3, R, R, generator=g)
-            t0 = time.perf_counter()
-            sampler_oracle.pc_sample(cfg, full_sd, "vesde", kw, x0, nz, snr=cfg.sampling.snr, eps=1e-5, max_steps=steps)
-            return (time.perf_counter() - t0) / steps
-        t_probe = cpu_iter(2, 1)                       # warm-up + per-image cost probe
-        cb = int(max(2, min(args.cpu_batch, 20.0 / max(t_probe / 2, 1e-3))))
-        t_cpu = cpu_iter(cb, 1)
-        out["cpu_baseline"] = {"value": cb / (args.sde_steps * t_cpu), "unit": "images/s", "cores": cores, "kind": "port",
-                               "sample": "1 PC iteration (2 U-Net evaluations) at batch %d with the torch-CPU oracle "
-                                         "(oracle/sampler_oracle.py) on %d threads, extrapolated to N=%d: %.2f s per iteration"
-                                         % (cb, cores, args.sde_steps, t_cpu)}
-
+    del eng, model
+    torch.cuda.empty_cache()
     if not args.no_train:
         # second headline quantity of BASELINE.json's metric ("... + sec/train-step"): reported inside the same JSON line
-        del sampler, eng, prog
-        torch.cuda.empty_cache()
         tr = bench_train(args, _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous"), dev, dist, world, rank, sync_all)
         out["train"] = tr
+        torch.cuda.empty_cache()
+    if not args.no_extras:
+        # the other BASELINE configs, compact, so that the driver's default run witnesses them
+        extra = {}
+        r3, e3, m3, _, _ = bench_pc(args, "ve/ffhq_256_ncsnpp_continuous", 16, 2000, dev, dist, world, rank, min(args.steps, 5), 2, False)
+        extra["ffhq256"] = r3
+        del e3, m3
+        torch.cuda.empty_cache()
+        extra["subvp_ode"] = bench_ode_compact(args, dev, dist, world, rank)
+        out["extra"] = extra
 
     if rank == 0:
         print(json.dumps(out))

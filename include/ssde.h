@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SSDE_ABI_VERSION 2
+#define SSDE_ABI_VERSION 3
 
 /* ---- prologue applied to a source tensor while it is staged into LDS ---- */
 enum {
@@ -171,6 +171,8 @@ typedef struct ssde_sumsq_args {  /* out_a[n] = sum(a[n,:]^2), out_b likewise */
 } ssde_sumsq_args;
 typedef struct ssde_randn_args {  /* Philox4x32-10 (rocRAND device API) standard normals */
   float* dst; int64_t numel; uint64_t seed; const int32_t* step_ptr; int32_t stream_id; int32_t _pad0;
+  const uint64_t* seed_ptr;  /* optional device word ADDED to `seed` at run time: one captured graph serves every seed
+                                (the reference draws fresh torch.randn_like noise on every call, sampling.py:197,275) */
 } ssde_randn_args;
 typedef struct ssde_langevin_args {
   /* step = (snr * mean_n(||z||) / mean_n(||g||))^2 * 2 * alpha ; x_mean = x + step*g ; x = x_mean + sqrt(2*step)*z */

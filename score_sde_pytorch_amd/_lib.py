@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libssde_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_SILU = 0, 1, 2, 3
 TILE_AUTO, TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32, TILE_WINOGRAD = 0, 1, 2, 3, 4, 5
@@ -83,7 +83,7 @@ class SumsqArgs(C.Structure):
 
 class RandnArgs(C.Structure):
     _fields_ = [("dst", _fp), ("numel", C.c_int64), ("seed", C.c_uint64), ("step_ptr", _fp),
-                ("stream_id", C.c_int32), ("_pad0", C.c_int32)]
+                ("stream_id", C.c_int32), ("_pad0", C.c_int32), ("seed_ptr", _fp)]
 
 
 class LangevinArgs(C.Structure):

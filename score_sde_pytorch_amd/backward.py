@@ -112,7 +112,24 @@ class FlatParams:
     def grad_run(self, params):
         o = self.index[id(params[0])][0]
         n = sum(self.index[id(p)][1] for p in params)
+        # remembered for TrainEngine.grad_buckets: a kernel handed this pointer writes n floats, not one parameter
+        runs = self.__dict__.setdefault("runs", {})
+        runs[o] = max(runs.get(o, 0), n)
         return self.grad[o:o + n]
+
+    def write_extent(self, off):
+        """Floats a backward op holding a pointer at float offset `off` of the gradient buffer may write: the recorded
+        multi-parameter run starting there, else the rest of the parameter containing `off`."""
+        n = self.__dict__.get("runs", {}).get(off, 0)
+        if getattr(self, "_starts", None) is None:
+            self._starts = sorted((o, ln) for o, ln in self.index.values())
+        import bisect
+        i = bisect.bisect_right(self._starts, (off, float("inf"))) - 1
+        if i >= 0:
+            o, ln = self._starts[i]
+            if off < o + ln:
+                n = max(n, o + ln - off)
+        return max(n, 1)
 
     def attach_grads(self):
         """Expose the flat gradient buffer through `p.grad` (views, no copies)."""
@@ -424,8 +441,9 @@ class TrainEngine(E.UNetEngine):
         """[(lo, hi, op_end)] from the END of the flat gradient buffer to its start: the slice [lo, hi) is final once the
         backward ops before index `op_end` have run.  The backward walks the network in reverse while the flat buffer
         is laid out in forward order, so the tail of the buffer completes first; `op_end` is found by scanning every
-        pointer field of every backward op for addresses inside the flat gradient (a slice is final after the LAST op
-        that holds a pointer at or beyond its start -- conservative for ops that write runs of several parameters)."""
+        pointer field of every backward op for addresses inside the flat gradient; a slice is final after the LAST op
+        whose write extent (FlatParams.write_extent: its parameter, or the multi-parameter run it was handed) reaches
+        at or beyond the slice's start -- an op whose pointer lies below `lo` but whose run crosses it counts too."""
         if getattr(self, "_buckets", None) is not None and self._buckets[0] == bucket_floats:
             return self._buckets[1]
         import ctypes as C
@@ -465,7 +483,7 @@ class TrainEngine(E.UNetEngine):
             bounds.append((0, hi))
         buckets = []
         for lo, hi_ in bounds:
-            last = max([i for off, i in touch if off >= lo], default=self.n_fwd - 1)
+            last = max([i for off, i in touch if off + self.flat.write_extent(off) > lo], default=self.n_fwd - 1)
             buckets.append((lo, hi_, last + 1))
         self._buckets = (bucket_floats, buckets)
         return buckets

@@ -84,7 +84,7 @@ def get_pc_inpainter(sde, predictor, corrector, inverse_scaler, snr, n_steps=1, 
     run = _controlled_pc(sde, predictor, corrector, inverse_scaler, snr, n_steps, probability_flow, continuous, denoise,
                          eps, ident, ident, dict(M=None, invM=None))
 
-    def pc_inpainter(model, data, mask, prior=None, noises=None, seed=0, use_graph=True, max_steps=None):
+    def pc_inpainter(model, data, mask, prior=None, noises=None, seed=None, use_graph=True, max_steps=None):
         with torch.no_grad():
             prior = sde.prior_sampling(data.shape) if prior is None else prior
             x = data * mask + prior.to(data.device) * (1. - mask)                       # :74
@@ -116,7 +116,7 @@ def get_pc_colorizer(sde, predictor, corrector, inverse_scaler, snr, n_steps=1, 
     run = _controlled_pc(sde, predictor, corrector, inverse_scaler, snr, n_steps, probability_flow, continuous, denoise,
                          eps, decouple, couple, dict(M=M.flatten().tolist(), invM=invM.flatten().tolist()))
 
-    def pc_colorizer(model, gray_scale_img, prior=None, noises=None, seed=0, use_graph=True, max_steps=None):
+    def pc_colorizer(model, gray_scale_img, prior=None, noises=None, seed=None, use_graph=True, max_steps=None):
         with torch.no_grad():
             shape = gray_scale_img.shape
             mask = get_mask(gray_scale_img)

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
 }
 
 template <typename K>
-int set_lds_once(K kfn, int bytes, bool* done) {
+int set_lds_once(K kfn, int bytes, std::atomic<bool>* done) {   // idempotent: a lost race only sets the attribute twice
   if (!*done) {
     SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     *done = true;
@@ -384,7 +384,7 @@ extern "C" int ssde_attention(const ssde_attn_args* a, void* stream) {
   SSDE_REQUIRE(a->n > 0 && a->l > 0 && a->l <= kLMax, "attention: token count %d outside 1..%d", a->l, kLMax);
   SSDE_REQUIRE(a->c > 0 && a->c % 32 == 0, "attention: channels must be a multiple of 32 (got %d)", a->c);
   const int lds = kAttnLdsFloats * 4;
-  static bool attr_set = false;   // set once, outside any stream capture
+  static std::atomic<bool> attr_set{false};   // set once, outside any stream capture
   if (int rc = set_lds_once(attn_kernel, lds, &attr_set)) return rc;
   hipLaunchKernelGGL(attn_kernel, dim3(ssde_cdiv(a->l, kQB), a->n), dim3(256), lds, static_cast<hipStream_t>(stream),
                      a->qkv, a->dst, a->n, a->l, a->c, a->scale);
@@ -397,7 +397,7 @@ extern "C" int ssde_attention_bwd(const ssde_attn_bwd_args* a, void* stream) {
   SSDE_REQUIRE(a->n > 0 && a->l > 0 && a->l <= kLMax, "attention_bwd: token count %d outside 1..%d", a->l, kLMax);
   SSDE_REQUIRE(a->c > 0 && a->c % 32 == 0, "attention_bwd: channels must be a multiple of 32 (got %d)", a->c);
   const int lds = kBwdLdsFloats * 4;
-  static bool set_q = false, set_kv = false;
+  static std::atomic<bool> set_q{false}, set_kv{false};
   if (int rc = set_lds_once(attn_bwd_q_kernel, lds, &set_q)) return rc;
   if (int rc = set_lds_once(attn_bwd_kv_kernel, lds, &set_kv)) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -237,7 +237,7 @@ int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
   const int lds_ops = 2 * kStage * 4, lds_epi = 64 * (BN + 4) * 4;
   const int lds = lds_ops > lds_epi ? lds_ops : lds_epi;
   if (lds_out) { *lds_out = lds; return SSDE_OK; }
-  static bool attr_set = false;   // once, before any stream capture
+  static std::atomic<bool> attr_set{false};   // once, before any stream capture
   if (!attr_set) {
     SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm1x1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm1x1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

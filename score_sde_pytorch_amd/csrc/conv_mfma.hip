@@ -419,7 +419,7 @@ int launch_cfg(const ConvPlan& pl, hipStream_t st) {
 #define SSDE_CONV_LAUNCH(H3, H1)                                                                     \
   do {                                                                                               \
     auto kfn = conv_mfma_kernel<WM, WN, TM, TN, H3, H1>;                                             \
-    static bool attr_set = false; /* once per instantiation, before any stream capture */            \
+    static std::atomic<bool> attr_set{false}; /* once per instantiation, before any stream capture */            \
     if (!attr_set) {                                                                                 \
       SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                         \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));   \

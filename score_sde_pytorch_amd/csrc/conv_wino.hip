@@ -440,7 +440,7 @@ int ssde_conv_wino_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
   SSDE_REQUIRE(halo_px * 2 <= kMaxRaw * kStagers, "conv(winograd): halo of %d pixels exceeds the staging plan", halo_px);
   const int lds = (4 * kStageFloats + 4 * halo_px * 2) * 4;
   if (lds_out) { *lds_out = lds; return SSDE_OK; }
-  static bool attr_set = false;   // once, before any stream capture
+  static std::atomic<bool> attr_set{false};   // once, before any stream capture
   if (!attr_set) {
     SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -108,7 +108,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ a,
 // ---- standard-normal noise, Philox4x32-10 through rocRAND's device API ----------------
 // (the reference draws torch.randn_like on the device, sampling.py:197,275)
 __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ dst, size_t numel, unsigned long long seed,
-                                                    const int* __restrict__ step_ptr, int stream_id) {
+                                                    const int* __restrict__ step_ptr, int stream_id,
+                                                    const unsigned long long* __restrict__ seed_ptr) {
+  if (seed_ptr) seed += *seed_ptr;
   const unsigned long long step = step_ptr ? (unsigned long long)(*step_ptr) : 0ull;
   const unsigned long long gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   rocrand_state_philox4x32_10 st;
@@ -303,7 +305,8 @@ extern "C" int ssde_randn(const ssde_randn_args* a, void* stream) {
   SSDE_REQUIRE(a && a->dst && a->numel > 0, "randn: bad args");
   SSDE_REQUIRE(a->stream_id >= 0 && a->stream_id < 16, "randn: stream_id must be in 0..15");
   hipLaunchKernelGGL(randn_kernel, dim3(grid_for((size_t)a->numel / 4, 256, 1024)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), a->dst, (size_t)a->numel, (unsigned long long)a->seed, a->step_ptr, a->stream_id);
+                     static_cast<hipStream_t>(stream), a->dst, (size_t)a->numel, (unsigned long long)a->seed, a->step_ptr, a->stream_id,
+                     reinterpret_cast<const unsigned long long*>(a->seed_ptr));
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;
 }

@@ -249,7 +249,7 @@ template <int KS, int CO_B, int CI_B>
 int launch(const WgParams& p, int lds_bytes, hipStream_t st) {
   constexpr int BCO = 2 * CO_B * 32, BCI = 2 * CI_B * 32;
   auto kfn = wgrad_kernel<KS, CO_B, CI_B>;
-  static bool attr_set = false;   // once per instantiation, before any stream capture
+  static std::atomic<bool> attr_set{false};   // once per instantiation, before any stream capture
   if (!attr_set) {
     SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;

@@ -420,7 +420,7 @@ int ssde_wgrad_wino_launch(const ssde_wgrad_args* a, void* stream) {
   }
   SSDE_REQUIRE(a->scratch, "wgrad(winograd): scratch missing");
   constexpr int lds = (4 * kStageFloats + kRawX + kRawG) * 4;
-  static bool attr_set = false;   // once, before any stream capture
+  static std::atomic<bool> attr_set{false};   // once, before any stream capture
   if (!attr_set) {
     SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

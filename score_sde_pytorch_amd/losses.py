@@ -184,7 +184,11 @@ class FusedTrainStep:
         self.losses = torch.zeros(n, **f32)
         self.loss = torch.zeros(1, **f32)
         self.hyper = torch.zeros(12, **f32)
-        self.hyper_host = torch.zeros(12, dtype=torch.float32, pin_memory=torch.cuda.is_available())
+        # ring of pinned staging buffers for the per-step scalars: the H2D copy is asynchronous and nothing else in the
+        # step synchronises the host, so a slot is rewritten only after the copy that last read it has completed
+        self._hyper_ring = [[torch.zeros(12, dtype=torch.float32, pin_memory=torch.cuda.is_available()), None]
+                            for _ in range(4)]
+        self._hyper_slot = 0
         self.gnorm = torch.zeros(1, **f32)
         self.partial = torch.zeros(1024, **f32)
         self._opt_prog = None
@@ -266,7 +270,7 @@ class FusedTrainStep:
         self.perturb_inputs(batch, t, z)
         eng = self.eng
         eng.weights.refresh()
-        eng.set_dropout_seed(self.steps_done * 7919 + 17 if seed is None else seed)
+        eng.set_dropout_seed(self._dropout_seed() if seed is None else seed)
         self._head[0].run()
         eng.run_forward()
         self._head[1].run()
@@ -283,6 +287,16 @@ class FusedTrainStep:
             else:
                 eng.run_backward()
         return self.loss
+
+    def _dropout_seed(self):
+        """Mask stream of this step: torch's seed (torch.manual_seed), the data-parallel rank and a per-call counter
+        that a resumed run continues from `state['step']` (the reference's dropout draws from torch's generator, so
+        replicas and resumed runs never replay the same masks)."""
+        import torch.distributed as dist
+        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        count = self.steps_done + int(getattr(self, "step_offset", 0))
+        word = (int(torch.initial_seed()) * 1000003 + rank * 7919 + 17) & 0xFFFFFFFFFFFF
+        return (word * 2654435761 + count * 40503) & 0x7FFFFFFF
 
     def optimizer_step(self, optimizer, ema, step, hyper):
         import torch.distributed as dist
@@ -305,11 +319,18 @@ class FusedTrainStep:
         t_adam = float(st0["step"]) + 1.0
         b1, b2 = group["betas"]
         decay = ema.next_decay() if ema is not None else 1.0
-        h = self.hyper_host
+        slot = self._hyper_ring[self._hyper_slot % len(self._hyper_ring)]
+        self._hyper_slot += 1
+        if slot[1] is not None:
+            slot[1].synchronize()
+        h = slot[0]
         h[0], h[1], h[2], h[3], h[4] = lr, b1, b2, group["eps"], group["weight_decay"]
         h[5] = hyper["grad_clip"]
         h[6], h[7], h[8] = 1.0 - b1 ** t_adam, float(np.sqrt(1.0 - b2 ** t_adam)), 1.0 - decay
         self.hyper.copy_(h, non_blocking=True)
+        if self.hyper.is_cuda:
+            slot[1] = torch.cuda.Event()
+            slot[1].record()
         self._optimizer_program(optimizer, ema).run()
         for p in self.flat.params:
             optimizer.state[p]["step"] += 1
@@ -362,6 +383,7 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
         if batch.is_cuda and _fused_candidate(state, loss_fn, optimize_fn, train):
             fs = fused_for(state, batch)
             if train:
+                fs.step_offset = int(state['step']) - fs.steps_done      # a restored checkpoint continues its mask stream
                 loss = fs.loss_and_grads(batch).clone()
                 fs.optimizer_step(state['optimizer'], state['ema'], state['step'], optimize_fn.ssde_hyper)
                 state['step'] += 1

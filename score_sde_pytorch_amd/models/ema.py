@@ -9,6 +9,13 @@ advances the counter when told the device already did the arithmetic.
 import torch
 
 
+def _touch(param):
+    """A parameter that is a view of a flat buffer (backward.FlatParams) also advances that buffer's generation."""
+    flat = getattr(param, "_ssde_flat", None)
+    if flat is not None:
+        flat.touch()
+
+
 class ExponentialMovingAverage:
     def __init__(self, parameters, decay, use_num_updates=True):
         if decay < 0.0 or decay > 1.0:
@@ -55,9 +62,13 @@ class ExponentialMovingAverage:
             flat.touch()
             return
         parameters = [p for p in parameters if p.requires_grad]
-        for s_param, param in zip(self.shadow_params, parameters):
-            if param.requires_grad:
-                param.data.copy_(s_param.data)
+        # `param.copy_` (not `param.data.copy_`) bumps Tensor._version: engine.WeightStore.refresh keys the re-pack of
+        # its kernel-layout weight copies on it, so an engine / captured sampler graph lowered before the swap sees it
+        with torch.no_grad():
+            for s_param, param in zip(self.shadow_params, parameters):
+                if param.requires_grad:
+                    param.copy_(s_param.data)
+                    _touch(param)
 
     def store(self, parameters):
         flat, parameters = self._flat_home(parameters)
@@ -74,8 +85,10 @@ class ExponentialMovingAverage:
             flat.data.copy_(self._stored_flat)
             flat.touch()
             return
-        for c_param, param in zip(self.collected_params, parameters):
-            param.data.copy_(c_param.data)
+        with torch.no_grad():
+            for c_param, param in zip(self.collected_params, parameters):
+                param.copy_(c_param.data)
+                _touch(param)
 
     def state_dict(self):
         return dict(decay=self.decay, num_updates=self.num_updates, shadow_params=self.shadow_params)

@@ -43,9 +43,15 @@ def broadcast_parameters(model, src=0):
     flat = getattr(model, "_flat_params", None)
     if flat is not None and flat.owns(model):
         dist.broadcast(flat.data, src=src)
+        flat.touch()            # out-of-band write: packed weight copies (engine.WeightStore) must be rebuilt
     else:
-        for p in model.parameters():
-            dist.broadcast(p.data, src=src)
+        with torch.no_grad():
+            for p in model.parameters():
+                buf = p.detach().clone()
+                dist.broadcast(buf, src=src)
+                p.copy_(buf)    # bumps Tensor._version, which WeightStore.refresh watches
+                if getattr(p, "_ssde_flat", None) is not None:
+                    p._ssde_flat.touch()
     for b in model.buffers():
         dist.broadcast(b.data, src=src)
 

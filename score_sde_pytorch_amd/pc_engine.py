@@ -134,6 +134,8 @@ class FusedPCSampler:
         self.gss = torch.zeros(B, device=device)
         self.zss = torch.zeros(B, device=device)
         self.step = torch.zeros(1, dtype=torch.int32, device=device)
+        # Philox seed word read by every RANDN op at run time: a fresh value per call, ONE program / captured graph
+        self.seed_word = torch.zeros(1, dtype=torch.int64, device=device)
         self.snr, self.B, self.per = float(snr), B, per
         # projection: None, or dict(M=[9 floats] | None, invM=...) -- the inpainting / colorization data-consistency step
         self.projection = projection
@@ -150,7 +152,7 @@ class FusedPCSampler:
         self._stream = None
 
     # -------------------------------------------------------------- program assembly
-    def _assemble(self, with_rng, seed):
+    def _assemble(self, with_rng):
         unet_ops = [self.unet.program.ops[i] for i in range(self.unet.program.n)]
         unet_cls, unet_fl = list(self.unet.program.classes), list(self.unet.program.flops)
         ops, classes, flops = [], [], []
@@ -168,7 +170,7 @@ class FusedPCSampler:
             if pj is None:
                 return
             if with_rng:
-                emit(L.OP_RANDN, L.RandnArgs, dst=noise, numel=self.B * self.per, seed=seed, step_ptr=self.step, stream_id=stream_id)
+                emit(L.OP_RANDN, L.RandnArgs, dst=noise, numel=self.B * self.per, seed=0, seed_ptr=self.seed_word, step_ptr=self.step, stream_id=stream_id)
             Cc = self.shape[1]
             emit(L.OP_PROJECT, L.ProjectArgs, x=self.x, x_mean=self.x_mean, data=self.proj_data, mask=self.proj_mask, noise=noise,
                  coef=self.tabs["proj"], step_ptr=self.step, n=self.B, c=Cc, hw=self.per // Cc,
@@ -188,7 +190,7 @@ class FusedPCSampler:
             for k in range(self.n_steps):
                 emit_unet()
                 if with_rng:
-                    emit(L.OP_RANDN, L.RandnArgs, dst=self.z_c, numel=self.B * self.per, seed=seed, step_ptr=self.step, stream_id=k)
+                    emit(L.OP_RANDN, L.RandnArgs, dst=self.z_c, numel=self.B * self.per, seed=0, seed_ptr=self.seed_word, step_ptr=self.step, stream_id=k)
                 if self.plan["corrector"] == "langevin":
                     emit(L.OP_SUMSQ, L.SumsqArgs, a=score, b=self.z_c, out_a=self.gss, out_b=self.zss, n=self.B, per=self.per)
                 emit(L.OP_LANGEVIN, L.LangevinArgs, x=self.x, x_mean=self.x_mean, grad=score, noise=self.z_c,
@@ -198,18 +200,27 @@ class FusedPCSampler:
         if self.plan["predictor"] != "none":
             emit_unet()
             if with_rng:
-                emit(L.OP_RANDN, L.RandnArgs, dst=self.z_p, numel=self.B * self.per, seed=seed, step_ptr=self.step, stream_id=8)
+                emit(L.OP_RANDN, L.RandnArgs, dst=self.z_p, numel=self.B * self.per, seed=0, seed_ptr=self.seed_word, step_ptr=self.step, stream_id=8)
             emit(L.OP_PREDICTOR, L.PredictorArgs, x=self.x, x_mean=self.x_mean, score=score, noise=self.z_p,
                  coef=self.tabs["coef"], step_ptr=self.step, numel=self.B * self.per)
         emit_projection(self.z_pp if self.projection is not None else None, 10)
         emit(L.OP_STEP_INC, L.StepIncArgs, step_ptr=self.step, delta=1)
         return E.Program(L.op_array(ops), classes, flops, self)
 
-    def step_program(self, with_rng=True, seed=0):
-        key = (with_rng, seed)
-        if key not in self._programs:
-            self._programs[key] = self._assemble(with_rng, seed)
-        return self._programs[key]
+    def step_program(self, with_rng=True):
+        if with_rng not in self._programs:
+            self._programs[with_rng] = self._assemble(with_rng)
+        return self._programs[with_rng]
+
+    def set_seed(self, seed=None):
+        """seed=None: a fresh 62-bit word from torch's default generator, i.e. new noise on every call exactly like the
+        reference's torch.randn_like (sampling.py:197,275), reproducible under torch.manual_seed and different across ranks
+        that seed differently; an explicit integer pins the noise (tests).  Returns the value used."""
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        self.seed_word.fill_(int(seed))
+        self.last_seed = int(seed)
+        return self.last_seed
 
     def nfe_per_step(self):
         return (self.n_steps if self.plan["corrector"] != "none" else 0) + (1 if self.plan["predictor"] != "none" else 0)
@@ -225,7 +236,7 @@ class FusedPCSampler:
         self.x_mean.copy_(self.x)
         self.step.zero_()
 
-    def run(self, x, noises=None, seed=0, use_graph=True, max_steps=None):
+    def run(self, x, noises=None, seed=None, use_graph=True, max_steps=None):
         """Run the loop from state `x`; returns (x, x_mean) clones shaped like `shape`."""
         self.unet.weights.refresh()
         self.reset(x)
@@ -242,7 +253,8 @@ class FusedPCSampler:
                 prog.run()
             self.last_path = "fused-eager"
         else:
-            prog = self.step_program(with_rng=True, seed=int(seed))
+            prog = self.step_program(with_rng=True)
+            self.set_seed(seed)
             self.run_steps(prog, steps, use_graph)
         return self.x.clone().view(self.shape), self.x_mean.clone().view(self.shape)
 

@@ -264,7 +264,7 @@ def get_pc_sampler(sde, shape, predictor, corrector, inverse_scaler, snr, n_step
                                             continuous=continuous, snr=snr, n_steps=n_steps)
     fused_cache = {}
 
-    def pc_sampler(model, x_init=None, noises=None, seed=0, use_graph=True, max_steps=None):
+    def pc_sampler(model, x_init=None, noises=None, seed=None, use_graph=True, max_steps=None):
         from . import pc_engine
         with torch.no_grad():
             x = (sde.prior_sampling(shape) if x_init is None else x_init).to(device)

@@ -468,78 +468,80 @@ def check_input_gradient_only(dev):
     assert rel_err(eng.gx_view(), gx_ref) < TOL_GRAD
 
 
-def check_likelihood(dev):
-    """likelihood.get_likelihood_fn on a small sub-VP DDPM++ net: bits/dim, latent and NFE against the same
-    algorithm driven by the CPU oracle's score (torch autograd for the divergence)."""
-    from scipy import integrate
+def _ode_case_model(dev):
     from score_sde_pytorch_amd.models import utils as mutils
-    from score_sde_pytorch_amd import likelihood, sde_lib
-    from oracle import unet_oracle
+    from score_sde_pytorch_amd import sde_lib
     cfg = small_cfg("ddpmpp")
     torch.manual_seed(0)
     model = mutils.get_model("ncsnpp")(cfg)
-    sd = {k: v.clone() for k, v in _util.load_seeded(model, seed=1).items()}
-    sd["sigmas"] = model.sigmas.clone()
+    _util.load_seeded(model, seed=1)
     model = model.to(dev).eval()
-    sde = sde_lib.subVPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales)
-    g = torch.Generator().manual_seed(5)
-    data = torch.rand(2, 3, 16, 16, generator=g) * 2 - 1
-    inv = lambda v: (v + 1.) / 2.  # noqa: E731
-    # the Hutchinson probe is drawn with torch.randint_like on the data's device (likelihood.py:76): inject one
-    # CPU-generated probe into both runs (device RNG streams differ)
+    return cfg, model, sde_lib.subVPSDE(**_util.ODE_CASE["sde_kwargs"])
+
+
+def check_likelihood(dev):
+    """likelihood.get_likelihood_fn against the REFERENCE's likelihood.get_likelihood_fn output stored in
+    tests/golden/ode_small.npz (oracle/gen_golden_ode.py ran /root/reference/likelihood.py:69-111 on the same
+    network, data and Hutchinson probe; sub-VP, RK45 rtol = atol = 1e-5, eps = 1e-5 -- BASELINE config #5's settings).
+
+    Tolerances, and why: the integration is adaptive over ~330 accepted steps through a random-weight network, so it
+    amplifies the per-evaluation fp32 difference between the HIP U-Net and the CPU one (<= 1e-4, typically 1e-5).  The
+    fixture records the amplification measured on the reference itself: scaling the input by (1 + 1e-6) moves bpd by
+    1.3e-5 and the latent by 1.3e-3 relative (`lik_sens_*`), i.e. x13 and x1300.  Hence: one right-hand-side
+    evaluation 1e-4; bpd 1e-3 relative; latent 5e-2 relative; NFE within 3 % (an accept/reject decision can flip)."""
+    from score_sde_pytorch_amd.models import utils as mutils
+    from score_sde_pytorch_amd import likelihood
+    gold = np.load(os.path.join(_util.GOLDEN, "ode_small.npz"))
+    case = _util.ODE_CASE
+    cfg, model, sde = _ode_case_model(dev)
+    _, data, epsilon = _util.ode_case_inputs()
+    inv = _util.ode_inverse_scaler
     shape = data.shape
-    epsilon = torch.randint(0, 2, shape, generator=g).float() * 2 - 1.
+    # the probe is drawn with torch.randint_like on the data's device (likelihood.py:76): inject the fixture's
     real = torch.randint_like
     torch.randint_like = lambda t, low=0, high=2, **kw: ((epsilon + 1.) / 2.).to(t.device)
     try:
-        bpd, z, nfe = likelihood.get_likelihood_fn(sde, inv, rtol=1e-3, atol=1e-3)(model, data.to(dev))
+        bpd, z, nfe = likelihood.get_likelihood_fn(sde, inv, rtol=case["rtol"], atol=case["atol"], eps=case["lik_eps"])(
+            model, data.to(dev))
     finally:
         torch.randint_like = real
-
-    def score(x, t):
-        std = sde.marginal_prob(torch.zeros_like(x), t)[1]
-        return -unet_oracle.ncsnpp_forward(cfg, sd, x, t * 999) / std[:, None, None, None]
-
-    def drift(x, t):
-        return sde.reverse(score, probability_flow=True).sde(x, t)[0]
-
-    def ode_func(t, y):
-        x = torch.from_numpy(y[:-2].reshape(shape)).float()
-        vt = torch.ones(2) * t
-        with torch.enable_grad():
-            x.requires_grad_(True)
-            d = drift(x, vt)
-            gfe = torch.autograd.grad(torch.sum(d * epsilon), x)[0]
-        div = torch.sum(gfe * epsilon, dim=(1, 2, 3))
-        return np.concatenate([d.detach().numpy().reshape(-1), div.numpy().reshape(-1)])
-    # (a) one evaluation of the ODE right-hand side (drift and Hutchinson divergence) at a fixed point
-    t_probe = 0.37
-    with torch.no_grad():
-        rhs_ref = ode_func(t_probe, np.concatenate([data.numpy().reshape(-1), np.zeros(2)]))
-    lk = likelihood.get_div_fn(lambda xx, tt: sde.reverse(mutils.get_score_fn(sde, model, train=False, continuous=True),
-                                                          probability_flow=True).sde(xx, tt)[0])
+    # (a) one evaluation of the augmented right-hand side at a fixed point (reference closures likelihood.py:26-37,59-67)
+    drift_fn = lambda xx, tt: sde.reverse(mutils.get_score_fn(sde, model, train=False, continuous=True),     # noqa: E731
+                                          probability_flow=True).sde(xx, tt)[0]
     with torch.no_grad(), likelihood._frozen(model):
         xd = data.to(dev).clone()
-        vt = torch.ones(2, device=dev) * t_probe
-        div = lk(xd, vt, epsilon.to(dev))
-        dr = sde.reverse(mutils.get_score_fn(sde, model, train=False, continuous=True), probability_flow=True).sde(xd, vt)[0]
-    assert rel_err(dr.reshape(-1), torch.from_numpy(rhs_ref[:-2])) < 1e-4
-    # the estimate eps^T J eps is a sum of 768 terms of mixed sign: compare on the scale of ||J eps|| ||eps||
+        vt = torch.ones(shape[0], device=dev) * case["t_probe"]
+        div = likelihood.get_div_fn(drift_fn)(xd, vt, epsilon.to(dev))
+        dr = drift_fn(xd, vt)
+    assert rel_err(dr, torch.from_numpy(gold["rhs_drift"])) < 1e-4
+    # eps^T J eps is a sum of 768 terms of mixed sign: compare on the scale of the number of terms
     scale = float(np.prod(shape[1:]))
-    assert float((div.cpu() - torch.from_numpy(rhs_ref[-2:]).float()).abs().max()) / scale < 1e-4, (div, rhs_ref[-2:])
-    # (b) the whole integration: adaptive steps through a random-weight network amplify fp32 rounding, so the end values
-    # are compared loosely
-    init = np.concatenate([data.numpy().reshape(-1), np.zeros(2)])
-    sol = integrate.solve_ivp(ode_func, (1e-5, sde.T), init, rtol=1e-3, atol=1e-3, method="RK45")
-    zr = torch.from_numpy(sol.y[:-2, -1].reshape(shape)).float()
-    dl = torch.from_numpy(sol.y[-2:, -1]).float()
-    bpd_ref = -(sde.prior_logp(zr) + dl) / np.log(2) / np.prod(shape[1:]) + (7. - inv(-1.))
-    assert abs(nfe - sol.nfev) <= 0.1 * sol.nfev, (nfe, sol.nfev)
-    # (the latent z itself is not compared: a random-weight drift is chaotic over t in [0, 1], the two trajectories
-    # separate by tens of percent from rounding alone, while the on-device integrator matches scipy's host loop on the
-    # SAME model to 2e-3 -- tests/test_sampler_gpu.py)
+    assert float((div.cpu() - torch.from_numpy(gold["rhs_div"])).abs().max()) / scale < 1e-4, (div, gold["rhs_div"])
+    # (b) the whole integration
+    ref_nfe = int(gold["lik_nfe"])
+    assert abs(nfe - ref_nfe) <= 0.03 * ref_nfe, (nfe, ref_nfe)
     assert torch.isfinite(bpd).all() and torch.isfinite(z).all()
-    assert float(((bpd.cpu() - bpd_ref) / bpd_ref).abs().max()) < 2e-2, (bpd, bpd_ref, nfe, sol.nfev)
+    assert rel_err(bpd, torch.from_numpy(gold["lik_bpd"])) < 1e-3, (bpd, gold["lik_bpd"])
+    assert rel_err(z, torch.from_numpy(gold["lik_z"])) < 5e-2
+
+
+def check_ode_sampler(dev, denoise):
+    """sampling.get_ode_sampler against the REFERENCE's get_ode_sampler output in tests/golden/ode_small.npz
+    (/root/reference/sampling.py:449-483 run by oracle/gen_golden_ode.py; sub-VP, RK45 rtol = atol = 1e-5, eps = 1e-3).
+    The reverse-time integration is well conditioned -- the fixture's `ode_sens`: input x (1 + 1e-6) moves the samples
+    by 1.7e-6 -- so the samples must agree to 1e-3 relative (ten times the 1e-4 forward tolerance) and the NFE to within
+    two steps (12 evaluations: an accept/reject decision near error_norm = 1 can flip)."""
+    from score_sde_pytorch_amd import sampling
+    gold = np.load(os.path.join(_util.GOLDEN, "ode_small.npz"))
+    case = _util.ODE_CASE
+    cfg, model, sde = _ode_case_model(dev)
+    z, _, _ = _util.ode_case_inputs()
+    smp = sampling.get_ode_sampler(sde, tuple(z.shape), _util.ode_inverse_scaler, denoise=denoise, rtol=case["rtol"],
+                                   atol=case["atol"], eps=case["sample_eps"], device=dev)
+    x, nfe = smp(model, z=z.to(dev))
+    tag = "ode_denoise" if denoise else "ode"
+    assert abs(nfe - int(gold[tag + "_nfe"])) <= 12, (nfe, int(gold[tag + "_nfe"]))
+    assert rel_err(x, torch.from_numpy(gold[tag + "_samples"])) < 1e-3
 
 
 def check_checkpoint_and_ema_swap(dev, tmp_path):

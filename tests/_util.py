@@ -135,3 +135,23 @@ def controllable_inputs(name, batch, n_steps, size, sigma_max):
     prior = torch.randn(batch, 3, size, size, generator=g) * sigma_max
     noises = torch.randn(n_steps, 4, batch, 3, size, size, generator=g)
     return data, mask, prior, noises
+
+
+# tests/golden/ode_small.npz (oracle/gen_golden_ode.py, from the reference's get_ode_sampler / get_likelihood_fn):
+# BASELINE config #5's path (sub-VP DDPM++, RK45 rtol = atol = 1e-5) on the small DDPM++ network
+ODE_CASE = dict(sde_kwargs=dict(beta_min=0.1, beta_max=20, N=1000), batch=2, size=16, rtol=1e-5, atol=1e-5,
+                sample_eps=1e-3, lik_eps=1e-5, t_probe=0.37)
+
+
+def ode_inverse_scaler(v):
+    return (v + 1.) / 2.
+
+
+def ode_case_inputs():
+    """latent z (ode_sampler's argument), data in [-1, 1) and the Rademacher probe of the likelihood case"""
+    g = torch.Generator().manual_seed(77)
+    B, R = ODE_CASE["batch"], ODE_CASE["size"]
+    z = torch.randn(B, 3, R, R, generator=g)
+    data = torch.rand(B, 3, R, R, generator=g) * 2 - 1
+    epsilon = torch.randint(0, 2, data.shape, generator=g).float() * 2 - 1.
+    return z, data, epsilon

@@ -1,0 +1,152 @@
+"""Parity at the sizes bench.py is quoted on (BASELINE.json configs[1..3]), under the PRODUCTION kernel heuristic
+(SSDE_WINOGRAD=1: the engine picks Winograd / direct / 1x1 kernels by problem size, and at these batches that mix
+differs from the one the small-batch tests exercise):
+
+  configs[1]  CIFAR-10 NCSN++ forward at batch 256, and one whole predictor-corrector iteration at batch 256
+  configs[2]  CIFAR-10 NCSN++ training: all 571 parameter gradients + the input gradient at batch 128
+  configs[3]  FFHQ-256 NCSN++ forward at batch 16
+
+each against the CPU oracle (oracle/unet_oracle.py, sampler_oracle.py -- pinned bit-exactly to the reference by
+tests/golden/, see test_oracle_golden.py).  The network treats samples independently (GroupNorm statistics are
+per sample, attention is per image), so the oracle is evaluated in chunks of the batch to bound host memory; the
+parameter gradient of the batch is the sum of the chunks' gradients.
+
+Tolerances (fp32, max-abs error / max-abs reference): forward 1e-4, PC iteration 2e-4, gradients 2e-4 -- the same as at
+small batch.  Host cost: ~2-3 minutes of CPU oracle in total on the GPU box.
+"""
+import numpy as np
+import pytest
+import torch
+
+import _util
+from _util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _production_heuristic(monkeypatch):
+    monkeypatch.setenv("SSDE_WINOGRAD", "1")
+    n = torch.get_num_threads()
+    torch.set_num_threads(min(64, __import__("os").cpu_count() or 1))    # large oracle batches scale well over cores
+    yield
+    torch.set_num_threads(n)
+
+
+def _model(cfg):
+    from score_sde_pytorch_amd.models import utils as mutils
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    sd = dict(_util.load_seeded(model, seed=1))
+    sd["sigmas"] = model.sigmas.clone()
+    return model.cuda().eval(), sd
+
+
+def _oracle_forward(cfg, sd, x, cond, chunk):
+    from oracle import unet_oracle
+    with torch.no_grad():
+        return torch.cat([unet_oracle.ncsnpp_forward(cfg, sd, x[i:i + chunk], cond[i:i + chunk])
+                          for i in range(0, x.shape[0], chunk)])
+
+
+def _kernel_mix(engine):
+    """how many 3x3 convolutions of the lowered program run on the Winograd kernel / the direct kernel"""
+    from score_sde_pytorch_amd import _lib as L
+    wino = direct = 0
+    for i in range(engine.program.n):
+        op = engine.program.ops[i]
+        if op.kind == L.OP_CONV and op.u.conv.ksize == 3:
+            if op.u.conv.tile == L.TILE_WINOGRAD:
+                wino += 1
+            else:
+                direct += 1
+    return wino, direct
+
+
+def test_cifar_forward_batch256():
+    cfg = _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous")
+    model, sd = _model(cfg)
+    B = 256
+    g = torch.Generator().manual_seed(256)
+    sig = torch.exp(torch.rand(B, generator=g) * (np.log(50.0) - np.log(0.01)) + np.log(0.01)).float()
+    x = torch.rand(B, 3, 32, 32, generator=g) + sig[:, None, None, None] * torch.randn(B, 3, 32, 32, generator=g)
+    with torch.no_grad():
+        y = model(x.cuda(), sig.cuda())
+    ref = _oracle_forward(cfg, sd, x, sig, 64)
+    wino, direct = _kernel_mix(next(iter(model._engines.values())))
+    assert wino >= 40 and direct >= 10, (wino, direct)          # the heuristic mix the bench times (65 / 28 in round 1)
+    assert torch.isfinite(y).all()
+    assert rel_err(y, ref) < 1e-4, rel_err(y, ref)
+    # per-sample: no image may hide behind the batch maximum
+    per = (y.cpu() - ref).reshape(B, -1).abs().max(dim=1)[0] / ref.reshape(B, -1).abs().max(dim=1)[0]
+    assert float(per.max()) < 2e-4, float(per.max())
+
+
+def test_cifar_pc_iteration_batch256():
+    """one corrector + predictor iteration (2 U-Net evaluations, Langevin batch-mean step size over all 256 samples,
+    reverse-diffusion update) with injected noise, at the N=1000 schedule of configs[1]"""
+    from oracle import sampler_oracle
+    from score_sde_pytorch_amd import sde_lib, sampling
+    cfg = _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous")
+    model, sd = _model(cfg)
+    B, N = 256, 1000
+    sde = sde_lib.VESDE(sigma_min=0.01, sigma_max=50, N=N)
+    g = torch.Generator().manual_seed(1000)
+    x_T = torch.randn(B, 3, 32, 32, generator=g) * 50.0
+    noises = torch.randn(1, 2, B, 3, 32, 32, generator=g)
+    sampler = sampling.get_pc_sampler(sde, (B, 3, 32, 32), sampling.ReverseDiffusionPredictor, sampling.LangevinCorrector,
+                                      lambda v: v, snr=0.16, n_steps=1, probability_flow=False, continuous=True,
+                                      denoise=False, eps=1e-5, device="cuda")
+    out, _ = sampler(model, x_init=x_T, noises=noises, max_steps=1)
+    assert sampler.last_path == "fused-eager"
+    ref = sampler_oracle.pc_sample(cfg, sd, "vesde", dict(sigma_min=0.01, sigma_max=50, N=N), x_T, noises, snr=0.16,
+                                   n_steps=1, eps=1e-5, denoise=False, max_steps=1)
+    r = ref["x_steps"][0]
+    mse = float(((out.cpu().double() - r.double()) ** 2).mean())
+    assert mse <= 1e-8 * float(r.abs().max()) ** 2, mse          # north_star's pixel-MSE yardstick
+    assert rel_err(out, r) < 2e-4
+    # score-norm yardstick: ||score|| of the second evaluation, read back from the engine, vs the oracle's
+    s = sampler.engine.unet.output_view()
+    norm = float(torch.norm(s.reshape(B, -1), dim=-1).mean())
+    assert abs(norm - ref["score_norms"][1]) / ref["score_norms"][1] < 1e-4
+
+
+def test_cifar_gradients_batch128():
+    """configs[2]'s per-GPU batch: every parameter gradient and the input gradient vs autograd through the oracle"""
+    import _train_checks as T
+    from score_sde_pytorch_amd import backward as Bk
+    cfg = _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous", dropout=0.0)
+    model, sd = _model(cfg)
+    B, chunk = 128, 16
+    g = torch.Generator().manual_seed(128)
+    x = torch.randn(B, 3, 32, 32, generator=g) * 2
+    cond = torch.exp(torch.rand(B, generator=g) * 4 - 2)
+    gout = torch.randn(B, 3, 32, 32, generator=g)
+    ys, gxs, ref = [], [], None
+    for i in range(0, B, chunk):
+        y_c, gx_c, gr = T.oracle_grads(cfg, sd, x[i:i + chunk], cond[i:i + chunk], gout[i:i + chunk])
+        ys.append(y_c); gxs.append(gx_c)
+        ref = gr if ref is None else {k: ref[k] + v for k, v in gr.items()}
+    eng = Bk.TrainEngine(model, B, 32, 32, torch.device("cuda"), input_grad=True, dropout=False)
+    y = eng.forward_train(x.cuda(), cond.cuda()).clone()
+    assert rel_err(y, torch.cat(ys)) < 1e-4
+    eng.backward(gout.cuda())
+    assert rel_err(eng.gx_view(), torch.cat(gxs)) < T.TOL_GRAD
+    worst = T.compare_param_grads(model, eng.flat, ref)
+    assert worst < T.TOL_GRAD
+
+
+def test_ffhq256_forward_batch16():
+    cfg = _util.cfgs.get_config("ve/ffhq_256_ncsnpp_continuous")
+    model, sd = _model(cfg)
+    B = 16
+    g = torch.Generator().manual_seed(16)
+    sig = torch.exp(torch.rand(B, generator=g) * (np.log(348.0) - np.log(0.01)) + np.log(0.01)).float()
+    x = torch.rand(B, 3, 256, 256, generator=g) + sig[:, None, None, None] * torch.randn(B, 3, 256, 256, generator=g)
+    with torch.no_grad():
+        y = model(x.cuda(), sig.cuda())
+    ref = _oracle_forward(cfg, sd, x, sig, 4)
+    assert torch.isfinite(y).all()
+    assert rel_err(y, ref) < 1e-4, rel_err(y, ref)
+    per = (y.cpu() - ref).reshape(B, -1).abs().max(dim=1)[0] / ref.reshape(B, -1).abs().max(dim=1)[0]
+    assert float(per.max()) < 2e-4, float(per.max())

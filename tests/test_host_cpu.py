@@ -228,3 +228,50 @@ def test_on_device_rk45_reproduces_scipy():
         y, nfev = ode.solve_rk45(lambda t, y: At @ y + math.sin(3 * t) * torch.from_numpy(b), span, torch.from_numpy(y0), 1e-5, 1e-5)
         assert nfev == sol.nfev
         assert float(np.abs(sol.y[:, -1] - y.numpy()).max()) < 1e-12
+
+
+def test_ema_swap_and_restore_invalidate_packed_weights():
+    """ExponentialMovingAverage.copy_to / restore (non-flat path) must be visible to WeightStore.refresh: an engine or
+    captured sampler graph lowered BEFORE the swap keeps packed kernel-layout copies keyed on Tensor._version /
+    the flat buffer's generation (`param.data.copy_` bumps neither)."""
+    from score_sde_pytorch_amd import engine as E
+    from score_sde_pytorch_amd.models import utils as mutils, ema as ema_mod
+    cfg = _util.small_config("ncsnpp")
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    _util.load_seeded(model, seed=1)
+    eng = E.UNetEngine(model, 2, 16, 16, torch.device("cpu"))          # dry lowering: packs weights, runs nothing
+    ema = ema_mod.ExponentialMovingAverage(model.parameters(), decay=0.999)
+    with torch.no_grad():
+        for s in ema.shadow_params:
+            s.mul_(1.25)
+    w = model.all_modules[3].weight                                    # first conv
+    entry = next(e for e in eng.weights.entries if any(src is w for src in e[1]))
+    before = entry[0].clone()
+    ema.store(model.parameters())
+    ema.copy_to(model.parameters())
+    eng.weights.refresh(on_device=False)
+    swapped = entry[0].clone()
+    assert not torch.equal(before, swapped)
+    assert torch.allclose(swapped, before * 1.25)
+    ema.restore(model.parameters())
+    eng.weights.refresh(on_device=False)
+    assert torch.equal(entry[0], before)
+
+
+def test_grad_run_extents_are_recorded():
+    """FlatParams.write_extent: a pointer handed out by grad_run covers the whole multi-parameter run (grad_buckets
+    uses it so that a bucket is not all-reduced before an op writing across its lower boundary has run)."""
+    from score_sde_pytorch_amd import backward as B
+    from score_sde_pytorch_amd.models import utils as mutils
+    cfg = _util.small_config("ncsnpp")
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    flat = B.FlatParams(model, torch.device("cpu"))
+    ws, bs = model.flat_param_groups()
+    run = flat.grad_run(ws)
+    o = flat.index[id(ws[0])][0]
+    assert flat.write_extent(o) == run.numel() == sum(w.numel() for w in ws)
+    o1, n1 = flat.index[id(ws[1])]
+    assert flat.write_extent(o1) == n1                                  # a plain parameter pointer covers that parameter
+    assert flat.write_extent(o1 + 5) == n1 - 5

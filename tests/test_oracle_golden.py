@@ -111,3 +111,23 @@ def test_oracle_upfirdn_edge_cases():
     x = torch.randn(2, 3, 8, 8)
     assert uo.downsample_2d(x, [1, 3, 3, 1]).shape == (2, 3, 4, 4)
     assert torch.allclose(uo.naive_downsample_2d(uo.naive_upsample_2d(x)), x)
+
+
+def test_ode_oracle_reproduces_reference():
+    """probability-flow ODE sampler and one right-hand-side evaluation of the likelihood ODE against the REFERENCE's
+    get_ode_sampler / get_div_fn outputs (tests/golden/ode_small.npz, oracle/gen_golden_ode.py).  The full likelihood
+    integration (2000 evaluations with autograd, ~70 s) is asserted by the generator, not re-run here."""
+    from oracle import ode_oracle
+    gold = np.load(os.path.join(_util.GOLDEN, "ode_small.npz"))
+    case = _util.ODE_CASE
+    cfg = _util.small_config("ddpmpp")
+    sd = _sd_for(cfg)
+    z, data, epsilon = _util.ode_case_inputs()
+    x, nfe = ode_oracle.ode_sample(cfg, sd, "subvpsde", case["sde_kwargs"], z, rtol=case["rtol"], atol=case["atol"],
+                                   eps=case["sample_eps"], denoise=True)
+    assert nfe == int(gold["ode_denoise_nfe"])
+    assert rel_err(_util.ode_inverse_scaler(x), torch.from_numpy(gold["ode_denoise_samples"])) < 1e-5
+    sde = ode_oracle.S.make_sde("subvpsde", **case["sde_kwargs"])
+    d, div = ode_oracle.rhs_augmented(cfg, sd, sde, data, torch.ones(data.shape[0]) * case["t_probe"], epsilon)
+    assert rel_err(d, torch.from_numpy(gold["rhs_drift"])) < 2e-6
+    assert rel_err(div, torch.from_numpy(gold["rhs_div"])) < 1e-4

@@ -111,6 +111,22 @@ def test_graph_replay_equals_eager_and_is_reproducible():
     assert torch.isfinite(a).all()
     assert torch.equal(a, b) and torch.equal(a, c)
     assert not torch.equal(a, d)
+    # one program / one captured graph serves every seed (the seed is a device word, not a baked constant)
+    assert len(sampler.engine._programs) == 1
+
+
+def test_default_noise_is_fresh_per_call_like_randn_like():
+    """Without an explicit seed every call draws new noise, as the reference's torch.randn_like does
+    (sampling.py:197,275); torch.manual_seed makes the sequence of calls reproducible."""
+    cfg, model, sde, sampler = _setup(n_steps_sde=4)
+    x_T, _ = _util.pc_case_inputs(8, 4)
+    torch.manual_seed(5)
+    a, _ = sampler(model, x_init=x_T)
+    b, _ = sampler(model, x_init=x_T)
+    torch.manual_seed(5)
+    a2, _ = sampler(model, x_init=x_T)
+    assert not torch.equal(a, b)
+    assert torch.equal(a, a2)
 
 
 def test_vp_euler_maruyama_fused_matches_oracle():

@@ -81,8 +81,13 @@ def test_input_gradient_only_program():
     T.check_input_gradient_only("cuda")
 
 
-def test_likelihood_bits_per_dim():
+def test_likelihood_matches_reference_fixture():
     T.check_likelihood("cuda")
+
+
+@pytest.mark.parametrize("denoise", [False, True])
+def test_ode_sampler_matches_reference_fixture(denoise):
+    T.check_ode_sampler("cuda", denoise)
 
 
 def test_checkpoint_roundtrip_and_ema_swap(tmp_path):
