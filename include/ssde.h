@@ -87,6 +87,9 @@ typedef struct ssde_conv_args {
   float out_scale;       /* 1 or 1/sqrt(2)                                 */
   int32_t _pad1;
   float* dst;            /* [N, h_out, w_out, c_out]                       */
+  float* gn_part;        /* optional: GroupNorm partial statistics of dst, [N][S][c_out/4][3] = (mean, M2, count) per
+                          * (image, slice, channel quad), written by the epilogue; S = ssde_conv_gn_slices(args) > 0
+                          * (every workgroup tile lies inside one image).  Merged by ssde_gn_finalize. */
 } ssde_conv_args;
 
 enum { SSDE_TILE_AUTO = 0, SSDE_TILE_256x64 = 1, SSDE_TILE_128x64 = 2, SSDE_TILE_64x64 = 3, SSDE_TILE_256x32 = 4,
@@ -106,6 +109,16 @@ typedef struct ssde_gn_stats_args {
   int32_t slices; int32_t _pad0;
 } ssde_gn_stats_args;
 
+/* GroupNorm statistics from the PRODUCERS' partials instead of a pass over the tensor: merges, in a fixed order,
+ * the (mean, M2, count) triples the convolution epilogues wrote (ssde_conv_args.gn_part) over the slices and the
+ * channel quads of every group of a (possibly concatenated) tensor. */
+typedef struct ssde_gn_finalize_args {
+  const float* part0; const float* part1;   /* [N][slices][c/4][3]; part1 NULL when not a concat */
+  int32_t c0, c1, slices0, slices1;
+  int32_t n, groups; float eps; int32_t _pad0;
+  float* mean; float* rstd;                 /* [N, G] */
+} ssde_gn_finalize_args;
+
 /* ---- upfirdn2d (NHWC): zero-insert up, pad, FIR, decimate ------------------
  * replaces op/upfirdn2d.py:145-200 + op/upfirdn2d_kernel.cu:107-207 as used by
  * upsample_2d / downsample_2d / conv_downsample_2d (up_or_down_sampling.py:144-257)
@@ -120,6 +133,8 @@ typedef struct ssde_upfirdn_args {
   float* dst;                    /* [N, h_out, w_out, c] */
   int32_t accumulate;            /* dst += result (gradient accumulation in backward programs) */
   int32_t _pad0;
+  float* dst2;                   /* optional second output: the same filter applied to the source WITHOUT its prologue
+                                    (a residual block resamples act(GroupNorm(x)) and x, layerspp.py:250-258) */
 } ssde_upfirdn_args;
 
 /* ---- single-head self-attention core ----------------------------------------
@@ -343,6 +358,10 @@ typedef struct ssde_axpy_args {   /* dst = (acc ? dst : 0) + alpha * x, optional
 /* ---- single-op launch entry points ------------------------------------------ */
 int ssde_conv2d(const ssde_conv_args* a, void* stream);
 int ssde_groupnorm_stats(const ssde_gn_stats_args* a, void* stream);
+int ssde_gn_finalize(const ssde_gn_finalize_args* a, void* stream);
+/* slices per image of the GroupNorm partials this launch would write (plan only, no device access); 0 = this
+ * launch cannot produce them (a workgroup tile would span several images, or c_out % 4 != 0) */
+int ssde_conv_gn_slices(const ssde_conv_args* a);
 int ssde_upfirdn2d(const ssde_upfirdn_args* a, void* stream);
 int ssde_attention(const ssde_attn_args* a, void* stream);
 int ssde_embed(const ssde_embed_args* a, void* stream);
@@ -379,7 +398,8 @@ enum {
   SSDE_OP_LANGEVIN = 11, SSDE_OP_PREDICTOR = 12, SSDE_OP_FILL = 13, SSDE_OP_STEP_INC = 14,
   SSDE_OP_WGRAD = 15, SSDE_OP_COLSUM = 16, SSDE_OP_GN_BWD_REDUCE = 17, SSDE_OP_PROLOGUE_BWD = 18,
   SSDE_OP_ATTN_BWD = 19, SSDE_OP_PERTURB = 20, SSDE_OP_DSM_LOSS = 21, SSDE_OP_SUMSQ_FLAT = 22,
-  SSDE_OP_ADAM = 23, SSDE_OP_MEMSET = 24, SSDE_OP_AXPY = 25, SSDE_OP_PACK = 26, SSDE_OP_PROJECT = 27
+  SSDE_OP_ADAM = 23, SSDE_OP_MEMSET = 24, SSDE_OP_AXPY = 25, SSDE_OP_PACK = 26, SSDE_OP_PROJECT = 27,
+  SSDE_OP_GN_FINALIZE = 28
 };
 typedef struct ssde_op {
   int32_t kind; int32_t flops_class;   /* flops_class: free tag echoed by timing */
@@ -392,7 +412,7 @@ typedef struct ssde_op {
     ssde_wgrad_args wgrad; ssde_colsum_args colsum; ssde_gn_bwd_reduce_args gn_bwd; ssde_prologue_bwd_args pro_bwd;
     ssde_attn_bwd_args attn_bwd; ssde_perturb_args perturb; ssde_dsm_loss_args dsm_loss;
     ssde_sumsq_flat_args sumsq_flat; ssde_adam_args adam; ssde_memset_args memset; ssde_axpy_args axpy;
-    ssde_pack_args pack; ssde_project_args project;
+    ssde_pack_args pack; ssde_project_args project; ssde_gn_finalize_args gn_fin;
   } u;
 } ssde_op;
 

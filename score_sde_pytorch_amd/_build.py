@@ -54,5 +54,27 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, defines):
+    """A/B timing only: libssde_hip_<name>.so under csrc/build/variants, every source compiled with the given -D flags
+    (e.g. ["-DSSDE_WINO_SCHED=0"]); loaded through SSDE_LIB_PATH.  Not part of build()."""
+    vdir = os.path.join(CSRC, "build", "variants", name)
+    os.makedirs(vdir, exist_ok=True)
+
+    def compile_one(src_name):
+        obj = os.path.join(vdir, src_name.replace(".hip", ".o"))
+        r = subprocess.run([HIPCC] + FLAGS + list(defines) + ["-c", os.path.join(CSRC, src_name), "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (src_name, r.stderr))
+        return obj
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    lib = os.path.join(HERE, "..", "tools", "variants", "libssde_hip_%s.so" % name)
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s" % r.stderr)
+    return os.path.abspath(lib)
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -8,14 +8,16 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libssde_hip.so")
+# SSDE_LIB_PATH: developer switch for A/B timing of kernel variants built by _build.build_variant (tools/ab_bench.sh)
+LIB_PATH = os.environ.get("SSDE_LIB_PATH") or os.path.join(_HERE, "libssde_hip.so")
 ABI_VERSION = 3
 
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_SILU = 0, 1, 2, 3
 TILE_AUTO, TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32, TILE_WINOGRAD = 0, 1, 2, 3, 4, 5
 (OP_CONV, OP_GN_STATS, OP_UPFIRDN, OP_ATTN, OP_EMBED, OP_TO_NHWC, OP_TO_NCHW, OP_BIAS_ACT, OP_SUMSQ,
  OP_RANDN, OP_LANGEVIN, OP_PREDICTOR, OP_FILL, OP_STEP_INC, OP_WGRAD, OP_COLSUM, OP_GN_BWD_REDUCE, OP_PROLOGUE_BWD,
- OP_ATTN_BWD, OP_PERTURB, OP_DSM_LOSS, OP_SUMSQ_FLAT, OP_ADAM, OP_MEMSET, OP_AXPY, OP_PACK, OP_PROJECT) = range(1, 28)
+ OP_ATTN_BWD, OP_PERTURB, OP_DSM_LOSS, OP_SUMSQ_FLAT, OP_ADAM, OP_MEMSET, OP_AXPY, OP_PACK, OP_PROJECT,
+ OP_GN_FINALIZE) = range(1, 29)
 PACK_CONV3, PACK_WINO3, PACK_MATRIX, PACK_VECTOR = 1, 2, 3, 4
 
 _fp = C.c_void_p  # device pointers are passed as integers
@@ -35,7 +37,7 @@ class ConvArgs(C.Structure):
                 ("h_out", C.c_int32), ("w_out", C.c_int32), ("c_out", C.c_int32),
                 ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("tile", C.c_int32),
                 ("bias", _fp), ("chan_add", _fp), ("chan_add_ld", C.c_int32), ("resid_post", C.c_int32),
-                ("resid", _fp), ("out_scale", C.c_float), ("_pad1", C.c_int32), ("dst", _fp)]
+                ("resid", _fp), ("out_scale", C.c_float), ("_pad1", C.c_int32), ("dst", _fp), ("gn_part", _fp)]
 
 
 class GnStatsArgs(C.Structure):
@@ -44,12 +46,17 @@ class GnStatsArgs(C.Structure):
                 ("mean", _fp), ("rstd", _fp), ("scratch", _fp), ("slices", C.c_int32), ("_pad0", C.c_int32)]
 
 
+class GnFinalizeArgs(C.Structure):
+    _fields_ = [("part0", _fp), ("part1", _fp), ("c0", C.c_int32), ("c1", C.c_int32), ("slices0", C.c_int32), ("slices1", C.c_int32),
+                ("n", C.c_int32), ("groups", C.c_int32), ("eps", C.c_float), ("_pad0", C.c_int32), ("mean", _fp), ("rstd", _fp)]
+
+
 class UpfirdnArgs(C.Structure):
     _fields_ = [("src", Src), ("n", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32), ("c", C.c_int32),
                 ("h_out", C.c_int32), ("w_out", C.c_int32),
                 ("up", C.c_int32), ("down", C.c_int32), ("pad0", C.c_int32), ("pad1", C.c_int32),
                 ("kh", C.c_int32), ("kw", C.c_int32), ("k", C.c_float * 16), ("dst", _fp),
-                ("accumulate", C.c_int32), ("_pad0", C.c_int32)]
+                ("accumulate", C.c_int32), ("_pad0", C.c_int32), ("dst2", _fp)]
 
 
 class AttnArgs(C.Structure):
@@ -185,7 +192,7 @@ class _OpUnion(C.Union):
                 ("wgrad", WgradArgs), ("colsum", ColsumArgs), ("gn_bwd", GnBwdReduceArgs), ("pro_bwd", PrologueBwdArgs),
                 ("attn_bwd", AttnBwdArgs), ("perturb", PerturbArgs), ("dsm_loss", DsmLossArgs),
                 ("sumsq_flat", SumsqFlatArgs), ("adam", AdamArgs), ("memset", MemsetArgs), ("axpy", AxpyArgs),
-                ("pack", PackArgs), ("project", ProjectArgs)]
+                ("pack", PackArgs), ("project", ProjectArgs), ("gn_fin", GnFinalizeArgs)]
 
 
 class Op(C.Structure):
@@ -197,7 +204,8 @@ _UNION_FIELD = {OP_CONV: "conv", OP_GN_STATS: "gn", OP_UPFIRDN: "fir", OP_ATTN: 
                 OP_RANDN: "randn", OP_LANGEVIN: "langevin", OP_PREDICTOR: "predictor", OP_FILL: "fill",
                 OP_STEP_INC: "step_inc", OP_WGRAD: "wgrad", OP_COLSUM: "colsum", OP_GN_BWD_REDUCE: "gn_bwd",
                 OP_PROLOGUE_BWD: "pro_bwd", OP_ATTN_BWD: "attn_bwd", OP_PERTURB: "perturb", OP_DSM_LOSS: "dsm_loss",
-                OP_SUMSQ_FLAT: "sumsq_flat", OP_ADAM: "adam", OP_MEMSET: "memset", OP_AXPY: "axpy", OP_PACK: "pack", OP_PROJECT: "project"}
+                OP_SUMSQ_FLAT: "sumsq_flat", OP_ADAM: "adam", OP_MEMSET: "memset", OP_AXPY: "axpy", OP_PACK: "pack", OP_PROJECT: "project",
+                OP_GN_FINALIZE: "gn_fin"}
 
 EXPORTS = ["ssde_conv2d", "ssde_groupnorm_stats", "ssde_upfirdn2d", "ssde_attention", "ssde_embed", "ssde_to_nhwc",
            "ssde_to_nchw", "ssde_fused_bias_act", "ssde_sumsq", "ssde_randn", "ssde_langevin_update",
@@ -206,7 +214,7 @@ EXPORTS = ["ssde_conv2d", "ssde_groupnorm_stats", "ssde_upfirdn2d", "ssde_attent
            "ssde_abi_version", "ssde_sizeof_op", "ssde_last_error", "ssde_conv_lds_bytes",
            "ssde_conv_wgrad", "ssde_colsum", "ssde_gn_bwd_reduce", "ssde_prologue_bwd", "ssde_attention_bwd",
            "ssde_perturb", "ssde_dsm_loss", "ssde_sumsq_flat", "ssde_adam_clip_ema", "ssde_memset", "ssde_axpy",
-           "ssde_wgrad_scratch_floats", "ssde_pack_weights", "ssde_project_update"]
+           "ssde_wgrad_scratch_floats", "ssde_pack_weights", "ssde_project_update", "ssde_gn_finalize", "ssde_conv_gn_slices"]
 
 _lib = None
 
@@ -235,9 +243,11 @@ def bind(lib):
                       ("ssde_gn_bwd_reduce", GnBwdReduceArgs), ("ssde_prologue_bwd", PrologueBwdArgs),
                       ("ssde_attention_bwd", AttnBwdArgs), ("ssde_perturb", PerturbArgs), ("ssde_dsm_loss", DsmLossArgs),
                       ("ssde_sumsq_flat", SumsqFlatArgs), ("ssde_adam_clip_ema", AdamArgs), ("ssde_memset", MemsetArgs),
-                      ("ssde_axpy", AxpyArgs), ("ssde_pack_weights", PackArgs), ("ssde_project_update", ProjectArgs)]:
+                      ("ssde_axpy", AxpyArgs), ("ssde_pack_weights", PackArgs), ("ssde_project_update", ProjectArgs),
+                      ("ssde_gn_finalize", GnFinalizeArgs)]:
         getattr(lib, name).argtypes = [C.POINTER(typ), C.c_void_p]
     lib.ssde_conv_lds_bytes.argtypes = [C.POINTER(ConvArgs)]
+    lib.ssde_conv_gn_slices.argtypes = [C.POINTER(ConvArgs)]
     lib.ssde_wgrad_scratch_floats.argtypes = [C.POINTER(WgradArgs)]
     lib.ssde_wgrad_scratch_floats.restype = C.c_int64
     if lib.ssde_abi_version() != ABI_VERSION:

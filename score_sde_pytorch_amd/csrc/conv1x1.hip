@@ -36,6 +36,7 @@ struct GemmParams {
   const float* resid; int resid_post;
   float scale;
   float* dst;
+  float* gn_part;          // GroupNorm partials of dst: one entry per 64-row half tile (HW % 64 == 0), see ssde_store_tile
 };
 
 template <bool kGn>
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(kThreads, 4) void gemm1x1_kernel(const GemmParams p
   // (a half tile is 33 KB: with the 37 KB of operand stages four workgroups fit a CU and cover each other's pipeline
   // fill and epilogue; the loops are short -- K = 128 .. 512 -- so those fixed costs matter)
   constexpr int LDT = BN + 4;
-  SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, p.Cout};
+  SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, p.Cout, p.gn_part};
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     if ((wave >> 1) == half) {
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(kThreads, 4) void gemm1x1_kernel(const GemmParams p
       pix = (size_t)m;
       img = m / p.HW;
       return true;
-    });
+    }, p.gn_part ? (m0 >> 6) + half : -1);
     __syncthreads();
   }
 }
@@ -234,6 +235,8 @@ int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
   p.m_tiles = ssde_cdiv(p.M, BM); p.n_tiles = ssde_cdiv(a->c_out, BN);
   p.bias = a->bias; p.chan_add = a->chan_add; p.chan_add_ld = a->chan_add_ld;
   p.resid = a->resid; p.resid_post = a->resid_post; p.scale = a->out_scale; p.dst = a->dst;
+  p.gn_part = a->gn_part;
+  SSDE_REQUIRE(!a->gn_part || (p.HW % 64 == 0 && a->c_out % 4 == 0), "conv1x1: GroupNorm partials need H*W %% 64 == 0");
   const int lds_ops = 2 * kStage * 4, lds_epi = 64 * (BN + 4) * 4;
   const int lds = lds_ops > lds_epi ? lds_ops : lds_epi;
   if (lds_out) { *lds_out = lds; return SSDE_OK; }

@@ -44,6 +44,7 @@ struct ConvKParams {
   int resid_post;
   float scale;
   float* dst;
+  float* gn_part;          // GroupNorm partials of dst (one image per tile), see ssde_store_tile
 };
 
 constexpr int kThreads = 256;
@@ -286,7 +287,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvKParam
         smem[m * LDT + wn0 + b * 32 + li] = acc[a][b][r];
       }
   __syncthreads();
-  SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, g.Cout};
+  SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, g.Cout, p.gn_part};
+  const int gn_entry = p.gn_part ? img0 * g.tiles_per_img + trem : -1;        // make_plan: IMGS == 1
   ssde_store_tile(smem, BM, LDT, BN, n0, e, kThreads, [&](int m, size_t& pix, int& img) {
     const int c = m & (TW - 1);
     const int rr = (m >> g.lTW) & (TH - 1);
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvKParam
     if (img >= g.N || oy >= g.Hout || ox >= g.Wout) return false;
     pix = ((size_t)img * g.Hout + oy) * g.Wout + ox;
     return true;
-  });
+  }, gn_entry);
 }
 
 struct TileCfg { int bm, bn; };
@@ -307,6 +309,7 @@ struct ConvPlan {
   int lds_bytes;
   int grid;
   bool has3, has1;
+  int gn_slices;           // slices per image of the GroupNorm partials (0: a tile spans several images)
 };
 
 int src_check(const ssde_src& s, const char* what) {
@@ -396,6 +399,9 @@ int make_plan(const ssde_conv_args* a, ConvPlan* pl) {
   g.n_tiles = ssde_cdiv(a->c_out, bn);
   kp.bias = a->bias; kp.chan_add = a->chan_add; kp.chan_add_ld = a->chan_add_ld;
   kp.resid = a->resid; kp.resid_post = a->resid_post; kp.scale = a->out_scale; kp.dst = a->dst;
+  kp.gn_part = a->gn_part;
+  pl->gn_slices = (imgs == 1 && a->c_out % 4 == 0) ? g.tiles_per_img * (kThreads / 64) : 0;
+  SSDE_REQUIRE(!a->gn_part || pl->gn_slices > 0, "conv: GroupNorm partials need one image per tile and c_out %% 4 == 0");
 
   int lds = 0;
   if (pl->has3) {
@@ -451,6 +457,24 @@ extern "C" int ssde_conv2d(const ssde_conv_args* a, void* stream) {
   }
   ssde_set_error("conv: unreachable tile %d", pl.tile);
   return SSDE_EINVAL;
+}
+
+extern "C" int ssde_conv_gn_slices(const ssde_conv_args* a) {
+  if (!a || a->c_out % 4 != 0) return 0;
+  ssde_conv_args q = *a;
+  q.gn_part = nullptr;
+  if (q.tile == SSDE_TILE_WINOGRAD) {
+    int s = 0;
+    if (ssde_conv_wino_launch(&q, reinterpret_cast<void*>(1), &s)) return 0;     // plan-only query form
+    return s;
+  }
+  if (q.dst && ssde_conv1x1_wants(&q)) {
+    const int hw = q.h_out * q.w_out;
+    return hw % 64 == 0 ? (hw / 64) * 4 : 0;    // the GEMM kernel stores 64-row half tiles of linear pixel rows, 4 waves each
+  }
+  ConvPlan pl;
+  if (make_plan(&q, &pl)) return 0;
+  return pl.gn_slices;
 }
 
 extern "C" int ssde_conv_lds_bytes(const ssde_conv_args* a) {

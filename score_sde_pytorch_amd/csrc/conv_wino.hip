@@ -37,6 +37,47 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Schedule of the asynchronous issue work (A/B-timed on the MI355X with tools/ab_bench.sh, round 2):
+//   0  weight-DMA pieces / halo loads ride between the MFMAs of the matrix phases (round 1)        203-229 TF/s
+//   1  matrix phases are pure MFMA + fragment reads, waves 4-7 issue every VMEM instruction in their staging phase:
+//      SLOWER (176-208 TF/s) -- the burst of 32 KB of LDS-DMA plus the halo loads, issued at once beside the other
+//      waves' fragment reads, costs more than the issue slots it frees (an MFMA wave has idle issue slots anyway)
+//   2  schedule 0, and waves 4-7 read their first fragments before the barrier that opens their matrix phase
+#ifndef SSDE_WINO_SCHED
+#define SSDE_WINO_SCHED 0
+#endif
+// Issue priority (s_setprio) of the two waves of a SIMD: 1 = the wave in its matrix phase runs at priority 1 (round 1);
+// 0 = no priorities; 2 = the STAGING wave's short VALU / LDS bursts outrank the matrix wave's MFMA stream.
+// s_memtime traces (tools/wino_trace.py) showed why 2 wins: at 1 the staging wave is starved until the matrix wave has
+// issued its last MFMA, so the prologue (GroupNorm + SiLU, ~900 VALU cycles) ran AFTER the 2750-cycle matrix phase
+// instead of inside it (phase 1: 3880 -> 3500 cycles); fp32 MFMA and VALU do not co-execute, so the VALU cycles are
+// paid either way, but their LDS / VMEM latencies now hide under the other wave's MFMAs.
+#ifndef SSDE_WINO_PRIO
+#define SSDE_WINO_PRIO 2
+#endif
+// GroupNorm parameters of the prologue: 0 = global loads issued between the MFMAs of the staging waves' matrix phase
+// (round 1: 10 extra VMEM instructions + their address arithmetic per stage in the matrix stream);
+// 1 = mean / rstd of the tile's images and gamma / beta parked in LDS once per workgroup, read in store_stage.
+// Together with priority 2: +3..5 % on every BASELINE shape (gpurun_out/conv_ab_r2e.txt).
+#ifndef SSDE_WINO_GNLDS
+#define SSDE_WINO_GNLDS 1
+#endif
+
+// -DSSDE_WINO_TRACE (tools/wino_trace.py, a variant library only): s_memtime stamps of waves 0 and 4 of the first and of
+// the last workgroup, to see where a workgroup's cycles go (fill, the two phases of a stage, barriers, epilogue).
+#ifdef SSDE_WINO_TRACE
+__device__ unsigned long long* g_wino_trace;
+extern "C" int ssde_debug_wino_trace(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_wino_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -5;
+}
+#define SSDE_TR(slot)                                                                                     \
+  do {                                                                                                    \
+    if (tr_on) g_wino_trace[tr_base + (slot)] = __builtin_amdgcn_s_memtime();                             \
+  } while (0)
+#else
+#define SSDE_TR(slot) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int kThreads = 512;
@@ -55,6 +96,7 @@ struct WinoParams {
   const float* resid; int resid_post;
   float scale;
   float* dst;
+  float* gn_part;          // GroupNorm partials of dst (one image per tile: IMGS == 1), see ssde_store_tile
 };
 
 template <bool kGn>      // GroupNorm prologue: compile-time, so that the staging loads below are straight-line code
@@ -62,7 +104,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
   SSDE_LDS(smem);
   float* Vb = smem;                          // [2][kStageFloats]
   float* Ub = smem + 2 * kStageFloats;       // [2][kStageFloats]
-  float* raw = smem + 4 * kStageFloats;      // [4 pairs][halo_px][2]
+  float* raw = smem + 4 * kStageFloats;      // [4 pairs][halo_px][2]; then (SSDE_WINO_GNLDS) the GroupNorm tables
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lq = lane >> 4;
 
@@ -71,6 +113,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
   const int xcd = bid & 7, l = bid >> 3;
   const int nt = l % p.n_tiles;
   const int mt = (l / p.n_tiles) * 8 + xcd;
+#ifdef SSDE_WINO_TRACE
+  const bool tr_on = lane == 0 && (wave & 3) == 0 && (bid == 0 || bid == (int)gridDim.x - 8) && g_wino_trace != nullptr;
+  const int tr_base = ((bid == 0 ? 0 : 1) * 2 + (wave >> 2)) * 64;
+#endif
+  SSDE_TR(0);
   if (mt >= p.m_tiles) return;
 
   const int TWt = 1 << p.lTWt, THt = 1 << p.lTHt;       // tiles per patch row / column
@@ -88,6 +135,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
   SsdePro pro = ssde_pro_decode(s);
   pro.gn = kGn;
   const int cpg = kGn ? Ctot / s.gn_groups : 1;
+  const float inv_cpg = 1.0f / (float)cpg;
 
   // ---- per-thread raw staging plan: item = (halo pixel, channel half) ----
   const int sid = tid & (kStagers - 1);          // index among the 256 staging threads (waves 4-7) / transform threads (0-3)
@@ -118,6 +166,22 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
   }
   const int t_vcol = ((t_tile ^ ((t_pair & 1) << 4)) + t_pair * 64) * 2;
 
+#if SSDE_WINO_GNLDS
+  // GroupNorm tables in LDS: (mean, rstd) of every (tile image, group), gamma and beta of every channel
+  float* gn_tab = raw + 8 * halo_px;         // [IMGS][groups][2]
+  float* gb_tab = gn_tab + 2 * IMGS * (kGn ? s.gn_groups : 0);   // [2][Ctot]
+  if (kGn) {
+    for (int q = tid; q < IMGS * s.gn_groups; q += kThreads) {
+      const int il = q / s.gn_groups, img = img0 + il < p.N ? img0 + il : 0;
+      const int gi = img * s.gn_groups + (q - il * s.gn_groups);
+      *reinterpret_cast<float2*>(gn_tab + 2 * q) = make_float2(s.gn_mean[gi], s.gn_rstd[gi]);
+    }
+    for (int q = tid; q < Ctot; q += kThreads) { gb_tab[q] = s.gn_gamma[q]; gb_tab[Ctot + q] = s.gn_beta[q]; }
+  }                                          // published by the first pipeline barrier
+  int gil[kMaxRaw];
+#pragma unroll
+  for (int it = 0; it < kMaxRaw; ++it) gil[it] = (goff[it] >= 0 ? gimg[it] - img0 : 0) * (kGn ? s.gn_groups : 0);
+#endif
   float4 rv[kMaxRaw];
   float mu[kMaxRaw], rs[kMaxRaw];
   float4 gam = make_float4(1.f, 1.f, 1.f, 1.f), bet = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -143,8 +207,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
     }
     // GroupNorm parameters first (two pieces), the halo float4s after them: the LAST load is issued at position 5 at the
     // latest, >= 500 matrix cycles before the barrier behind which store_stage consumes all of them
+#if SSDE_WINO_GNLDS
+    constexpr int kFirstRaw = 0;
+    if (false) {
+#else
     constexpr int kFirstRaw = kGn ? 2 : 0;
     if (kGn && k < 2) {
+#endif
       if (k == 0) {
         gam = *reinterpret_cast<const float4*>(s.gn_gamma + ld_cg);
         bet = *reinterpret_cast<const float4*>(s.gn_beta + ld_cg);
@@ -190,6 +259,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
   // prologue + raw LDS store (channel-pair major)
   auto store_stage = [&]() {
     const int half = sid & 1;
+#if SSDE_WINO_GNLDS
+    if (kGn) {
+      const int cg = (c_cur + half * 4) < Ctot ? c_cur + half * 4 : 0;
+      gam = *reinterpret_cast<const float4*>(gb_tab + cg);
+      bet = *reinterpret_cast<const float4*>(gb_tab + Ctot + cg);
+      const int g = (int)(((float)cg + 0.5f) * inv_cpg);      // cg / cpg, exact for these small integers
+#pragma unroll
+      for (int it = 0; it < kMaxRaw; ++it) {
+        const float2 mr = *reinterpret_cast<const float2*>(gn_tab + 2 * (gil[it] + g));
+        mu[it] = mr.x; rs[it] = mr.y;
+      }
+    }
+#endif
 #pragma unroll
     for (int it = 0; it < kMaxRaw; ++it) {
       if (goff[it] == -2) continue;
@@ -254,14 +336,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
   // `piece(ps)`: a slice of this wave's asynchronous issue work for a later stage (weight DMA / halo loads), placed
   // between the two MFMA quartets of position ps so that its VALU / VMEM issue slots hide under the matrix pipe.
   // sched_barrier(0) closes every position: nothing moves across, the pieces cannot be hoisted in front of the MFMAs.
-  auto mfma_stage = [&](const float* Vc, const float* Uc, auto&& piece) {
-    float2 af[2][2], bf[2][2];
+  float2 af[2][2], bf[2][2];
+  // first fragments of a stage; a wave whose V / U stage is already published issues this BEFORE the barrier that opens
+  // its matrix phase (the barrier's lgkmcnt(0) completes it), so the phase starts with an MFMA instead of an LDS round trip
+  auto preload = [&](const float* Vc, const float* Uc) {
 #pragma unroll
     for (int a = 0; a < 2; ++a) af[0][a] = *reinterpret_cast<const float2*>(Vc + aoff[a]);
 #pragma unroll
     for (int b = 0; b < 2; ++b) bf[0][b] = *reinterpret_cast<const float2*>(Uc + boff[b]);
+  };
+  auto mfma_stage = [&](const float* Vc, const float* Uc, auto&& piece) {
     __builtin_amdgcn_sched_barrier(0);
+#if SSDE_WINO_PRIO == 1
     __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
       const int cur = ps & 1;
@@ -292,46 +380,140 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+#if SSDE_WINO_PRIO == 1
     __builtin_amdgcn_s_setprio(0);
+#endif
   };
+#if SSDE_WINO_PRIO == 2
+#define SSDE_STAGING_HI() __builtin_amdgcn_s_setprio(2)
+#define SSDE_STAGING_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define SSDE_STAGING_HI() do { } while (0)
+#define SSDE_STAGING_LO() do { } while (0)
+#endif
 
   // ---- pipeline prologue: stage 0 staged, stage 1 in flight ----
   const int last = nst - 1;
+  SSDE_TR(1);
+#if SSDE_WINO_SCHED != 1
+  // the asynchronous issue work rides between the MFMAs of the matrix phases
+#if SSDE_WINO_GNLDS
+  if (ph == 1) load_stage(0);
+  else dma_weights(0, Ub);
+  if (kGn) __syncthreads();                  // publishes the GroupNorm tables filled above
+  if (ph == 1) store_stage();
+#else
   if (ph == 1) { load_stage(0); store_stage(); }
   else dma_weights(0, Ub);
+#endif
   SSDE_LDS_BARRIER();
+  SSDE_TR(2);
   if (ph == 0) { transform(Vb); SSDE_WAIT_VMCNT(0); }
   else load_stage(min(1, last));
   SSDE_LDS_BARRIER();
+  SSDE_TR(3);
 
   for (int st = 0; st < nst; ++st) {
     const float* Vc = Vb + (st & 1) * kStageFloats;
     const float* Uc = Ub + (st & 1) * kStageFloats;
     float* Vn = Vb + ((st + 1) & 1) * kStageFloats;
     float* Un = Ub + ((st + 1) & 1) * kStageFloats;
-    // phase 1: waves 0-3 start the weight DMA of st+1 and run the matrix pipe; waves 4-7 apply the prologue to the
-    // halo of st+1 (loaded during their previous matrix phase) and store it
-    // (past the last stage both issue a redundant copy of it instead of branching: the issue code stays in the
-    // basic block of the MFMAs; the stray DMA lands in the idle U buffer and is waited for before the epilogue)
     if (ph == 0) {
       const int sn = min(st + 1, last);
+      preload(Vc, Uc);
       mfma_stage(Vc, Uc, [&](int k) { dma_piece(sn, Un, k); });
-    } else if (st + 1 < nst) {
-      store_stage();
+    } else {
+      SSDE_STAGING_HI();
+      if (st + 1 < nst) store_stage();
+      SSDE_STAGING_LO();
+#if SSDE_WINO_SCHED == 2
+      preload(Vc, Uc);
+#endif
     }
+    if (st < 8) SSDE_TR(4 + st * 4);
     SSDE_LDS_BARRIER();
-    // phase 2: waves 4-7 put the halo loads of st+2 in flight and run the matrix pipe; waves 0-3 transform st+1 and
-    // make sure their DMA has landed before the barrier that publishes U(st+1)
+    if (st < 8) SSDE_TR(5 + st * 4);
     if (ph == 1) {
       const int sn = min(st + 2, last);
+#if SSDE_WINO_SCHED != 2
+      preload(Vc, Uc);
+#endif
       mfma_stage(Vc, Uc, [&](int k) { load_piece(sn, k); });
     } else {
+      SSDE_STAGING_HI();
       if (st + 1 < nst) transform(Vn);
+      SSDE_STAGING_LO();
       SSDE_WAIT_VMCNT(0);
     }
+    if (st < 8) SSDE_TR(6 + st * 4);
     SSDE_LDS_BARRIER();
+    if (st < 8) SSDE_TR(7 + st * 4);
   }
+#else
+  // The matrix phases are PURE MFMA + fragment-read streams.  Every VMEM instruction (the 8 LDS-DMA pieces of the next
+  // weight stage, the halo float4 loads and GroupNorm parameters of the stage after next) is issued by waves 4-7 in
+  // phase 1, i.e. in the phase in which they do NOT own the matrix pipe: issued between MFMAs, an LDS-DMA piece held
+  // the issuing wave's next MFMA back by 60-185 cycles (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"), ~1000
+  // cycles per 4096-cycle stage.  In-order VMEM return + the staging waves' vmcnt(0) at the end of their matrix phase
+  // (two phases after the issue) publishes the weights; the halo registers are consumed one stage later.
+  //   phase 1: waves 0-3 MFMA(k)                       waves 4-7 prologue + raw store (k+1); halo loads (k+2); weight DMA (k+1)
+  //   phase 2: waves 4-7 MFMA(k), then vmcnt(0)        waves 0-3 input transform raw -> V(k+1)
+  // Waves 4-7 read their first fragments of stage k before the barrier that opens phase 2 (V(k), U(k) are published).
+  if (ph == 1) {
+    dma_weights(0, Ub);
+    load_stage(0);
+  }
+#if SSDE_WINO_GNLDS
+  if (kGn) __syncthreads();                  // publishes the GroupNorm tables filled above
+#endif
+  if (ph == 1) {
+    store_stage();
+    load_stage(min(1, last));
+    SSDE_WAIT_VMCNT(0);
+  }
+  SSDE_LDS_BARRIER();
+  SSDE_TR(2);
+  if (ph == 0) transform(Vb);
+  SSDE_LDS_BARRIER();
+  SSDE_TR(3);
+
+  for (int st = 0; st < nst; ++st) {
+    const float* Vc = Vb + (st & 1) * kStageFloats;
+    const float* Uc = Ub + (st & 1) * kStageFloats;
+    float* Vn = Vb + ((st + 1) & 1) * kStageFloats;
+    float* Un = Ub + ((st + 1) & 1) * kStageFloats;
+    if (ph == 0) {
+      preload(Vc, Uc);
+      mfma_stage(Vc, Uc, [](int) {});
+    } else {
+      SSDE_STAGING_HI();
+      if (st + 1 < nst) {
+        store_stage();
+        if (st + 2 < nst) load_stage(st + 2);
+        dma_weights(st + 1, Un);
+      }
+      SSDE_STAGING_LO();
+      preload(Vc, Uc);
+    }
+    if (st < 8) SSDE_TR(4 + st * 4);
+    SSDE_LDS_BARRIER();
+    if (st < 8) SSDE_TR(5 + st * 4);
+    if (ph == 1) {
+      mfma_stage(Vc, Uc, [](int) {});
+      SSDE_WAIT_VMCNT(0);
+    } else if (st + 1 < nst) {
+      SSDE_STAGING_HI();
+      transform(Vn);
+      SSDE_STAGING_LO();
+    }
+    if (st < 8) SSDE_TR(6 + st * 4);
+    SSDE_LDS_BARRIER();
+    if (st < 8) SSDE_TR(7 + st * 4);
+  }
+#endif
+  SSDE_TR(40);
   __syncthreads();
+  SSDE_TR(41);
 
   // ---- output transform Y = A^T M A: this wave's two transform rows (register local) ----
   // A^T = [[1,1,1,0],[0,1,-1,-1]]; rows py = 2*ph, 2*ph+1 contribute  At[dy][py] * sum_px At[dx][px] M[py][px]
@@ -367,7 +549,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
           xch[((((wave & 3) * 2 + a) * 2 + b) * 4 + r) * 64 + lane] =
               make_float4(yp[a][b][r][0], yp[a][b][r][1], yp[a][b][r][2], yp[a][b][r][3]);
   }
+  SSDE_TR(42);
   __syncthreads();
+  SSDE_TR(43);
   // waves 0-3 complete Y and park it in LDS as [256 local pixels = tile * 4 + dy * 2 + dx][64 couts + 4] (above the
   // 64 KB exchange area); then all 8 waves store it with coalesced float4s (ssde_store_tile)
   constexpr int LDT = 68;
@@ -388,8 +572,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
           dstp[3 * LDT] = yp[a][b][r][3] + o.w;
         }
   }
+  SSDE_TR(44);
   __syncthreads();
-  SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, p.Cout};
+  SSDE_TR(45);
+  SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, p.Cout, p.gn_part};
+  const int gn_entry = p.gn_part ? img0 * p.tiles_per_img + trem : -1;        // launcher: IMGS == 1
   ssde_store_tile(outs, 256, LDT, 64, n0, e, kThreads, [&](int row, size_t& pix, int& img) {
     const int tile = row >> 2, dy = (row >> 1) & 1, dx = row & 1;
     const int il = tile >> (p.lTWt + p.lTHt);
@@ -399,7 +586,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
     if (img >= p.N || oy >= p.H || ox >= p.W) return false;
     pix = ((size_t)img * p.H + oy) * p.W + ox;
     return true;
-  });
+  }, gn_entry);
+  SSDE_TR(46);
 }
 
 int pow2_floor(int v) { int q = 1; while (q * 2 <= v) q *= 2; return q; }
@@ -436,9 +624,16 @@ int ssde_conv_wino_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
   p.n_tiles = ssde_cdiv(a->c_out, 64);
   p.bias = a->bias; p.chan_add = a->chan_add; p.chan_add_ld = a->chan_add_ld;
   p.resid = a->resid; p.resid_post = a->resid_post; p.scale = a->out_scale; p.dst = a->dst;
+  p.gn_part = a->gn_part;
+  SSDE_REQUIRE(!a->gn_part || (imgs == 1 && a->c_out % 4 == 0), "conv(winograd): GroupNorm partials need one image per tile");
+  if (lds_out && stream == reinterpret_cast<void*>(1)) { *lds_out = (imgs == 1 && a->c_out % 4 == 0) ? p.tiles_per_img * (kThreads / 64) : 0; return SSDE_OK; }
   const int halo_px = imgs * (2 * tht + 2) * (2 * twt + 2);
   SSDE_REQUIRE(halo_px * 2 <= kMaxRaw * kStagers, "conv(winograd): halo of %d pixels exceeds the staging plan", halo_px);
-  const int lds = (4 * kStageFloats + 4 * halo_px * 2) * 4;
+  int lds = (4 * kStageFloats + 4 * halo_px * 2) * 4;
+#if SSDE_WINO_GNLDS
+  if (s.pro_mode == SSDE_PRO_GN || s.pro_mode == SSDE_PRO_GN_SILU) lds += (2 * imgs * s.gn_groups + 2 * (s.c0 + s.c1)) * 4;
+  SSDE_REQUIRE(lds <= 160 * 1024, "conv(winograd): %d bytes of LDS", lds);
+#endif
   if (lds_out) { *lds_out = lds; return SSDE_OK; }
   static std::atomic<bool> attr_set{false};   // once, before any stream capture
   if (!attr_set) {

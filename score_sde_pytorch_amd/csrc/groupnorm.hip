@@ -118,7 +118,47 @@ __global__ void gn_finalize_kernel(const GnParams p) {
   p.rstd[idx] = 1.0f / sqrtf(var + p.eps);
 }
 
+// Statistics from the producers' partials (ssde_store_tile): one thread per (image, group) merges, in a fixed order,
+// the (mean, M2, count) triples of every slice and channel quad of its group -- a few dozen merges.
+struct GnFinParams {
+  const float* part0; const float* part1;
+  int c0, c1, s0, s1, n, groups; float eps;
+  float* mean; float* rstd;
+};
+__global__ __launch_bounds__(256) void gn_part_finalize_kernel(const GnFinParams p) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= p.n * p.groups) return;
+  const int n = idx / p.groups, g = idx - n * p.groups;
+  const int cpq = (p.c0 + p.c1) / p.groups / 4;        // channel quads per group
+  const int q0 = g * cpq, Q0 = p.c0 >> 2, Q1 = p.c1 >> 2;
+  float cnt = 0.f, m = 0.f, M2 = 0.f;
+  for (int q = q0; q < q0 + cpq; ++q) {
+    const bool second = q >= Q0;
+    const float* part = second ? p.part1 : p.part0;
+    const int S = second ? p.s1 : p.s0, Q = second ? Q1 : Q0, qq = second ? q - Q0 : q;
+    for (int s = 0; s < S; ++s) {
+      const float* e = part + (((size_t)n * S + s) * Q + qq) * 3;
+      ssde_stat_merge(cnt, m, M2, e[2], e[0], e[1]);
+    }
+  }
+  const float var = cnt > 0.f ? M2 / cnt : 0.f;
+  p.mean[idx] = m;
+  p.rstd[idx] = 1.0f / sqrtf(var + p.eps);
+}
+
 }  // namespace
+
+extern "C" int ssde_gn_finalize(const ssde_gn_finalize_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->part0 && a->mean && a->rstd, "gn_finalize: null args");
+  const int C = a->c0 + a->c1;
+  SSDE_REQUIRE(a->c0 > 0 && a->c0 % 4 == 0 && a->c1 % 4 == 0 && (a->c1 == 0 || a->part1), "gn_finalize: bad channel counts");
+  SSDE_REQUIRE(a->groups > 0 && C % a->groups == 0 && (C / a->groups) % 4 == 0, "gn_finalize: channels-per-group must be a multiple of 4");
+  SSDE_REQUIRE(a->n > 0 && a->slices0 > 0 && (a->c1 == 0 || a->slices1 > 0), "gn_finalize: bad shape");
+  GnFinParams p{a->part0, a->part1, a->c0, a->c1, a->slices0, a->slices1, a->n, a->groups, a->eps, a->mean, a->rstd};
+  hipLaunchKernelGGL(gn_part_finalize_kernel, dim3(ssde_cdiv(a->n * a->groups, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}
 
 extern "C" int ssde_groupnorm_stats(const ssde_gn_stats_args* a, void* stream) {
   SSDE_REQUIRE(a && a->p0 && a->mean && a->rstd, "gn_stats: null args");

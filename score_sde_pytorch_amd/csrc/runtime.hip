@@ -45,6 +45,7 @@ static int run_one(const ssde_op& op, void* stream) {
     case SSDE_OP_MEMSET: return ssde_memset(&op.u.memset, stream);
     case SSDE_OP_AXPY: return ssde_axpy(&op.u.axpy, stream);
     case SSDE_OP_PACK: return ssde_pack_weights(&op.u.pack, stream);
+    case SSDE_OP_GN_FINALIZE: return ssde_gn_finalize(&op.u.gn_fin, stream);
   }
   ssde_set_error("program: unknown op kind %d", op.kind);
   return SSDE_EINVAL;

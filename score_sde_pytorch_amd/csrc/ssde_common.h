@@ -145,12 +145,33 @@ __device__ __forceinline__ float4 ssde_pro_apply(float4 v, float mu, float rs, c
 struct SsdeEpi {
   const float* bias; const float* chan_add; int chan_add_ld;
   const float* resid; int resid_post; float scale; float* dst; int Cout;
+  float* gn_part = nullptr;   // optional GroupNorm partial statistics of the stored tensor, see ssde_store_tile
 };
+
+// Chan's pairwise merge of (count, mean, M2 = sum of squared deviations); exact for n_b == 0
+__device__ __forceinline__ void ssde_stat_merge(float& n, float& m, float& M2, float nb, float mb, float M2b) {
+  const float nt = n + nb;
+  const float d = mb - m;
+  const float f = nt > 0.f ? nb * __builtin_amdgcn_rcpf(nt) : 0.f;      // counts are small integers: ~1 ulp is plenty
+  m += d * f;
+  M2 += M2b + d * d * n * f;
+  n = nt;
+}
 // pixfn(row, pix, img) -> false when the row is outside the tensor.  ncols must be a multiple of 4.
+//
+// GroupNorm statistics of the tensor being written (e.gn_part != nullptr, gn_entry >= 0): the next layer normalises this
+// tensor per (image, group of channels) (layerspp.py:67,219,231); instead of re-reading it from HBM with
+// gn_stats_kernel, the workgroup reduces the values it stores -- all rows of ONE image (the launcher guarantees it) --
+// to one (mean, M2, count) triple per wave and channel quad: gn_part[((gn_entry * nwaves + wave) * Cout/4 + quad) * 3 ...],
+// gn_entry = image * tiles_per_image + tile.  ssde_gn_finalize merges slices and quads into groups in a fixed order
+// (deterministic, no atomics).  A thread owns one channel quad (nthreads % (ncols/4) == 0): sums relative to its first
+// value (no cancellation), lanes of equal quad merged by wave shuffles.
 template <class PixFn>
-__device__ __forceinline__ void ssde_store_tile(const float* tile, int rows, int ld, int ncols, int n0, const SsdeEpi& e,
-                                                int nthreads, PixFn pixfn) {
+__device__ __forceinline__ void ssde_store_tile(float* tile, int rows, int ld, int ncols, int n0, const SsdeEpi& e,
+                                                int nthreads, PixFn pixfn, int gn_entry = -1) {
   const int c4n = ncols >> 2;
+  const bool stats = e.gn_part != nullptr && gn_entry >= 0;
+  float st_p = 0.f, st_s1 = 0.f, st_s2 = 0.f, st_n = 0.f;
   for (int q = threadIdx.x; q < rows * c4n; q += nthreads) {
     const int row = q / c4n, c = (q - row * c4n) * 4;
     const int j = n0 + c;
@@ -172,6 +193,13 @@ __device__ __forceinline__ void ssde_store_tile(const float* tile, int rows, int
       for (int k = 0; k < 4; ++k) v[k] *= e.scale;
       if (e.resid && e.resid_post) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
       *reinterpret_cast<float4*>(e.dst + pix * e.Cout + j) = make_float4(v[0], v[1], v[2], v[3]);
+      if (stats) {
+        if (st_n == 0.f) st_p = v[0];
+        const float d0 = v[0] - st_p, d1 = v[1] - st_p, d2 = v[2] - st_p, d3 = v[3] - st_p;
+        st_s1 += (d0 + d1) + (d2 + d3);
+        st_s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        st_n += 4.f;
+      }
     } else {
       for (int k = 0; k < 4 && j + k < e.Cout; ++k) {
         float x = v[k];
@@ -183,6 +211,22 @@ __device__ __forceinline__ void ssde_store_tile(const float* tile, int rows, int
         if (e.resid && e.resid_post) x += r;
         e.dst[pix * e.Cout + j + k] = x;
       }
+    }
+  }
+  if (stats) {                                  // uniform over the workgroup
+    float n = st_n, m = 0.f, M2 = 0.f;
+    if (n > 0.f) { const float rn = __builtin_amdgcn_rcpf(n); m = st_p + st_s1 * rn; M2 = st_s2 - st_s1 * st_s1 * rn; M2 = M2 < 0.f ? 0.f : M2; }
+    for (int o = c4n; o < 64; o <<= 1) {        // lanes l, l + c4n, l + 2 c4n, ... hold the same channel quad
+      const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(m, o, 64), Mb = __shfl_xor(M2, o, 64);
+      if (threadIdx.x & o) { float tn = nb, tm = mb, tM = Mb; ssde_stat_merge(tn, tm, tM, n, m, M2); n = tn; m = tm; M2 = tM; }
+      else ssde_stat_merge(n, m, M2, nb, mb, Mb);   // both partners merge lower-lane-first: identical results
+    }
+    // one entry per WAVE (no workgroup barrier, no LDS round trip in the exposed tail of the kernel): the finalize kernel
+    // merges nthreads / 64 times as many slices, a few hundred floats per (image, group)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nthreads >> 6;
+    if (lane < c4n && n0 + 4 * lane < e.Cout) {
+      float* o = e.gn_part + (((size_t)gn_entry * nw + wave) * (e.Cout >> 2) + (n0 >> 2) + lane) * 3;
+      o[0] = m; o[1] = M2; o[2] = n;
     }
   }
 }

@@ -89,7 +89,7 @@ _STRUCT = {L.OP_CONV: L.ConvArgs, L.OP_GN_STATS: L.GnStatsArgs, L.OP_UPFIRDN: L.
            L.OP_STEP_INC: L.StepIncArgs, L.OP_WGRAD: L.WgradArgs, L.OP_COLSUM: L.ColsumArgs,
            L.OP_GN_BWD_REDUCE: L.GnBwdReduceArgs, L.OP_PROLOGUE_BWD: L.PrologueBwdArgs, L.OP_ATTN_BWD: L.AttnBwdArgs,
            L.OP_PERTURB: L.PerturbArgs, L.OP_DSM_LOSS: L.DsmLossArgs, L.OP_SUMSQ_FLAT: L.SumsqFlatArgs,
-           L.OP_ADAM: L.AdamArgs, L.OP_MEMSET: L.MemsetArgs, L.OP_AXPY: L.AxpyArgs}
+           L.OP_ADAM: L.AdamArgs, L.OP_MEMSET: L.MemsetArgs, L.OP_AXPY: L.AxpyArgs, L.OP_GN_FINALIZE: L.GnFinalizeArgs}
 
 
 class ProgramBuilder:
@@ -151,8 +151,13 @@ class ProgramBuilder:
         self.blocks = blocks
         self.arena_bytes = sum(t.numel() for t in blocks) * _FLT
         ops, classes, flops, starts = [], [], [], []
-        for kind, fields, fclass, fl in self.specs:
+        fused_fir = _fir_pairs(self.specs)
+        for si, (kind, fields, fclass, fl) in enumerate(self.specs):
             starts.append(len(ops))
+            if si in fused_fir:
+                if fused_fir[si] is None:
+                    continue                     # the raw-source half of a pair: issued by its partner through dst2
+                fields = dict(fields, dst2=fused_fir[si])
             for sub_fields, sub_class, sub_fl in _expand(kind, fields, fclass, fl):
                 args = _STRUCT[kind]()
                 _fill(args, sub_fields)
@@ -164,6 +169,27 @@ class ProgramBuilder:
         return prog
 
 
+def _fir_pairs(specs):
+    """A residual block resamples act(GroupNorm(x)) and x with the same FIR (layerspp.py:250-258): two adjacent
+    OP_UPFIRDN specs on one source, the first with a prologue, the second without.  They run as ONE launch that reads x
+    once (ssde_upfirdn_args.dst2); the specs stay separate for the backward lowering.  Returns {spec index: dst2 | None}."""
+    import os
+    out = {}
+    if os.environ.get("SSDE_FUSE_FIR", "1") == "0":
+        return out
+    same = ("n", "h_in", "w_in", "c", "h_out", "w_out", "up", "down", "pad0", "pad1", "kh", "kw", "k")
+    for i in range(len(specs) - 1):
+        (k0, f0, _, _), (k1, f1, _, _) = specs[i], specs[i + 1]
+        if k0 != L.OP_UPFIRDN or k1 != L.OP_UPFIRDN or i in out:
+            continue
+        if f0["src"]["p0"] is not f1["src"]["p0"] or f0["src"]["pro_mode"] == L.PRO_NONE or f1["src"]["pro_mode"] != L.PRO_NONE:
+            continue
+        if f0.get("accumulate") or f1.get("accumulate") or any(f0[k] != f1[k] for k in same):
+            continue
+        out[i], out[i + 1] = f1["dst"], None
+    return out
+
+
 def _expand(kind, fields, fclass, fl):
     """One lowering spec -> the C ops that execute it.  A fused (3x3 + 1x1 skip) convolution whose 3x3 part runs on
     the Winograd kernel is issued as two launches: tmp = conv3x3 + bias + temb addend, then the 1x1 GEMM with tmp as
@@ -173,7 +199,7 @@ def _expand(kind, fields, fclass, fl):
     px = fields["n"] * fields["h_out"] * fields["w_out"]
     fl1 = 2.0 * px * (fields["aux"]["c0"] + fields["aux"]["c1"]) * fields["c_out"]
     a = dict(fields)
-    a.update(aux=_NOSRC, w_aux=None, resid=None, resid_post=0, out_scale=1.0, dst=fields["_split_tmp"])
+    a.update(aux=_NOSRC, w_aux=None, resid=None, resid_post=0, out_scale=1.0, dst=fields["_split_tmp"], gn_part=None)
     b = dict(fields)
     b.update(main=_NOSRC, w_main=None, ksize=0, bias=None, chan_add=None, chan_add_ld=0, resid=fields["_split_tmp"],
              resid_post=0, tile=L.TILE_AUTO)
@@ -473,6 +499,31 @@ class Lowering:
 
     def __init__(self, builder, weights, batch):
         self.b, self.w, self.n = builder, weights, batch
+        self.parts = {}      # id(activation Buf) -> (partials Buf, slices per image, channels): written by its producer's epilogue
+
+    def _gn_slices(self, fields):
+        """Slices per image of the GroupNorm partials the LAST launch of this conv spec would write (0: not available)."""
+        import os
+        if os.environ.get("SSDE_GN_FUSE", "1") == "0":
+            return 0
+        sub = _expand(L.OP_CONV, fields, 0, 0.0)[-1][0]
+        a = L.ConvArgs()
+        dummy = 0x1000                                            # the planner only tests pointers for presence
+        for src_name in ("main", "aux"):
+            src, dst = sub[src_name], getattr(a, src_name)
+            dst.p0 = dummy if src["p0"] is not None else None
+            dst.p1 = dummy if src["p1"] is not None else None
+            dst.c0, dst.c1, dst.pro_mode, dst.gn_groups = src["c0"], src["c1"], src["pro_mode"], src["gn_groups"]
+            if src["gn_groups"]:
+                dst.gn_mean = dst.gn_rstd = dst.gn_gamma = dst.gn_beta = dummy
+            if src["drop_thresh"]:
+                dst.drop_thresh, dst.drop_seed = src["drop_thresh"], dummy
+        a.w_main = dummy if sub["w_main"] is not None else None
+        a.w_aux = dummy if sub["w_aux"] is not None else None
+        for k in ("n", "h_in", "w_in", "h_out", "w_out", "c_out", "ksize", "stride", "pad", "tile"):
+            setattr(a, k, sub[k])
+        a.dst = dummy
+        return int(L.load().ssde_conv_gn_slices(C.byref(a)))
 
     # -- GroupNorm statistics of a (possibly concatenated) NHWC source
     def gn_stats(self, t, c, hw, gn_module, t2=None, c2=0):
@@ -480,6 +531,16 @@ class Lowering:
         groups = gn_module.num_groups
         mean = self.b.buf(self.n, groups, name="gn_mean")
         rstd = self.b.buf(self.n, groups, name="gn_rstd")
+        p0, p1 = self.parts.get(id(t)), (self.parts.get(id(t2)) if t2 is not None else None)
+        if p0 is not None and p0[2] == c and (t2 is None or (p1 is not None and p1[2] == c2)) and (ctot // groups) % 4 == 0:
+            # the producers' epilogues already reduced this tensor: merge their partials (no pass over the activations)
+            self.b.add(L.OP_GN_FINALIZE, dict(part0=p0[0], part1=p1[0] if p1 else None, c0=c, c1=c2, slices0=p0[1],
+                                              slices1=p1[1] if p1 else 0, n=self.n, groups=groups, eps=float(gn_module.eps),
+                                              mean=mean, rstd=rstd), FC_GN)
+            gamma = self.w.vector([gn_module.weight])
+            beta = self.w.vector([gn_module.bias])
+            assert ctot == gn_module.num_channels
+            return dict(groups=groups, mean=mean, rstd=rstd, gamma=gamma, beta=beta)
         slices = max(1, min(int(math.ceil(256 / self.n)), hw // 64)) if hw >= 128 else 1
         scratch = self.b.buf(self.n * slices * groups * 2, name="gn_scratch") if slices > 1 else None
         self.b.add(L.OP_GN_STATS, dict(p0=t, p1=t2, c0=c, c1=c2, n=self.n, hw=hw, groups=groups, eps=float(gn_module.eps),
@@ -491,8 +552,10 @@ class Lowering:
 
     def conv(self, dst, h_out, w_out, c_out, main=None, w_main=None, h_in=0, w_in=0, stride=1, pad=1,
              aux=None, w_aux=None, bias=None, chan_add=None, chan_add_ld=0, resid=None, scale=1.0, tile=L.TILE_AUTO,
-             resid_post=0, wino=False):
-        """wino=True: w_main is Winograd-packed (see wino_ok); a fused 1x1 source then runs as a second launch."""
+             resid_post=0, wino=False, stats=False):
+        """wino=True: w_main is Winograd-packed (see wino_ok); a fused 1x1 source then runs as a second launch.
+        stats=True: dst feeds a GroupNorm later -- when the launch plan allows it (ssde_conv_gn_slices) the epilogue
+        also writes the tensor's partial statistics and gn_stats() turns into a finalize of a few thousand floats."""
         split_tmp = None
         if wino:
             assert main is not None and stride == 1 and pad == 1 and (h_in, w_in) == (h_out, w_out)
@@ -505,13 +568,19 @@ class Lowering:
             flops += 2.0 * px * 9 * (main["c0"] + main["c1"]) * c_out
         if aux is not None:
             flops += 2.0 * px * (aux["c0"] + aux["c1"]) * c_out
-        self.b.add(L.OP_CONV, dict(
+        fields = dict(
             main=main if main is not None else _NOSRC, aux=aux if aux is not None else _NOSRC,
             w_main=w_main, w_aux=w_aux, n=self.n, h_in=h_in, w_in=w_in, h_out=h_out, w_out=w_out, c_out=c_out,
             ksize=3 if main is not None else 0, stride=stride, pad=pad, tile=tile, bias=bias, chan_add=chan_add,
-            chan_add_ld=chan_add_ld, resid_post=resid_post, resid=resid, out_scale=float(scale), dst=dst,
-            _split_tmp=split_tmp),
-            FC_CONV3 if main is not None else FC_CONV1, flops)
+            chan_add_ld=chan_add_ld, resid_post=resid_post, resid=resid, out_scale=float(scale), dst=dst, gn_part=None,
+            _split_tmp=split_tmp)
+        if stats and isinstance(dst, Buf):
+            slices = self._gn_slices(fields)
+            if slices > 0:
+                part = self.b.buf(self.n, slices, c_out // 4, 3, name="gn_part")
+                fields["gn_part"] = part
+                self.parts[id(dst)] = (part, slices, c_out)
+        self.b.add(L.OP_CONV, fields, FC_CONV3 if main is not None else FC_CONV1, flops)
 
     def wino_ok(self, h, w, c_out, c_in):
         """Winograd F(2x2,3x3) pays when the matrix pipe is the bound: even outputs, enough channels to fill the
@@ -639,7 +708,7 @@ class UNetEngine:
         conv_in = mods[idx]; idx += 1
         h = b.buf(n, H, W, nf, name="h0")
         low.conv(h, H, W, nf, main=_src(x0, cpad), w_main=self._w3(conv_in, cin_pad=cpad), h_in=H, w_in=W,
-                 bias=self._bias(conv_in))
+                 bias=self._bias(conv_in), stats=True)
         hs = [(h, nf, H, W)]
         cur_c = nf
 
@@ -667,7 +736,7 @@ class UNetEngine:
                         raise NotImplementedError("progressive_combine='cat' is not lowered (no shipped config uses it)")
                     hn = b.buf(n, hh, ww, cur_c, name="combine")
                     low.conv(hn, hh, ww, cur_c, aux=_src(pyr, pyr_c), w_aux=self._w1(comb.Conv_0, cin_pad=pyr_c),
-                             bias=self._bias(comb.Conv_0), resid=h, scale=1.0)
+                             bias=self._bias(comb.Conv_0), resid=h, scale=1.0, stats=True)
                     h = hn
                 elif model.progressive_input == "residual":
                     down = mods[idx]; idx += 1
@@ -677,7 +746,8 @@ class UNetEngine:
                     pf, ph, pw = low.upfirdn(_src(pyr, pyr_c), pyr_c, hh * 2, ww * 2, fir_taps(fk), pad=(2, 2), name="pyr_fir")
                     hn = b.buf(n, hh, ww, cur_c, name="pyr")
                     low.conv(hn, hh, ww, cur_c, main=_src(pf, pyr_c), w_main=self._w3(down.Conv2d_0, cin_pad=pyr_c),
-                             h_in=ph, w_in=pw, stride=2, pad=0, bias=self._bias(down.Conv2d_0), resid=h, scale=skip_scale)
+                             h_in=ph, w_in=pw, stride=2, pad=0, bias=self._bias(down.Conv2d_0), resid=h, scale=skip_scale,
+                             stats=True)
                     pyr, pyr_c, h = hn, cur_c, hn
                 hs.append((h, cur_c, hh, ww))
 
@@ -766,7 +836,7 @@ class UNetEngine:
         wino0 = low.wino_ok(hh, ww, cout, main0["c0"] + main0["c1"])
         wino1 = low.wino_ok(hh, ww, cout, cout)
         low.conv(h1, hh, ww, cout, main=main0, w_main=self._w3(m.Conv_0, wino=wino0), h_in=hh, w_in=ww, bias=self._bias(m.Conv_0),
-                 chan_add=chan_add, chan_add_ld=ld, wino=wino0)
+                 chan_add=chan_add, chan_add_ld=ld, wino=wino0, stats=True)
         gn1 = low.gn_stats(h1, cout, hh * ww, m.GroupNorm_1)
         out = b.buf(n, hh, ww, cout, name="res_out")
         self._n_res += 1
@@ -775,11 +845,12 @@ class UNetEngine:
         if hasattr(m, "Conv_2"):
             bsum = self.weights.vector([m.Conv_1.bias, m.Conv_2.bias], mode="sum")
             low.conv(out, hh, ww, cout, main=main1, w_main=self._w3(m.Conv_1, wino=wino1), h_in=hh, w_in=ww,
-                     aux=_src(skip_t, skip_c, skip_t2, skip_c2), w_aux=self._w1(m.Conv_2), bias=bsum, scale=scale, wino=wino1)
+                     aux=_src(skip_t, skip_c, skip_t2, skip_c2), w_aux=self._w1(m.Conv_2), bias=bsum, scale=scale, wino=wino1,
+                     stats=True)
         else:
             assert skip_t2 is None
             low.conv(out, hh, ww, cout, main=main1, w_main=self._w3(m.Conv_1, wino=wino1), h_in=hh, w_in=ww,
-                     bias=self._bias(m.Conv_1), resid=skip_t, scale=scale, wino=wino1)
+                     bias=self._bias(m.Conv_1), resid=skip_t, scale=scale, wino=wino1, stats=True)
         return out, cout
 
     # -- AttnBlockpp (layerspp.py:75-91)
@@ -797,7 +868,7 @@ class UNetEngine:
         out = b.buf(n, hh, ww, c, name="attn_out")
         low.conv(out, hh, ww, c, aux=_src(ao, c), w_aux=self.weights.matrix([(m.NIN_3.W, True)]),
                  bias=self.weights.vector([m.NIN_3.b]), resid=t,
-                 scale=INV_SQRT2 if m.skip_rescale else 1.0)
+                 scale=INV_SQRT2 if m.skip_rescale else 1.0, stats=True)
         return out
 
     # ------------------------------------------------------------------ execution

@@ -90,22 +90,27 @@ def conv2d(x=None, weight=None, bias=None, stride=1, pad=1, x2=None, pro=L.PRO_N
     return dst
 
 
-def upfirdn2d_nhwc(x, kernel, up=1, down=1, pad=(0, 0), pro=L.PRO_NONE, gn=None):
+def upfirdn2d_nhwc(x, kernel, up=1, down=1, pad=(0, 0), pro=L.PRO_NONE, gn=None, dual=False, accumulate_into=None):
+    """dual=True also returns the same filter applied to the source without its prologue (one launch, dst2);
+    accumulate_into: an existing output tensor the result is added to."""
     _need_cuda(x)
     n, h, w, c = x.shape
     kh, kw = kernel.shape
     h_out = (h * up + pad[0] + pad[1] - kh) // down + 1
     w_out = (w * up + pad[0] + pad[1] - kw) // down + 1
-    dst = torch.empty(n, h_out, w_out, c, device=x.device)
+    dst = torch.empty(n, h_out, w_out, c, device=x.device) if accumulate_into is None else accumulate_into
+    dst2 = torch.empty(n, h_out, w_out, c, device=x.device) if dual else None
     a = L.UpfirdnArgs()
     _fill_src(a.src, x, None, pro, gn)
+    a.accumulate = int(accumulate_into is not None)
+    a.dst2 = _p(dst2) if dual else None
     a.n, a.h_in, a.w_in, a.c, a.h_out, a.w_out = n, h, w, c, h_out, w_out
     a.up, a.down, a.pad0, a.pad1, a.kh, a.kw = up, down, pad[0], pad[1], kh, kw
     for i, v in enumerate(np.asarray(kernel.detach().cpu(), dtype=np.float32).reshape(-1).tolist()):
         a.k[i] = v
     a.dst = _p(dst)
     L.check(L.load().ssde_upfirdn2d(C.byref(a), _stream()), "ssde_upfirdn2d")
-    return dst
+    return (dst, dst2) if dual else dst
 
 
 def attention(qkv, channels):

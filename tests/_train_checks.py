@@ -170,6 +170,93 @@ def check_backward_ops(dev):
         assert rel_err(pp, p_ref.detach()) < 1e-6 and rel_err(ema, ema_ref) < 1e-6
 
 
+def check_upfirdn_tiles(dev):
+    """The LDS-staged FIR kernel (channels % 32 == 0, 4x4 taps) in all three modes and their gradient shapes, with
+    ragged sizes (partial tiles, odd maps), an asymmetric kernel (flip), the GroupNorm+SiLU prologue applied once in LDS,
+    the dual output (act(GN(x)) and x filtered in one launch) and accumulation, against the oracle's restatement of
+    upfirdn2d_native (op/upfirdn2d.py:159-200).  Tolerance 2e-6 (16-term sums) / 1e-5 with the prologue."""
+    from score_sde_pytorch_amd import hipops as ops, _lib as L
+    from oracle import unet_oracle as uo
+    g = torch.Generator().manual_seed(31)
+    kasym = (torch.arange(16, dtype=torch.float32).reshape(4, 4) + 1) / 30.0
+    ksym = torch.tensor(uo.setup_fir_kernel([1, 3, 3, 1]))
+    d = lambda t: t.to(dev)   # noqa: E731
+    for (n, c, h, w) in [(2, 32, 5, 7), (1, 64, 20, 12), (3, 32, 16, 16), (2, 32, 1, 1)]:
+        x = torch.randn(n, c, h, w, generator=g)
+        for up, down, pad in [(2, 1, (2, 1)), (1, 2, (1, 1)), (1, 1, (2, 2)), (1, 1, (1, 2)), (2, 1, (1, 2))]:
+            if (h * up + pad[0] + pad[1] - 4) // down + 1 < 1 or (w * up + pad[0] + pad[1] - 4) // down + 1 < 1:
+                continue
+            for k in (kasym, ksym * up * up):
+                y = ops.upfirdn2d_nhwc(d(nhwc(x)), k, up=up, down=down, pad=pad)
+                ref = uo.upfirdn2d(x, k, up=up, down=down, pad=pad)
+                assert tuple(nchw(y.cpu()).shape) == tuple(ref.shape), (up, down, pad)
+                assert rel_err(nchw(y.cpu()), ref) < 2e-6, (n, c, h, w, up, down, pad)
+    # prologue once in LDS + dual output + accumulate
+    x = torch.randn(2, 64, 12, 20, generator=g) + 0.5
+    gamma, beta = 1 + 0.1 * torch.randn(64, generator=g), 0.1 * torch.randn(64, generator=g)
+    xd = d(nhwc(x))
+    mean, rstd = ops.groupnorm_stats(xd, 16)
+    act = F.silu(F.group_norm(x, 16, gamma, beta, 1e-6))
+    for up, down, pad, gain in [(2, 1, (2, 1), 4.0), (1, 2, (1, 1), 1.0)]:
+        k = ksym * gain
+        y, y2 = ops.upfirdn2d_nhwc(xd, k, up=up, down=down, pad=pad, pro=L.PRO_GN_SILU, gn=(mean, rstd, d(gamma), d(beta), 16),
+                                   dual=True)
+        assert rel_err(nchw(y.cpu()), uo.upfirdn2d(act, k, up=up, down=down, pad=pad)) < 1e-5
+        assert rel_err(nchw(y2.cpu()), uo.upfirdn2d(x, k, up=up, down=down, pad=pad)) < 2e-6
+        base = torch.randn(y.shape, generator=g)
+        acc = d(base.clone())
+        ops.upfirdn2d_nhwc(xd, k, up=up, down=down, pad=pad, accumulate_into=acc)
+        assert rel_err(acc.cpu(), base + nhwc(uo.upfirdn2d(x, k, up=up, down=down, pad=pad))) < 2e-6
+
+
+def check_fused_gn_statistics(dev, monkeypatch):
+    """GroupNorm statistics from the producers' epilogues (ssde_conv_args.gn_part + ssde_gn_finalize) against the
+    standalone reduction kernel (SSDE_GN_FUSE=0) on the same network: the lowered program must contain finalize ops,
+    every (mean, rstd) pair must match the standalone kernel's to 1e-5, and both outputs must match the oracle."""
+    import ctypes as C
+    from score_sde_pytorch_amd import engine as E, _lib as L
+    from score_sde_pytorch_amd.models import utils as mutils
+    from oracle import unet_oracle
+    cfg = _util.small_config("ncsnpp", image_size=32, ch_mult=(1, 2, 2), num_res_blocks=2, attn=(16,))
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    sd = dict(_util.load_seeded(model, seed=1)); sd["sigmas"] = model.sigmas.clone()
+    model = model.to(dev).eval()
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(3, 3, 32, 32, generator=g) + 2 * torch.randn(3, 3, 32, 32, generator=g)
+    sig = torch.tensor([0.05, 1.3, 20.0])
+    lib = L.load()
+    cuda = str(dev).startswith("cuda")
+    outs, seqs = {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SSDE_GN_FUSE", mode)
+        eng = E.UNetEngine(model, 3, 32, 32, torch.device(dev))
+        prog = eng.program
+        kinds = [int(prog.ops[i].kind) for i in range(prog.n)]
+        n_fin, n_std = kinds.count(L.OP_GN_FINALIZE), kinds.count(L.OP_GN_STATS)
+        assert (n_fin > 10) if mode == "1" else (n_fin == 0), (mode, n_fin, n_std)
+        eng.weights.refresh()
+        eng.load_inputs(x.to(dev).contiguous(), sig.to(dev))
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream if cuda else 0)
+        seq = []
+        for si, (kind, f, _, _) in enumerate(eng.b.specs):          # spec by spec: statistics buffers are recycled later
+            lo, hi = prog.spec_start[si], prog.spec_start[si + 1]
+            if hi > lo:
+                ptr = C.cast(C.byref(prog.ops, lo * C.sizeof(L.Op)), C.POINTER(L.Op))
+                L.check(lib.ssde_program_run(ptr, hi - lo, st))
+            if kind in (L.OP_GN_FINALIZE, L.OP_GN_STATS):
+                n = f["n"] * f["groups"]
+                seq.append((f["mean"].tensor[:n].cpu().clone(), f["rstd"].tensor[:n].cpu().clone()))
+        outs[mode] = eng.output_view().cpu().clone()
+        seqs[mode] = seq
+    ref = unet_oracle.ncsnpp_forward(cfg, sd, x, sig)
+    assert rel_err(outs["1"], ref) < 1e-4 and rel_err(outs["0"], ref) < 1e-4
+    assert len(seqs["1"]) == len(seqs["0"]) > 20
+    for (m1, r1), (m0, r0) in zip(seqs["1"], seqs["0"]):
+        assert float((m1 - m0).abs().max()) <= 1e-5 * max(1.0, float(m0.abs().max()))
+        assert rel_err(r1, r0) < 1e-5
+
+
 def check_dropout_mask(dev):
     """The dropout mask is a pure function of (seed word, salt, element index): forward conv, weight gradient
     and GroupNorm backward regenerate the SAME mask (numpy restatement of the hash as the witness)."""

@@ -24,6 +24,14 @@ def test_dropout_mask_is_regenerated_identically():
     T.check_dropout_mask("cpu")
 
 
+def test_upfirdn_lds_tiles():
+    T.check_upfirdn_tiles("cpu")
+
+
+def test_groupnorm_statistics_from_producer_epilogues(monkeypatch):
+    T.check_fused_gn_statistics("cpu", monkeypatch)
+
+
 @pytest.mark.parametrize("kind", ["ncsnpp", "ddpmpp", "ffhq"])
 def test_whole_network_gradients(kind):
     T.check_unet_grads(kind, "cpu")

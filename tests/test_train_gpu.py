@@ -18,6 +18,14 @@ def test_dropout_mask_is_regenerated_identically():
     T.check_dropout_mask("cuda")
 
 
+def test_upfirdn_lds_tiles():
+    T.check_upfirdn_tiles("cuda")
+
+
+def test_groupnorm_statistics_from_producer_epilogues(monkeypatch):
+    T.check_fused_gn_statistics("cuda", monkeypatch)
+
+
 @pytest.mark.parametrize("kind", ["ncsnpp", "ddpmpp", "ffhq"])
 def test_whole_network_gradients_small(kind):
     T.check_unet_grads(kind, "cuda", batch=3)
