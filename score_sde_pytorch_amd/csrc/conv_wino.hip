@@ -62,6 +62,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef SSDE_WINO_GNLDS
 #define SSDE_WINO_GNLDS 1
 #endif
+// s_sleep argument (units of 64 cycles) between the 8 LDS groups of the input transform; 0 = one burst (round 1).
+// A/B on the MI355X (gpurun_out/conv_ab_r2g.txt): 1 = +3 % on every shape, 2 = neutral, 3 = slower (the transform itself
+// becomes the critical path of the phase).
+#ifndef SSDE_WINO_TSLEEP
+#define SSDE_WINO_TSLEEP 1
+#endif
 
 // -DSSDE_WINO_TRACE (tools/wino_trace.py, a variant library only): s_memtime stamps of waves 0 and 4 of the first and of
 // the last workgroup, to see where a workgroup's cycles go (fill, the two phases of a stage, barriers, epilogue).
@@ -283,21 +289,30 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
       *reinterpret_cast<float2*>(raw + ((2 * half + 1) * halo_px + hp) * 2) = make_float2(v.z, v.w);
     }
   };
-  // V = B^T d B for this thread's (tile, channel pair), both channels at once
+  // V = B^T d B for this thread's (tile, channel pair), both channels at once.
+  // The 16 LDS reads and 16 LDS writes are issued in 8 groups of 4 with s_sleep in between (SSDE_WINO_TSLEEP): as one
+  // burst at the start of the phase, the 4 x 32 LDS operations of the transforming waves queue in front of the matrix
+  // waves' fragment reads, which are prefetched only one position (256 matrix cycles) ahead -- the matrix phase of
+  // waves 4-7 took 3260 cycles instead of 2750 (tools/wino_trace.py).  Groups of 4 keep the LDS queue shorter than
+  // that prefetch distance, and the transforming waves have ~2000 idle cycles in this phase anyway.
   auto transform = [&](float* Vn) {
     const float* rp = raw + (t_pair * halo_px + t_base) * 2;
-    float2 d[4][4];
-#pragma unroll
-    for (int y = 0; y < 4; ++y)
-#pragma unroll
-      for (int x = 0; x < 4; ++x) d[y][x] = *reinterpret_cast<const float2*>(rp + (y * HWd + x) * 2);
     float2 r[4][4];
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-      r[0][x] = make_float2(d[0][x].x - d[2][x].x, d[0][x].y - d[2][x].y);
-      r[1][x] = make_float2(d[1][x].x + d[2][x].x, d[1][x].y + d[2][x].y);
-      r[2][x] = make_float2(d[2][x].x - d[1][x].x, d[2][x].y - d[1][x].y);
-      r[3][x] = make_float2(d[1][x].x - d[3][x].x, d[1][x].y - d[3][x].y);
+      const float2 d0 = *reinterpret_cast<const float2*>(rp + (0 * HWd + x) * 2);
+      const float2 d1 = *reinterpret_cast<const float2*>(rp + (1 * HWd + x) * 2);
+      const float2 d2 = *reinterpret_cast<const float2*>(rp + (2 * HWd + x) * 2);
+      const float2 d3 = *reinterpret_cast<const float2*>(rp + (3 * HWd + x) * 2);
+      r[0][x] = make_float2(d0.x - d2.x, d0.y - d2.y);
+      r[1][x] = make_float2(d1.x + d2.x, d1.y + d2.y);
+      r[2][x] = make_float2(d2.x - d1.x, d2.y - d1.y);
+      r[3][x] = make_float2(d1.x - d3.x, d1.y - d3.y);
+#if SSDE_WINO_TSLEEP > 0
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_sleep(SSDE_WINO_TSLEEP);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
@@ -309,6 +324,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
       *reinterpret_cast<float2*>(Vn + (y * 4 + 1) * 512 + t_vcol) = v1;
       *reinterpret_cast<float2*>(Vn + (y * 4 + 2) * 512 + t_vcol) = v2;
       *reinterpret_cast<float2*>(Vn + (y * 4 + 3) * 512 + t_vcol) = v3;
+#if SSDE_WINO_TSLEEP > 0
+      if (y < 3) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_sleep(SSDE_WINO_TSLEEP);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
     }
   };
 
