@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kThreads, 4) void gemm1x1_kernel(const GemmParams p
           }
     }
     __syncthreads();
-    ssde_store_tile(smem, 64, LDT, BN, n0, e, kThreads, [&](int row, size_t& pix, int& img) {
+    ssde_store_tile<64, BN, kThreads, 1>(smem, LDT, n0, e, [&](int row, size_t& pix, int& img) {
       const int m = m0 + half * 64 + row;
       if (m >= p.M) return false;
       pix = (size_t)m;

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvKParam
   __syncthreads();
   SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, g.Cout, p.gn_part};
   const int gn_entry = p.gn_part ? img0 * g.tiles_per_img + trem : -1;        // make_plan: IMGS == 1
-  ssde_store_tile(smem, BM, LDT, BN, n0, e, kThreads, [&](int m, size_t& pix, int& img) {
+  ssde_store_tile<BM, BN, kThreads>(smem, LDT, n0, e, [&](int m, size_t& pix, int& img) {
     const int c = m & (TW - 1);
     const int rr = (m >> g.lTW) & (TH - 1);
     img = img0 + (m >> (g.lTW + g.lTH));

@@ -599,7 +599,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
   SSDE_TR(45);
   SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, p.Cout, p.gn_part};
   const int gn_entry = p.gn_part ? img0 * p.tiles_per_img + trem : -1;        // launcher: IMGS == 1
-  ssde_store_tile(outs, 256, LDT, 64, n0, e, kThreads, [&](int row, size_t& pix, int& img) {
+  ssde_store_tile<256, 64, kThreads>(outs, LDT, n0, e, [&](int row, size_t& pix, int& img) {
     const int tile = row >> 2, dy = (row >> 1) & 1, dx = row & 1;
     const int il = tile >> (p.lTWt + p.lTHt);
     const int tr = (tile >> p.lTWt) & (THt - 1), tc = tile & (TWt - 1);

@@ -166,41 +166,67 @@ __device__ __forceinline__ void ssde_stat_merge(float& n, float& m, float& M2, f
 // gn_entry = image * tiles_per_image + tile.  ssde_gn_finalize merges slices and quads into groups in a fixed order
 // (deterministic, no atomics).  A thread owns one channel quad (nthreads % (ncols/4) == 0): sums relative to its first
 // value (no cancellation), lanes of equal quad merged by wave shuffles.
-template <class PixFn>
-__device__ __forceinline__ void ssde_store_tile(float* tile, int rows, int ld, int ncols, int n0, const SsdeEpi& e,
-                                                int nthreads, PixFn pixfn, int gn_entry = -1) {
-  const int c4n = ncols >> 2;
+template <int ROWS, int NCOLS, int NT, int BATCH = 4, class PixFn>
+__device__ __forceinline__ void ssde_store_tile(float* tile, int ld, int n0, const SsdeEpi& e, PixFn pixfn, int gn_entry = -1) {
+  constexpr int C4N = NCOLS / 4, TOTAL = ROWS * C4N, ITERS = TOTAL / NT, RSTEP = NT / C4N;
+  static_assert(TOTAL % NT == 0 && NT % C4N == 0 && 64 % C4N == 0, "a thread owns one channel quad of ITERS rows");
+  const int c = ((int)threadIdx.x % C4N) * 4, row0 = (int)threadIdx.x / C4N;
+  const int j = n0 + c;
   const bool stats = e.gn_part != nullptr && gn_entry >= 0;
   float st_p = 0.f, st_s1 = 0.f, st_s2 = 0.f, st_n = 0.f;
-  for (int q = threadIdx.x; q < rows * c4n; q += nthreads) {
-    const int row = q / c4n, c = (q - row * c4n) * 4;
-    const int j = n0 + c;
-    if (j >= e.Cout) continue;
-    size_t pix; int img;
-    if (!pixfn(row, pix, img)) continue;
-    const float4 t = *reinterpret_cast<const float4*>(tile + row * ld + c);
-    float v[4] = {t.x, t.y, t.z, t.w};
-    if (j + 4 <= e.Cout && (e.Cout & 3) == 0) {
-      if (e.bias) { const float4 b = *reinterpret_cast<const float4*>(e.bias + j); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-      if (e.chan_add) {
-        const float4 a = *reinterpret_cast<const float4*>(e.chan_add + (size_t)img * e.chan_add_ld + j);
-        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
-      }
-      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e.resid) r = *reinterpret_cast<const float4*>(e.resid + pix * e.Cout + j);
-      if (e.resid && !e.resid_post) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+  if ((e.Cout & 3) == 0) {
+    // The rows of a thread are processed in batches of up to 4: all residual / per-sample loads of a batch are issued
+    // before the first value is needed.  (As one load per loop trip the 4..16 trips each waited out a full memory
+    // latency: this loop was ~5000 of the ~10000 exposed epilogue cycles of a conv_wino workgroup, tools/wino_trace.py.)
+    const bool col_ok = j < e.Cout;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e.bias && col_ok) bias4 = *reinterpret_cast<const float4*>(e.bias + j);
+    constexpr int B = ITERS >= BATCH ? BATCH : ITERS;      // BATCH: 12 registers per row in flight
+    static_assert(ITERS % B == 0, "row batches");
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] *= e.scale;
-      if (e.resid && e.resid_post) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
-      *reinterpret_cast<float4*>(e.dst + pix * e.Cout + j) = make_float4(v[0], v[1], v[2], v[3]);
-      if (stats) {
-        if (st_n == 0.f) st_p = v[0];
-        const float d0 = v[0] - st_p, d1 = v[1] - st_p, d2 = v[2] - st_p, d3 = v[3] - st_p;
-        st_s1 += (d0 + d1) + (d2 + d3);
-        st_s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-        st_n += 4.f;
+    for (int it0 = 0; it0 < ITERS; it0 += B) {
+      float4 t[B], r[B], a[B];
+      size_t pix[B];
+      bool ok[B];
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const int row = row0 + (it0 + b) * RSTEP;
+        int img = 0;
+        pix[b] = 0;
+        ok[b] = col_ok && pixfn(row, pix[b], img);
+        t[b] = *reinterpret_cast<const float4*>(tile + row * ld + c);
+        r[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+        a[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok[b] && e.resid) r[b] = *reinterpret_cast<const float4*>(e.resid + pix[b] * e.Cout + j);
+        if (ok[b] && e.chan_add) a[b] = *reinterpret_cast<const float4*>(e.chan_add + (size_t)img * e.chan_add_ld + j);
       }
-    } else {
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        if (!ok[b]) continue;
+        float v[4] = {t[b].x + bias4.x + a[b].x, t[b].y + bias4.y + a[b].y, t[b].z + bias4.z + a[b].z, t[b].w + bias4.w + a[b].w};
+        const float4 rr = r[b];
+        if (!e.resid_post) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= e.scale;
+        if (e.resid_post) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
+        *reinterpret_cast<float4*>(e.dst + pix[b] * e.Cout + j) = make_float4(v[0], v[1], v[2], v[3]);
+        if (stats) {
+          if (st_n == 0.f) st_p = v[0];
+          const float d0 = v[0] - st_p, d1 = v[1] - st_p, d2 = v[2] - st_p, d3 = v[3] - st_p;
+          st_s1 += (d0 + d1) + (d2 + d3);
+          st_s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+          st_n += 4.f;
+        }
+      }
+    }
+  } else {
+    // channel counts that are not a multiple of 4 (the 3-channel image ends): element-wise
+    for (int it = 0; it < ITERS; ++it) {
+      const int row = row0 + it * RSTEP;
+      size_t pix; int img;
+      if (j >= e.Cout || !pixfn(row, pix, img)) continue;
+      const float4 t = *reinterpret_cast<const float4*>(tile + row * ld + c);
+      const float v[4] = {t.x, t.y, t.z, t.w};
       for (int k = 0; k < 4 && j + k < e.Cout; ++k) {
         float x = v[k];
         if (e.bias) x += e.bias[j + k];
@@ -216,16 +242,16 @@ __device__ __forceinline__ void ssde_store_tile(float* tile, int rows, int ld, i
   if (stats) {                                  // uniform over the workgroup
     float n = st_n, m = 0.f, M2 = 0.f;
     if (n > 0.f) { const float rn = __builtin_amdgcn_rcpf(n); m = st_p + st_s1 * rn; M2 = st_s2 - st_s1 * st_s1 * rn; M2 = M2 < 0.f ? 0.f : M2; }
-    for (int o = c4n; o < 64; o <<= 1) {        // lanes l, l + c4n, l + 2 c4n, ... hold the same channel quad
+    for (int o = C4N; o < 64; o <<= 1) {        // lanes l, l + C4N, l + 2 C4N, ... hold the same channel quad
       const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(m, o, 64), Mb = __shfl_xor(M2, o, 64);
       if (threadIdx.x & o) { float tn = nb, tm = mb, tM = Mb; ssde_stat_merge(tn, tm, tM, n, m, M2); n = tn; m = tm; M2 = tM; }
       else ssde_stat_merge(n, m, M2, nb, mb, Mb);   // both partners merge lower-lane-first: identical results
     }
     // one entry per WAVE (no workgroup barrier, no LDS round trip in the exposed tail of the kernel): the finalize kernel
-    // merges nthreads / 64 times as many slices, a few hundred floats per (image, group)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nthreads >> 6;
-    if (lane < c4n && n0 + 4 * lane < e.Cout) {
-      float* o = e.gn_part + (((size_t)gn_entry * nw + wave) * (e.Cout >> 2) + (n0 >> 2) + lane) * 3;
+    // merges NT / 64 times as many slices, a few hundred floats per (image, group)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < C4N && n0 + 4 * lane < e.Cout) {
+      float* o = e.gn_part + (((size_t)gn_entry * (NT / 64) + wave) * (e.Cout >> 2) + (n0 >> 2) + lane) * 3;
       o[0] = m; o[1] = M2; o[2] = n;
     }
   }
