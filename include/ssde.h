@@ -19,6 +19,7 @@
 #ifndef SSDE_H_
 #define SSDE_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -425,6 +426,59 @@ int ssde_graph_launch(void* graph, void* stream);
 int ssde_graph_destroy(void* graph);
 
 /* ---- misc --------------------------------------------------------------------- */
+/* ---- plans: a lowered program as a position-independent blob, for hosts without Python --------------------------
+ * SURVEY 8(b).  The lowering of NCSNpp.forward (models/ncsnpp.py:232-381) and of pc_sampler's loop body
+ * (sampling.py:403-407) lives in ONE place, score_sde_pytorch_amd/engine.py + pc_engine.py; plan_export.py serialises
+ * its result.  Layout of a blob (little endian, all structs below packed as declared):
+ *   ssde_plan_header | ssde_plan_region[n_regions] | ssde_op[n_ops] | ssde_op[n_refresh_ops] |
+ *   ssde_plan_reloc[n_relocs] | ssde_plan_param_entry[n_params] | data[data_bytes]
+ * Every pointer field of every op (and of the weight re-pack descriptor tables, which live in constant regions) is
+ * zero in the blob and listed as a relocation (region, byte offset).  ssde_plan_load allocates the regions with
+ * hipMalloc, uploads the constant ones, patches the pointers. */
+enum { SSDE_REGION_ZERO = 0,    /* activations, I/O, sampler state: zero-initialised                      */
+       SSDE_REGION_CONST = 1 }; /* initial contents in the blob: packed weights, parameters, tables       */
+enum { SSDE_RELOC_OP = 0, SSDE_RELOC_REFRESH_OP = 1, SSDE_RELOC_REGION = 2 };
+enum { SSDE_PLAN_UNET = 0, SSDE_PLAN_PC = 1 };
+enum { SSDE_IO_X = 0, SSDE_IO_COND = 1, SSDE_IO_SIGMA = 2, SSDE_IO_STD = 3, SSDE_IO_OUT = 4, SSDE_IO_XMEAN = 5,
+       SSDE_IO_STEP = 6, SSDE_IO_SEED = 7 };
+typedef struct ssde_plan_header {
+  char magic[8];                /* "SSDEPLN1" */
+  int32_t abi_version, sizeof_op;
+  int32_t n_regions, n_ops, n_refresh_ops, n_relocs, n_params;
+  int32_t kind;                 /* SSDE_PLAN_* */
+  int32_t batch, channels, height, width;
+  int32_t nfe_per_iteration;    /* sampler plans: U-Net evaluations per PC iteration; else 1 */
+  int32_t sde_steps;            /* sampler plans: N (length of the step tables) */
+  int32_t io[8];                /* region ids by SSDE_IO_*; -1 = absent */
+  int64_t data_bytes;
+} ssde_plan_header;
+typedef struct ssde_plan_region { int64_t bytes; int64_t data_offset; int32_t kind; int32_t _pad0; char name[32]; } ssde_plan_region;
+typedef struct ssde_plan_reloc {
+  int32_t target_kind;          /* SSDE_RELOC_*: where the pointer is stored */
+  int32_t target;               /* op index / region id */
+  int64_t byte_offset;          /* of the pointer field inside the op / the region */
+  int32_t region; int32_t _pad0;/* what it points to */
+  int64_t offset;
+} ssde_plan_reloc;
+typedef struct ssde_plan_param_entry { char name[96]; int32_t region; int32_t _pad0; int64_t offset; int64_t numel; } ssde_plan_param_entry;
+typedef struct ssde_plan ssde_plan;
+
+int ssde_plan_load(const void* blob, size_t bytes, ssde_plan** out);
+int ssde_plan_load_file(const char* path, ssde_plan** out);
+int ssde_plan_destroy(ssde_plan* p);
+int ssde_plan_info(const ssde_plan* p, ssde_plan_header* out);
+/* device address of a parameter in the reference's layout, by state_dict name (index < 0) or by index */
+int ssde_plan_param(const ssde_plan* p, const char* name, int32_t index, float** dev, int64_t* numel, const char** name_out);
+/* after writing parameters: rebuild every kernel-layout weight copy on the device (ssde_pack_weights) */
+int ssde_plan_refresh_weights(ssde_plan* p, void* stream);
+/* replaces NCSNpp.forward (models/ncsnpp.py:232): device pointers x, out [B,C,H,W], cond [B]; sigma / std NULL unless
+ * the plan has those inputs (discrete labels with scale_by_sigma; VP score head, models/utils.py:147-159) */
+int ssde_unet_forward(ssde_plan* p, const float* x, const float* cond, const float* sigma, const float* std_, float* out, void* stream);
+/* replaces pc_sampler's loop (sampling.py:390-409): load the prior sample, run iterations, read the state */
+int ssde_pc_reset(ssde_plan* p, const float* x_T, uint64_t seed, void* stream);
+int ssde_pc_run(ssde_plan* p, int32_t n_iterations, int32_t use_graph, void* stream);
+int ssde_pc_state(ssde_plan* p, float* x, float* x_mean, void* stream);
+
 int ssde_abi_version(void);
 int ssde_sizeof_op(void);             /* lets the ctypes mirror verify its layout */
 const char* ssde_last_error(void);
