@@ -356,6 +356,21 @@ typedef struct ssde_axpy_args {   /* dst = (acc ? dst : 0) + alpha * x, optional
   const float* x; const float* gate; float* dst; int64_t numel; float alpha; int32_t acc;
 } ssde_axpy_args;
 
+/* ---- adaptive RK45 (Dormand-Prince) stage arithmetic on the device ------------------
+ * replaces the numpy side of scipy.integrate.solve_ivp(method='RK45') as the reference drives it
+ * (sampling.py:466-475, likelihood.py:90-99): fp64 state and stage slopes K[7][n] stay in HBM. */
+typedef struct ssde_rk_coefs { double v[7]; } ssde_rk_coefs;
+typedef struct ssde_rk_combine_args {     /* dst = y + sum_{j < terms} coef[j] * K[j]   (coef = a_sj * h); dst32 = (float)dst or NULL */
+  const double* y; const double* k; int64_t n; int32_t terms; int32_t _pad0; ssde_rk_coefs coef; double* dst; float* dst32;
+} ssde_rk_combine_args;
+typedef struct ssde_rk_error_args {       /* out[0] = sqrt(mean(((sum_j coef[j] K[j]) / (atol + max(|y|,|y_new|) rtol))^2)), coef = E_j * h */
+  const double* y; const double* y_new; const double* k; int64_t n; ssde_rk_coefs coef; double atol, rtol;
+  double* partial; int32_t partial_len; int32_t _pad0; double* out;
+} ssde_rk_error_args;
+typedef struct ssde_pf_drift_args {       /* dst = (double)(a * x - (g2 * score) * 0.5) in fp32, RSDE.sde with probability_flow (sde_lib.py:93-97) */
+  const float* x; const float* score; double* dst; int64_t numel; float a, g2;
+} ssde_pf_drift_args;
+
 /* ---- single-op launch entry points ------------------------------------------ */
 int ssde_conv2d(const ssde_conv_args* a, void* stream);
 int ssde_groupnorm_stats(const ssde_gn_stats_args* a, void* stream);
@@ -376,6 +391,9 @@ int ssde_predictor_update(const ssde_predictor_args* a, void* stream);
 int ssde_fill_from_table(const ssde_fill_args* a, void* stream);
 int ssde_step_inc(const ssde_step_inc_args* a, void* stream);
 int ssde_project_update(const ssde_project_args* a, void* stream);
+int ssde_rk_combine(const ssde_rk_combine_args* a, void* stream);
+int ssde_rk_error_norm(const ssde_rk_error_args* a, void* stream);
+int ssde_pf_drift(const ssde_pf_drift_args* a, void* stream);
 int ssde_conv_wgrad(const ssde_wgrad_args* a, void* stream);
 int ssde_colsum(const ssde_colsum_args* a, void* stream);
 int ssde_gn_bwd_reduce(const ssde_gn_bwd_reduce_args* a, void* stream);

@@ -46,6 +46,20 @@ class GnStatsArgs(C.Structure):
                 ("mean", _fp), ("rstd", _fp), ("scratch", _fp), ("slices", C.c_int32), ("_pad0", C.c_int32)]
 
 
+class RkCombineArgs(C.Structure):
+    _fields_ = [("y", _fp), ("k", _fp), ("n", C.c_int64), ("terms", C.c_int32), ("_pad0", C.c_int32), ("coef", C.c_double * 7),
+                ("dst", _fp), ("dst32", _fp)]
+
+
+class RkErrorArgs(C.Structure):
+    _fields_ = [("y", _fp), ("y_new", _fp), ("k", _fp), ("n", C.c_int64), ("coef", C.c_double * 7), ("atol", C.c_double),
+                ("rtol", C.c_double), ("partial", _fp), ("partial_len", C.c_int32), ("_pad0", C.c_int32), ("out", _fp)]
+
+
+class PfDriftArgs(C.Structure):
+    _fields_ = [("x", _fp), ("score", _fp), ("dst", _fp), ("numel", C.c_int64), ("a", C.c_float), ("g2", C.c_float)]
+
+
 class GnFinalizeArgs(C.Structure):
     _fields_ = [("part0", _fp), ("part1", _fp), ("c0", C.c_int32), ("c1", C.c_int32), ("slices0", C.c_int32), ("slices1", C.c_int32),
                 ("n", C.c_int32), ("groups", C.c_int32), ("eps", C.c_float), ("_pad0", C.c_int32), ("mean", _fp), ("rstd", _fp)]
@@ -214,7 +228,7 @@ EXPORTS = ["ssde_conv2d", "ssde_groupnorm_stats", "ssde_upfirdn2d", "ssde_attent
            "ssde_abi_version", "ssde_sizeof_op", "ssde_last_error", "ssde_conv_lds_bytes",
            "ssde_conv_wgrad", "ssde_colsum", "ssde_gn_bwd_reduce", "ssde_prologue_bwd", "ssde_attention_bwd",
            "ssde_perturb", "ssde_dsm_loss", "ssde_sumsq_flat", "ssde_adam_clip_ema", "ssde_memset", "ssde_axpy",
-           "ssde_wgrad_scratch_floats", "ssde_pack_weights", "ssde_project_update", "ssde_gn_finalize", "ssde_conv_gn_slices",
+           "ssde_wgrad_scratch_floats", "ssde_pack_weights", "ssde_project_update", "ssde_gn_finalize", "ssde_conv_gn_slices", "ssde_rk_combine", "ssde_rk_error_norm", "ssde_pf_drift",
            # plan-level entry points (csrc/plan.hip; argument types: plan_export.bind)
            "ssde_plan_load", "ssde_plan_load_file", "ssde_plan_destroy", "ssde_plan_info", "ssde_plan_param",
            "ssde_plan_refresh_weights", "ssde_unet_forward", "ssde_pc_reset", "ssde_pc_run", "ssde_pc_state"]
@@ -247,7 +261,8 @@ def bind(lib):
                       ("ssde_attention_bwd", AttnBwdArgs), ("ssde_perturb", PerturbArgs), ("ssde_dsm_loss", DsmLossArgs),
                       ("ssde_sumsq_flat", SumsqFlatArgs), ("ssde_adam_clip_ema", AdamArgs), ("ssde_memset", MemsetArgs),
                       ("ssde_axpy", AxpyArgs), ("ssde_pack_weights", PackArgs), ("ssde_project_update", ProjectArgs),
-                      ("ssde_gn_finalize", GnFinalizeArgs)]:
+                      ("ssde_gn_finalize", GnFinalizeArgs), ("ssde_rk_combine", RkCombineArgs),
+                      ("ssde_rk_error_norm", RkErrorArgs), ("ssde_pf_drift", PfDriftArgs)]:
         getattr(lib, name).argtypes = [C.POINTER(typ), C.c_void_p]
     lib.ssde_conv_lds_bytes.argtypes = [C.POINTER(ConvArgs)]
     lib.ssde_conv_gn_slices.argtypes = [C.POINTER(ConvArgs)]

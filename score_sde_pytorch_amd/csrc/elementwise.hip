@@ -301,6 +301,90 @@ extern "C" int ssde_sumsq(const ssde_sumsq_args* a, void* stream) {
   return SSDE_OK;
 }
 
+// ---- Dormand-Prince RK45 stage arithmetic for the probability-flow ODE sampler / likelihood (sampling.py:466-475,
+// likelihood.py:90-99: scipy.integrate.solve_ivp on fp64 numpy state in the reference).  The fp64 state and the 7 stage
+// slopes K_j live on the device; one launch forms a stage argument (and its fp32 copy, the U-Net input: the reference
+// casts the state to float32 per evaluation, models/utils.py:186-188), one launch + a fixed-order finish form scipy's
+// RMS error norm -- the only scalar the host reads per step.
+__global__ __launch_bounds__(256) void rk_combine_kernel(const double* __restrict__ y, const double* __restrict__ k, size_t n, int terms,
+                                                         ssde_rk_coefs c, double* __restrict__ dst, float* __restrict__ dst32) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    // scipy: dy = np.dot(K[:s].T, a[:s]) * h ; y + dy   -- here a_j * h is folded on the host, summed j = 0, 1, ...
+    double dy = 0.0;
+    for (int j = 0; j < terms; ++j) dy += k[(size_t)j * n + i] * c.v[j];
+    const double v = y[i] + dy;
+    dst[i] = v;
+    if (dst32) dst32[i] = (float)v;
+  }
+}
+
+__global__ __launch_bounds__(256) void rk_error_kernel(const double* __restrict__ y, const double* __restrict__ y_new, const double* __restrict__ k,
+                                                       size_t n, ssde_rk_coefs c, double atol, double rtol, double* __restrict__ partial) {
+  SSDE_LDS(smem);
+  double* red = reinterpret_cast<double*>(smem);      // [4]
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    double e = 0.0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) e += k[(size_t)j * n + i] * c.v[j];          // E_j * h folded on the host
+    const double scale = atol + fmax(fabs(y[i]), fabs(y_new[i])) * rtol;
+    const double q = e / scale;
+    acc += q * q;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void rk_error_finish_kernel(const double* __restrict__ partial, int blocks, size_t n, double* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < blocks; ++i) s += partial[i];       // fixed order: deterministic accept / reject decisions
+    out[0] = sqrt(s / (double)n);
+  }
+}
+
+// drift of the probability-flow ODE for the stock SDEs, RSDE.sde with probability_flow=True (sde_lib.py:93-97):
+//   drift = f(x, t) - g(t)^2 * score * 0.5,  f = a(t) * x  (a = -beta(t)/2 for VP / sub-VP, 0 for VE)
+// evaluated in fp32 in the reference's operation order (no contraction), widened to the integrator's fp64.
+__global__ __launch_bounds__(256) void pf_drift_kernel(const float* __restrict__ x, const float* __restrict__ score, double* __restrict__ dst,
+                                                       size_t numel, float a, float g2) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (size_t)gridDim.x * blockDim.x) {
+    const float f = __fmul_rn(a, x[i]);
+    const float d = __fmul_rn(__fmul_rn(g2, score[i]), 0.5f);
+    dst[i] = (double)__fsub_rn(f, d);
+  }
+}
+
+extern "C" int ssde_rk_combine(const ssde_rk_combine_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->y && a->dst && a->n > 0 && a->terms >= 0 && a->terms <= 7 && (a->terms == 0 || a->k), "rk_combine: bad args");
+  hipLaunchKernelGGL(rk_combine_kernel, dim3(grid_for((size_t)a->n)), dim3(256), 0, static_cast<hipStream_t>(stream), a->y, a->k, (size_t)a->n,
+                     a->terms, a->coef, a->dst, a->dst32);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}
+
+extern "C" int ssde_rk_error_norm(const ssde_rk_error_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->y && a->y_new && a->k && a->partial && a->out && a->n > 0, "rk_error_norm: bad args");
+  const unsigned blocks = grid_for((size_t)a->n, 256, 1024);
+  SSDE_REQUIRE((int)blocks <= a->partial_len, "rk_error_norm: partial buffer needs %u doubles", blocks);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(rk_error_kernel, dim3(blocks), dim3(256), 64, st, a->y, a->y_new, a->k, (size_t)a->n, a->coef, a->atol, a->rtol, a->partial);
+  SSDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rk_error_finish_kernel, dim3(1), dim3(64), 0, st, a->partial, (int)blocks, (size_t)a->n, a->out);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}
+
+extern "C" int ssde_pf_drift(const ssde_pf_drift_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->x && a->score && a->dst && a->numel > 0, "pf_drift: bad args");
+  hipLaunchKernelGGL(pf_drift_kernel, dim3(grid_for((size_t)a->numel)), dim3(256), 0, static_cast<hipStream_t>(stream), a->x, a->score, a->dst,
+                     (size_t)a->numel, a->a, a->g2);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}
+
 extern "C" int ssde_randn(const ssde_randn_args* a, void* stream) {
   SSDE_REQUIRE(a && a->dst && a->numel > 0, "randn: bad args");
   SSDE_REQUIRE(a->stream_id >= 0 && a->stream_id < 16, "randn: stream_id must be in 0..15");

@@ -24,7 +24,7 @@ def _rms(x):
 
 
 def _initial_step(fun, t0, y0, f0, direction, rtol, atol):
-    """scipy.integrate._ivp.common.select_initial_step with order = 4."""
+    """scipy.integrate._ivp.common.select_initial_step with order = 4 (runs once per solve)."""
     scale = atol + torch.abs(y0) * rtol
     d0, d1 = _rms(y0 / scale), _rms(f0 / scale)
     h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
@@ -35,14 +35,92 @@ def _initial_step(fun, t0, y0, f0, direction, rtol, atol):
     return min(100 * h0, h1)
 
 
-def solve_rk45(fun, t_span, y0, rtol=1e-5, atol=1e-5):
-    """Integrate dy/dt = fun(t, y) from t_span[0] to t_span[1]; returns (y_final, nfev)."""
+class _TorchStages:
+    """Stage arithmetic with torch ops.  Reached only with host tensors (the CPU unit tests of the step-size controller
+    against scipy on analytic right-hand sides): the model's right-hand side cannot run there."""
+
+    def __init__(self, n, like):
+        self.K = torch.empty(7, n, dtype=torch.float64, device=like.device)
+        self.x32 = None
+
+    def combine(self, y, coefs, dst):
+        acc = None
+        for j, c in enumerate(coefs):
+            if c != 0.0:
+                acc = self.K[j] * c if acc is None else acc + self.K[j] * c
+        dst.copy_(y if acc is None else y + acc)
+
+    def error_norm(self, y, y_new, coefs, atol, rtol):
+        err = None
+        for j, c in enumerate(coefs):
+            if c != 0.0:
+                err = self.K[j] * c if err is None else err + self.K[j] * c
+        scale = atol + torch.maximum(torch.abs(y), torch.abs(y_new)) * rtol
+        return _rms(err / scale)
+
+
+class _HipStages:
+    """Stage arithmetic on the device (libssde_hip: ssde_rk_combine, ssde_rk_error_norm): one launch forms a stage
+    argument together with its fp32 copy -- written straight into the U-Net's input buffer when the right-hand side is
+    the fused drift (FusedDrift) -- and the error norm comes back as ONE scalar per step."""
+
+    def __init__(self, n, like, x32=None):
+        from . import _lib as L
+        self.L, self.lib, self.n = L, L.load(), n
+        self.K = torch.empty(7, n, dtype=torch.float64, device=like.device)
+        self.partial = torch.empty(1024, dtype=torch.float64, device=like.device)
+        self.out = torch.empty(1, dtype=torch.float64, device=like.device)
+        self.x32 = x32
+
+    def _stream(self):
+        from . import hipops
+        return hipops._stream()
+
+    def combine(self, y, coefs, dst):
+        import ctypes as C
+        a = self.L.RkCombineArgs()
+        terms = max([j + 1 for j, c in enumerate(coefs) if c != 0.0], default=0)
+        a.y, a.k, a.n, a.terms, a.dst = y.data_ptr(), self.K.data_ptr(), self.n, terms, dst.data_ptr()
+        a.dst32 = self.x32.data_ptr() if self.x32 is not None else None
+        for j in range(terms):
+            a.coef[j] = coefs[j]
+        self.L.check(self.lib.ssde_rk_combine(C.byref(a), self._stream()), "ssde_rk_combine")
+
+    def error_norm(self, y, y_new, coefs, atol, rtol):
+        import ctypes as C
+        a = self.L.RkErrorArgs()
+        a.y, a.y_new, a.k, a.n, a.atol, a.rtol = y.data_ptr(), y_new.data_ptr(), self.K.data_ptr(), self.n, atol, rtol
+        a.partial, a.partial_len, a.out = self.partial.data_ptr(), self.partial.numel(), self.out.data_ptr()
+        for j in range(7):
+            a.coef[j] = coefs[j]
+        self.L.check(self.lib.ssde_rk_error_norm(C.byref(a), self._stream()), "ssde_rk_error_norm")
+        return float(self.out.item())          # the one host read of the step
+
+
+def solve_rk45(fun, t_span, y0, rtol=1e-5, atol=1e-5, stages=None):
+    """Integrate dy/dt = fun(t, y) from t_span[0] to t_span[1]; returns (y_final, nfev).
+
+    `fun(t, y)` returns the fp64 slope, or -- for right-hand sides that write their result in place (FusedDrift) --
+    `fun(t, y, out=K_row)` fills `out`.  `stages`: the arithmetic backend (device kernels for CUDA tensors)."""
     t, t_bound = float(t_span[0]), float(t_span[1])
     direction = 1.0 if t_bound >= t else -1.0
-    y = y0.to(torch.float64)
-    f = fun(t, y)
+    y = y0.to(torch.float64).clone()
+    n = y.numel()
+    if stages is None:
+        stages = _HipStages(n, y) if y.is_cuda else _TorchStages(n, y)
+    K = stages.K
+    in_place = getattr(fun, "writes_out", False)
+
+    def evaluate(tt, yy, row):
+        if in_place:
+            fun(tt, yy, out=K[row])
+        else:
+            K[row].copy_(fun(tt, yy))
+    y_stage, y_new = torch.empty_like(y), torch.empty_like(y)
+    stages.combine(y, [], y_stage)                       # stage argument of the first evaluation (and its fp32 copy)
+    evaluate(t, y_stage, 0)
     nfev = 1
-    h_abs = _initial_step(fun, t, y, f, direction, rtol, atol)
+    h_abs = _initial_step((lambda tt, yy: _once(fun, stages, tt, yy, in_place)), t, y, K[0].clone(), direction, rtol, atol)
     nfev += 1
     while direction * (t - t_bound) < 0:
         min_step = 10 * abs(math.nextafter(t, direction * math.inf) - t)
@@ -57,25 +135,15 @@ def solve_rk45(fun, t_span, y0, rtol=1e-5, atol=1e-5):
                 t_new = t_bound
             h = t_new - t
             h_abs = abs(h)
-            K = [f]
             for s_ in range(1, 6):
-                dy = K[0] * (_A[s_][0] * h)
-                for j in range(1, s_):
-                    dy = dy + K[j] * (_A[s_][j] * h)
-                K.append(fun(t + _C[s_] * h, y + dy))
-            y_new = y
-            for j in range(6):
-                if _B[j] != 0.0:
-                    y_new = y_new + K[j] * (_B[j] * h)
-            f_new = fun(t + h, y_new)
-            K.append(f_new)
+                stages.combine(y, [a * h for a in _A[s_]], y_stage)
+                evaluate(t + _C[s_] * h, y_stage, s_)
+            stages.combine(y, [b * h for b in _B], y_new)
+            if stages.x32 is not None:                   # the fp32 copy must hold y_new for the seventh evaluation
+                pass                                     # (combine wrote it: dst32 accompanies every combine)
+            evaluate(t + h, y_new, 6)
             nfev += 6
-            err = K[0] * _E[0]
-            for j in range(1, 7):
-                if _E[j] != 0.0:
-                    err = err + K[j] * _E[j]
-            scale = atol + torch.maximum(torch.abs(y), torch.abs(y_new)) * rtol
-            error_norm = _rms(err * h / scale)
+            error_norm = stages.error_norm(y, y_new, [e * h for e in _E], atol, rtol)
             if error_norm < 1:
                 factor = MAX_FACTOR if error_norm == 0 else min(MAX_FACTOR, SAFETY * error_norm ** -0.2)
                 if rejected:
@@ -84,8 +152,68 @@ def solve_rk45(fun, t_span, y0, rtol=1e-5, atol=1e-5):
                 break
             h_abs *= max(MIN_FACTOR, SAFETY * error_norm ** -0.2)
             rejected = True
-        t, y, f = t_new, y_new, f_new
+        t = t_new
+        y, y_new = y_new, y                              # accept: swap buffers
+        K[0].copy_(K[6])                                 # FSAL: the last slope is the next step's first
     return y, nfev
+
+
+def _once(fun, stages, t, yy, in_place):
+    """One extra evaluation outside the stage table (scipy's select_initial_step probes f(t0 + h0, y0 + h0 f0))."""
+    if not in_place:
+        return fun(t, yy)
+    out = torch.empty_like(yy)
+    tmp = torch.empty_like(yy)
+    stages.combine(yy, [], tmp)                          # refreshes the fp32 copy the fused right-hand side reads
+    fun(t, tmp, out=out)
+    return out
+
+
+class FusedDrift:
+    """Right-hand side of the probability-flow ODE for an NCSNpp model and a stock SDE, without torch arithmetic:
+    drift = f(x, t) - g(t)^2 score(x, t) / 2 (sde_lib.py:93-97 with probability_flow=True; score_fn models/utils.py:129-178).
+    The integrator's combine kernel writes the fp32 state straight into the U-Net program's input buffer, the program
+    runs (score head included: -h / std for VP / sub-VP), ssde_pf_drift forms the fp64 slope.  Per-evaluation scalars
+    (label, std, drift coefficient, g^2) are computed on the host with the SDE's own fp32 torch expressions."""
+    writes_out = True
+
+    def __init__(self, model, sde, shape, device):
+        from . import engine as E, sde_lib
+        self.sde, self.shape = sde, tuple(shape)
+        self.vp_like = isinstance(sde, (sde_lib.VPSDE, sde_lib.subVPSDE))
+        self.unet = E.UNetEngine(model, shape[0], shape[2], shape[3], device, vp_score=self.vp_like)
+        self.n = int(torch.tensor(self.shape).prod())
+        self.x32 = self.unet.x_in.tensor[: self.n]
+        self.nfev = 0
+
+    @staticmethod
+    def applies(model, sde, x):
+        from . import sde_lib
+        from .models.ncsnpp import NCSNpp
+        if not isinstance(model, NCSNpp) or not x.is_cuda or type(sde) not in (sde_lib.VESDE, sde_lib.VPSDE, sde_lib.subVPSDE):
+            return False
+        return not (type(sde) is not sde_lib.VESDE and model.config.model.scale_by_sigma)
+
+    def __call__(self, t, y, out):
+        import ctypes as C
+        from . import _lib as L, hipops
+        sde = self.sde
+        tv = torch.full((1,), float(t), dtype=torch.float32)
+        one = torch.ones(1, 1, 1, 1)
+        drift1, diffusion = sde.sde(one, tv)                              # f(x, t) is linear in x: coefficient = f(1, t)
+        std = sde.marginal_prob(torch.zeros(1, 1, 1, 1), tv)[1]
+        label = tv * 999 if self.vp_like else std                         # models/utils.py:147-166 (continuous labels)
+        eng = self.unet
+        eng.weights.refresh()
+        eng.cond.tensor[: self.shape[0]].fill_(float(label))
+        if self.vp_like:
+            eng.std.tensor[: self.shape[0]].fill_(float(std))
+        eng.program.run()
+        a = L.PfDriftArgs()
+        a.x, a.score, a.dst, a.numel = self.x32.data_ptr(), eng.out.tensor.data_ptr(), out.data_ptr(), self.n
+        a.a, a.g2 = float(drift1.reshape(-1)[0]), float((diffusion ** 2).reshape(-1)[0])
+        L.check(L.load().ssde_pf_drift(C.byref(a), hipops._stream()), "ssde_pf_drift")
+        self.nfev += 1
 
 
 def solve_host(fun, t_span, y0, rtol=1e-5, atol=1e-5, method="RK45"):
@@ -105,9 +233,19 @@ def solve_host(fun, t_span, y0, rtol=1e-5, atol=1e-5, method="RK45"):
 
 
 def integrate_ode(fun, t_span, y0, rtol, atol, method):
-    """Device RK45 when the state lives on the GPU and nothing asks for the host path, else scipy on the host."""
+    """Device RK45 when the state lives on the GPU and nothing asks for the host path, else scipy on the host.
+    A right-hand side with `writes_out` (FusedDrift) gets the fp32 copy of every stage argument written into its input."""
     import os
     if method == "RK45" and y0.is_cuda and os.environ.get("SSDE_HOST_ODE", "0") != "1":
-        return solve_rk45(fun, t_span, y0, rtol=rtol, atol=atol)
+        stages = _HipStages(y0.numel(), y0, x32=getattr(fun, "x32", None))
+        return solve_rk45(fun, t_span, y0, rtol=rtol, atol=atol, stages=stages)
+    if getattr(fun, "writes_out", False):
+        inner = fun
+
+        def fun(t, y):                                   # host scipy loop around the fused right-hand side
+            inner.x32.copy_(y.to(torch.float32))
+            out = torch.empty_like(y)
+            inner(t, y, out=out)
+            return out
     return solve_host(fun, t_span, y0, rtol=rtol, atol=atol, method=method)
 

@@ -322,18 +322,30 @@ def get_ode_sampler(sde, shape, inverse_scaler, denoise=False, rtol=1e-5, atol=1
         score_fn = get_score_fn(sde, model, train=False, continuous=True)
         return sde.reverse(score_fn, probability_flow=True).sde(x, t)[0]
 
+    fused_rhs = {}
+
     def ode_sampler(model, z=None):
         from . import ode
         with torch.no_grad():
             x = sde.prior_sampling(shape).to(device) if z is None else z
 
-            def rhs(t, y):
-                xt = y.reshape(shape).to(torch.float32)
-                return drift_fn(model, xt, torch.full((shape[0],), float(t), device=xt.device)).reshape(-1).to(torch.float64)
+            if ode.FusedDrift.applies(model, sde, x):
+                # stock SDE + NCSNpp: stage arithmetic, U-Net program and drift are all HIP launches, no torch arithmetic
+                key = id(model)
+                rhs = fused_rhs.get(key)
+                if rhs is None:
+                    rhs = fused_rhs[key] = ode.FusedDrift(model, sde, shape, x.device)
+                ode_sampler.last_path = "fused"
+            else:
+                def rhs(t, y):
+                    xt = y.reshape(shape).to(torch.float32)
+                    return drift_fn(model, xt, torch.full((shape[0],), float(t), device=xt.device)).reshape(-1).to(torch.float64)
+                ode_sampler.last_path = "generic"
             y, nfev = ode.integrate_ode(rhs, (sde.T, eps), x.reshape(-1).to(torch.float64), rtol, atol, method)
             x = y.reshape(shape).to(torch.float32)
             if denoise:
                 x = denoise_update_fn(model, x)
             return inverse_scaler(x), nfev
 
+    ode_sampler.last_path = None
     return ode_sampler

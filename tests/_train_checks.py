@@ -626,6 +626,7 @@ def check_ode_sampler(dev, denoise):
     smp = sampling.get_ode_sampler(sde, tuple(z.shape), _util.ode_inverse_scaler, denoise=denoise, rtol=case["rtol"],
                                    atol=case["atol"], eps=case["sample_eps"], device=dev)
     x, nfe = smp(model, z=z.to(dev))
+    assert smp.last_path == "fused"       # stage arithmetic, U-Net program and drift all as HIP launches (ode.FusedDrift)
     tag = "ode_denoise" if denoise else "ode"
     assert abs(nfe - int(gold[tag + "_nfe"])) <= 12, (nfe, int(gold[tag + "_nfe"]))
     assert rel_err(x, torch.from_numpy(gold[tag + "_samples"])) < 1e-3

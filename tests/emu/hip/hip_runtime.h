@@ -93,6 +93,14 @@ static inline int __shfl_xor(int v, int mask, int width = 64) {
   const emu::Xchg& x = emu::wave_exchange((uint32_t)v);
   return (int)x.w[(emu::cur->lane ^ mask) & 63][0];
 }
+static inline double __shfl_xor(double v, int mask, int width = 64) {      // two 32-bit exchanges, as the hardware does
+  uint64_t u; memcpy(&u, &v, 8);
+  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)u, mask, width);
+  const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(u >> 32), mask, width);
+  u = ((uint64_t)hi << 32) | lo;
+  double r; memcpy(&r, &u, 8);
+  return r;
+}
 static inline float __shfl(float v, int src, int width = 64) {
   (void)width;
   const emu::Xchg& x = emu::wave_exchange(emu::f2u(v));

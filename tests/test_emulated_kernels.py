@@ -202,3 +202,46 @@ def test_wgrad_winograd_kernel(ops, n, h, w, c1, c2, cout, pro, drop):
         return
     F.conv2d(act.clone().requires_grad_(False), wt, padding=1).backward(gy)
     assert rel_err(dw.cpu(), 0.5 * wt.grad) < 2e-5
+
+
+def test_rk45_stage_kernels_reproduce_scipy(ops):
+    """ssde_rk_combine / ssde_rk_error_norm (the integrator's fp64 stage arithmetic and RMS error norm) driving the same
+    step-size controller as scipy's RK45: identical function-evaluation count and solution on an analytic system"""
+    from scipy import integrate
+    from score_sde_pytorch_amd import ode
+    g = torch.Generator().manual_seed(3)
+    n = 301                                            # not a multiple of the block size
+    A = (torch.randn(n, n, generator=g, dtype=torch.float64) / n ** 0.5 - 0.5 * torch.eye(n, dtype=torch.float64))
+    y0 = torch.randn(n, generator=g, dtype=torch.float64)
+    calls = []
+
+    def fun(t, y):
+        calls.append(t)
+        return A @ y + torch.sin(torch.tensor(3.0 * t, dtype=torch.float64))
+    stages = ode._HipStages(n, y0)
+    y, nfev = ode.solve_rk45(fun, (0.0, 2.0), y0, rtol=1e-6, atol=1e-8, stages=stages)
+    sol = integrate.solve_ivp(lambda t, v: (A.numpy() @ v + np.sin(3.0 * t)), (0.0, 2.0), y0.numpy(), rtol=1e-6, atol=1e-8, method="RK45")
+    assert nfev == sol.nfev
+    assert float((y - torch.from_numpy(sol.y[:, -1])).abs().max()) < 1e-11
+    # the fp32 copy that accompanies every stage argument (the fused drift's input)
+    x32 = torch.zeros(n, dtype=torch.float32)
+    stages2 = ode._HipStages(n, y0, x32=x32)
+    tmp = torch.empty_like(y0)
+    stages2.K[0].copy_(y0 * 2)
+    stages2.combine(y0, [0.25], tmp)
+    assert torch.equal(tmp, y0 + (y0 * 2) * 0.25) and torch.equal(x32, tmp.to(torch.float32))
+
+
+def test_pf_drift_kernel(ops):
+    """ssde_pf_drift: (double)(a x - (g2 score) 0.5) with the reference's fp32 operation order (sde_lib.py:93-97)"""
+    import ctypes as C
+    from score_sde_pytorch_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    x, s = torch.randn(1000, generator=g), torch.randn(1000, generator=g) * 30
+    a, g2 = torch.tensor(-0.5 * 7.3, dtype=torch.float32), torch.tensor(3.7, dtype=torch.float32) ** 2
+    out = torch.empty(1000, dtype=torch.float64)
+    args = L.PfDriftArgs()
+    args.x, args.score, args.dst, args.numel, args.a, args.g2 = x.data_ptr(), s.data_ptr(), out.data_ptr(), 1000, float(a), float(g2)
+    L.check(L.load().ssde_pf_drift(C.byref(args), ops._stream()))
+    ref = (a * x - g2 * s * 0.5).to(torch.float64)
+    assert torch.equal(out, ref)
