@@ -109,12 +109,29 @@ def bench_train(args, cfg, dev, dist, world, rank, sync_all):
     sec = dt / k
     fs = step_fn.fused_for(state, batch)
     eng = fs.eng
+    exposed_ms = None
+    if dist is not None:
+        # the same steps without the gradient exchange (replicas diverge -- timing only, the last thing this model does):
+        # the difference is the part of the bucketed all-reduce that the backward program does not hide
+        fs.skip_exchange = True
+        for _ in range(w):
+            step_fn(state, batch)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step_fn(state, batch)
+        sync_all()
+        dt0 = time.perf_counter() - t0
+        t = torch.tensor([dt0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exposed_ms = (sec - float(t.item()) / k) * 1e3
+        fs.skip_exchange = False
     fl = np.array(eng.program.flops)
     out = {"metric": "sec_per_train_step", "value": sec, "unit": "s/step", "higher_is_better": False,
            "batch_per_gpu": Bt, "global_batch": Bt * world, "images_per_sec": world * Bt / sec, "steps": k, "warmup": w,
            "loss": float(loss), "dropout": float(cfg.model.dropout), "path": "fused (losses.FusedTrainStep)",
            "algorithmic_tflops": float(fl.sum()) / sec / 1e12, "gflop_per_image": float(fl.sum()) / Bt / 1e9,
-           "grad_allreduce_mb": eng.flat.numel * 4 / 1e6 if world > 1 else 0.0,
+           "grad_allreduce_mb": eng.flat.numel * 4 / 1e6 if world > 1 else 0.0, "allreduce_exposed_ms": exposed_ms,
            "arena_gb": eng.b.arena_bytes / 1e9}
     if rank == 0 and not args.no_roofline:
         ms = np.array(eng.program.run_range_timed(0, eng.program.n))
@@ -378,10 +395,27 @@ def cpu_baseline(args, cfg, model, sd, R, N):
     iterations; and DSM training steps (forward + autograd backward + clip + Adam + EMA) at the largest batch the budget allows."""
     from oracle import sampler_oracle, unet_oracle
     total = os.cpu_count() or 1
-    cores = max(1, min(args.cpu_threads or 64, total))
-    torch.set_num_threads(cores)
     full_sd = {k: v.detach().cpu() for k, v in sd.items()}
     full_sd["sigmas"] = model.sigmas.cpu()
+    if args.cpu_threads:
+        cores = max(1, min(args.cpu_threads, total))
+    else:
+        # oneDNN does not scale monotonically on this host (the same PC iteration ran 3x slower per image on 64 threads
+        # than on 16): probe a few thread counts on one small forward each and keep the fastest
+        from oracle import unet_oracle as _uo
+        xs = torch.randn(8, 3, R, R)
+        sg = torch.ones(8)
+        best, cores = None, 1
+        for c in sorted({min(c, total) for c in (8, 16, 32, 64, 128, total)}):
+            torch.set_num_threads(c)
+            with torch.no_grad():
+                _uo.ncsnpp_forward(cfg, full_sd, xs, sg)
+                t0 = time.perf_counter()
+                _uo.ncsnpp_forward(cfg, full_sd, xs, sg)
+                dt = time.perf_counter() - t0
+            if best is None or dt < best:
+                best, cores = dt, c
+    torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(3)
     kw = dict(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=N)
 
@@ -498,7 +532,8 @@ def main():
             traffic = prof["hbm_traffic"]["conv_wino_kernel"]["hbm_bytes_per_launch"]
             m = prof.get("mfma", {}).get("conv_wino_kernel", {})
             if m.get("SQ_VALU_MFMA_BUSY_CYCLES") and m.get("GRBM_GUI_ACTIVE"):
-                mfma_busy = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * m["GRBM_GUI_ACTIVE"])
+                # 1024 SIMDs; rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs
+                mfma_busy = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * m["GRBM_GUI_ACTIVE"] / 8.0)
             out["config"]["pmc_source"] = os.path.basename(summ)
         except Exception:
             pass

@@ -587,7 +587,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
         for (int r = 0; r < 4; ++r) {
           const int tile = tb0 + a * 16 + 4 * lq + r;
           const float4 o = xch[(((wave * 2 + a) * 2 + b) * 4 + r) * 64 + lane];
-          float* dstp = outs + (tile * 4) * LDT + cb0 + b * 16 + li;
+          // column bit 4 flipped for odd lq (= rows with bit 4 set): the two 16-lane groups of a 32-lane LDS write cycle
+          // hit different banks (row pitch 68: 16 rows are a multiple of 32 banks apart)
+          float* dstp = outs + (tile * 4) * LDT + cb0 + ((b ^ (lq & 1)) * 16) + li;
           dstp[0 * LDT] = yp[a][b][r][0] + o.x;
           dstp[1 * LDT] = yp[a][b][r][1] + o.y;
           dstp[2 * LDT] = yp[a][b][r][2] + o.z;
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
   SSDE_TR(45);
   SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, p.Cout, p.gn_part};
   const int gn_entry = p.gn_part ? img0 * p.tiles_per_img + trem : -1;        // launcher: IMGS == 1
-  ssde_store_tile<256, 64, kThreads>(outs, LDT, n0, e, [&](int row, size_t& pix, int& img) {
+  ssde_store_tile<256, 64, kThreads, 4, 1>(outs, LDT, n0, e, [&](int row, size_t& pix, int& img) {
     const int tile = row >> 2, dy = (row >> 1) & 1, dx = row & 1;
     const int il = tile >> (p.lTWt + p.lTHt);
     const int tr = (tile >> p.lTWt) & (THt - 1), tc = tile & (TWt - 1);

@@ -166,7 +166,9 @@ __device__ __forceinline__ void ssde_stat_merge(float& n, float& m, float& M2, f
 // gn_entry = image * tiles_per_image + tile.  ssde_gn_finalize merges slices and quads into groups in a fixed order
 // (deterministic, no atomics).  A thread owns one channel quad (nthreads % (ncols/4) == 0): sums relative to its first
 // value (no cancellation), lanes of equal quad merged by wave shuffles.
-template <int ROWS, int NCOLS, int NT, int BATCH = 4, class PixFn>
+// SWZ = 1: the tile was parked with column bit 4 flipped on rows with bit 4 set (conv_wino.hip: makes its 64 scalar
+// LDS writes per lane bank-conflict free); undone here on the float4 row reads.
+template <int ROWS, int NCOLS, int NT, int BATCH = 4, int SWZ = 0, class PixFn>
 __device__ __forceinline__ void ssde_store_tile(float* tile, int ld, int n0, const SsdeEpi& e, PixFn pixfn, int gn_entry = -1) {
   constexpr int C4N = NCOLS / 4, TOTAL = ROWS * C4N, ITERS = TOTAL / NT, RSTEP = NT / C4N;
   static_assert(TOTAL % NT == 0 && NT % C4N == 0 && 64 % C4N == 0, "a thread owns one channel quad of ITERS rows");
@@ -194,7 +196,7 @@ __device__ __forceinline__ void ssde_store_tile(float* tile, int ld, int n0, con
         int img = 0;
         pix[b] = 0;
         ok[b] = col_ok && pixfn(row, pix[b], img);
-        t[b] = *reinterpret_cast<const float4*>(tile + row * ld + c);
+        t[b] = *reinterpret_cast<const float4*>(tile + row * ld + (SWZ ? (c ^ (((row >> 4) & 1) << 4)) : c));
         r[b] = make_float4(0.f, 0.f, 0.f, 0.f);
         a[b] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok[b] && e.resid) r[b] = *reinterpret_cast<const float4*>(e.resid + pix[b] * e.Cout + j);
@@ -225,7 +227,7 @@ __device__ __forceinline__ void ssde_store_tile(float* tile, int ld, int n0, con
       const int row = row0 + it * RSTEP;
       size_t pix; int img;
       if (j >= e.Cout || !pixfn(row, pix, img)) continue;
-      const float4 t = *reinterpret_cast<const float4*>(tile + row * ld + c);
+      const float4 t = *reinterpret_cast<const float4*>(tile + row * ld + (SWZ ? (c ^ (((row >> 4) & 1) << 4)) : c));
       const float v[4] = {t.x, t.y, t.z, t.w};
       for (int k = 0; k < 4 && j + k < e.Cout; ++k) {
         float x = v[k];

@@ -276,7 +276,7 @@ class FusedTrainStep:
         self._head[1].run()
         self._pending = []
         if spec["train"]:
-            if self._world() > 1:
+            if self._world() > 1 and not getattr(self, "skip_exchange", False):
                 # data parallel: ~32 MB buckets of the flat gradient are all-reduced (RCCL, its own stream) as soon as the
                 # backward ops that finalise them are enqueued, overlapping the rest of the backward program
                 import torch.distributed as dist
@@ -300,7 +300,8 @@ class FusedTrainStep:
 
     def optimizer_step(self, optimizer, ema, step, hyper):
         import torch.distributed as dist
-        if self._world() > 1:                        # gradients were pre-scaled by 1/world in the loss head
+        # skip_exchange: bench.py times the step without the gradient all-reduce to report how much of it is exposed
+        if self._world() > 1 and not getattr(self, "skip_exchange", False):     # gradients were pre-scaled by 1/world in the loss head
             if getattr(self, "_pending", None):
                 for work in self._pending:           # bucketed all-reduces started during the backward program
                     work.wait()
