@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=256, help="batch of the CPU-oracle sampler sample (config batch)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0: min(64, all))")
-    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="CPU-work budget per baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-work budget per baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the compact ffhq256 / subvp_ode measurements")
     ap.add_argument("--dump-ops", type=str, default="")
     ap.add_argument("--no-train", action="store_true", help="skip the DSM training-step measurement")
@@ -403,10 +403,10 @@ def cpu_baseline(args, cfg, model, sd, R, N):
         # oneDNN does not scale monotonically on this host (the same PC iteration ran 3x slower per image on 64 threads
         # than on 16): probe a few thread counts on one small forward each and keep the fastest
         from oracle import unet_oracle as _uo
-        xs = torch.randn(8, 3, R, R)
-        sg = torch.ones(8)
+        xs = torch.randn(4, 3, R, R)
+        sg = torch.ones(4)
         best, cores = None, 1
-        for c in sorted({min(c, total) for c in (8, 16, 32, 64, 128, total)}):
+        for c in sorted({min(c, total) for c in (16, 32, 64, total)}):
             torch.set_num_threads(c)
             with torch.no_grad():
                 _uo.ncsnpp_forward(cfg, full_sd, xs, sg)
@@ -464,6 +464,13 @@ def cpu_baseline(args, cfg, model, sd, R, N):
                     "measured_batch": tb, "cores": cores,
                     "sample": "1 warm-up + %d timed DSM steps (oracle forward, torch autograd backward, clip + Adam + EMA) at batch %d" % (n_timed, tb)}
     return out
+
+
+_T0 = time.perf_counter()
+
+
+def _phase(msg):
+    print("[bench %7.1f s] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
 
 def main():
@@ -566,8 +573,10 @@ def main():
             with open(args.dump_ops, "w") as f:
                 json.dump(rows, f)
 
+    _phase("sampler + roofline done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, cfg, model, sd, R, args.sde_steps)
+        _phase("cpu baseline done")
 
     del eng, model
     torch.cuda.empty_cache()
@@ -576,15 +585,18 @@ def main():
         tr = bench_train(args, _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous"), dev, dist, world, rank, sync_all)
         out["train"] = tr
         torch.cuda.empty_cache()
+        _phase("train step done")
     if not args.no_extras:
         # the other BASELINE configs, compact, so that the driver's default run witnesses them
         extra = {}
         r3, e3, m3, _, _ = bench_pc(args, "ve/ffhq_256_ncsnpp_continuous", 16, 2000, dev, dist, world, rank, min(args.steps, 5), 2, False)
         extra["ffhq256"] = r3
+        _phase("ffhq256 done")
         del e3, m3
         torch.cuda.empty_cache()
         extra["subvp_ode"] = bench_ode_compact(args, dev, dist, world, rank)
         out["extra"] = extra
+        _phase("subvp_ode done")
 
     if rank == 0:
         print(json.dumps(out))
