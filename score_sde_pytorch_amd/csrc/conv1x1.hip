@@ -36,7 +36,8 @@ struct GemmParams {
   const float* resid; int resid_post;
   float scale;
   float* dst;
-  float* gn_part;          // GroupNorm partials of dst: one entry per 64-row half tile (HW % 64 == 0), see ssde_store_tile
+  float* gn_part;          // GroupNorm partials of dst: per 64-row half tile (HW % 64 == 0) or per whole image (HW < 64), see ssde_store_tile
+  int lHW, gn_entries;
 };
 
 template <bool kGn>
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(kThreads, 4) void gemm1x1_kernel(const GemmParams p
       pix = (size_t)m;
       img = m / p.HW;
       return true;
-    }, p.gn_part ? (m0 >> 6) + half : -1);
+    }, p.gn_part ? (p.HW >= 64 ? (m0 >> 6) + half : (m0 + half * 64) / p.HW) : -1, p.HW >= 64 ? 30 : p.lHW, p.gn_entries);
     __syncthreads();
   }
 }
@@ -236,7 +237,10 @@ int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
   p.bias = a->bias; p.chan_add = a->chan_add; p.chan_add_ld = a->chan_add_ld;
   p.resid = a->resid; p.resid_post = a->resid_post; p.scale = a->out_scale; p.dst = a->dst;
   p.gn_part = a->gn_part;
-  SSDE_REQUIRE(!a->gn_part || (p.HW % 64 == 0 && a->c_out % 4 == 0), "conv1x1: GroupNorm partials need H*W %% 64 == 0");
+  const bool gn_ok = a->c_out % 4 == 0 && (p.HW % 64 == 0 || (p.HW >= 8 && p.HW < 64 && 64 % p.HW == 0));
+  SSDE_REQUIRE(!a->gn_part || gn_ok, "conv1x1: GroupNorm partials need H*W %% 64 == 0 or a power of two in 8..32");
+  p.lHW = ssde_ilog2(p.HW);
+  p.gn_entries = p.HW >= 64 ? a->n * (p.HW / 64) : a->n;
   const int lds_ops = 2 * kStage * 4, lds_epi = 64 * (BN + 4) * 4;
   const int lds = lds_ops > lds_epi ? lds_ops : lds_epi;
   if (lds_out) { *lds_out = lds; return SSDE_OK; }

@@ -288,7 +288,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvKParam
       }
   __syncthreads();
   SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, g.Cout, p.gn_part};
-  const int gn_entry = p.gn_part ? img0 * g.tiles_per_img + trem : -1;        // make_plan: IMGS == 1
+  const int gn_entry = p.gn_part ? img0 * g.tiles_per_img + trem : -1;        // IMGS > 1: tiles_per_img == 1
+  const int rpi_log2 = IMGS > 1 ? g.lTW + g.lTH : 30;                          // rows per image = TW * TH
   ssde_store_tile<BM, BN, kThreads>(smem, LDT, n0, e, [&](int m, size_t& pix, int& img) {
     const int c = m & (TW - 1);
     const int rr = (m >> g.lTW) & (TH - 1);
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvKParam
     if (img >= g.N || oy >= g.Hout || ox >= g.Wout) return false;
     pix = ((size_t)img * g.Hout + oy) * g.Wout + ox;
     return true;
-  }, gn_entry);
+  }, gn_entry, rpi_log2, g.N * g.tiles_per_img);
 }
 
 struct TileCfg { int bm, bn; };
@@ -400,7 +401,9 @@ int make_plan(const ssde_conv_args* a, ConvPlan* pl) {
   kp.bias = a->bias; kp.chan_add = a->chan_add; kp.chan_add_ld = a->chan_add_ld;
   kp.resid = a->resid; kp.resid_post = a->resid_post; kp.scale = a->out_scale; kp.dst = a->dst;
   kp.gn_part = a->gn_part;
-  pl->gn_slices = (imgs == 1 && a->c_out % 4 == 0) ? g.tiles_per_img * (kThreads / 64) : 0;
+  // part of one image per tile, or whole images of at least one epilogue trip (kThreads / (bn / 4) rows) each
+  const bool gn_ok = a->c_out % 4 == 0 && (imgs == 1 || (g.tiles_per_img == 1 && tw * th >= kThreads / (bn / 4)));
+  pl->gn_slices = gn_ok ? g.tiles_per_img * (kThreads / 64) : 0;
   SSDE_REQUIRE(!a->gn_part || pl->gn_slices > 0, "conv: GroupNorm partials need one image per tile and c_out %% 4 == 0");
 
   int lds = 0;
@@ -469,8 +472,11 @@ extern "C" int ssde_conv_gn_slices(const ssde_conv_args* a) {
     return s;
   }
   if (q.dst && ssde_conv1x1_wants(&q)) {
+    // the GEMM kernel stores 64-row half tiles of linear pixel rows, 4 waves each: part of one image, or whole images
+    // of at least one epilogue trip (8 rows) each
     const int hw = q.h_out * q.w_out;
-    return hw % 64 == 0 ? (hw / 64) * 4 : 0;    // the GEMM kernel stores 64-row half tiles of linear pixel rows, 4 waves each
+    if (hw % 64 == 0) return (hw / 64) * 4;
+    return (hw >= 8 && hw < 64 && 64 % hw == 0) ? 4 : 0;
   }
   ConvPlan pl;
   if (make_plan(&q, &pl)) return 0;

@@ -102,7 +102,7 @@ struct WinoParams {
   const float* resid; int resid_post;
   float scale;
   float* dst;
-  float* gn_part;          // GroupNorm partials of dst (one image per tile: IMGS == 1), see ssde_store_tile
+  float* gn_part;          // GroupNorm partials of dst (a tile holds part of one image, or several whole images), see ssde_store_tile
 };
 
 template <bool kGn>      // GroupNorm prologue: compile-time, so that the staging loads below are straight-line code
@@ -600,7 +600,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
   __syncthreads();
   SSDE_TR(45);
   SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, p.Cout, p.gn_part};
-  const int gn_entry = p.gn_part ? img0 * p.tiles_per_img + trem : -1;        // launcher: IMGS == 1
+  const int gn_entry = p.gn_part ? img0 * p.tiles_per_img + trem : -1;        // IMGS > 1: tiles_per_img == 1, trem == 0
+  const int rpi_log2 = IMGS > 1 ? 8 - (6 - p.lTWt - p.lTHt) : 30;             // rows per image: 256 / IMGS
   ssde_store_tile<256, 64, kThreads, 4, 1>(outs, LDT, n0, e, [&](int row, size_t& pix, int& img) {
     const int tile = row >> 2, dy = (row >> 1) & 1, dx = row & 1;
     const int il = tile >> (p.lTWt + p.lTHt);
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino_kernel(const WinoParams
     if (img >= p.N || oy >= p.H || ox >= p.W) return false;
     pix = ((size_t)img * p.H + oy) * p.W + ox;
     return true;
-  }, gn_entry);
+  }, gn_entry, rpi_log2, p.N * p.tiles_per_img);
   SSDE_TR(46);
 }
 
@@ -649,8 +650,11 @@ int ssde_conv_wino_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
   p.bias = a->bias; p.chan_add = a->chan_add; p.chan_add_ld = a->chan_add_ld;
   p.resid = a->resid; p.resid_post = a->resid_post; p.scale = a->out_scale; p.dst = a->dst;
   p.gn_part = a->gn_part;
-  SSDE_REQUIRE(!a->gn_part || (imgs == 1 && a->c_out % 4 == 0), "conv(winograd): GroupNorm partials need one image per tile");
-  if (lds_out && stream == reinterpret_cast<void*>(1)) { *lds_out = (imgs == 1 && a->c_out % 4 == 0) ? p.tiles_per_img * (kThreads / 64) : 0; return SSDE_OK; }
+  // GroupNorm partials: a tile is part of one image (tiles_per_img slices) or holds `imgs` whole images (1 slice each,
+  // tiles_per_img == 1); 256 / imgs rows per image >= the 32 rows of one epilogue trip
+  const bool gn_ok = a->c_out % 4 == 0 && (imgs == 1 || (p.tiles_per_img == 1 && imgs <= 8));
+  SSDE_REQUIRE(!a->gn_part || gn_ok, "conv(winograd): GroupNorm partials not available for this tiling");
+  if (lds_out && stream == reinterpret_cast<void*>(1)) { *lds_out = gn_ok ? p.tiles_per_img * (kThreads / 64) : 0; return SSDE_OK; }
   const int halo_px = imgs * (2 * tht + 2) * (2 * twt + 2);
   SSDE_REQUIRE(halo_px * 2 <= kMaxRaw * kStagers, "conv(winograd): halo of %d pixels exceeds the staging plan", halo_px);
   int lds = (4 * kStageFloats + 4 * halo_px * 2) * 4;

@@ -168,14 +168,37 @@ __device__ __forceinline__ void ssde_stat_merge(float& n, float& m, float& M2, f
 // value (no cancellation), lanes of equal quad merged by wave shuffles.
 // SWZ = 1: the tile was parked with column bit 4 flipped on rows with bit 4 set (conv_wino.hip: makes its 64 scalar
 // LDS writes per lane bank-conflict free); undone here on the float4 row reads.
+// Tiles that hold several whole images (maps of 8x8 and smaller): rpi_log2 = log2(rows per image); all threads are on
+// the same image in one loop trip (rows per image >= NT / (NCOLS/4), checked by the launchers), the partial of an image
+// is flushed when its last row has been stored, entries gn_entry, gn_entry + 1, ... (< gn_entry_max: the batch tail).
 template <int ROWS, int NCOLS, int NT, int BATCH = 4, int SWZ = 0, class PixFn>
-__device__ __forceinline__ void ssde_store_tile(float* tile, int ld, int n0, const SsdeEpi& e, PixFn pixfn, int gn_entry = -1) {
+__device__ __forceinline__ void ssde_store_tile(float* tile, int ld, int n0, const SsdeEpi& e, PixFn pixfn, int gn_entry = -1,
+                                                int rpi_log2 = 30, int gn_entry_max = 0x7fffffff) {
   constexpr int C4N = NCOLS / 4, TOTAL = ROWS * C4N, ITERS = TOTAL / NT, RSTEP = NT / C4N;
   static_assert(TOTAL % NT == 0 && NT % C4N == 0 && 64 % C4N == 0, "a thread owns one channel quad of ITERS rows");
   const int c = ((int)threadIdx.x % C4N) * 4, row0 = (int)threadIdx.x / C4N;
   const int j = n0 + c;
   const bool stats = e.gn_part != nullptr && gn_entry >= 0;
   float st_p = 0.f, st_s1 = 0.f, st_s2 = 0.f, st_n = 0.f;
+  const int rpi_mask = (rpi_log2 < 30 ? (1 << rpi_log2) : ROWS) - 1;
+  // partial statistics of the image whose rows end with loop trip `it`: lanes of equal channel quad merged by shuffles,
+  // one entry per WAVE (no workgroup barrier, no LDS round trip in the exposed tail of the kernel)
+  auto flush = [&](int it) {
+    float n = st_n, m = 0.f, M2 = 0.f;
+    if (n > 0.f) { const float rn = __builtin_amdgcn_rcpf(n); m = st_p + st_s1 * rn; M2 = st_s2 - st_s1 * st_s1 * rn; M2 = M2 < 0.f ? 0.f : M2; }
+    for (int o = C4N; o < 64; o <<= 1) {        // lanes l, l + C4N, l + 2 C4N, ... hold the same channel quad
+      const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(m, o, 64), Mb = __shfl_xor(M2, o, 64);
+      if (threadIdx.x & o) { float tn = nb, tm = mb, tM = Mb; ssde_stat_merge(tn, tm, tM, n, m, M2); n = tn; m = tm; M2 = tM; }
+      else ssde_stat_merge(n, m, M2, nb, mb, Mb);   // both partners merge lower-lane-first: identical results
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int entry = gn_entry + ((it * RSTEP) >> (rpi_log2 < 30 ? rpi_log2 : 30));
+    if (lane < C4N && n0 + 4 * lane < e.Cout && entry < gn_entry_max) {
+      float* o = e.gn_part + (((size_t)entry * (NT / 64) + wave) * (e.Cout >> 2) + (n0 >> 2) + lane) * 3;
+      o[0] = m; o[1] = M2; o[2] = n;
+    }
+    st_p = st_s1 = st_s2 = st_n = 0.f;
+  };
   if ((e.Cout & 3) == 0) {
     // The rows of a thread are processed in batches of up to 4: all residual / per-sample loads of a batch are issued
     // before the first value is needed.  (As one load per loop trip the 4..16 trips each waited out a full memory
@@ -204,21 +227,24 @@ __device__ __forceinline__ void ssde_store_tile(float* tile, int ld, int n0, con
       }
 #pragma unroll
       for (int b = 0; b < B; ++b) {
-        if (!ok[b]) continue;
-        float v[4] = {t[b].x + bias4.x + a[b].x, t[b].y + bias4.y + a[b].y, t[b].z + bias4.z + a[b].z, t[b].w + bias4.w + a[b].w};
-        const float4 rr = r[b];
-        if (!e.resid_post) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
+        if (ok[b]) {
+          float v[4] = {t[b].x + bias4.x + a[b].x, t[b].y + bias4.y + a[b].y, t[b].z + bias4.z + a[b].z, t[b].w + bias4.w + a[b].w};
+          const float4 rr = r[b];
+          if (!e.resid_post) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] *= e.scale;
-        if (e.resid_post) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
-        *reinterpret_cast<float4*>(e.dst + pix[b] * e.Cout + j) = make_float4(v[0], v[1], v[2], v[3]);
-        if (stats) {
-          if (st_n == 0.f) st_p = v[0];
-          const float d0 = v[0] - st_p, d1 = v[1] - st_p, d2 = v[2] - st_p, d3 = v[3] - st_p;
-          st_s1 += (d0 + d1) + (d2 + d3);
-          st_s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-          st_n += 4.f;
+          for (int k = 0; k < 4; ++k) v[k] *= e.scale;
+          if (e.resid_post) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
+          *reinterpret_cast<float4*>(e.dst + pix[b] * e.Cout + j) = make_float4(v[0], v[1], v[2], v[3]);
+          if (stats) {
+            if (st_n == 0.f) st_p = v[0];
+            const float d0 = v[0] - st_p, d1 = v[1] - st_p, d2 = v[2] - st_p, d3 = v[3] - st_p;
+            st_s1 += (d0 + d1) + (d2 + d3);
+            st_s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            st_n += 4.f;
+          }
         }
+        // uniform over the workgroup: the rows of an image are complete after this trip
+        if (stats && (((it0 + b + 1) * RSTEP) & rpi_mask) == 0) flush(it0 + b);
       }
     }
   } else {
@@ -239,22 +265,6 @@ __device__ __forceinline__ void ssde_store_tile(float* tile, int ld, int n0, con
         if (e.resid && e.resid_post) x += r;
         e.dst[pix * e.Cout + j + k] = x;
       }
-    }
-  }
-  if (stats) {                                  // uniform over the workgroup
-    float n = st_n, m = 0.f, M2 = 0.f;
-    if (n > 0.f) { const float rn = __builtin_amdgcn_rcpf(n); m = st_p + st_s1 * rn; M2 = st_s2 - st_s1 * st_s1 * rn; M2 = M2 < 0.f ? 0.f : M2; }
-    for (int o = C4N; o < 64; o <<= 1) {        // lanes l, l + C4N, l + 2 C4N, ... hold the same channel quad
-      const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(m, o, 64), Mb = __shfl_xor(M2, o, 64);
-      if (threadIdx.x & o) { float tn = nb, tm = mb, tM = Mb; ssde_stat_merge(tn, tm, tM, n, m, M2); n = tn; m = tm; M2 = tM; }
-      else ssde_stat_merge(n, m, M2, nb, mb, Mb);   // both partners merge lower-lane-first: identical results
-    }
-    // one entry per WAVE (no workgroup barrier, no LDS round trip in the exposed tail of the kernel): the finalize kernel
-    // merges NT / 64 times as many slices, a few hundred floats per (image, group)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane < C4N && n0 + 4 * lane < e.Cout) {
-      float* o = e.gn_part + (((size_t)gn_entry * (NT / 64) + wave) * (e.Cout >> 2) + (n0 >> 2) + lane) * 3;
-      o[0] = m; o[1] = M2; o[2] = n;
     }
   }
 }
