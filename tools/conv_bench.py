@@ -46,9 +46,11 @@ def time_conv(n, cin, cout, h, tile, gn=False, reps=5):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     shapes = [(128, 128, 32), (256, 128, 32), (256, 256, 16), (512, 256, 16), (256, 256, 8), (384, 128, 32)]
+    if os.environ.get("CONV_BENCH_SMALL"):
+        shapes = [(256, 256, 4), (512, 256, 4), (128, 256, 8), (256, 256, 8)]
     for cin, cout, h in shapes:
         for gn in ((0, 1, 2, 3) if os.environ.get("CONV_BENCH_PROLOGUES") else (0, 1)):   # 1 GN+SiLU, 2 GN, 3 SiLU
             d, dms = time_conv(n, cin, cout, h, L.TILE_AUTO, gn)
-            wv, wms = time_conv(n, cin, cout, h, L.TILE_WINOGRAD, gn)
+            wv, wms = time_conv(n, cin, cout, h, L.TILE_WINOGRAD, gn) if h >= 8 else (0.0, float('inf'))
             print("B=%d %4d->%4d @%2dx%-2d gn=%d  direct %6.1f TF/s (%.3f ms)   winograd %6.1f TF/s (%.3f ms)   x%.2f"
                   % (n, cin, cout, h, h, gn, d, dms, wv, wms, dms / wms), flush=True)
