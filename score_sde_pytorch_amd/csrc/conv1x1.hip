@@ -22,6 +22,28 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// -DSSDE_GEMM_TRACE (tools/gemm_trace.py, a variant library only): s_memtime stamps of wave 0 of the first workgroup
+#ifdef SSDE_GEMM_TRACE
+__device__ unsigned long long* g_gemm_trace;
+extern "C" int ssde_debug_gemm_trace(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -5;
+}
+#define SSDE_GT(slot)                                                                  \
+  do {                                                                                 \
+    if (gt_on) g_gemm_trace[(slot)] = __builtin_amdgcn_s_memtime();                    \
+  } while (0)
+#else
+#define SSDE_GT(slot) do { } while (0)
+#endif
+
+// epilogue rows in flight per thread (12 registers each) and workgroups per CU the kernel is compiled for
+#ifndef SSDE_GEMM_BATCH
+#define SSDE_GEMM_BATCH 1
+#endif
+#ifndef SSDE_GEMM_OCC
+#define SSDE_GEMM_OCC 4
+#endif
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -41,12 +63,16 @@ struct GemmParams {
 };
 
 template <bool kGn>
-__global__ __launch_bounds__(kThreads, 4) void gemm1x1_kernel(const GemmParams p) {
+__global__ __launch_bounds__(kThreads, SSDE_GEMM_OCC) void gemm1x1_kernel(const GemmParams p) {
   SSDE_LDS(smem);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
   const int xcd = blockIdx.x & 7, lin = blockIdx.x >> 3;
   const int nt = lin % p.n_tiles, mt = (lin / p.n_tiles) * 8 + xcd;
+#ifdef SSDE_GEMM_TRACE
+  const bool gt_on = tid == 0 && blockIdx.x == 0 && g_gemm_trace != nullptr;
+#endif
+  SSDE_GT(0);
   if (mt >= p.m_tiles) return;
   const int m0 = mt * BM, n0 = nt * BN;
   const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
@@ -141,9 +167,11 @@ __global__ __launch_bounds__(kThreads, 4) void gemm1x1_kernel(const GemmParams p
 #pragma unroll
   for (int b = 0; b < 2; ++b) boff[b] = (BM + wn0 + b * 32 + li) * LDK + 2 * lh;
 
+  SSDE_GT(1);
   load_stage(0);
   store_stage(0, smem);
   __syncthreads();
+  SSDE_GT(2);
   for (int st = 0; st < nst; ++st) {
     const float* cur = smem + (st & 1) * kStage;
     const bool has_next = st + 1 < nst;
@@ -174,9 +202,13 @@ __global__ __launch_bounds__(kThreads, 4) void gemm1x1_kernel(const GemmParams p
       if (t + 1 < BK / 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
     }
+    if (st < 8) SSDE_GT(4 + st * 4);
     if (has_next) store_stage(st + 1, smem + ((st + 1) & 1) * kStage);
+    if (st < 8) SSDE_GT(5 + st * 4);
     __syncthreads();
+    if (st < 8) SSDE_GT(6 + st * 4);
   }
+  SSDE_GT(40);
 
   // ---- epilogue: accumulators -> LDS tile [64][BN + 4] -> coalesced float4 rows, the two 64-row halves in turn
   // (a half tile is 33 KB: with the 37 KB of operand stages four workgroups fit a CU and cover each other's pipeline
@@ -197,14 +229,16 @@ __global__ __launch_bounds__(kThreads, 4) void gemm1x1_kernel(const GemmParams p
           }
     }
     __syncthreads();
-    ssde_store_tile<64, BN, kThreads, 1>(smem, LDT, n0, e, [&](int row, size_t& pix, int& img) {
+    ssde_store_tile<64, BN, kThreads, SSDE_GEMM_BATCH>(smem, LDT, n0, e, [&](int row, size_t& pix, int& img) {
       const int m = m0 + half * 64 + row;
       if (m >= p.M) return false;
       pix = (size_t)m;
       img = m / p.HW;
       return true;
     }, p.gn_part ? (p.HW >= 64 ? (m0 >> 6) + half : (m0 + half * 64) / p.HW) : -1, p.HW >= 64 ? 30 : p.lHW, p.gn_entries);
+    SSDE_GT(41 + half * 2);
     __syncthreads();
+    SSDE_GT(42 + half * 2);
   }
 }
 
