@@ -14,7 +14,7 @@ from score_sde_pytorch_amd import hipops as ops, _lib as L  # noqa: E402
 from score_sde_pytorch_amd.engine import pack_conv_weight, pack_wino_weight  # noqa: E402
 
 
-def time_conv(n, cin, cout, h, tile, gn=False, reps=5):
+def time_conv(n, cin, cout, h, tile, gn=False, reps=5, resid=False):
     dev = "cuda"
     x = torch.randn(n, h, h, cin, device=dev)
     w = torch.randn(cout, cin, 3, 3, device=dev) / np.sqrt(9 * cin)
@@ -27,6 +27,9 @@ def time_conv(n, cin, cout, h, tile, gn=False, reps=5):
     ops._fill_src(a.main, x, None, {0: L.PRO_NONE, 1: L.PRO_GN_SILU, 2: L.PRO_GN, 3: L.PRO_SILU}[int(gn)], gnt)
     wp = (pack_wino_weight if tile == L.TILE_WINOGRAD else pack_conv_weight)(w)
     dst = torch.empty(n, h, h, cout, device=dev)
+    if resid:
+        rs = torch.randn(n, h, h, cout, device=dev)
+        a.resid = rs.data_ptr()
     a.w_main, a.ksize, a.stride, a.pad, a.h_in, a.w_in = wp.data_ptr(), 3, 1, 1, h, h
     a.n, a.h_out, a.w_out, a.c_out, a.out_scale, a.dst, a.tile = n, h, h, cout, 1.0, dst.data_ptr(), tile
     lib = L.load()
@@ -50,7 +53,8 @@ if __name__ == "__main__":
         shapes = [(256, 256, 4), (512, 256, 4), (128, 256, 8), (256, 256, 8)]
     for cin, cout, h in shapes:
         for gn in ((0, 1, 2, 3) if os.environ.get("CONV_BENCH_PROLOGUES") else (0, 1)):   # 1 GN+SiLU, 2 GN, 3 SiLU
-            d, dms = time_conv(n, cin, cout, h, L.TILE_AUTO, gn)
-            wv, wms = time_conv(n, cin, cout, h, L.TILE_WINOGRAD, gn) if h >= 8 else (0.0, float('inf'))
+            rs = bool(os.environ.get("CONV_BENCH_RESID"))     # + residual input (the second convolution of a block)
+            d, dms = time_conv(n, cin, cout, h, L.TILE_AUTO, gn, resid=rs)
+            wv, wms = time_conv(n, cin, cout, h, L.TILE_WINOGRAD, gn, resid=rs) if h >= 8 else (0.0, float('inf'))
             print("B=%d %4d->%4d @%2dx%-2d gn=%d  direct %6.1f TF/s (%.3f ms)   winograd %6.1f TF/s (%.3f ms)   x%.2f"
                   % (n, cin, cout, h, h, gn, d, dms, wv, wms, dms / wms), flush=True)
