@@ -45,16 +45,30 @@ struct ConvKParams {
   float scale;
   float* dst;
   float* gn_part;          // GroupNorm partials of dst (one image per tile), see ssde_store_tile
+  int ksplit;              // 1, or 2: two workgroups per tile, each reducing half of the input-channel chunks
+  unsigned* sync;          // ksplit == 2: this launch's (ticket, ready) pairs, one per tile (zero before and after)
 };
 
 constexpr int kThreads = 256;
+// input channels per LDS stage of the 3x3 phase: 8; 16 for the 64 x 64 tile when its halo fits the staging plan (small
+// maps: short loops and two barriers per stage -- 4x4 at batch 256: 62 -> 72 TF/s)
+#ifndef SSDE_CONV_BKC64
+#define SSDE_CONV_BKC64 16
+#endif
+
+// Small feature maps (4x4 at batch 256: 256 tiles of 64 pixels x 64 channels) give a launch of one workgroup per CU,
+// and a lone workgroup has nobody to cover its staging latency.  Such launches split the reduction over two
+// workgroups on the same XCD; whichever finishes first leaves its raw sums in the tile's own part of dst, the other adds
+// them to its own and runs the epilogue.  x + y == y + x bit for bit, so the result does not depend on who came first.
+constexpr int kSyncSlots = 1 << 17;            // pairs; a launch takes m_tiles * n_tiles of them from a rotating cursor
+__device__ unsigned g_conv_sync[kSyncSlots * 2];
 
 // One reduction phase: KS x KS taps over source `s`, BKC input channels per stage.
 template <int KS, int BKC, int BM, int BN, int TM, int TN, int MAXI>
 __device__ __forceinline__ void conv_phase(const ssde_src& s, const float* __restrict__ wpk,
                                            const ConvGeom& g, int stride, int pad, int Hs, int Ws,
                                            int img0, int ty, int tx, int n0, int wm0, int wn0,
-                                           f32x16 (&acc)[TM][TN], float* smem) {
+                                           f32x16 (&acc)[TM][TN], float* smem, int ks, int ksplit) {
   constexpr int T = KS * KS;
   constexpr int F4 = BKC / 4;
   constexpr int LDA = BKC + 4;
@@ -110,6 +124,7 @@ __device__ __forceinline__ void conv_phase(const ssde_src& s, const float* __res
   const int Ctot = s.c0 + s.c1;
   const int ncin8 = (Ctot + 7) >> 3;
   const int nchunks = (Ctot + BKC - 1) / BKC;
+  const int ch0 = nchunks * ks / ksplit, ch1 = nchunks * (ks + 1) / ksplit;     // this workgroup's share of the reduction
   const SsdePro pro = ssde_pro_decode(s);
   const int cpg = pro.gn ? Ctot / s.gn_groups : 1;
   constexpr int B_ITEMS = T * BN * F4;
@@ -193,12 +208,13 @@ __device__ __forceinline__ void conv_phase(const ssde_src& s, const float* __res
   };
 
   // software pipeline: the global loads of stage ch+1 are in flight while stage ch runs on the matrix pipe
-  load_stage(0);
+  if (ch0 >= ch1) return;
+  load_stage(ch0);
   __syncthreads();       // the previous phase's fragment reads are done
   store_stage();
   __syncthreads();
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const bool has_next = ch + 1 < nchunks;
+  for (int ch = ch0; ch < ch1; ++ch) {
+    const bool has_next = ch + 1 < ch1;
     if (has_next) load_stage(ch + 1);
     // ---- MFMA: every tap re-uses the staged halo ----
 #pragma unroll
@@ -231,7 +247,7 @@ __device__ __forceinline__ void conv_phase(const ssde_src& s, const float* __res
   }
 }
 
-template <int WM, int WN, int TM, int TN, bool HAS3, bool HAS1>
+template <int WM, int WN, int TM, int TN, bool HAS3, bool HAS1, int BKC3>
 __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvKParams p) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   SSDE_LDS(smem);
@@ -243,7 +259,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvKParam
   const int bid = blockIdx.x;
   const int xcd = bid & 7, l = bid >> 3;
   const int nt = l % g.n_tiles;
-  const int mt = (l / g.n_tiles) * 8 + xcd;
+  const int ks = (l / g.n_tiles) % p.ksplit;                  // the two halves of a tile: same XCD, 8 * n_tiles blocks apart
+  const int mt = (l / (g.n_tiles * p.ksplit)) * 8 + xcd;
   if (mt >= g.m_tiles) return;
 
   const int IMGS = BM >> (g.lTW + g.lTH);
@@ -265,11 +282,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvKParam
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   if constexpr (HAS3)
-    conv_phase<3, 8, BM, BN, TM, TN, 5>(p.main, p.w_main, g, g.stride, g.pad, g.Hin, g.Win,
-                                         img0, ty, tx, n0, wm0, wn0, acc, smem);
+    conv_phase<3, BKC3, BM, BN, TM, TN, 5>(p.main, p.w_main, g, g.stride, g.pad, g.Hin, g.Win,
+                                         img0, ty, tx, n0, wm0, wn0, acc, smem, ks, p.ksplit);
   if constexpr (HAS1)
     conv_phase<1, 32, BM, BN, TM, TN, (BM * 8) / kThreads>(p.aux, p.w_aux, g, 1, 0, g.Hout, g.Wout,
-                                                          img0, ty, tx, n0, wm0, wn0, acc, smem);
+                                                          img0, ty, tx, n0, wm0, wn0, acc, smem, ks, p.ksplit);
 
   // ---- epilogue: accumulators -> LDS tile [BM pixels][BN + 4] -> coalesced float4 stores (ssde_store_tile) ----
   const int lane = threadIdx.x & 63;
@@ -287,10 +304,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvKParam
         smem[m * LDT + wn0 + b * 32 + li] = acc[a][b][r];
       }
   __syncthreads();
-  SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, g.Cout, p.gn_part};
-  const int gn_entry = p.gn_part ? img0 * g.tiles_per_img + trem : -1;        // IMGS > 1: tiles_per_img == 1
-  const int rpi_log2 = IMGS > 1 ? g.lTW + g.lTH : 30;                          // rows per image = TW * TH
-  ssde_store_tile<BM, BN, kThreads>(smem, LDT, n0, e, [&](int m, size_t& pix, int& img) {
+  auto pixfn = [&](int m, size_t& pix, int& img) {
     const int c = m & (TW - 1);
     const int rr = (m >> g.lTW) & (TH - 1);
     img = img0 + (m >> (g.lTW + g.lTH));
@@ -298,7 +312,69 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvKParam
     if (img >= g.N || oy >= g.Hout || ox >= g.Wout) return false;
     pix = ((size_t)img * g.Hout + oy) * g.Wout + ox;
     return true;
-  }, gn_entry, rpi_log2, g.N * g.tiles_per_img);
+  };
+  if constexpr (BM == 64 && BN == 64) if (p.ksplit == 2) {
+    // ---- hand-over between the two halves of the reduction (see g_conv_sync) ----
+    unsigned* sy = p.sync + 2 * (mt * g.n_tiles + nt);
+    int* ticket = reinterpret_cast<int*>(smem + BM * LDT);
+    if (threadIdx.x == 0) *ticket = (int)atomicAdd(sy, 1u);
+    __syncthreads();
+    const bool first = *ticket == 0;
+    // The sums travel as agent-scope (sc1) dword accesses, which are coherent at the device level by themselves: a
+    // __threadfence() here is a write-back of the whole L2 per workgroup (measured: the split launch 40 % SLOWER than the
+    // unsplit one), and all that is needed is that the stores are acknowledged before the flag goes up.
+    if (!first) {
+      if (threadIdx.x == 0)
+        while (__hip_atomic_load(sy + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(4);
+      __syncthreads();
+    }
+    constexpr int QN = BN / 4;            // float4 columns of a tile row
+    constexpr int ITERS = BM * QN / kThreads;
+    float* tp[ITERS];
+    float* dp[ITERS];
+    float o[ITERS][4];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int q = threadIdx.x + it * kThreads;
+      const int m = q / QN, j = (q % QN) * 4;
+      size_t pix; int img;
+      const bool ok = pixfn(m, pix, img) && n0 + j < g.Cout;     // c_out % 4 == 0 on this path
+      tp[it] = smem + m * LDT + j;
+      dp[it] = ok ? p.dst + pix * g.Cout + n0 + j : nullptr;
+    }
+    if (first) {
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it)
+        if (dp[it]) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) __hip_atomic_store(dp[it] + k, tp[it][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+      // all loads in flight before the first add
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          o[it][k] = dp[it] ? __hip_atomic_load(dp[it] + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tp[it][k] += o[it][k];
+    }
+    if (first) {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0);      // every store of this thread is acknowledged ...
+      __syncthreads();                    // ... and every thread's
+      if (threadIdx.x == 0) atomicAdd(sy + 1, 1u);
+      return;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { sy[0] = 0u; sy[1] = 0u; }            // ready for the next launch that is dealt these slots
+  }
+  SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, g.Cout, p.gn_part};
+  const int gn_entry = p.gn_part ? img0 * g.tiles_per_img + trem : -1;        // IMGS > 1: tiles_per_img == 1
+  const int rpi_log2 = IMGS > 1 ? g.lTW + g.lTH : 30;                          // rows per image = TW * TH
+  ssde_store_tile<BM, BN, kThreads>(smem, LDT, n0, e, pixfn, gn_entry, rpi_log2, g.N * g.tiles_per_img);
 }
 
 struct TileCfg { int bm, bn; };
@@ -310,6 +386,7 @@ struct ConvPlan {
   int lds_bytes;
   int grid;
   bool has3, has1;
+  int bkc;                 // input channels per stage of the 3x3 phase
   int gn_slices;           // slices per image of the GroupNorm partials (0: a tile spans several images)
 };
 
@@ -373,10 +450,14 @@ int make_plan(const ssde_conv_args* a, ConvPlan* pl) {
   SSDE_REQUIRE(tile >= 1 && tile <= 4, "conv: bad tile id %d", tile);
   (void)SSDE_TILE_WINOGRAD;
   int lTW = 0, lTH = 0;
+  pl->bkc = 8;
+  const char* be = getenv("SSDE_CONV_BKC64");            // "8": the 8-channel stages everywhere (A/B, tests)
+  const bool deep_ok = !be || atoi(be) != 8;
   if (pl->has3) {
     // the halo of the chosen tile must fit the per-thread staging plan (5 x 256 float4 items)
     while (true) {
       const int px = halo_px(kTiles[tile].bm, a->w_out, a->h_out, a->stride, 3, &lTW, &lTH);
+      pl->bkc = (deep_ok && tile == SSDE_TILE_64x64 && px * (SSDE_CONV_BKC64 / 4) <= 5 * kThreads) ? SSDE_CONV_BKC64 : 8;
       if (px * 2 <= 5 * kThreads) break;
       SSDE_REQUIRE(tile != SSDE_TILE_64x64, "conv: halo too large for any tile");
       tile = (tile == SSDE_TILE_256x32) ? SSDE_TILE_64x64 : tile + 1;   // 256x64 -> 128x64 -> 64x64
@@ -409,25 +490,45 @@ int make_plan(const ssde_conv_args* a, ConvPlan* pl) {
   int lds = 0;
   if (pl->has3) {
     const int px = imgs * ((th - 1) * g.stride + 3) * ((tw - 1) * g.stride + 3);
-    lds = (((px * 12 + 3) & ~3) + 9 * bn * 12) * 4;
+    const int lda = pl->bkc + 4;
+    lds = (((px * lda + 3) & ~3) + 9 * bn * lda) * 4;
   }
   if (pl->has1) {
     const int l1 = (bm * 36 + bn * 36) * 4;
     if (l1 > lds) lds = l1;
   }
-  const int epi_bytes = bm * (bn + 4) * 4;          // the epilogue parks the output tile in LDS
+  const int epi_bytes = bm * (bn + 4) * 4 + 16;     // the epilogue parks the output tile in LDS (+ the hand-over ticket)
   pl->lds_bytes = lds > epi_bytes ? lds : epi_bytes;
   pl->tile = tile;
-  pl->grid = ssde_cdiv(g.m_tiles, 8) * 8 * g.n_tiles;
+  // split the reduction when the launch would leave every CU with at most one workgroup (see g_conv_sync)
+  const char* se = getenv("SSDE_CONV_KSPLIT");           // read per call: the tests compare both forms in one process
+  const bool split_ok = !se || atoi(se) != 0;
+  const int wgs = ssde_cdiv(g.m_tiles, 8) * 8 * g.n_tiles;
+  const int ctot = pl->has3 ? a->main.c0 + a->main.c1 : 0;
+  kp.ksplit = (split_ok && pl->has3 && tile == SSDE_TILE_64x64 && wgs <= 320 && ctot >= 128 && a->c_out % 4 == 0 &&
+               a->resid != a->dst && g.m_tiles * g.n_tiles <= kSyncSlots / 4) ? 2 : 1;
+  kp.sync = nullptr;
+  pl->grid = wgs * kp.ksplit;
   return SSDE_OK;
 }
 
-template <int WM, int WN, int TM, int TN>
-int launch_cfg(const ConvPlan& pl, hipStream_t st) {
+template <int WM, int WN, int TM, int TN, int BKC3 = 8>
+int launch_cfg(ConvPlan& pl, hipStream_t st) {
   dim3 grid(pl.grid), block(kThreads);
+  if (pl.kp.ksplit == 2) {
+    // a fresh run of slots per launch: launches in flight on different streams (or captured into different graphs)
+    // never share a pair unless more than kSyncSlots pairs are dealt in between
+    static std::atomic<unsigned> cursor{0};
+    const unsigned need = (unsigned)(pl.kp.g.m_tiles * pl.kp.g.n_tiles);
+    unsigned at = cursor.fetch_add(need) % kSyncSlots;
+    if (at + need > kSyncSlots) at = 0;
+    unsigned* base = nullptr;
+    SSDE_HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_conv_sync)));
+    pl.kp.sync = base + 2 * (size_t)at;
+  }
 #define SSDE_CONV_LAUNCH(H3, H1)                                                                     \
   do {                                                                                               \
-    auto kfn = conv_mfma_kernel<WM, WN, TM, TN, H3, H1>;                                             \
+    auto kfn = conv_mfma_kernel<WM, WN, TM, TN, H3, H1, BKC3>;                                       \
     static std::atomic<bool> attr_set{false}; /* once per instantiation, before any stream capture */            \
     if (!attr_set) {                                                                                 \
       SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                         \
@@ -455,7 +556,7 @@ extern "C" int ssde_conv2d(const ssde_conv_args* a, void* stream) {
   switch (pl.tile) {
     case SSDE_TILE_256x64: return launch_cfg<4, 1, 2, 2>(pl, st);
     case SSDE_TILE_128x64: return launch_cfg<4, 1, 1, 2>(pl, st);
-    case SSDE_TILE_64x64:  return launch_cfg<2, 2, 1, 1>(pl, st);
+    case SSDE_TILE_64x64:  return pl.bkc == 8 ? launch_cfg<2, 2, 1, 1>(pl, st) : launch_cfg<2, 2, 1, 1, SSDE_CONV_BKC64>(pl, st);
     case SSDE_TILE_256x32: return launch_cfg<4, 1, 2, 1>(pl, st);
   }
   ssde_set_error("conv: unreachable tile %d", pl.tile);

@@ -734,3 +734,63 @@ def check_checkpoint_and_ema_swap(dev, tmp_path):
         assert torch.equal(a, b.detach())
     with torch.no_grad():
         assert torch.equal(infer(model, xq, sq), y_raw)
+
+
+def check_conv_split_reduction(dev, monkeypatch, n, repeats=3):
+    """3x3 convolutions on small maps split the input-channel reduction over two workgroups that meet in dst
+    (conv_mfma.hip, g_conv_sync).  With the full fused form (concat source, GroupNorm+SiLU prologue, bias, per-image
+    addend, residual, scale, GroupNorm partials of the result): the split launch must match the torch reference, give
+    the same bits on every repeat (the hand-over order is free, x + y == y + x), leave its flags clear for the next
+    launch, and its GroupNorm partials must finalize to the statistics of its own output."""
+    import ctypes as C
+    import numpy as np
+    import torch.nn.functional as F
+    from score_sde_pytorch_amd import hipops as ops, _lib as L
+    from score_sde_pytorch_amd.engine import pack_conv_weight
+    lib = L.load()
+    g = torch.Generator().manual_seed(12)
+    for (c0, c1, cout, h) in ((256, 0, 256, 4), (128, 128, 192, 4), (128, 0, 64, 2)):
+        cin = c0 + c1
+        x0 = (torch.randn(n, h, h, c0, generator=g) * 1.5 + 0.3).to(dev)
+        x1 = torch.randn(n, h, h, c1, generator=g).to(dev) if c1 else None
+        xcat = torch.cat([x0, x1], -1) if c1 else x0
+        w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
+        b, gamma, beta = torch.randn(cout, generator=g), torch.randn(cin, generator=g), torch.randn(cin, generator=g)
+        resid, ca = torch.randn(n, h, h, cout, generator=g).to(dev), torch.randn(n, cout, generator=g).to(dev)
+        G = 32
+        mean, rstd = ops.groupnorm_stats(x0, G, 1e-6, x2=x1)
+        gn = (mean, rstd, gamma.to(dev), beta.to(dev), G)
+        wp, bd = pack_conv_weight(w.to(dev)), b.to(dev)
+        outs = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("SSDE_CONV_KSPLIT", mode)
+            for rep in range(repeats if mode == "1" else 1):
+                a = L.ConvArgs()
+                ops._fill_src(a.main, x0, x1, L.PRO_GN_SILU, gn)
+                dst = torch.full((n, h, h, cout), float("nan"), device=dev)
+                a.w_main, a.ksize, a.stride, a.pad, a.h_in, a.w_in = wp.data_ptr(), 3, 1, 1, h, h
+                a.n, a.h_out, a.w_out, a.c_out, a.out_scale, a.dst, a.tile = n, h, h, cout, 0.7, dst.data_ptr(), L.TILE_AUTO
+                a.bias, a.chan_add, a.chan_add_ld, a.resid = bd.data_ptr(), ca.data_ptr(), cout, resid.data_ptr()
+                sl = lib.ssde_conv_gn_slices(C.byref(a))
+                part = torch.full((n, max(sl, 1), cout // 4, 3), float("nan"), device=dev)
+                if sl > 0:
+                    a.gn_part = part.data_ptr()
+                L.check(lib.ssde_conv2d(C.byref(a), ops._stream()))
+                outs.setdefault(mode, []).append((dst, part, sl))
+        ref = F.conv2d(F.silu(F.group_norm(xcat.cpu().permute(0, 3, 1, 2), G, gamma, beta, 1e-6)), w, b, padding=1)
+        ref = ((ref + ca.cpu()[:, :, None, None]).permute(0, 2, 3, 1) + resid.cpu()) * 0.7
+        y = outs["1"][0][0]
+        assert _util.rel_err(y.cpu(), ref) < 2e-5, (c0, c1, cout, h)
+        assert _util.rel_err(outs["0"][0][0].cpu(), ref) < 2e-5
+        for dst, _, _ in outs["1"][1:]:
+            assert torch.equal(dst, y), "split reduction is not reproducible"
+        dst, part, sl = outs["1"][-1]
+        if sl > 0:
+            Go = 32 if (cout // 32) % 4 == 0 else 16
+            f = L.GnFinalizeArgs()
+            m2, r2 = torch.zeros(n, Go, device=dev), torch.zeros(n, Go, device=dev)
+            f.part0, f.c0, f.slices0, f.n, f.groups, f.eps = part.data_ptr(), cout, sl, n, Go, 1e-6
+            f.mean, f.rstd = m2.data_ptr(), r2.data_ptr()
+            L.check(lib.ssde_gn_finalize(C.byref(f), ops._stream()))
+            mr, rr = ops.groupnorm_stats(dst, Go, 1e-6)
+            assert (m2 - mr).abs().max().item() < 1e-5 and ((r2 - rr).abs() / rr).max().item() < 1e-4

@@ -173,6 +173,9 @@ using std::max;
 using std::min;
 static inline int min(int a, unsigned b) { return a < (int)b ? a : (int)b; }
 
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) ((void)(*(p) = (v)))
 // atomics: workgroups run one after another and fibers are cooperative, so plain RMW is atomic
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
@@ -207,6 +210,8 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, h
 enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 2; }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+#define HIP_SYMBOL(X) (X)
+template <class T> static inline hipError_t hipGetSymbolAddress(void** p, const T& sym) { *p = const_cast<void*>(static_cast<const void*>(&sym)); return hipSuccess; }
 static inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return hipSuccess; }
 
