@@ -96,7 +96,10 @@ typedef struct ssde_conv_args {
 enum { SSDE_TILE_AUTO = 0, SSDE_TILE_256x64 = 1, SSDE_TILE_128x64 = 2, SSDE_TILE_64x64 = 3, SSDE_TILE_256x32 = 4,
        /* Winograd F(2x2,3x3) kernel (3x3, stride 1, pad 1, even output, no aux): w_main must then be packed as
         * [ceil(Cin/8)][ceil(Cout/64)][16 positions][4 channel pairs][64 couts, bit 4 ^= pair parity][2], G g G^T */
-       SSDE_TILE_WINOGRAD = 5 };
+       SSDE_TILE_WINOGRAD = 5,
+       /* Winograd F(4x4,3x3) kernel (3x3, stride 1, pad 1, output a multiple of 4, no aux): w_main packed as
+        * [ceil(Cin/4)][ceil(Cout/64)][36 positions][64 couts][4 channels], G g G^T with the 6x3 G of F(4,3) */
+       SSDE_TILE_WINOGRAD4 = 6 };
 
 /* ---- GroupNorm statistics: mean / rstd per (sample, group) -----------------
  * replaces the reduction half of nn.GroupNorm(min(C/4,32), C, eps=1e-6)

@@ -448,6 +448,7 @@ int make_plan(const ssde_conv_args* a, ConvPlan* pl) {
     if (a->w_out * a->h_out * a->n < kTiles[tile].bm && tile != SSDE_TILE_256x32) tile = SSDE_TILE_64x64;
   }
   SSDE_REQUIRE(tile >= 1 && tile <= 4, "conv: bad tile id %d", tile);
+  (void)SSDE_TILE_WINOGRAD4;
   (void)SSDE_TILE_WINOGRAD;
   int lTW = 0, lTH = 0;
   pl->bkc = 8;
@@ -549,6 +550,7 @@ int launch_cfg(ConvPlan& pl, hipStream_t st) {
 
 extern "C" int ssde_conv2d(const ssde_conv_args* a, void* stream) {
   if (a && a->tile == SSDE_TILE_WINOGRAD) return ssde_conv_wino_launch(a, stream, nullptr);
+  if (a && a->tile == SSDE_TILE_WINOGRAD4) return ssde_conv_wino4_launch(a, stream, nullptr);
   if (a && a->dst && ssde_conv1x1_wants(a)) return ssde_conv1x1_launch(a, stream, nullptr);   // 1x1-only: GEMM kernel (conv1x1.hip)
   ConvPlan pl;
   if (int rc = make_plan(a, &pl)) return rc;
@@ -567,9 +569,9 @@ extern "C" int ssde_conv_gn_slices(const ssde_conv_args* a) {
   if (!a || a->c_out % 4 != 0) return 0;
   ssde_conv_args q = *a;
   q.gn_part = nullptr;
-  if (q.tile == SSDE_TILE_WINOGRAD) {
+  if (q.tile == SSDE_TILE_WINOGRAD || q.tile == SSDE_TILE_WINOGRAD4) {
     int s = 0;
-    if (ssde_conv_wino_launch(&q, reinterpret_cast<void*>(1), &s)) return 0;     // plan-only query form
+    if ((q.tile == SSDE_TILE_WINOGRAD ? ssde_conv_wino_launch : ssde_conv_wino4_launch)(&q, reinterpret_cast<void*>(1), &s)) return 0;     // plan-only query form
     return s;
   }
   if (q.dst && ssde_conv1x1_wants(&q)) {
@@ -585,9 +587,9 @@ extern "C" int ssde_conv_gn_slices(const ssde_conv_args* a) {
 }
 
 extern "C" int ssde_conv_lds_bytes(const ssde_conv_args* a) {
-  if (a && a->tile == SSDE_TILE_WINOGRAD) {
+  if (a && (a->tile == SSDE_TILE_WINOGRAD || a->tile == SSDE_TILE_WINOGRAD4)) {
     int lds = 0;
-    if (int rc = ssde_conv_wino_launch(a, nullptr, &lds)) return rc;
+    if (int rc = (a->tile == SSDE_TILE_WINOGRAD ? ssde_conv_wino_launch : ssde_conv_wino4_launch)(a, nullptr, &lds)) return rc;
     return lds;
   }
   if (a && a->dst && ssde_conv1x1_wants(a)) {

@@ -1,0 +1,387 @@
+// 3x3 / stride 1 / pad 1 convolution by Winograd F(4x4, 3x3) on the exact-fp32 matrix pipe.
+//
+//   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A     with 6x6 transformed tiles, 4x4 outputs per tile (Lavin & Gray,
+//                                                    interpolation points 0, +-1, +-2)
+// Per 4x4 output tile and (ci, co) pair the 144 multiply-adds of the direct form become 36 (F(2x2,3x3), conv_wino.hip:
+// 64): the matrix pipe does 4x less work than the direct kernel and 1.78x less than F(2x2,3x3).  The price is
+// rounding: the transforms multiply by up to 8 and the products are ~4-5x less accurate than F(2x2,3x3) in fp32.
+// tools/experiments/wino43_error_budget.py runs the whole CIFAR-10 NCSN++ with every 3x3 layer in this form against
+// an fp64 run: 2.5e-6 .. 1.3e-5 relative L2 error of the score (direct fp32: 4e-7 .. 1.2e-5), against the 1e-4 the
+// parity tests allow.
+//
+// One workgroup (8 waves, two per SIMD) owns 32 tiles (a 32x16 output patch, or whole small images) x 64 output
+// channels x all 36 transform positions; K advances 4 input channels per stage:
+//   raw halo (+ fused GroupNorm / SiLU / dropout prologue)      -> LDS raw[pair][pixel][2]
+//   input transform B^T d B in two 1-D passes, in place         -> LDS V[pos][tile][4]      (18 KB)
+//   host-transformed weights G g G^T, packed as the LDS image   -> LDS U[pos][cout][4]      (36 KB, by LDS-DMA)
+//   wave (q, h) = 9 positions {q, q+4, ..} x (32 tiles x 32 couts) on v_mfma_f32_32x32x2_f32: a lane's ds_read_b64 is
+//   the channel pair (2k, 2k+1), k = lane >> 5 = the MFMA k index, one read of each operand feeds two MFMAs; all 64
+//   lanes of a fragment read are 512 contiguous bytes (no bank conflicts)
+// V, U and raw are double buffered; two LDS-only barriers per stage.  The 36 positions of an output live in 4 waves,
+// so the workgroup exchanges the products through LDS once (per 32-cout half: 36 x 32 x 32 floats = the whole LDS),
+// every thread applies A^T M A to one (tile, cout pair), and the result goes through the shared coalesced epilogue
+// (ssde_store_tile: bias, temb addend, residual, scale, GroupNorm partials).
+#include "ssde_common.h"
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int kThreads = 512;
+constexpr int kPos = 36, kTiles = 32, kKc = 4;
+constexpr int kVFloats = kPos * kTiles * kKc;       // 4608: one V stage
+constexpr int kUFloats = kPos * 64 * kKc;           // 9216: one U stage
+constexpr int kMaxRaw = 2;                          // float4 halo items per thread per stage (halo <= 1024 pixels)
+constexpr int kLdm = 34;                            // row pitch of the product exchange [pos][tile][32 couts]
+constexpr int kLdt = 36;                            // row pitch of the parked output tile [512 pixels][32 couts]
+
+struct Wino4Params {
+  ssde_src src;
+  const float* wpk;        // [ceil(C/4)][n_tiles][36][64][4] (LDS image per stage)
+  int N, H, W, Cout;
+  int lTWt, lTHt;          // log2 tiles per patch row / column
+  int tiles_x, tiles_per_img, m_tiles, n_tiles;
+  const float* bias; const float* chan_add; int chan_add_ld;
+  const float* resid; int resid_post;
+  float scale;
+  float* dst;
+  float* gn_part;
+};
+
+// 1-D input transform (one column / row of B^T d, B^T rows: [4,0,-5,0,1,0] [0,-4,-4,1,1,0] [0,4,-4,-1,1,0]
+// [0,-2,-1,2,1,0] [0,2,-1,-2,1,0] [0,4,0,-5,0,1]), two channels at once
+__device__ __forceinline__ void bt6(const float2 (&d)[6], float2 (&o)[6]) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const float d0 = e ? d[0].y : d[0].x, d1 = e ? d[1].y : d[1].x, d2 = e ? d[2].y : d[2].x;
+    const float d3 = e ? d[3].y : d[3].x, d4 = e ? d[4].y : d[4].x, d5 = e ? d[5].y : d[5].x;
+    const float t1 = d4 - 4.f * d2, t2 = d3 - 4.f * d1, t3 = d4 - d2, t4 = d3 - d1;
+    const float o0 = 4.f * d0 - 5.f * d2 + d4, o1 = t1 + t2, o2 = t1 - t2, o3 = t3 + 2.f * t4, o4 = t3 - 2.f * t4;
+    const float o5 = 4.f * d1 - 5.f * d3 + d5;
+    if (e) { o[0].y = o0; o[1].y = o1; o[2].y = o2; o[3].y = o3; o[4].y = o4; o[5].y = o5; }
+    else   { o[0].x = o0; o[1].x = o1; o[2].x = o2; o[3].x = o3; o[4].x = o4; o[5].x = o5; }
+  }
+}
+
+template <bool kGn>
+__global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Params p) {
+  SSDE_LDS(smem);
+  float* Vb = smem;                            // [2][kVFloats]
+  float* Ub = smem + 2 * kVFloats;             // [2][kUFloats]
+  float* rawb = Ub + 2 * kUFloats;             // [2][2 pairs][halo_px][2], then the GroupNorm tables
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+
+  // XCD-aware order (as conv_mfma.hip): the cout tiles of one pixel tile run on one XCD
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, l = bid >> 3;
+  const int nt = l % p.n_tiles;
+  const int mt = (l / p.n_tiles) * 8 + xcd;
+  if (mt >= p.m_tiles) return;
+
+  const int TWt = 1 << p.lTWt, THt = 1 << p.lTHt;
+  const int IMGS = kTiles >> (p.lTWt + p.lTHt);
+  const int HWd = 4 * TWt + 2, HH = 4 * THt + 2;
+  const int halo_px = IMGS * HH * HWd;
+  const int raw_stride = 4 * halo_px;          // floats per raw buffer
+  const int img0 = (mt / p.tiles_per_img) * IMGS;
+  const int trem = mt % p.tiles_per_img;
+  const int ty = trem / p.tiles_x, tx = trem % p.tiles_x;
+  const int n0 = nt * 64;
+
+  const ssde_src& s = p.src;
+  const int Ctot = s.c0 + s.c1;
+  const int nst = (Ctot + 3) >> 2;
+  SsdePro pro = ssde_pro_decode(s);
+  pro.gn = kGn;
+  const int cpg = kGn ? Ctot / s.gn_groups : 1;
+  const float inv_cpg = 1.0f / (float)cpg;
+
+  // ---- raw staging plan: item = halo pixel (its 4 channels of the stage are one float4) ----
+  int goff[kMaxRaw], gil[kMaxRaw];
+#pragma unroll
+  for (int it = 0; it < kMaxRaw; ++it) {
+    const int q = tid + it * kThreads;
+    goff[it] = -2; gil[it] = 0;
+    if (q < halo_px) {
+      const int il = q / (HH * HWd);
+      const int rem = q - il * (HH * HWd);
+      const int hy = rem / HWd, hx = rem - hy * HWd;
+      const int iy = ty * 4 * THt - 1 + hy, ix = tx * 4 * TWt - 1 + hx;
+      const int img = img0 + il;
+      const bool inb = img < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      goff[it] = inb ? (img * p.H + iy) * p.W + ix : -1;
+      gil[it] = inb ? il * (kGn ? s.gn_groups : 0) : 0;
+    }
+  }
+  // ---- transform plan: thread (line x = tid >> 6 of the 6x6 tile, item = tid & 63 = (tile, channel pair)); 384 threads ----
+  const int t_line = tid >> 6, t_tile = (tid & 63) >> 1, t_pair = tid & 1;
+  int t_base;
+  {
+    const int il = t_tile >> (p.lTWt + p.lTHt);
+    const int tr = (t_tile >> p.lTWt) & (THt - 1), tc = t_tile & (TWt - 1);
+    t_base = (il * HH + 4 * tr) * HWd + 4 * tc;
+  }
+  const int t_vcol = t_tile * 4 + t_pair * 2;
+
+  // GroupNorm tables in LDS: (mean, rstd) of every (tile image, group), gamma and beta of every channel
+  float* gn_tab = rawb + 2 * raw_stride;       // [IMGS][groups][2]
+  float* gb_tab = gn_tab + 2 * IMGS * (kGn ? s.gn_groups : 0);   // [2][Ctot]
+  if (kGn) {
+    for (int q = tid; q < IMGS * s.gn_groups; q += kThreads) {
+      const int il = q / s.gn_groups, img = img0 + il < p.N ? img0 + il : 0;
+      const int gi = img * s.gn_groups + (q - il * s.gn_groups);
+      *reinterpret_cast<float2*>(gn_tab + 2 * q) = make_float2(s.gn_mean[gi], s.gn_rstd[gi]);
+    }
+    for (int q = tid; q < Ctot; q += kThreads) { gb_tab[q] = s.gn_gamma[q]; gb_tab[Ctot + q] = s.gn_beta[q]; }
+  }
+
+  float4 rv[kMaxRaw];
+  int c_cur = 0;
+  // branch-free global loads of stage st (items outside the image read a clamped, valid address and are zeroed below)
+  auto load_raw = [&](int st) {
+    const int c_base = st * 4;
+    c_cur = c_base;
+    const bool second = c_base >= s.c0;
+    const float* bp = (second ? s.p1 : s.p0) + (second ? c_base - s.c0 : c_base);
+    const int C = second ? s.c1 : s.c0;
+#pragma unroll
+    for (int it = 0; it < kMaxRaw; ++it)
+      rv[it] = *reinterpret_cast<const float4*>(bp + (size_t)(goff[it] >= 0 ? goff[it] : 0) * C);
+  };
+  // prologue + raw LDS store (channel-pair major)
+  auto store_raw = [&](float* rw) {
+    float4 gam = make_float4(1.f, 1.f, 1.f, 1.f), bet = make_float4(0.f, 0.f, 0.f, 0.f);
+    int g = 0;
+    if (kGn) {
+      gam = *reinterpret_cast<const float4*>(gb_tab + c_cur);
+      bet = *reinterpret_cast<const float4*>(gb_tab + Ctot + c_cur);
+      g = (int)(((float)c_cur + 0.5f) * inv_cpg);          // c_cur / cpg, exact for these small integers
+    }
+#pragma unroll
+    for (int it = 0; it < kMaxRaw; ++it) {
+      if (goff[it] == -2) continue;
+      float mu = 0.f, rs = 1.f;
+      if (kGn) { const float2 mr = *reinterpret_cast<const float2*>(gn_tab + 2 * (gil[it] + g)); mu = mr.x; rs = mr.y; }
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (goff[it] >= 0)
+        v = ssde_pro_apply(rv[it], mu, rs, gam, bet, (uint32_t)goff[it] * (uint32_t)Ctot + (uint32_t)c_cur, pro);
+      const int q = tid + it * kThreads;
+      *reinterpret_cast<float2*>(rw + q * 2) = make_float2(v.x, v.y);
+      *reinterpret_cast<float2*>(rw + (halo_px + q) * 2) = make_float2(v.z, v.w);
+    }
+  };
+  // B^T d B in two 1-D passes over the 6x6 tile, the second in place: pass 1 thread = (column x), pass 2 thread = (row y)
+  auto pass1 = [&](const float* rw, float* Vn) {
+    if (t_line < 6) {
+      const float* rp = rw + (t_pair * halo_px + t_base + t_line) * 2;
+      float2 d[6], o[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) d[a] = *reinterpret_cast<const float2*>(rp + a * HWd * 2);
+      bt6(d, o);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) *reinterpret_cast<float2*>(Vn + (a * 6 + t_line) * (kTiles * 4) + t_vcol) = o[a];
+    }
+  };
+  auto pass2 = [&](float* Vn) {
+    if (t_line < 6) {
+      float* vp = Vn + (t_line * 6) * (kTiles * 4) + t_vcol;
+      float2 d[6], o[6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) d[b] = *reinterpret_cast<const float2*>(vp + b * (kTiles * 4));
+      bt6(d, o);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) *reinterpret_cast<float2*>(vp + b * (kTiles * 4)) = o[b];
+    }
+  };
+  // weights of stage st: the host packed them as the LDS image; 36 pieces of 1 KB, wave w moves pieces w, w + 8, ...
+  auto dma_weights = [&](int st, float* Un) {
+    const float* gsrc = p.wpk + ((size_t)st * p.n_tiles + nt) * kUFloats + lane * 4;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int piece = wave + 8 * k;
+      if (piece < kPos) SSDE_GLDS16_OFF(gsrc + piece * 256, Un + piece * 256, 0);
+    }
+  };
+
+  const int wq = wave >> 1, wh = wave & 1;      // this wave's positions wq + 4 j and its 32-cout half
+  f32x16 acc[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int a_off = li * 4 + 2 * lh, b_off = (wh * 32 + li) * 4 + 2 * lh;
+  auto mfma_range = [&](const float* Vc, const float* Uc, auto j0c, auto j1c) {
+    constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
+#pragma unroll
+    for (int j = J0; j < J1; ++j) {
+      const int pos = wq + 4 * j;
+      const float2 a = *reinterpret_cast<const float2*>(Vc + pos * (kTiles * 4) + a_off);
+      const float2 b = *reinterpret_cast<const float2*>(Uc + pos * (64 * 4) + b_off);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[j], 0, 0, 0);
+    }
+  };
+
+  // ---- pipeline fill ----
+  load_raw(0);
+  dma_weights(0, Ub);
+  __syncthreads();                             // publishes the GroupNorm tables
+  store_raw(rawb);
+  if (nst > 1) load_raw(1);
+  SSDE_LDS_BARRIER();
+  pass1(rawb, Vb);
+  SSDE_LDS_BARRIER();
+  pass2(Vb);
+  if (nst > 1) store_raw(rawb + raw_stride);
+  SSDE_WAIT_VMCNT(0);
+  SSDE_LDS_BARRIER();
+
+  for (int st = 0; st < nst; ++st) {
+    const int cur = st & 1, nxt = cur ^ 1;
+    const float* Vc = Vb + cur * kVFloats;
+    const float* Uc = Ub + cur * kUFloats;
+    float* Vn = Vb + nxt * kVFloats;
+    const bool has1 = st + 1 < nst, has2 = st + 2 < nst;
+    if (has1) dma_weights(st + 1, Ub + nxt * kUFloats);
+    if (has2) load_raw(st + 2);
+    if (has1) pass1(rawb + nxt * raw_stride, Vn);
+    mfma_range(Vc, Uc, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+    SSDE_LDS_BARRIER();
+    if (has1) pass2(Vn);
+    mfma_range(Vc, Uc, std::integral_constant<int, 5>{}, std::integral_constant<int, 9>{});
+    if (has2) store_raw(rawb + cur * raw_stride);
+    SSDE_WAIT_VMCNT(0);
+    SSDE_LDS_BARRIER();
+  }
+
+  // ---- epilogue, one 32-cout half at a time ----
+  SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, p.Cout, p.gn_part};
+  const int gn_entry = p.gn_part ? img0 * p.tiles_per_img + trem : -1;        // IMGS > 1: tiles_per_img == 1, trem == 0
+  const int rpi_log2 = IMGS > 1 ? 9 - (5 - p.lTWt - p.lTHt) : 30;             // rows per image: 512 / IMGS
+  const int e_tile = tid >> 4, e_cp = tid & 15;
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    if (wh == half) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          smem[((wq + 4 * j) * kTiles + m) * kLdm + li] = acc[j][r];
+        }
+    }
+    __syncthreads();
+    // Y = A^T M A for (tile, couts 2 cp, 2 cp + 1); A^T rows [1,1,1,1,1,0] [0,1,-1,2,-2,0] [0,1,1,4,4,0] [0,1,-1,8,-8,1]
+    float2 y[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) y[a][b] = make_float2(0.f, 0.f);
+    const float* mp = smem + e_tile * kLdm + 2 * e_cp;
+#pragma unroll
+    for (int px = 0; px < 6; ++px) {
+      float2 m[6];
+#pragma unroll
+      for (int py = 0; py < 6; ++py) m[py] = *reinterpret_cast<const float2*>(mp + (py * 6 + px) * (kTiles * kLdm));
+      float2 t[4];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float m0 = c ? m[0].y : m[0].x, m1 = c ? m[1].y : m[1].x, m2 = c ? m[2].y : m[2].x;
+        const float m3 = c ? m[3].y : m[3].x, m4 = c ? m[4].y : m[4].x, m5 = c ? m[5].y : m[5].x;
+        const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+        const float t0 = m0 + s1 + s2, t1 = d1 + 2.f * d2, t2 = s1 + 4.f * s2, t3 = d1 + 8.f * d2 + m5;
+        if (c) { t[0].y = t0; t[1].y = t1; t[2].y = t2; t[3].y = t3; }
+        else   { t[0].x = t0; t[1].x = t1; t[2].x = t2; t[3].x = t3; }
+      }
+      // column px of A: (1, 0, 0, 0), (1, 1, 1, 1), (1, -1, 1, -1), (1, 2, 4, 8), (1, -2, 4, -8), (0, 0, 0, 1)
+      constexpr float kA[6][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f},
+                                  {1.f, 2.f, 4.f, 8.f}, {1.f, -2.f, 4.f, -8.f}, {0.f, 0.f, 0.f, 1.f}};
+#pragma unroll
+      for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx)
+          if (kA[px][dx] != 0.f) { y[dy][dx].x += kA[px][dx] * t[dy].x; y[dy][dx].y += kA[px][dx] * t[dy].y; }
+    }
+    __syncthreads();                           // every thread has read its products: the parked tile may overwrite them
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 4; ++dx)
+        *reinterpret_cast<float2*>(smem + (e_tile * 16 + dy * 4 + dx) * kLdt + 2 * e_cp) = y[dy][dx];
+    __syncthreads();
+    ssde_store_tile<512, 32, kThreads, 4, 0>(smem, kLdt, n0 + half * 32, e, [&](int row, size_t& pix, int& img) {
+      const int tile = row >> 4, dy = (row >> 2) & 3, dx = row & 3;
+      const int il = tile >> (p.lTWt + p.lTHt);
+      const int tr = (tile >> p.lTWt) & (THt - 1), tc = tile & (TWt - 1);
+      img = img0 + il;
+      const int oy = (ty * THt + tr) * 4 + dy, ox = (tx * TWt + tc) * 4 + dx;
+      if (img >= p.N || oy >= p.H || ox >= p.W) return false;
+      pix = ((size_t)img * p.H + oy) * p.W + ox;
+      return true;
+    }, gn_entry, rpi_log2, p.N * p.tiles_per_img);
+    __syncthreads();
+  }
+}
+
+int pow2_floor(int v) { int q = 1; while (q * 2 <= v) q *= 2; return q; }
+
+}  // namespace
+
+// stream == (void*)1 with lds_out: plan-only query of the GroupNorm slices per image (conv_mfma.hip, ssde_conv_gn_slices)
+int ssde_conv_wino4_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
+  SSDE_REQUIRE(a && a->dst && a->main.p0 && a->w_main, "conv(winograd 4x4): null args");
+  SSDE_REQUIRE(a->ksize == 3 && a->stride == 1 && a->pad == 1, "conv(winograd 4x4): needs 3x3, stride 1, pad 1");
+  SSDE_REQUIRE(a->aux.p0 == nullptr, "conv(winograd 4x4): fused 1x1 source not supported (issue it as a second conv)");
+  SSDE_REQUIRE(a->h_in == a->h_out && a->w_in == a->w_out && a->h_out % 4 == 0 && a->w_out % 4 == 0 && a->h_out >= 8 && a->w_out >= 8,
+               "conv(winograd 4x4): same-size output, multiples of 4, at least 8x8 (got %dx%d)", a->h_out, a->w_out);
+  const ssde_src& s = a->main;
+  SSDE_REQUIRE(s.c0 > 0 && s.c0 % 4 == 0 && s.c1 % 4 == 0 && (s.c1 == 0 || s.p1), "conv(winograd 4x4): channels must be multiples of 4");
+  const bool gn = s.pro_mode == SSDE_PRO_GN || s.pro_mode == SSDE_PRO_GN_SILU;
+  if (gn) {
+    SSDE_REQUIRE(s.gn_groups > 0 && (s.c0 + s.c1) % s.gn_groups == 0 && ((s.c0 + s.c1) / s.gn_groups) % 4 == 0,
+                 "conv(winograd 4x4): GroupNorm needs channels-per-group %% 4 == 0");
+    SSDE_REQUIRE(s.gn_mean && s.gn_rstd && s.gn_gamma && s.gn_beta, "conv(winograd 4x4): GroupNorm pointers missing");
+  }
+  SSDE_REQUIRE(s.drop_thresh == 0 || s.drop_seed, "conv(winograd 4x4): dropout seed pointer missing");
+  Wino4Params p;
+  p.src = s; p.wpk = a->w_main;
+  p.N = a->n; p.H = a->h_out; p.W = a->w_out; p.Cout = a->c_out;
+  const int twt = pow2_floor((a->w_out / 4) < 8 ? (a->w_out / 4) : 8);
+  int tht = kTiles / twt; if (tht > a->h_out / 4) tht = a->h_out / 4;
+  tht = pow2_floor(tht);
+  const int imgs = kTiles / (twt * tht);
+  p.lTWt = ssde_ilog2(twt); p.lTHt = ssde_ilog2(tht);
+  p.tiles_x = ssde_cdiv(a->w_out, 4 * twt);
+  p.tiles_per_img = p.tiles_x * ssde_cdiv(a->h_out, 4 * tht);
+  p.m_tiles = ssde_cdiv(a->n, imgs) * p.tiles_per_img;
+  p.n_tiles = ssde_cdiv(a->c_out, 64);
+  p.bias = a->bias; p.chan_add = a->chan_add; p.chan_add_ld = a->chan_add_ld;
+  p.resid = a->resid; p.resid_post = a->resid_post; p.scale = a->out_scale; p.dst = a->dst;
+  p.gn_part = a->gn_part;
+  // GroupNorm partials: a tile is part of one image (tiles_per_img slices of 8 wave entries) or holds `imgs` whole
+  // images; 512 / imgs rows per image >= the 64 rows of one epilogue trip
+  const bool gn_ok = a->c_out % 4 == 0 && (imgs == 1 || (p.tiles_per_img == 1 && imgs <= 8));
+  SSDE_REQUIRE(!a->gn_part || gn_ok, "conv(winograd 4x4): GroupNorm partials not available for this tiling");
+  if (lds_out && stream == reinterpret_cast<void*>(1)) { *lds_out = gn_ok ? p.tiles_per_img * (kThreads / 64) : 0; return SSDE_OK; }
+  const int halo_px = imgs * (4 * tht + 2) * (4 * twt + 2);
+  SSDE_REQUIRE(halo_px <= kMaxRaw * kThreads, "conv(winograd 4x4): halo of %d pixels exceeds the staging plan", halo_px);
+  int lds = (2 * kVFloats + 2 * kUFloats + 2 * 4 * halo_px) * 4;
+  if (gn) lds += (2 * imgs * s.gn_groups + 2 * (s.c0 + s.c1)) * 4;
+  const int lds_epi = kPos * kTiles * kLdm * 4;
+  if (lds < lds_epi) lds = lds_epi;
+  SSDE_REQUIRE(lds <= 160 * 1024, "conv(winograd 4x4): %d bytes of LDS", lds);
+  if (lds_out) { *lds_out = lds; return SSDE_OK; }
+  static std::atomic<bool> attr_set{false};   // once, before any stream capture
+  if (!attr_set) {
+    SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const dim3 grid(ssde_cdiv(p.m_tiles, 8) * 8 * p.n_tiles);
+  if (gn) hipLaunchKernelGGL(conv_wino4_kernel<true>, grid, dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL(conv_wino4_kernel<false>, grid, dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}

@@ -294,6 +294,22 @@ def pack_wino_weight(w):
     return out.contiguous()
 
 
+_WINO4_G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                         [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=torch.float64)
+
+
+def pack_wino4_weight(w):
+    """[Cout, Cin, 3, 3] -> Winograd F(4x4,3x3) weights U = G g G^T (formed in fp64, stored in fp32) arranged as the LDS
+    image conv_wino4.hip reads: [ceil(Cin/4)][ceil(Cout/64)][36 positions][64 couts][4 channels]."""
+    cout, cin = w.shape[0], w.shape[1]
+    G = _WINO4_G.to(w.device)
+    u = torch.einsum("ak,ockl,bl->ocab", G, w.detach().to(torch.float64), G).to(torch.float32)     # [Cout, Cin, 6, 6]
+    c4, nt = (cin + 3) // 4, (cout + 63) // 64
+    full = torch.zeros(nt * 64, c4 * 4, 36, dtype=torch.float32, device=w.device)
+    full[:cout, :cin] = u.reshape(cout, cin, 36)
+    return full.reshape(nt, 64, c4, 4, 36).permute(2, 0, 4, 1, 3).contiguous()     # [c4, nt, pos, co, e]
+
+
 def pack_matrix(w):
     """[Cout, Cin] (nn.Linear / 1x1 conv orientation) -> [ceil(Cin/8)][roundup(Cout,64)][8]."""
     return pack_conv_weight(w.reshape(w.shape[0], w.shape[1], 1, 1))

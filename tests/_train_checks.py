@@ -794,3 +794,65 @@ def check_conv_split_reduction(dev, monkeypatch, n, repeats=3):
             L.check(lib.ssde_gn_finalize(C.byref(f), ops._stream()))
             mr, rr = ops.groupnorm_stats(dst, Go, 1e-6)
             assert (m2 - mr).abs().max().item() < 1e-5 and ((r2 - rr).abs() / rr).max().item() < 1e-4
+
+
+def check_conv_winograd4(dev, big=False):
+    """conv_wino4.hip (F(4x4,3x3)): plain convolutions over the tilings it knows (part of one image, several whole
+    images, ragged batch tails, cout tiles that are not full), then the fully fused form (concat source, GroupNorm + SiLU
+    prologue, bias, per-image addend, residual, scale, GroupNorm partials of the result) against torch.  Tolerance 2e-5:
+    F(4x4,3x3) rounds ~5x coarser than the direct kernel (tools/experiments/wino43_error_budget.py)."""
+    import ctypes as C
+    import numpy as np
+    import torch.nn.functional as F
+    from score_sde_pytorch_amd import hipops as ops, _lib as L
+    from score_sde_pytorch_amd.engine import pack_wino4_weight
+    lib = L.load()
+    g = torch.Generator().manual_seed(2)
+    plain = [(1, 8, 64, 16), (2, 32, 64, 8), (3, 16, 96, 8), (1, 12, 128, 32)]
+    if big:
+        plain += [(16, 128, 128, 32), (9, 256, 256, 16), (20, 256, 256, 8), (2, 128, 128, 64)]
+    for (n, cin, cout, h) in plain:
+        x = torch.randn(n, cin, h, h, generator=g)
+        w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
+        b = torch.randn(cout, generator=g)
+        y = ops.conv2d(x.permute(0, 2, 3, 1).contiguous().to(dev), w.to(dev), b.to(dev), tile=L.TILE_WINOGRAD4)
+        ref = F.conv2d(x, w, b, padding=1)
+        assert _util.rel_err(y.cpu().permute(0, 3, 1, 2), ref) < 2e-5, (n, cin, cout, h)
+    fused = [(5, 32, 16, 64, 16), (9, 64, 0, 96, 8), (3, 24, 32, 128, 32)]
+    if big:
+        fused += [(12, 128, 128, 128, 32), (10, 256, 256, 256, 16)]
+    for (n, c0, c1, cout, h) in fused:
+        cin = c0 + c1
+        x0 = torch.randn(n, h, h, c0, generator=g) * 1.5 + 0.3
+        x1 = torch.randn(n, h, h, c1, generator=g) if c1 else None
+        xcat = torch.cat([x0, x1], -1) if c1 else x0
+        w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
+        b, gamma, beta = torch.randn(cout, generator=g), torch.randn(cin, generator=g), torch.randn(cin, generator=g)
+        resid, ca = torch.randn(n, h, h, cout, generator=g), torch.randn(n, cout, generator=g)
+        G = 32 if cin % 32 == 0 and (cin // 32) % 4 == 0 else cin // 4
+        x0d, x1d = x0.to(dev), (x1.to(dev) if c1 else None)
+        mean, rstd = ops.groupnorm_stats(x0d, G, 1e-6, x2=x1d)
+        a = L.ConvArgs()
+        gn = (mean, rstd, gamma.to(dev), beta.to(dev), G)          # _fill_src borrows the pointers: keep the tensors
+        ops._fill_src(a.main, x0d, x1d, L.PRO_GN_SILU, gn)
+        wp, bd, cad, rd = pack_wino4_weight(w.to(dev)), b.to(dev), ca.to(dev), resid.to(dev)
+        dst = torch.full((n, h, h, cout), float("nan"), device=dev)
+        a.w_main, a.ksize, a.stride, a.pad, a.h_in, a.w_in = wp.data_ptr(), 3, 1, 1, h, h
+        a.n, a.h_out, a.w_out, a.c_out, a.out_scale, a.dst, a.tile = n, h, h, cout, 0.7, dst.data_ptr(), L.TILE_WINOGRAD4
+        a.bias, a.chan_add, a.chan_add_ld, a.resid = bd.data_ptr(), cad.data_ptr(), cout, rd.data_ptr()
+        sl = lib.ssde_conv_gn_slices(C.byref(a))
+        assert sl > 0
+        part = torch.full((n, sl, cout // 4, 3), float("nan"), device=dev)
+        a.gn_part = part.data_ptr()
+        L.check(lib.ssde_conv2d(C.byref(a), ops._stream()))
+        xn = F.silu(F.group_norm(xcat.permute(0, 3, 1, 2), G, gamma, beta, 1e-6))
+        ref = ((F.conv2d(xn, w, b, padding=1) + ca[:, :, None, None]).permute(0, 2, 3, 1) + resid) * 0.7
+        assert _util.rel_err(dst.cpu(), ref) < 2e-5, (n, c0, c1, cout, h)
+        Go = cout // 4
+        f = L.GnFinalizeArgs()
+        m2, r2 = torch.zeros(n, Go, device=dev), torch.zeros(n, Go, device=dev)
+        f.part0, f.c0, f.slices0, f.n, f.groups, f.eps = part.data_ptr(), cout, sl, n, Go, 1e-6
+        f.mean, f.rstd = m2.data_ptr(), r2.data_ptr()
+        L.check(lib.ssde_gn_finalize(C.byref(f), ops._stream()))
+        mr, rr = ops.groupnorm_stats(dst, Go, 1e-6)
+        assert (m2 - mr).abs().max().item() < 1e-5 and ((r2 - rr).abs() / rr).max().item() < 1e-4

@@ -32,6 +32,10 @@ def test_groupnorm_statistics_from_producer_epilogues(monkeypatch):
     T.check_fused_gn_statistics("cpu", monkeypatch)
 
 
+def test_conv3x3_winograd_f4x4():
+    T.check_conv_winograd4("cpu", big=False)
+
+
 def test_conv_reduction_split_over_two_workgroups(monkeypatch):
     T.check_conv_split_reduction("cpu", monkeypatch, n=5)
 

@@ -26,6 +26,10 @@ def test_groupnorm_statistics_from_producer_epilogues(monkeypatch):
     T.check_fused_gn_statistics("cuda", monkeypatch)
 
 
+def test_conv3x3_winograd_f4x4():
+    T.check_conv_winograd4("cuda", big=True)
+
+
 def test_conv_reduction_split_over_two_workgroups(monkeypatch):
     T.check_conv_split_reduction("cuda", monkeypatch, n=256)
 
