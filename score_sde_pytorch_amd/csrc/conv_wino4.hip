@@ -26,6 +26,29 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// -DSSDE_W4_TRACE (tools/wino4_trace.py, a variant library only): s_memtime stamps of waves 0 and 7 of the first workgroup
+#ifdef SSDE_W4_TRACE
+__device__ unsigned long long* g_w4_trace;
+extern "C" int ssde_debug_w4_trace(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_w4_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -5;
+}
+#define SSDE_TR(slot)                                                                                     \
+  do {                                                                                                    \
+    if (tr_on) g_w4_trace[tr_base + (slot)] = __builtin_amdgcn_s_memtime();                               \
+  } while (0)
+#else
+#define SSDE_TR(slot) do { } while (0)
+#endif
+
+#ifndef SSDE_W4_WLOAD
+#define SSDE_W4_WLOAD 1
+#endif
+// 0: a stage is issue / pass 1 / MFMA / barrier / pass 2 / MFMA / staging in program order; 1: the asynchronous issues and
+// the LDS round trips of the two transform passes ride between the MFMAs
+#ifndef SSDE_W4_LOOP
+#define SSDE_W4_LOOP 1
+#endif
+
 namespace {
 
 constexpr int kThreads = 512;
@@ -33,8 +56,8 @@ constexpr int kPos = 36, kTiles = 32, kKc = 4;
 constexpr int kVFloats = kPos * kTiles * kKc;       // 4608: one V stage
 constexpr int kUFloats = kPos * 64 * kKc;           // 9216: one U stage
 constexpr int kMaxRaw = 2;                          // float4 halo items per thread per stage (halo <= 1024 pixels)
-constexpr int kLdm = 34;                            // row pitch of the product exchange [pos][tile][32 couts]
-constexpr int kLdt = 36;                            // row pitch of the parked output tile [512 pixels][32 couts]
+constexpr int kLdm = 66;                            // row pitch of the product exchange [pos][16 tiles][64 couts]
+constexpr int kLdt = 68;                            // row pitch of the parked output tile [256 pixels][64 couts]
 
 struct Wino4Params {
   ssde_src src;
@@ -78,6 +101,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
   const int xcd = bid & 7, l = bid >> 3;
   const int nt = l % p.n_tiles;
   const int mt = (l / p.n_tiles) * 8 + xcd;
+#ifdef SSDE_W4_TRACE
+  const bool tr_on = lane == 0 && (wave == 0 || wave == 7) && bid == 0 && g_w4_trace != nullptr;
+  const int tr_base = (wave == 0 ? 0 : 1) * 128;
+#endif
+  SSDE_TR(0);
   if (mt >= p.m_tiles) return;
 
   const int TWt = 1 << p.lTWt, THt = 1 << p.lTHt;
@@ -140,15 +168,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
   float4 rv[kMaxRaw];
   int c_cur = 0;
   // branch-free global loads of stage st (items outside the image read a clamped, valid address and are zeroed below)
+  const float* ld_bp = nullptr; int ld_C = 0;
+  auto load_piece = [&](int st, int k) {
+    if (k == 0) {
+      const int c_base = st * 4;
+      c_cur = c_base;
+      const bool second = c_base >= s.c0;
+      ld_bp = (second ? s.p1 : s.p0) + (second ? c_base - s.c0 : c_base);
+      ld_C = second ? s.c1 : s.c0;
+    }
+    rv[k] = *reinterpret_cast<const float4*>(ld_bp + (size_t)(goff[k] >= 0 ? goff[k] : 0) * ld_C);
+  };
   auto load_raw = [&](int st) {
-    const int c_base = st * 4;
-    c_cur = c_base;
-    const bool second = c_base >= s.c0;
-    const float* bp = (second ? s.p1 : s.p0) + (second ? c_base - s.c0 : c_base);
-    const int C = second ? s.c1 : s.c0;
 #pragma unroll
-    for (int it = 0; it < kMaxRaw; ++it)
-      rv[it] = *reinterpret_cast<const float4*>(bp + (size_t)(goff[it] >= 0 ? goff[it] : 0) * C);
+    for (int k = 0; k < kMaxRaw; ++k) load_piece(st, k);
   };
   // prologue + raw LDS store (channel-pair major)
   auto store_raw = [&](float* rw) {
@@ -195,14 +228,47 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       for (int b = 0; b < 6; ++b) *reinterpret_cast<float2*>(vp + b * (kTiles * 4)) = o[b];
     }
   };
-  // weights of stage st: the host packed them as the LDS image; 36 pieces of 1 KB, wave w moves pieces w, w + 8, ...
+  // weights of stage st: the host packed them as the LDS image (36 KB per stage).  SSDE_W4_WLOAD:
+  //   0  LDS-DMA, 36 pieces of 1 KB, wave w moves pieces w, w + 8, ..; M0 and a 64-bit address per piece
+  //   1  LDS-DMA, a contiguous run of 5 (waves 0-3) or 4 pieces per wave: one base, immediate offsets -2048 .. +2048
+  //   2  plain global loads into registers at the top of the stage, ds_write_b128 at its end
+#if SSDE_W4_WLOAD == 2
+  float4 uw[5];
+#endif
   auto dma_weights = [&](int st, float* Un) {
+#if SSDE_W4_WLOAD == 0
     const float* gsrc = p.wpk + ((size_t)st * p.n_tiles + nt) * kUFloats + lane * 4;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
       const int piece = wave + 8 * k;
       if (piece < kPos) SSDE_GLDS16_OFF(gsrc + piece * 256, Un + piece * 256, 0);
     }
+#elif SSDE_W4_WLOAD == 1
+    const int p0 = wave < 4 ? 5 * wave : 20 + 4 * (wave - 4);
+    const float* gsrc = p.wpk + ((size_t)st * p.n_tiles + nt) * kUFloats + (p0 + 2) * 256 + lane * 4;
+    float* ldst = Un + (p0 + 2) * 256;
+    SSDE_GLDS16_OFF(gsrc, ldst, -2048);
+    SSDE_GLDS16_OFF(gsrc, ldst, -1024);
+    SSDE_GLDS16_OFF(gsrc, ldst, 0);
+    SSDE_GLDS16_OFF(gsrc, ldst, 1024);
+    if (wave < 4) SSDE_GLDS16_OFF(gsrc, ldst, 2048);
+#else
+    const float4* gsrc = reinterpret_cast<const float4*>(p.wpk + ((size_t)st * p.n_tiles + nt) * kUFloats) + tid;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) uw[k] = gsrc[k * kThreads];
+    uw[4] = gsrc[tid < 256 ? 4 * kThreads : 0];
+    (void)Un;
+#endif
+  };
+  auto park_weights = [&](float* Un) {
+#if SSDE_W4_WLOAD == 2
+    float4* d = reinterpret_cast<float4*>(Un) + tid;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k * kThreads] = uw[k];
+    if (tid < 256) d[4 * kThreads] = uw[4];
+#else
+    (void)Un;
+#endif
   };
 
   const int wq = wave >> 1, wh = wave & 1;      // this wave's positions wq + 4 j and its 32-cout half
@@ -225,6 +291,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
   };
 
   // ---- pipeline fill ----
+  SSDE_TR(1);
   load_raw(0);
   dma_weights(0, Ub);
   __syncthreads();                             // publishes the GroupNorm tables
@@ -235,8 +302,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
   SSDE_LDS_BARRIER();
   pass2(Vb);
   if (nst > 1) store_raw(rawb + raw_stride);
+  park_weights(Ub);
   SSDE_WAIT_VMCNT(0);
   SSDE_LDS_BARRIER();
+  SSDE_TR(2);
 
   for (int st = 0; st < nst; ++st) {
     const int cur = st & 1, nxt = cur ^ 1;
@@ -244,47 +313,145 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
     const float* Uc = Ub + cur * kUFloats;
     float* Vn = Vb + nxt * kVFloats;
     const bool has1 = st + 1 < nst, has2 = st + 2 < nst;
+#if SSDE_W4_LOOP == 0
     if (has1) dma_weights(st + 1, Ub + nxt * kUFloats);
+    if (st < 8) SSDE_TR(8 + st * 10 + 9);
     if (has2) load_raw(st + 2);
+    if (st < 8) SSDE_TR(8 + st * 10 + 0);
     if (has1) pass1(rawb + nxt * raw_stride, Vn);
+    if (st < 8) SSDE_TR(8 + st * 10 + 1);
     mfma_range(Vc, Uc, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+    if (st < 8) SSDE_TR(8 + st * 10 + 2);
     SSDE_LDS_BARRIER();
+    if (st < 8) SSDE_TR(8 + st * 10 + 3);
     if (has1) pass2(Vn);
+    if (st < 8) SSDE_TR(8 + st * 10 + 4);
     mfma_range(Vc, Uc, std::integral_constant<int, 5>{}, std::integral_constant<int, 9>{});
-    if (has2) store_raw(rawb + cur * raw_stride);
-    SSDE_WAIT_VMCNT(0);
-    SSDE_LDS_BARRIER();
-  }
-
-  // ---- epilogue, one 32-cout half at a time ----
-  SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, p.Cout, p.gn_part};
-  const int gn_entry = p.gn_part ? img0 * p.tiles_per_img + trem : -1;        // IMGS > 1: tiles_per_img == 1, trem == 0
-  const int rpi_log2 = IMGS > 1 ? 9 - (5 - p.lTWt - p.lTHt) : 30;             // rows per image: 512 / IMGS
-  const int e_tile = tid >> 4, e_cp = tid & 15;
-#pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
-    if (wh == half) {
+    if (st < 8) SSDE_TR(8 + st * 10 + 5);
+#else
+    {
+      // One wave's stage: 6 LDS reads of transform pass 1 | positions 0,1 (+ halo loads, weight pieces) | pass-1 arithmetic
+      // and 6 LDS writes | positions 2-4 (+ weight pieces) | barrier | pass-2 reads | positions 5,6 | pass-2 arithmetic and
+      // writes | positions 7,8.  A wave issues in order, and an MFMA only occupies the matrix pipe: the LDS round trips and
+      // the VMEM issue stalls now pass while the wave's own MFMAs execute.
+      const bool tl_ok = has1 && t_line < 6;
+      float2 td[6], to[6];
+      float2 af[2], bf[2];
+      float* Un = Ub + nxt * kUFloats;
+      const int dp0 = wave < 4 ? 5 * wave : 20 + 4 * (wave - 4);
+      const float* dsrc = p.wpk + ((size_t)min(st + 1, nst - 1) * p.n_tiles + nt) * kUFloats + (dp0 + 2) * 256 + lane * 4;
+      float* ddst = Un + (dp0 + 2) * 256;
+      af[0] = *reinterpret_cast<const float2*>(Vc + wq * (kTiles * 4) + a_off);
+      bf[0] = *reinterpret_cast<const float2*>(Uc + wq * (64 * 4) + b_off);
+      if (tl_ok) {
+        const float* rp = rawb + nxt * raw_stride + (t_pair * halo_px + t_base + t_line) * 2;
 #pragma unroll
-      for (int j = 0; j < 9; ++j)
+        for (int a = 0; a < 6; ++a) td[a] = *reinterpret_cast<const float2*>(rp + a * HWd * 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#define SSDE_W4_POS(J)                                                                                          \
+      do {                                                                                                         \
+        if ((J) + 1 < 9) {                                                                                         \
+          af[((J) + 1) & 1] = *reinterpret_cast<const float2*>(Vc + (wq + 4 * ((J) + 1)) * (kTiles * 4) + a_off);  \
+          bf[((J) + 1) & 1] = *reinterpret_cast<const float2*>(Uc + (wq + 4 * ((J) + 1)) * (64 * 4) + b_off);     \
+        }                                                                                                          \
+        acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(J) & 1].x, bf[(J) & 1].x, acc[J], 0, 0, 0);             \
+        acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(J) & 1].y, bf[(J) & 1].y, acc[J], 0, 0, 0);             \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+      } while (0)
+      SSDE_W4_POS(0);
+      if (has2) load_piece(st + 2, 0);
+      if (has1) SSDE_GLDS16_OFF(dsrc, ddst, -2048);
+      __builtin_amdgcn_sched_barrier(0);
+      SSDE_W4_POS(1);
+      if (has2) load_piece(st + 2, 1);
+      if (has1) SSDE_GLDS16_OFF(dsrc, ddst, -1024);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tl_ok) {
+        bt6(td, to);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          smem[((wq + 4 * j) * kTiles + m) * kLdm + li] = acc[j][r];
-        }
+        for (int a = 0; a < 6; ++a) *reinterpret_cast<float2*>(Vn + (a * 6 + t_line) * (kTiles * 4) + t_vcol) = to[a];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      SSDE_W4_POS(2);
+      if (has1) SSDE_GLDS16_OFF(dsrc, ddst, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      SSDE_W4_POS(3);
+      if (has1) SSDE_GLDS16_OFF(dsrc, ddst, 1024);
+      __builtin_amdgcn_sched_barrier(0);
+      SSDE_W4_POS(4);
+      if (has1 && wave < 4) SSDE_GLDS16_OFF(dsrc, ddst, 2048);
+      if (st < 8) SSDE_TR(8 + st * 10 + 2);
+      SSDE_LDS_BARRIER();
+      if (st < 8) SSDE_TR(8 + st * 10 + 3);
+      float* vp = Vn + (t_line * 6) * (kTiles * 4) + t_vcol;
+      if (tl_ok) {
+#pragma unroll
+        for (int b = 0; b < 6; ++b) td[b] = *reinterpret_cast<const float2*>(vp + b * (kTiles * 4));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      SSDE_W4_POS(5);
+      SSDE_W4_POS(6);
+      if (tl_ok) {
+        bt6(td, to);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) *reinterpret_cast<float2*>(vp + b * (kTiles * 4)) = to[b];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      SSDE_W4_POS(7);
+      SSDE_W4_POS(8);
+#undef SSDE_W4_POS
+      if (st < 8) SSDE_TR(8 + st * 10 + 5);
     }
+#endif
+    if (has2) store_raw(rawb + cur * raw_stride);
+    if (has1) park_weights(Ub + nxt * kUFloats);
+    if (st < 8) SSDE_TR(8 + st * 10 + 6);
+    SSDE_WAIT_VMCNT(0);
+    if (st < 8) SSDE_TR(8 + st * 10 + 7);
+    SSDE_LDS_BARRIER();
+    if (st < 8) SSDE_TR(8 + st * 10 + 8);
+  }
+  SSDE_TR(3);
+
+  // ---- epilogue, 16 tiles (= accumulator rows r < 8, then r >= 8 of every wave) at a time ----
+  // The products of a round go to LDS as M[pos][tile 16][64 couts] (pitch kLdm), every thread applies A^T M A to one
+  // (tile, cout pair), parks the 4x4 outputs as [256 pixels][64 couts] and the shared epilogue stores them.  All waves
+  // take part in both rounds and each round retires half of a wave's accumulators, so nothing spills.  (Rounds over
+  // the two 32-cout halves instead kept 144 accumulators live through the transform of the other half: 81 scratch
+  // stores per lane and 105 k cycles of epilogue per workgroup, tools/wino4_trace.py.)
+  SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, p.Cout, p.gn_part};
+  // GroupNorm partials: one entry per (image, workgroup tile, round) when the tile is part of one image; per image when a
+  // round holds IMGS / 2 whole images (IMGS >= 2: 16 / (tiles per image) images per round)
+  const int gn_base = !p.gn_part ? -1 : (IMGS == 1 ? (img0 * p.tiles_per_img + trem) * 2 : img0);
+  const int rpi_log2 = IMGS > 2 ? 8 - (4 - p.lTWt - p.lTHt) : 30;             // rows per image in a round: 256 / (IMGS / 2)
+  const int e_tl = tid >> 5, e_cp = tid & 31;
+  float* park = smem;                                                         // [256][kLdt], aliases the products
+#pragma unroll
+  for (int rnd = 0; rnd < 2; ++rnd) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+      for (int r8 = 0; r8 < 8; ++r8) {
+        const int r = rnd * 8 + r8;
+        const int tl = (r & 3) + 4 * lh + 8 * ((r >> 2) & 1);
+        smem[((wq + 4 * j) * 16 + tl) * kLdm + wh * 32 + li] = acc[j][r];
+      }
+    if (rnd == 0) SSDE_TR(100);
     __syncthreads();
+    if (rnd == 0) SSDE_TR(101);
     // Y = A^T M A for (tile, couts 2 cp, 2 cp + 1); A^T rows [1,1,1,1,1,0] [0,1,-1,2,-2,0] [0,1,1,4,4,0] [0,1,-1,8,-8,1]
     float2 y[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) y[a][b] = make_float2(0.f, 0.f);
-    const float* mp = smem + e_tile * kLdm + 2 * e_cp;
+    const float* mp = smem + e_tl * kLdm + 2 * e_cp;
 #pragma unroll
     for (int px = 0; px < 6; ++px) {
       float2 m[6];
 #pragma unroll
-      for (int py = 0; py < 6; ++py) m[py] = *reinterpret_cast<const float2*>(mp + (py * 6 + px) * (kTiles * kLdm));
+      for (int py = 0; py < 6; ++py) m[py] = *reinterpret_cast<const float2*>(mp + (py * 6 + px) * (16 * kLdm));
       float2 t[4];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
@@ -304,15 +471,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
         for (int dx = 0; dx < 4; ++dx)
           if (kA[px][dx] != 0.f) { y[dy][dx].x += kA[px][dx] * t[dy].x; y[dy][dx].y += kA[px][dx] * t[dy].y; }
     }
+    if (rnd == 0) SSDE_TR(102);
     __syncthreads();                           // every thread has read its products: the parked tile may overwrite them
+    if (rnd == 0) SSDE_TR(103);
 #pragma unroll
     for (int dy = 0; dy < 4; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 4; ++dx)
-        *reinterpret_cast<float2*>(smem + (e_tile * 16 + dy * 4 + dx) * kLdt + 2 * e_cp) = y[dy][dx];
+        *reinterpret_cast<float2*>(park + (e_tl * 16 + dy * 4 + dx) * kLdt + 2 * e_cp) = y[dy][dx];
+    if (rnd == 0) SSDE_TR(104);
     __syncthreads();
-    ssde_store_tile<512, 32, kThreads, 4, 0>(smem, kLdt, n0 + half * 32, e, [&](int row, size_t& pix, int& img) {
-      const int tile = row >> 4, dy = (row >> 2) & 3, dx = row & 3;
+    if (rnd == 0) SSDE_TR(105);
+    const int gn_entry = gn_base < 0 ? -1 : (IMGS == 1 ? gn_base + rnd : gn_base + rnd * (IMGS >> 1));
+    ssde_store_tile<256, 64, kThreads, 4, 0>(park, kLdt, n0, e, [&](int row, size_t& pix, int& img) {
+      const int tile = rnd * 16 + (row >> 4), dy = (row >> 2) & 3, dx = row & 3;
       const int il = tile >> (p.lTWt + p.lTHt);
       const int tr = (tile >> p.lTWt) & (THt - 1), tc = tile & (TWt - 1);
       img = img0 + il;
@@ -320,9 +492,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       if (img >= p.N || oy >= p.H || ox >= p.W) return false;
       pix = ((size_t)img * p.H + oy) * p.W + ox;
       return true;
-    }, gn_entry, rpi_log2, p.N * p.tiles_per_img);
-    __syncthreads();
+    }, gn_entry, rpi_log2, IMGS == 1 ? p.N * p.tiles_per_img * 2 : p.N);
+    if (rnd == 0) SSDE_TR(106);
+    if (rnd == 0) { __syncthreads(); SSDE_TR(4); }
   }
+  SSDE_TR(5);
 }
 
 int pow2_floor(int v) { int q = 1; while (q * 2 <= v) q *= 2; return q; }
@@ -360,16 +534,20 @@ int ssde_conv_wino4_launch(const ssde_conv_args* a, void* stream, int* lds_out) 
   p.bias = a->bias; p.chan_add = a->chan_add; p.chan_add_ld = a->chan_add_ld;
   p.resid = a->resid; p.resid_post = a->resid_post; p.scale = a->out_scale; p.dst = a->dst;
   p.gn_part = a->gn_part;
-  // GroupNorm partials: a tile is part of one image (tiles_per_img slices of 8 wave entries) or holds `imgs` whole
-  // images; 512 / imgs rows per image >= the 64 rows of one epilogue trip
+  // GroupNorm partials: a workgroup tile is part of one image (two epilogue rounds: 2 x tiles_per_img slices of 8 wave
+  // entries) or holds `imgs` >= 2 whole images (imgs / 2 per round; 512 / imgs rows per image >= the 32 rows of one
+  // epilogue trip)
   const bool gn_ok = a->c_out % 4 == 0 && (imgs == 1 || (p.tiles_per_img == 1 && imgs <= 8));
   SSDE_REQUIRE(!a->gn_part || gn_ok, "conv(winograd 4x4): GroupNorm partials not available for this tiling");
-  if (lds_out && stream == reinterpret_cast<void*>(1)) { *lds_out = gn_ok ? p.tiles_per_img * (kThreads / 64) : 0; return SSDE_OK; }
+  if (lds_out && stream == reinterpret_cast<void*>(1)) {
+    *lds_out = gn_ok ? (imgs == 1 ? 2 * p.tiles_per_img : 1) * (kThreads / 64) : 0;
+    return SSDE_OK;
+  }
   const int halo_px = imgs * (4 * tht + 2) * (4 * twt + 2);
   SSDE_REQUIRE(halo_px <= kMaxRaw * kThreads, "conv(winograd 4x4): halo of %d pixels exceeds the staging plan", halo_px);
   int lds = (2 * kVFloats + 2 * kUFloats + 2 * 4 * halo_px) * 4;
   if (gn) lds += (2 * imgs * s.gn_groups + 2 * (s.c0 + s.c1)) * 4;
-  const int lds_epi = kPos * kTiles * kLdm * 4;
+  const int lds_epi = kPos * 16 * kLdm * 4;
   if (lds < lds_epi) lds = lds_epi;
   SSDE_REQUIRE(lds <= 160 * 1024, "conv(winograd 4x4): %d bytes of LDS", lds);
   if (lds_out) { *lds_out = lds; return SSDE_OK; }
