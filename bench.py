@@ -17,7 +17,8 @@ data: synthetic prior noise.  fp32 end to end (dtype "f32"), as the reference.
 The JSON line also carries
   roofline     -- the dominant kernel class (the 3x3 convolution launches of one U-Net evaluation, HIP events on the
                   launch stream).  `frac` = EXECUTED matrix FLOP/s over the 157.3 TFLOP/s fp32 MFMA peak: a launch on
-                  the Winograd F(2x2,3x3) kernel executes 1/2.25 of its direct-form FLOPs, so it is counted at that
+                  the Winograd F(2x2,3x3) kernel executes 1/2.25 of its direct-form FLOPs, one on the F(4x4,3x3) kernel
+                  1/4, and they are counted at that
                   (this is the matrix-pipe utilisation SQ_VALU_MFMA_BUSY_CYCLES shows in profiles/);
                   `frac_algorithmic` = direct-form FLOP/s over the same peak (can exceed 1).  `by_class` adds the
                   fraction of every other kernel class against ITS roofline: 1x1 GEMMs and attention against the
@@ -45,6 +46,7 @@ import torch  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_TBS = 8.0              # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured float4 copy)
 WINOGRAD_FLOP_RATIO = 2.25      # F(2x2,3x3): 16 instead of 36 multiply-adds per 2x2 output tile and (ci, co)
+WINOGRAD4_FLOP_RATIO = 4.0      # F(4x4,3x3): 36 instead of 144 per 4x4 output tile and (ci, co)
 
 
 def parse():
@@ -279,8 +281,10 @@ def roofline_of(prog, E, L, reps=3):
     ms = acc / reps
     cls = np.array(prog.classes)
     fl = np.array(prog.flops)
-    wino = np.array([int(prog.ops[i].kind) == L.OP_CONV and prog.ops[i].u.conv.tile == L.TILE_WINOGRAD for i in range(prog.n)])
-    executed = np.where(wino, fl / WINOGRAD_FLOP_RATIO, fl)
+    tiles = np.array([int(prog.ops[i].u.conv.tile) if int(prog.ops[i].kind) == L.OP_CONV else -1 for i in range(prog.n)])
+    wino4 = tiles == L.TILE_WINOGRAD4
+    wino = (tiles == L.TILE_WINOGRAD) | wino4
+    executed = np.where(wino4, fl / WINOGRAD4_FLOP_RATIO, np.where(wino, fl / WINOGRAD_FLOP_RATIO, fl))
     nbytes = np.array([op_bytes(prog.ops[i]) for i in range(prog.n)])
     conv3 = cls == E.FC_CONV3
     t3 = float(ms[conv3].sum()) * 1e-3
@@ -306,9 +310,12 @@ def roofline_of(prog, E, L, reps=3):
         by_class["pc_update"] = {"launches": int(upd.sum()), "ms": t * 1e3, "bound": "hbm", "algorithmic_gb": float(nbytes[upd].sum()) / 1e9,
                                  "achieved_tbs": float(nbytes[upd].sum()) / t / 1e12,
                                  "frac": float(nbytes[upd].sum()) / t / 1e12 / PEAK_HBM_TBS}
-    wl = [i for i in range(prog.n) if wino[i]]
+    # the dominant kernel: the Winograd kernel that takes the larger share of the time
+    dom4 = float(ms[wino4].sum()) >= float(ms[wino & ~wino4].sum())
+    wl = [i for i in range(prog.n) if (wino4[i] if dom4 else (wino[i] and not wino4[i]))]
     alg_bytes_wino = float(np.mean([conv_bytes(prog.ops[i].u.conv) for i in wl])) if wl else None
-    return dict(ms=ms, cls=cls, fl=fl, wino=wino, executed=executed, conv3=conv3, by_class=by_class,
+    return dict(ms=ms, cls=cls, fl=fl, wino=wino, wino4=wino4, dominant="conv_wino4_kernel" if dom4 else "conv_wino_kernel",
+                executed=executed, conv3=conv3, by_class=by_class,
                 achieved_exec=achieved_exec, achieved_alg=achieved_alg, alg_bytes_wino=alg_bytes_wino)
 
 
@@ -536,8 +543,8 @@ def main():
             summ = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_profile_summary.json")))[-1]
             with open(summ) as f:
                 prof = json.load(f)
-            traffic = prof["hbm_traffic"]["conv_wino_kernel"]["hbm_bytes_per_launch"]
-            m = prof.get("mfma", {}).get("conv_wino_kernel", {})
+            traffic = prof["hbm_traffic"][roof["dominant"]]["hbm_bytes_per_launch"]
+            m = prof.get("mfma", {}).get(roof["dominant"], {})
             if m.get("SQ_VALU_MFMA_BUSY_CYCLES") and m.get("GRBM_GUI_ACTIVE"):
                 # 1024 SIMDs; rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs
                 mfma_busy = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * m["GRBM_GUI_ACTIVE"] / 8.0)
@@ -546,16 +553,17 @@ def main():
             pass
         n3 = int(roof["conv3"].sum())
         n3w = int((roof["conv3"] & roof["wino"]).sum())
+        n3w4 = int((roof["conv3"] & roof["wino4"]).sum())
         out["roofline"] = {
             "bound": "mfma", "achieved": roof["achieved_exec"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": roof["achieved_exec"] / PEAK_FP32_MFMA_TFLOPS,
             "achieved_algorithmic": roof["achieved_alg"], "frac_algorithmic": roof["achieved_alg"] / PEAK_FP32_MFMA_TFLOPS,
             "traffic": traffic, "traffic_algorithmic": roof["alg_bytes_wino"], "mfma_busy_pmc": mfma_busy,
-            "kernel": "the %d 3x3 convolution launches of one U-Net evaluation: %d on conv_wino_kernel (Winograd F(2x2,3x3), fp32 MFMA), "
-                      "%d on conv_mfma_kernel (direct)" % (n3, n3w, n3 - n3w),
-            "note": "achieved = EXECUTED matrix FLOPs (Winograd launches at 1/2.25 of their direct-form FLOPs) / HIP-event time of "
-                    "those launches; achieved_algorithmic = direct-form FLOPs / the same time; traffic(_algorithmic) = bytes per "
-                    "conv_wino_kernel launch (PMC / op list)",
+            "kernel": "the %d 3x3 convolution launches of one U-Net evaluation: %d on conv_wino4_kernel (Winograd F(4x4,3x3), fp32 MFMA), "
+                      "%d on conv_wino_kernel (F(2x2,3x3)), %d on conv_mfma_kernel (direct)" % (n3, n3w4, n3w - n3w4, n3 - n3w),
+            "note": "achieved = EXECUTED matrix FLOPs (F(4x4,3x3) launches at 1/4, F(2x2,3x3) launches at 1/2.25 of their direct-form "
+                    "FLOPs) / HIP-event time of those launches; achieved_algorithmic = direct-form FLOPs / the same time; "
+                    "traffic(_algorithmic) = bytes per %s launch (PMC / op list)" % roof["dominant"],
             "unet_eval_ms_eager_events": float(roof["ms"].sum()),
             "by_class": roof["by_class"]}
         if args.dump_ops:

@@ -342,7 +342,8 @@ typedef struct ssde_memset_args { void* dst; int64_t bytes; int32_t value; int32
  * G g G^T; 1x1 / NIN / Linear: [cin/8][cout_pad][8]; input-gradient variants transposed + rotated), the
  * parameters stay in the reference layouts (state_dict compatibility).  One launch per kind re-packs
  * every weight of the model from a device-resident descriptor table. */
-enum { SSDE_PACK_CONV3 = 1, SSDE_PACK_WINO3 = 2, SSDE_PACK_MATRIX = 3, SSDE_PACK_VECTOR = 4 };
+enum { SSDE_PACK_CONV3 = 1, SSDE_PACK_WINO3 = 2, SSDE_PACK_MATRIX = 3, SSDE_PACK_VECTOR = 4,
+       SSDE_PACK_WINO4 = 5 /* conv -> the F(4x4,3x3) image of SSDE_TILE_WINOGRAD4 */ };
 typedef struct ssde_pack_desc {
   const float* src;        /* parameter: conv [cout][cin][3][3]; matrix [cout][cin]; vector [n] */
   const float* src2;       /* vector: optional second addend (Conv_1.bias + Conv_2.bias) */

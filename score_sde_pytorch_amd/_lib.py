@@ -18,7 +18,7 @@ TILE_AUTO, TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32, TILE_WINOGRAD, TIL
  OP_RANDN, OP_LANGEVIN, OP_PREDICTOR, OP_FILL, OP_STEP_INC, OP_WGRAD, OP_COLSUM, OP_GN_BWD_REDUCE, OP_PROLOGUE_BWD,
  OP_ATTN_BWD, OP_PERTURB, OP_DSM_LOSS, OP_SUMSQ_FLAT, OP_ADAM, OP_MEMSET, OP_AXPY, OP_PACK, OP_PROJECT,
  OP_GN_FINALIZE) = range(1, 29)
-PACK_CONV3, PACK_WINO3, PACK_MATRIX, PACK_VECTOR = 1, 2, 3, 4
+PACK_CONV3, PACK_WINO3, PACK_MATRIX, PACK_VECTOR, PACK_WINO4 = 1, 2, 3, 4, 5
 
 _fp = C.c_void_p  # device pointers are passed as integers
 

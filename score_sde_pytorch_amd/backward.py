@@ -340,9 +340,10 @@ class TrainEngine(E.UNetEngine):
             dst, resid = b.buf(n, h_in, w_in, ctot, name="dP"), None
         gsrc = _src(g, g_ld)
         if ksize == 3:
-            wino = stride == 1 and low.wino_ok(h_in, w_in, ctot, g_ld)
-            pack = E.pack_wino_weight if wino else E.pack_conv_weight
-            wd = self.weights.derived(wpacked, lambda w: pack(w.permute(1, 0, 2, 3).flip(2, 3)), "dgrad_wino" if wino else "dgrad")
+            wino = low.wino_ok(h_in, w_in, ctot, g_ld) if stride == 1 else 0
+            pack = {4: E.pack_wino4_weight, 2: E.pack_wino_weight}.get(wino, E.pack_conv_weight)
+            wd = self.weights.derived(wpacked, lambda w: pack(w.permute(1, 0, 2, 3).flip(2, 3)),
+                                      {4: "dgrad_wino4", 2: "dgrad_wino"}.get(wino, "dgrad"))
             if stride == 1:
                 low.conv(dst, h_in, w_in, ctot, main=gsrc, w_main=wd, h_in=ho, w_in=wo, stride=1, pad=1, resid=resid,
                          resid_post=1, scale=scale, wino=wino)

@@ -560,6 +560,38 @@ __global__ __launch_bounds__(256) void pack_wino3_kernel(const ssde_pack_desc* _
   }
 }
 
+// Winograd F(4x4,3x3): U = G g G^T with the 6x3 G of conv_wino4.hip, stored as its LDS image
+// [ceil(cin/4)][ceil(cout/64)][36][64][4].  One thread = one (cout, cin): it reads the 3x3 filter once and writes its 36
+// positions (consecutive lanes = the 4 channels of consecutive couts: 1 KB runs per position).  The products are formed in
+// fp64 and rounded once, like the host packing (engine.pack_wino4_weight).
+__global__ __launch_bounds__(256) void pack_wino4_kernel(const ssde_pack_desc* __restrict__ table) {
+  const ssde_pack_desc d = table[blockIdx.y];
+  const int ntl = (d.cout_l + 63) / 64;
+  const double G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                          {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+  const size_t items = (size_t)d.n / 36;
+  for (size_t it = (size_t)blockIdx.x * 256 + threadIdx.x; it < items; it += (size_t)gridDim.x * 256) {
+    const int e = (int)(it & 3), cs = (int)((it >> 2) & 63);
+    const size_t r = it >> 8;
+    const int nt = (int)(r % ntl), c4 = (int)(r / ntl);
+    const int co = nt * 64 + cs, ci = c4 * 4 + e;
+    double w[3][3], t[6][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int l = 0; l < 3; ++l) w[k][l] = (double)pack_w3(d, co, ci, k, l);
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int l = 0; l < 3; ++l) t[a][l] = G[a][0] * w[0][l] + G[a][1] * w[1][l] + G[a][2] * w[2][l];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b)
+        d.dst[((r * 36 + a * 6 + b) * 64 + cs) * 4 + e] = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
+  }
+}
+
 // matrix parts (source-driven): dst[(col/8)*ld + row][col%8] = src[i][j]; flags&1 swaps the roles of i and j
 __global__ __launch_bounds__(256) void pack_matrix_kernel(const ssde_pack_desc* __restrict__ table) {
   const ssde_pack_desc d = table[blockIdx.y];
@@ -588,6 +620,7 @@ extern "C" int ssde_pack_weights(const ssde_pack_args* a, void* stream) {
   switch (a->kind) {
     case SSDE_PACK_CONV3: hipLaunchKernelGGL(pack_conv3_kernel, grid, dim3(256), 0, st, a->table); break;
     case SSDE_PACK_WINO3: hipLaunchKernelGGL(pack_wino3_kernel, grid, dim3(256), 0, st, a->table); break;
+    case SSDE_PACK_WINO4: hipLaunchKernelGGL(pack_wino4_kernel, grid, dim3(256), 0, st, a->table); break;
     case SSDE_PACK_MATRIX: hipLaunchKernelGGL(pack_matrix_kernel, grid, dim3(256), 0, st, a->table); break;
     case SSDE_PACK_VECTOR: hipLaunchKernelGGL(pack_vector_kernel, grid, dim3(256), 0, st, a->table); break;
     default: ssde_set_error("pack_weights: unknown kind %d", a->kind); return SSDE_EINVAL;

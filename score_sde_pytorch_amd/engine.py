@@ -343,8 +343,9 @@ class WeightStore:
 
     # -- typed registrations -------------------------------------------------------------------
     def conv3(self, param, cin_pad=None, cout_pad=None, wino=False):
-        """[Cout, Cin, 3, 3] conv weight, optionally zero-padded to cin_pad / cout_pad channels; wino: packed for the
-        Winograd kernel (G g G^T, conv_wino.hip) instead of the direct one."""
+        """[Cout, Cin, 3, 3] conv weight, optionally zero-padded to cin_pad / cout_pad channels; wino (see
+        Lowering.wino_ok): 2 / True = packed for the Winograd F(2x2,3x3) kernel (G g G^T, conv_wino.hip), 4 = for the
+        F(4x4,3x3) kernel (conv_wino4.hip), 0 = for the direct one."""
         def logical(w):
             w = w.to(torch.float32)
             if cin_pad and w.shape[1] < cin_pad:
@@ -355,8 +356,8 @@ class WeightStore:
         cout_l, cin_l = max(param.shape[0], cout_pad or 0), max(param.shape[1], cin_pad or 0)
         meta = dict(kind="conv3", sources=[param], logical=logical, dims=(cout_l, cin_l),
                     parts=[dict(param=param, row0=0, rows=param.shape[0], transpose=False)], cin_store=param.shape[1])
-        pack = pack_wino_weight if wino else pack_conv_weight
-        recipe = [dict(kind=L.PACK_WINO3 if wino else L.PACK_CONV3, src=param, cout=param.shape[0], cin=param.shape[1],
+        pack = pack_wino4_weight if wino == 4 else pack_wino_weight if wino else pack_conv_weight
+        recipe = [dict(kind=L.PACK_WINO4 if wino == 4 else L.PACK_WINO3 if wino else L.PACK_CONV3, src=param, cout=param.shape[0], cin=param.shape[1],
                        cout_l=cout_l, cin_l=cin_l, flags=0, n="dst")]
         return self.add([param], lambda w: pack(logical(w)), meta, recipe)
 
@@ -407,14 +408,15 @@ class WeightStore:
 
     def derived(self, packed, fn, tag):
         """The input-gradient packing of an existing entry's logical weight: fn(logical) -> packed, with tag
-        'dgrad' (direct conv / matrix) or 'dgrad_wino'."""
+        'dgrad' (direct conv / matrix), 'dgrad_wino' or 'dgrad_wino4'."""
         meta = self.meta[id(packed)]
         key = (id(packed), tag)
         if key not in self.meta:
             cout_l, cin_l = meta["dims"]
             if meta["kind"] == "conv3":
                 p_ = meta["sources"][0]
-                recipe = [dict(kind=L.PACK_WINO3 if tag == "dgrad_wino" else L.PACK_CONV3, src=p_, cout=p_.shape[0], cin=p_.shape[1],
+                kind = {"dgrad_wino": L.PACK_WINO3, "dgrad_wino4": L.PACK_WINO4}.get(tag, L.PACK_CONV3)
+                recipe = [dict(kind=kind, src=p_, cout=p_.shape[0], cin=p_.shape[1],
                                cout_l=cin_l, cin_l=cout_l, flags=1, n="dst")]
             else:
                 # D = M^T: part rows become column ranges; a transposed (NIN) part is read straight, a plain one swapped
@@ -569,13 +571,13 @@ class Lowering:
     def conv(self, dst, h_out, w_out, c_out, main=None, w_main=None, h_in=0, w_in=0, stride=1, pad=1,
              aux=None, w_aux=None, bias=None, chan_add=None, chan_add_ld=0, resid=None, scale=1.0, tile=L.TILE_AUTO,
              resid_post=0, wino=False, stats=False):
-        """wino=True: w_main is Winograd-packed (see wino_ok); a fused 1x1 source then runs as a second launch.
+        """wino (2 / True or 4): w_main is Winograd-packed (see wino_ok); a fused 1x1 source then runs as a second launch.
         stats=True: dst feeds a GroupNorm later -- when the launch plan allows it (ssde_conv_gn_slices) the epilogue
         also writes the tensor's partial statistics and gn_stats() turns into a finalize of a few thousand floats."""
         split_tmp = None
         if wino:
             assert main is not None and stride == 1 and pad == 1 and (h_in, w_in) == (h_out, w_out)
-            tile = L.TILE_WINOGRAD
+            tile = L.TILE_WINOGRAD4 if wino == 4 else L.TILE_WINOGRAD
             if aux is not None:
                 split_tmp = self.b.buf(self.n, h_out, w_out, c_out, name="wino_tmp")
         px = self.n * h_out * w_out
@@ -599,19 +601,30 @@ class Lowering:
         self.b.add(L.OP_CONV, fields, FC_CONV3 if main is not None else FC_CONV1, flops)
 
     def wino_ok(self, h, w, c_out, c_in):
-        """Winograd F(2x2,3x3) pays when the matrix pipe is the bound: even outputs, enough channels to fill the
-        64-cout tile and the 8-channel stages, and enough 64-tile x 64-cout workgroups to cover the 256 CUs (measured:
-        x1.2-1.5 over the direct kernel from 8x8 up at batch 256, x0.5 at 4x4 where only 64 workgroups exist).
-        SSDE_WINOGRAD=0 forces the direct (bitwise fmaf-chain) kernel, =2 forces Winograd wherever it is legal."""
+        """Which 3x3 / stride 1 kernel a layer gets: 0 = direct, 2 = Winograd F(2x2,3x3), 4 = F(4x4,3x3).
+        Winograd pays when the matrix pipe is the bound: enough channels to fill the 64-cout tile, and enough workgroups
+        to cover the 256 CUs (F(2x2,3x3): 64 tiles x 64 couts per workgroup -- measured x1.2-1.5 over the direct kernel
+        from 8x8 up at batch 256, x0.5 at 4x4 where only 64 workgroups exist).  F(4x4,3x3) does 1.78x less matrix work
+        again and is 15-23 % faster than F(2x2,3x3) from 16x16 maps up (profiles/r2_wino4_v3_interleaved.txt); its
+        workgroups cover 32 tiles = 512 pixels, so 8x8 maps at batch 256 would give 128 of them and stay on F(2x2,3x3).
+        Rounding: ~5x coarser than the direct form, 2.5e-6 .. 1.3e-5 on the whole network against the 1e-4 the parity
+        tests allow (tools/experiments/wino43_error_budget.py).
+        SSDE_WINOGRAD: 0 = direct (bitwise fmaf-chain) kernel everywhere, 1 = this heuristic (default), 2 = F(2x2,3x3)
+        wherever it is legal, 3 = the heuristic without F(4x4,3x3), 4 = F(4x4,3x3) wherever it is legal."""
         import os
         mode = os.environ.get("SSDE_WINOGRAD", "1")
         if mode == "0":
-            return False
-        legal = h % 2 == 0 and w % 2 == 0 and h >= 8 and w >= 8 and c_out >= 32 and c_in >= 8 and c_in % 8 == 0
-        if not legal or mode == "2":
-            return legal
-        workgroups = -(-(self.n * h * w) // 256) * -(-c_out // 64)
-        return workgroups >= 192
+            return 0
+        legal2 = h % 2 == 0 and w % 2 == 0 and h >= 8 and w >= 8 and c_out >= 32 and c_in >= 8 and c_in % 8 == 0
+        legal4 = h % 4 == 0 and w % 4 == 0 and h >= 8 and w >= 8 and c_out >= 32 and c_in >= 8 and c_in % 4 == 0
+        if mode == "4" and legal4:
+            return 4
+        if mode == "2" or mode == "4":
+            return 2 if legal2 else 0
+        n_tiles = -(-c_out // 64)
+        if mode != "3" and legal4 and h >= 16 and w >= 16 and -(-(self.n * h * w) // 512) * n_tiles >= 256:
+            return 4
+        return 2 if legal2 and -(-(self.n * h * w) // 256) * n_tiles >= 192 else 0
 
     def upfirdn(self, src, n_ch, h_in, w_in, taps, up=1, down=1, pad=(0, 0), name="fir"):
         kh, kw = taps.shape

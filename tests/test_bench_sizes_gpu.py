@@ -50,13 +50,14 @@ def _oracle_forward(cfg, sd, x, cond, chunk):
 
 
 def _kernel_mix(engine):
-    """how many 3x3 convolutions of the lowered program run on the Winograd kernel / the direct kernel"""
+    """how many 3x3 convolutions of the lowered program run on the Winograd kernels (F(2x2,3x3) and F(4x4,3x3)) / the
+    direct kernel"""
     from score_sde_pytorch_amd import _lib as L
     wino = direct = 0
     for i in range(engine.program.n):
         op = engine.program.ops[i]
         if op.kind == L.OP_CONV and op.u.conv.ksize == 3:
-            if op.u.conv.tile == L.TILE_WINOGRAD:
+            if op.u.conv.tile in (L.TILE_WINOGRAD, L.TILE_WINOGRAD4):
                 wino += 1
             else:
                 direct += 1

@@ -11,7 +11,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("conv_wino_kernel", "conv_mfma_kernel", "wgrad_kernel", "wgrad_reduce_kernel", "attn_kernel", "attn_bwd_q_kernel",
+    for key in ("conv_wino4_kernel", "conv_wino_kernel", "conv_mfma_kernel", "gemm1x1_kernel", "wgrad_wino_kernel", "wgrad_kernel", "wgrad_reduce_kernel", "attn_kernel", "attn_bwd_q_kernel",
                 "attn_bwd_kv_kernel", "gn_stats_kernel", "gn_bwd_reduce_kernel", "prologue_bwd_kernel", "colsum_kernel",
                 "upfirdn_kernel", "adam_kernel", "pack_wino3_kernel", "pack_conv3_kernel", "randn_kernel", "langevin_kernel",
                 "predictor_kernel", "sumsq_kernel"):
