@@ -12,15 +12,33 @@
 // One workgroup (8 waves, two per SIMD) owns 32 tiles (a 32x16 output patch, or whole small images) x 64 output
 // channels x all 36 transform positions; K advances 4 input channels per stage:
 //   raw halo (+ fused GroupNorm / SiLU / dropout prologue)      -> LDS raw[pair][pixel][2]
-//   input transform B^T d B in two 1-D passes, in place         -> LDS V[pos][tile][4]      (18 KB)
+//   input transform B^T d B in two 1-D passes, in place         -> LDS V[pos][tile][4]      (pitch 144 floats)
 //   host-transformed weights G g G^T, packed as the LDS image   -> LDS U[pos][cout][4]      (36 KB, by LDS-DMA)
 //   wave (q, h) = 9 positions {q, q+4, ..} x (32 tiles x 32 couts) on v_mfma_f32_32x32x2_f32: a lane's ds_read_b64 is
 //   the channel pair (2k, 2k+1), k = lane >> 5 = the MFMA k index, one read of each operand feeds two MFMAs; all 64
 //   lanes of a fragment read are 512 contiguous bytes (no bank conflicts)
-// V, U and raw are double buffered; two LDS-only barriers per stage.  The 36 positions of an output live in 4 waves,
-// so the workgroup exchanges the products through LDS once (per 32-cout half: 36 x 32 x 32 floats = the whole LDS),
-// every thread applies A^T M A to one (tile, cout pair), and the result goes through the shared coalesced epilogue
-// (ssde_store_tile: bias, temb addend, residual, scale, GroupNorm partials).
+// V, U and raw are double buffered, ONE LDS-only barrier per stage: a wave transforms 8 of the 64 (tile, channel pair)
+// items with all their 6 lines, so the second 1-D pass reads what the same wave wrote in the first.  Every wave runs the
+// same program; its halo loads, its 4-5 weight DMA pieces and the LDS round trips of the two transform passes ride
+// between its 18 MFMAs (an MFMA only occupies the matrix pipe; the wave keeps issuing).
+// The 36 positions of an output live in 4 waves, so the workgroup exchanges the products through LDS -- 16 tiles (half of
+// every wave's accumulators) at a time, M[pos][16 tiles][64 couts] = 150 KB -- every thread applies A^T M A to one
+// (tile, cout pair), and the result goes through the shared coalesced epilogue (ssde_store_tile: bias, temb addend,
+// residual, scale, GroupNorm partials).
+//
+// Measured on the MI355X at batch 256 (profiles/r2_wino4_*.txt, tools/conv_bench.py, tools/wino4_trace.py):
+//   v1  all waves in program order (issue, pass 1, MFMA, barrier, pass 2, MFMA, staging), exchange per 32-cout half
+//       150-234 TF/s direct-equivalent; the exchange kept 144 accumulators live (81 scratch stores per lane, 105 k cycles
+//       of epilogue per workgroup) and the 36 DMA pieces + halo loads stalled ~2000 cycles at the top of every stage
+//   v2  ping-pong roles as conv_wino.hip (waves 0-3 MFMA + DMA | waves 4-7 staging, then swapped): SLOWER, 114-164 TF/s
+//       -- four waves carry all the staging of a stage that has only 1152 matrix cycles per wave
+//       (tools/experiments/conv_wino4_pingpong.patch)
+//   v3  16-tile exchange rounds (epilogue 30 k cycles), issues and LDS round trips between the MFMAs: 217-268 TF/s
+//   v4  this file: one barrier per stage (wave-local transform items): 217-270 TF/s, 15-23 % over conv_wino.hip from
+//       16x16 maps up; v5 (waves 4-7 stage BEFORE their MFMAs, waves 0-3 after) was 3 % slower
+// rocprofv3 counters at 128 -> 128 channels, 32x32 (tools/w4_pmc.sh): matrix pipe 39 % busy (conv_wino.hip: 58 %, on
+// 1.78x more matrix work), waves 30 % parked (waitcnt / barrier), 41 % issue-stalled, VALU 14 %, LDS active 34 % of the
+// time with 35 % of it bank conflicts.
 #include "ssde_common.h"
 #include <type_traits>
 
@@ -40,20 +58,14 @@ extern "C" int ssde_debug_w4_trace(void* buf) {
 #define SSDE_TR(slot) do { } while (0)
 #endif
 
-#ifndef SSDE_W4_WLOAD
-#define SSDE_W4_WLOAD 1
-#endif
-// 0: a stage is issue / pass 1 / MFMA / barrier / pass 2 / MFMA / staging in program order; 1: the asynchronous issues and
-// the LDS round trips of the two transform passes ride between the MFMAs
-#ifndef SSDE_W4_LOOP
-#define SSDE_W4_LOOP 1
-#endif
 
 namespace {
 
 constexpr int kThreads = 512;
 constexpr int kPos = 36, kTiles = 32, kKc = 4;
-constexpr int kVFloats = kPos * kTiles * kKc;       // 4608: one V stage
+constexpr int kVP = kTiles * kKc + 16;               // floats per position of V: 128 + 16, so that the 6 lines x 8 items of a
+                                                    // wave's transform writes (b64) spread over all banks
+constexpr int kVFloats = kPos * kVP;                // one V stage
 constexpr int kUFloats = kPos * 64 * kKc;           // 9216: one U stage
 constexpr int kMaxRaw = 2;                          // float4 halo items per thread per stage (halo <= 1024 pixels)
 constexpr int kLdm = 66;                            // row pitch of the product exchange [pos][16 tiles][64 couts]
@@ -143,8 +155,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       gil[it] = inb ? il * (kGn ? s.gn_groups : 0) : 0;
     }
   }
-  // ---- transform plan: thread (line x = tid >> 6 of the 6x6 tile, item = tid & 63 = (tile, channel pair)); 384 threads ----
-  const int t_line = tid >> 6, t_tile = (tid & 63) >> 1, t_pair = tid & 1;
+  // ---- transform plan: a wave owns 8 of the 64 items (tile, channel pair) with all their 6 lines: lane = line * 8 + item
+  // (48 lanes), so that pass 2 reads what the SAME wave wrote in pass 1 -- LDS executes a wave's operations in order, and
+  // no workgroup barrier is needed between the passes ----
+  const int t_line = lane >> 3, t_tile = (wave * 8 + (lane & 7)) >> 1, t_pair = lane & 1;
   int t_base;
   {
     const int il = t_tile >> (p.lTWt + p.lTHt);
@@ -214,36 +228,23 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       for (int a = 0; a < 6; ++a) d[a] = *reinterpret_cast<const float2*>(rp + a * HWd * 2);
       bt6(d, o);
 #pragma unroll
-      for (int a = 0; a < 6; ++a) *reinterpret_cast<float2*>(Vn + (a * 6 + t_line) * (kTiles * 4) + t_vcol) = o[a];
+      for (int a = 0; a < 6; ++a) *reinterpret_cast<float2*>(Vn + (a * 6 + t_line) * kVP + t_vcol) = o[a];
     }
   };
   auto pass2 = [&](float* Vn) {
     if (t_line < 6) {
-      float* vp = Vn + (t_line * 6) * (kTiles * 4) + t_vcol;
+      float* vp = Vn + (t_line * 6) * kVP + t_vcol;
       float2 d[6], o[6];
 #pragma unroll
-      for (int b = 0; b < 6; ++b) d[b] = *reinterpret_cast<const float2*>(vp + b * (kTiles * 4));
+      for (int b = 0; b < 6; ++b) d[b] = *reinterpret_cast<const float2*>(vp + b * kVP);
       bt6(d, o);
 #pragma unroll
-      for (int b = 0; b < 6; ++b) *reinterpret_cast<float2*>(vp + b * (kTiles * 4)) = o[b];
+      for (int b = 0; b < 6; ++b) *reinterpret_cast<float2*>(vp + b * kVP) = o[b];
     }
   };
-  // weights of stage st: the host packed them as the LDS image (36 KB per stage).  SSDE_W4_WLOAD:
-  //   0  LDS-DMA, 36 pieces of 1 KB, wave w moves pieces w, w + 8, ..; M0 and a 64-bit address per piece
-  //   1  LDS-DMA, a contiguous run of 5 (waves 0-3) or 4 pieces per wave: one base, immediate offsets -2048 .. +2048
-  //   2  plain global loads into registers at the top of the stage, ds_write_b128 at its end
-#if SSDE_W4_WLOAD == 2
-  float4 uw[5];
-#endif
+  // weights of stage st: the host packed them as the LDS image (36 KB per stage), moved by LDS-DMA: a contiguous run of
+  // 5 (waves 0-3) or 4 pieces of 1 KB per wave, one base and immediate offsets -2048 .. +2048
   auto dma_weights = [&](int st, float* Un) {
-#if SSDE_W4_WLOAD == 0
-    const float* gsrc = p.wpk + ((size_t)st * p.n_tiles + nt) * kUFloats + lane * 4;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int piece = wave + 8 * k;
-      if (piece < kPos) SSDE_GLDS16_OFF(gsrc + piece * 256, Un + piece * 256, 0);
-    }
-#elif SSDE_W4_WLOAD == 1
     const int p0 = wave < 4 ? 5 * wave : 20 + 4 * (wave - 4);
     const float* gsrc = p.wpk + ((size_t)st * p.n_tiles + nt) * kUFloats + (p0 + 2) * 256 + lane * 4;
     float* ldst = Un + (p0 + 2) * 256;
@@ -252,23 +253,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
     SSDE_GLDS16_OFF(gsrc, ldst, 0);
     SSDE_GLDS16_OFF(gsrc, ldst, 1024);
     if (wave < 4) SSDE_GLDS16_OFF(gsrc, ldst, 2048);
-#else
-    const float4* gsrc = reinterpret_cast<const float4*>(p.wpk + ((size_t)st * p.n_tiles + nt) * kUFloats) + tid;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) uw[k] = gsrc[k * kThreads];
-    uw[4] = gsrc[tid < 256 ? 4 * kThreads : 0];
-    (void)Un;
-#endif
-  };
-  auto park_weights = [&](float* Un) {
-#if SSDE_W4_WLOAD == 2
-    float4* d = reinterpret_cast<float4*>(Un) + tid;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) d[k * kThreads] = uw[k];
-    if (tid < 256) d[4 * kThreads] = uw[4];
-#else
-    (void)Un;
-#endif
   };
 
   const int wq = wave >> 1, wh = wave & 1;      // this wave's positions wq + 4 j and its 32-cout half
@@ -278,18 +262,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   const int a_off = li * 4 + 2 * lh, b_off = (wh * 32 + li) * 4 + 2 * lh;
-  auto mfma_range = [&](const float* Vc, const float* Uc, auto j0c, auto j1c) {
-    constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
-#pragma unroll
-    for (int j = J0; j < J1; ++j) {
-      const int pos = wq + 4 * j;
-      const float2 a = *reinterpret_cast<const float2*>(Vc + pos * (kTiles * 4) + a_off);
-      const float2 b = *reinterpret_cast<const float2*>(Uc + pos * (64 * 4) + b_off);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[j], 0, 0, 0);
-    }
-  };
-
   // ---- pipeline fill ----
   SSDE_TR(1);
   load_raw(0);
@@ -302,7 +274,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
   SSDE_LDS_BARRIER();
   pass2(Vb);
   if (nst > 1) store_raw(rawb + raw_stride);
-  park_weights(Ub);
   SSDE_WAIT_VMCNT(0);
   SSDE_LDS_BARRIER();
   SSDE_TR(2);
@@ -313,27 +284,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
     const float* Uc = Ub + cur * kUFloats;
     float* Vn = Vb + nxt * kVFloats;
     const bool has1 = st + 1 < nst, has2 = st + 2 < nst;
-#if SSDE_W4_LOOP == 0
-    if (has1) dma_weights(st + 1, Ub + nxt * kUFloats);
-    if (st < 8) SSDE_TR(8 + st * 10 + 9);
-    if (has2) load_raw(st + 2);
-    if (st < 8) SSDE_TR(8 + st * 10 + 0);
-    if (has1) pass1(rawb + nxt * raw_stride, Vn);
-    if (st < 8) SSDE_TR(8 + st * 10 + 1);
-    mfma_range(Vc, Uc, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
-    if (st < 8) SSDE_TR(8 + st * 10 + 2);
-    SSDE_LDS_BARRIER();
-    if (st < 8) SSDE_TR(8 + st * 10 + 3);
-    if (has1) pass2(Vn);
-    if (st < 8) SSDE_TR(8 + st * 10 + 4);
-    mfma_range(Vc, Uc, std::integral_constant<int, 5>{}, std::integral_constant<int, 9>{});
-    if (st < 8) SSDE_TR(8 + st * 10 + 5);
-#else
     {
       // One wave's stage: 6 LDS reads of transform pass 1 | positions 0,1 (+ halo loads, weight pieces) | pass-1 arithmetic
-      // and 6 LDS writes | positions 2-4 (+ weight pieces) | barrier | pass-2 reads | positions 5,6 | pass-2 arithmetic and
-      // writes | positions 7,8.  A wave issues in order, and an MFMA only occupies the matrix pipe: the LDS round trips and
-      // the VMEM issue stalls now pass while the wave's own MFMAs execute.
+      // and 6 LDS writes | positions 2,3 (+ weight pieces) | pass-2 reads of the wave's OWN pass-1 lines (no barrier, see
+      // the transform plan) | positions 4,5 | pass-2 arithmetic and writes | positions 6-8.  A wave issues in order, and
+      // an MFMA only occupies the matrix pipe: the LDS round trips and the VMEM issue stalls pass while the wave's own
+      // MFMAs execute.  One barrier per stage.
       const bool tl_ok = has1 && t_line < 6;
       float2 td[6], to[6];
       float2 af[2], bf[2];
@@ -341,7 +297,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       const int dp0 = wave < 4 ? 5 * wave : 20 + 4 * (wave - 4);
       const float* dsrc = p.wpk + ((size_t)min(st + 1, nst - 1) * p.n_tiles + nt) * kUFloats + (dp0 + 2) * 256 + lane * 4;
       float* ddst = Un + (dp0 + 2) * 256;
-      af[0] = *reinterpret_cast<const float2*>(Vc + wq * (kTiles * 4) + a_off);
+      af[0] = *reinterpret_cast<const float2*>(Vc + wq * kVP + a_off);
       bf[0] = *reinterpret_cast<const float2*>(Uc + wq * (64 * 4) + b_off);
       if (tl_ok) {
         const float* rp = rawb + nxt * raw_stride + (t_pair * halo_px + t_base + t_line) * 2;
@@ -352,7 +308,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
 #define SSDE_W4_POS(J)                                                                                          \
       do {                                                                                                         \
         if ((J) + 1 < 9) {                                                                                         \
-          af[((J) + 1) & 1] = *reinterpret_cast<const float2*>(Vc + (wq + 4 * ((J) + 1)) * (kTiles * 4) + a_off);  \
+          af[((J) + 1) & 1] = *reinterpret_cast<const float2*>(Vc + (wq + 4 * ((J) + 1)) * kVP + a_off);  \
           bf[((J) + 1) & 1] = *reinterpret_cast<const float2*>(Uc + (wq + 4 * ((J) + 1)) * (64 * 4) + b_off);     \
         }                                                                                                          \
         acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(J) & 1].x, bf[(J) & 1].x, acc[J], 0, 0, 0);             \
@@ -370,7 +326,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       if (tl_ok) {
         bt6(td, to);
 #pragma unroll
-        for (int a = 0; a < 6; ++a) *reinterpret_cast<float2*>(Vn + (a * 6 + t_line) * (kTiles * 4) + t_vcol) = to[a];
+        for (int a = 0; a < 6; ++a) *reinterpret_cast<float2*>(Vn + (a * 6 + t_line) * kVP + t_vcol) = to[a];
       }
       __builtin_amdgcn_sched_barrier(0);
       SSDE_W4_POS(2);
@@ -379,33 +335,29 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       SSDE_W4_POS(3);
       if (has1) SSDE_GLDS16_OFF(dsrc, ddst, 1024);
       __builtin_amdgcn_sched_barrier(0);
-      SSDE_W4_POS(4);
-      if (has1 && wave < 4) SSDE_GLDS16_OFF(dsrc, ddst, 2048);
-      if (st < 8) SSDE_TR(8 + st * 10 + 2);
-      SSDE_LDS_BARRIER();
-      if (st < 8) SSDE_TR(8 + st * 10 + 3);
-      float* vp = Vn + (t_line * 6) * (kTiles * 4) + t_vcol;
+      float* vp = Vn + (t_line * 6) * kVP + t_vcol;
       if (tl_ok) {
 #pragma unroll
-        for (int b = 0; b < 6; ++b) td[b] = *reinterpret_cast<const float2*>(vp + b * (kTiles * 4));
+        for (int b = 0; b < 6; ++b) td[b] = *reinterpret_cast<const float2*>(vp + b * kVP);
       }
       __builtin_amdgcn_sched_barrier(0);
+      SSDE_W4_POS(4);
+      if (has1 && wave < 4) SSDE_GLDS16_OFF(dsrc, ddst, 2048);
+      __builtin_amdgcn_sched_barrier(0);
       SSDE_W4_POS(5);
-      SSDE_W4_POS(6);
       if (tl_ok) {
         bt6(td, to);
 #pragma unroll
-        for (int b = 0; b < 6; ++b) *reinterpret_cast<float2*>(vp + b * (kTiles * 4)) = to[b];
+        for (int b = 0; b < 6; ++b) *reinterpret_cast<float2*>(vp + b * kVP) = to[b];
       }
       __builtin_amdgcn_sched_barrier(0);
+      SSDE_W4_POS(6);
       SSDE_W4_POS(7);
       SSDE_W4_POS(8);
 #undef SSDE_W4_POS
       if (st < 8) SSDE_TR(8 + st * 10 + 5);
     }
-#endif
     if (has2) store_raw(rawb + cur * raw_stride);
-    if (has1) park_weights(Ub + nxt * kUFloats);
     if (st < 8) SSDE_TR(8 + st * 10 + 6);
     SSDE_WAIT_VMCNT(0);
     if (st < 8) SSDE_TR(8 + st * 10 + 7);
