@@ -34,8 +34,9 @@
 //       -- four waves carry all the staging of a stage that has only 1152 matrix cycles per wave
 //       (tools/experiments/conv_wino4_pingpong.patch)
 //   v3  16-tile exchange rounds (epilogue 30 k cycles), issues and LDS round trips between the MFMAs: 217-268 TF/s
-//   v4  this file: one barrier per stage (wave-local transform items): 217-270 TF/s, 15-23 % over conv_wino.hip from
-//       16x16 maps up; v5 (waves 4-7 stage BEFORE their MFMAs, waves 0-3 after) was 3 % slower
+//   v4  this file: one barrier per stage (wave-local transform items), fragment reads 3 positions ahead: 223-277 TF/s,
+//       19-26 % over conv_wino.hip from 16x16 maps up; v5 (waves 4-7 stage BEFORE their MFMAs, waves 0-3 after) was 3 %
+//       slower; the weights through registers (global_load_dwordx4 + ds_write_b128) instead of LDS-DMA: 123-141 TF/s
 // rocprofv3 counters at 128 -> 128 channels, 32x32 (tools/w4_pmc.sh): matrix pipe 39 % busy (conv_wino.hip: 58 %, on
 // 1.78x more matrix work), waves 30 % parked (waitcnt / barrier), 41 % issue-stalled, VALU 14 %, LDS active 34 % of the
 // time with 35 % of it bank conflicts.
@@ -56,6 +57,12 @@ extern "C" int ssde_debug_w4_trace(void* buf) {
   } while (0)
 #else
 #define SSDE_TR(slot) do { } while (0)
+#endif
+
+
+// fragment reads run this many positions (2 MFMAs = 128 matrix cycles each) ahead of their MFMAs
+#ifndef SSDE_W4_PF
+#define SSDE_W4_PF 3
 #endif
 
 
@@ -292,13 +299,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       // MFMAs execute.  One barrier per stage.
       const bool tl_ok = has1 && t_line < 6;
       float2 td[6], to[6];
-      float2 af[2], bf[2];
+      float2 af[SSDE_W4_PF + 1], bf[SSDE_W4_PF + 1];
       float* Un = Ub + nxt * kUFloats;
+#define SSDE_W4_WPIECE(K, IMM) do { if (has1 && ((K) < 4 || wave < 4)) SSDE_GLDS16_OFF(dsrc, ddst, IMM); } while (0)
       const int dp0 = wave < 4 ? 5 * wave : 20 + 4 * (wave - 4);
       const float* dsrc = p.wpk + ((size_t)min(st + 1, nst - 1) * p.n_tiles + nt) * kUFloats + (dp0 + 2) * 256 + lane * 4;
       float* ddst = Un + (dp0 + 2) * 256;
-      af[0] = *reinterpret_cast<const float2*>(Vc + wq * kVP + a_off);
-      bf[0] = *reinterpret_cast<const float2*>(Uc + wq * (64 * 4) + b_off);
+#pragma unroll
+      for (int j = 0; j < SSDE_W4_PF; ++j) {
+        af[j] = *reinterpret_cast<const float2*>(Vc + (wq + 4 * j) * kVP + a_off);
+        bf[j] = *reinterpret_cast<const float2*>(Uc + (wq + 4 * j) * (64 * 4) + b_off);
+      }
       if (tl_ok) {
         const float* rp = rawb + nxt * raw_stride + (t_pair * halo_px + t_base + t_line) * 2;
 #pragma unroll
@@ -307,21 +318,23 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       __builtin_amdgcn_sched_barrier(0);
 #define SSDE_W4_POS(J)                                                                                          \
       do {                                                                                                         \
-        if ((J) + 1 < 9) {                                                                                         \
-          af[((J) + 1) & 1] = *reinterpret_cast<const float2*>(Vc + (wq + 4 * ((J) + 1)) * kVP + a_off);  \
-          bf[((J) + 1) & 1] = *reinterpret_cast<const float2*>(Uc + (wq + 4 * ((J) + 1)) * (64 * 4) + b_off);     \
+        if ((J) + SSDE_W4_PF < 9) {                                                                                \
+          af[((J) + SSDE_W4_PF) % (SSDE_W4_PF + 1)] =                                                              \
+              *reinterpret_cast<const float2*>(Vc + (wq + 4 * ((J) + SSDE_W4_PF)) * kVP + a_off);                  \
+          bf[((J) + SSDE_W4_PF) % (SSDE_W4_PF + 1)] =                                                              \
+              *reinterpret_cast<const float2*>(Uc + (wq + 4 * ((J) + SSDE_W4_PF)) * (64 * 4) + b_off);             \
         }                                                                                                          \
-        acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(J) & 1].x, bf[(J) & 1].x, acc[J], 0, 0, 0);             \
-        acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(J) & 1].y, bf[(J) & 1].y, acc[J], 0, 0, 0);             \
+        acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(J) % (SSDE_W4_PF + 1)].x, bf[(J) % (SSDE_W4_PF + 1)].x, acc[J], 0, 0, 0); \
+        acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(J) % (SSDE_W4_PF + 1)].y, bf[(J) % (SSDE_W4_PF + 1)].y, acc[J], 0, 0, 0); \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
       } while (0)
       SSDE_W4_POS(0);
       if (has2) load_piece(st + 2, 0);
-      if (has1) SSDE_GLDS16_OFF(dsrc, ddst, -2048);
+      SSDE_W4_WPIECE(0, -2048);
       __builtin_amdgcn_sched_barrier(0);
       SSDE_W4_POS(1);
       if (has2) load_piece(st + 2, 1);
-      if (has1) SSDE_GLDS16_OFF(dsrc, ddst, -1024);
+      SSDE_W4_WPIECE(1, -1024);
       __builtin_amdgcn_sched_barrier(0);
       if (tl_ok) {
         bt6(td, to);
@@ -330,10 +343,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       }
       __builtin_amdgcn_sched_barrier(0);
       SSDE_W4_POS(2);
-      if (has1) SSDE_GLDS16_OFF(dsrc, ddst, 0);
+      SSDE_W4_WPIECE(2, 0);
       __builtin_amdgcn_sched_barrier(0);
       SSDE_W4_POS(3);
-      if (has1) SSDE_GLDS16_OFF(dsrc, ddst, 1024);
+      SSDE_W4_WPIECE(3, 1024);
       __builtin_amdgcn_sched_barrier(0);
       float* vp = Vn + (t_line * 6) * kVP + t_vcol;
       if (tl_ok) {
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       }
       __builtin_amdgcn_sched_barrier(0);
       SSDE_W4_POS(4);
-      if (has1 && wave < 4) SSDE_GLDS16_OFF(dsrc, ddst, 2048);
+      SSDE_W4_WPIECE(4, 2048);
       __builtin_amdgcn_sched_barrier(0);
       SSDE_W4_POS(5);
       if (tl_ok) {
@@ -355,6 +368,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       SSDE_W4_POS(7);
       SSDE_W4_POS(8);
 #undef SSDE_W4_POS
+#undef SSDE_W4_WPIECE
       if (st < 8) SSDE_TR(8 + st * 10 + 5);
     }
     if (has2) store_raw(rawb + cur * raw_stride);
