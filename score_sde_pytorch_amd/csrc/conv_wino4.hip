@@ -65,6 +65,17 @@ extern "C" int ssde_debug_w4_trace(void* buf) {
 #ifndef SSDE_W4_PF
 #define SSDE_W4_PF 3
 #endif
+// 1: the short VALU / LDS bursts of the transforms and of the halo staging run at s_setprio 2 (as conv_wino.hip's staging)
+#ifndef SSDE_W4_PRIO
+#define SSDE_W4_PRIO 1
+#endif
+#if SSDE_W4_PRIO
+#define SSDE_W4_HI() __builtin_amdgcn_s_setprio(2)
+#define SSDE_W4_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define SSDE_W4_HI() do { } while (0)
+#define SSDE_W4_LO() do { } while (0)
+#endif
 
 
 namespace {
@@ -338,9 +349,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       SSDE_W4_WPIECE(1, -1024);
       __builtin_amdgcn_sched_barrier(0);
       if (tl_ok) {
+        SSDE_W4_HI();
         bt6(td, to);
 #pragma unroll
         for (int a = 0; a < 6; ++a) *reinterpret_cast<float2*>(Vn + (a * 6 + t_line) * kVP + t_vcol) = to[a];
+        SSDE_W4_LO();
       }
       __builtin_amdgcn_sched_barrier(0);
       SSDE_W4_POS(2);
@@ -360,9 +373,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       __builtin_amdgcn_sched_barrier(0);
       SSDE_W4_POS(5);
       if (tl_ok) {
+        SSDE_W4_HI();
         bt6(td, to);
 #pragma unroll
         for (int b = 0; b < 6; ++b) *reinterpret_cast<float2*>(vp + b * kVP) = to[b];
+        SSDE_W4_LO();
       }
       __builtin_amdgcn_sched_barrier(0);
       SSDE_W4_POS(6);
@@ -372,7 +387,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
 #undef SSDE_W4_WPIECE
       if (st < 8) SSDE_TR(8 + st * 10 + 5);
     }
+    SSDE_W4_HI();
     if (has2) store_raw(rawb + cur * raw_stride);
+    SSDE_W4_LO();
     if (st < 8) SSDE_TR(8 + st * 10 + 6);
     SSDE_WAIT_VMCNT(0);
     if (st < 8) SSDE_TR(8 + st * 10 + 7);
