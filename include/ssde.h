@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSDE_ABI_VERSION 3
+#define SSDE_ABI_VERSION 4   /* 4: SSDE_TILE_WINOGRAD4, SSDE_PACK_WINO4 (plans lowered with them need this library) */
 
 /* ---- prologue applied to a source tensor while it is staged into LDS ---- */
 enum {
