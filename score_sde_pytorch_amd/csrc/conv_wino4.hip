@@ -69,6 +69,9 @@ extern "C" int ssde_debug_w4_trace(void* buf) {
 #ifndef SSDE_W4_PRIO
 #define SSDE_W4_PRIO 1
 #endif
+#ifndef SSDE_W4_M0ONCE
+#define SSDE_W4_M0ONCE 0
+#endif
 #if SSDE_W4_PRIO
 #define SSDE_W4_HI() __builtin_amdgcn_s_setprio(2)
 #define SSDE_W4_LO() __builtin_amdgcn_s_setprio(0)
@@ -313,7 +316,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       float2 td[6], to[6];
       float2 af[SSDE_W4_PF + 1], bf[SSDE_W4_PF + 1];
       float* Un = Ub + nxt * kUFloats;
+#if SSDE_W4_M0ONCE
+      // M0 (the LDS base of the wave's run of pieces) is written with the first piece only
+#define SSDE_W4_WPIECE(K, IMM)                                                                          \
+      do {                                                                                               \
+        if (has1 && ((K) < 4 || wave < 4)) {                                                             \
+          if ((K) == 0) SSDE_GLDS16_OFF(dsrc, ddst, IMM);                                                \
+          else asm volatile("global_load_lds_dwordx4 %0, off offset:%1" : : "v"(dsrc), "n"(IMM) :);      \
+        }                                                                                                \
+      } while (0)
+#else
 #define SSDE_W4_WPIECE(K, IMM) do { if (has1 && ((K) < 4 || wave < 4)) SSDE_GLDS16_OFF(dsrc, ddst, IMM); } while (0)
+#endif
       const int dp0 = wave < 4 ? 5 * wave : 20 + 4 * (wave - 4);
       const float* dsrc = p.wpk + ((size_t)min(st + 1, nst - 1) * p.n_tiles + nt) * kUFloats + (dp0 + 2) * 256 + lane * 4;
       float* ddst = Un + (dp0 + 2) * 256;

@@ -82,6 +82,12 @@ def test_unet_forward_direct_kernel(monkeypatch):
     test_unet_forward_matches_reference_golden("unet_small_ncsnpp")
 
 
+@pytest.mark.parametrize("name", ["unet_small_ncsnpp", "unet_small_ffhq"])
+def test_unet_forward_winograd_f4x4_kernel(name, monkeypatch):
+    monkeypatch.setenv("SSDE_WINOGRAD", "4")
+    test_unet_forward_matches_reference_golden(name)
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_unet_forward_matches_reference_golden(name):
     from score_sde_pytorch_amd.models import utils as mutils

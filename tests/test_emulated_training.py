@@ -45,6 +45,12 @@ def test_whole_network_gradients(kind):
     T.check_unet_grads(kind, "cpu")
 
 
+def test_whole_network_gradients_winograd_f4x4(monkeypatch):
+    """forward and input-gradient convolutions on the F(4x4,3x3) kernel wherever it is legal"""
+    monkeypatch.setenv("SSDE_WINOGRAD", "4")
+    T.check_unet_grads("ncsnpp", "cpu")
+
+
 def test_autograd_bridge(monkeypatch):
     from score_sde_pytorch_amd.models import ncsnpp
     # the product refuses CPU tensors; under the emulator "device" memory IS host memory

@@ -44,6 +44,12 @@ def test_whole_network_gradients_cifar_ncsnpp():
     T.check_unet_grads("ncsnpp", "cuda", cfg=_util.cfgs.get_config("ve/cifar10_ncsnpp_continuous", dropout=0.0), batch=2)
 
 
+def test_whole_network_gradients_winograd_f4x4(monkeypatch):
+    """forward and input-gradient convolutions on the F(4x4,3x3) kernel wherever it is legal"""
+    monkeypatch.setenv("SSDE_WINOGRAD", "4")
+    T.check_unet_grads("ncsnpp", "cuda", batch=3)
+
+
 def test_autograd_bridge():
     T.check_autograd_bridge("cuda")
 

@@ -34,9 +34,10 @@ def _model(cfg):
 
 
 @pytest.mark.parametrize("name", ["unet_small_ncsnpp", "unet_small_ffhq", "unet_cifar_ncsnpp"])
-@pytest.mark.parametrize("mode", ["0", "1"])
+@pytest.mark.parametrize("mode", ["0", "1", "4"])
 def test_forward_direct_kernel_and_size_heuristic(name, mode, monkeypatch):
-    """SSDE_WINOGRAD=0: every 3x3 on the direct (bitwise fmaf-chain) kernel; =1: the production size heuristic"""
+    """SSDE_WINOGRAD=0: every 3x3 on the direct (bitwise fmaf-chain) kernel; =1: the production size heuristic; =4: the
+    F(4x4,3x3) kernel wherever it is legal (the suite's default is 2: F(2x2,3x3) wherever legal)"""
     monkeypatch.setenv("SSDE_WINOGRAD", mode)
     test_forward_matches_reference_golden(name)
 
