@@ -70,7 +70,7 @@ extern "C" int ssde_debug_w4_trace(void* buf) {
 #define SSDE_W4_PRIO 1
 #endif
 #ifndef SSDE_W4_M0ONCE
-#define SSDE_W4_M0ONCE 0
+#define SSDE_W4_M0ONCE 1
 #endif
 #if SSDE_W4_PRIO
 #define SSDE_W4_HI() __builtin_amdgcn_s_setprio(2)
