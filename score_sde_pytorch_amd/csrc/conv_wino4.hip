@@ -322,7 +322,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       do {                                                                                               \
         if (has1 && ((K) < 4 || wave < 4)) {                                                             \
           if ((K) == 0) SSDE_GLDS16_OFF(dsrc, ddst, IMM);                                                \
-          else asm volatile("global_load_lds_dwordx4 %0, off offset:%1" : : "v"(dsrc), "n"(IMM) :);      \
+          else SSDE_GLDS16_OFF_SAME_BASE(dsrc, ddst, IMM);                                               \
         }                                                                                                \
       } while (0)
 #else

@@ -68,6 +68,13 @@ static inline bool ssde_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
                :)
 #endif
 
+// The same piece with M0 left as the previous SSDE_GLDS16_OFF of this wave set it (same lds_wave_base, another immediate
+// offset): tests/test_isa_guards.py checks that nothing else in these kernels touches M0.
+#ifndef SSDE_GLDS16_OFF_SAME_BASE
+#define SSDE_GLDS16_OFF_SAME_BASE(gptr, lds_wave_base, imm) \
+  asm volatile("global_load_lds_dwordx4 %0, off offset:%1" : : "v"(gptr), "n"(imm) :)
+#endif
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which hipcc lowers
 // to s_waitcnt vmcnt(0) whenever an LDS-DMA (or any global load) is in flight: a full memory latency exposed at every
 // barrier.  This form waits for the wave's own LDS operations (lgkmcnt(0)), pins the compiler's ordering of memory
