@@ -121,6 +121,16 @@ __device__ __forceinline__ void bt6(const float2 (&d)[6], float2 (&o)[6]) {
   }
 }
 
+__device__ __forceinline__ void bt6(const ssde_f32x2 (&d)[6], ssde_f32x2 (&o)[6]) {
+  const ssde_f32x2 t1 = d[4] - 4.f * d[2], t2 = d[3] - 4.f * d[1], t3 = d[4] - d[2], t4 = d[3] - d[1];
+  o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+  o[1] = t1 + t2;
+  o[2] = t1 - t2;
+  o[3] = t3 + 2.f * t4;
+  o[4] = t3 - 2.f * t4;
+  o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+
 template <bool kGn>
 __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Params p) {
   SSDE_LDS(smem);
@@ -204,16 +214,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
   float4 rv[kMaxRaw];
   int c_cur = 0;
   // branch-free global loads of stage st (items outside the image read a clamped, valid address and are zeroed below)
-  const float* ld_bp = nullptr; int ld_C = 0;
+  const float* ld_bp = nullptr; bool ld_second = false;
   auto load_piece = [&](int st, int k) {
     if (k == 0) {
       const int c_base = st * 4;
       c_cur = c_base;
-      const bool second = c_base >= s.c0;
-      ld_bp = (second ? s.p1 : s.p0) + (second ? c_base - s.c0 : c_base);
-      ld_C = second ? s.c1 : s.c0;
+      ld_second = c_base >= s.c0;
+      ld_bp = (ld_second ? s.p1 : s.p0) + (ld_second ? c_base - s.c0 : c_base);
     }
-    rv[k] = *reinterpret_cast<const float4*>(ld_bp + (size_t)(goff[k] >= 0 ? goff[k] : 0) * ld_C);
+    rv[k] = *reinterpret_cast<const float4*>(ld_bp + (size_t)(goff[k] >= 0 ? goff[k] : 0) * (ld_second ? s.c1 : s.c0));
   };
   auto load_raw = [&](int st) {
 #pragma unroll
@@ -313,8 +322,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       // an MFMA only occupies the matrix pipe: the LDS round trips and the VMEM issue stalls pass while the wave's own
       // MFMAs execute.  One barrier per stage.
       const bool tl_ok = has1 && t_line < 6;
-      float2 td[6], to[6];
-      float2 af[SSDE_W4_PF + 1], bf[SSDE_W4_PF + 1];
+      ssde_f32x2 td[6], to[6];
+      ssde_lds_float* tw = (ssde_lds_float*)(Vn + t_line * kVP + t_vcol);            // pass-1 column of this lane
+      ssde_lds_float* vp = (ssde_lds_float*)(Vn + (t_line * 6) * kVP + t_vcol);      // pass-2 row of this lane
+      SSDE_OPAQUE_VGPR(tw);
+      SSDE_OPAQUE_VGPR(vp);
+      ssde_f32x2 af[SSDE_W4_PF + 1], bf[SSDE_W4_PF + 1];
       float* Un = Ub + nxt * kUFloats;
 #if SSDE_W4_M0ONCE
       // M0 (the LDS base of the wave's run of pieces) is written with the first piece only
@@ -331,24 +344,30 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       const int dp0 = wave < 4 ? 5 * wave : 20 + 4 * (wave - 4);
       const float* dsrc = p.wpk + ((size_t)min(st + 1, nst - 1) * p.n_tiles + nt) * kUFloats + (dp0 + 2) * 256 + lane * 4;
       float* ddst = Un + (dp0 + 2) * 256;
+      // one fragment base per operand, opaque to the compiler: the 9 positions are immediate offsets of the ds_read (left
+      // alone, hipcc kept a VGPR and a 3-operand add per position and operand: 18 VALU per stage and 16 registers)
+      ssde_lds_cfloat* va = (ssde_lds_cfloat*)(Vc + wq * kVP + a_off);
+      ssde_lds_cfloat* ua = (ssde_lds_cfloat*)(Uc + wq * (64 * 4) + b_off);
+      SSDE_OPAQUE_VGPR(va);
+      SSDE_OPAQUE_VGPR(ua);
 #pragma unroll
       for (int j = 0; j < SSDE_W4_PF; ++j) {
-        af[j] = *reinterpret_cast<const float2*>(Vc + (wq + 4 * j) * kVP + a_off);
-        bf[j] = *reinterpret_cast<const float2*>(Uc + (wq + 4 * j) * (64 * 4) + b_off);
+        af[j] = *(ssde_lds_cfloat2*)(va + 4 * j * kVP);
+        bf[j] = *(ssde_lds_cfloat2*)(ua + 4 * j * (64 * 4));
       }
       if (tl_ok) {
         const float* rp = rawb + nxt * raw_stride + (t_pair * halo_px + t_base + t_line) * 2;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) td[a] = *reinterpret_cast<const float2*>(rp + a * HWd * 2);
+        for (int a = 0; a < 6; ++a) { const float2 q = *reinterpret_cast<const float2*>(rp + a * HWd * 2); td[a].x = q.x; td[a].y = q.y; }
       }
       __builtin_amdgcn_sched_barrier(0);
 #define SSDE_W4_POS(J)                                                                                          \
       do {                                                                                                         \
         if ((J) + SSDE_W4_PF < 9) {                                                                                \
           af[((J) + SSDE_W4_PF) % (SSDE_W4_PF + 1)] =                                                              \
-              *reinterpret_cast<const float2*>(Vc + (wq + 4 * ((J) + SSDE_W4_PF)) * kVP + a_off);                  \
+              *(ssde_lds_cfloat2*)(va + 4 * ((J) + SSDE_W4_PF) * kVP);                                             \
           bf[((J) + SSDE_W4_PF) % (SSDE_W4_PF + 1)] =                                                              \
-              *reinterpret_cast<const float2*>(Uc + (wq + 4 * ((J) + SSDE_W4_PF)) * (64 * 4) + b_off);             \
+              *(ssde_lds_cfloat2*)(ua + 4 * ((J) + SSDE_W4_PF) * (64 * 4));                                        \
         }                                                                                                          \
         acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(J) % (SSDE_W4_PF + 1)].x, bf[(J) % (SSDE_W4_PF + 1)].x, acc[J], 0, 0, 0); \
         acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(J) % (SSDE_W4_PF + 1)].y, bf[(J) % (SSDE_W4_PF + 1)].y, acc[J], 0, 0, 0); \
@@ -366,7 +385,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
         SSDE_W4_HI();
         bt6(td, to);
 #pragma unroll
-        for (int a = 0; a < 6; ++a) *reinterpret_cast<float2*>(Vn + (a * 6 + t_line) * kVP + t_vcol) = to[a];
+        for (int a = 0; a < 6; ++a) *(ssde_lds_float2*)(tw + a * 6 * kVP) = to[a];
         SSDE_W4_LO();
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -376,10 +395,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       SSDE_W4_POS(3);
       SSDE_W4_WPIECE(3, 1024);
       __builtin_amdgcn_sched_barrier(0);
-      float* vp = Vn + (t_line * 6) * kVP + t_vcol;
       if (tl_ok) {
 #pragma unroll
-        for (int b = 0; b < 6; ++b) td[b] = *reinterpret_cast<const float2*>(vp + b * kVP);
+        for (int b = 0; b < 6; ++b) td[b] = *(ssde_lds_float2*)(vp + b * kVP);
       }
       __builtin_amdgcn_sched_barrier(0);
       SSDE_W4_POS(4);
@@ -390,7 +408,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
         SSDE_W4_HI();
         bt6(td, to);
 #pragma unroll
-        for (int b = 0; b < 6; ++b) *reinterpret_cast<float2*>(vp + b * kVP) = to[b];
+        for (int b = 0; b < 6; ++b) *(ssde_lds_float2*)(vp + b * kVP) = to[b];
         SSDE_W4_LO();
       }
       __builtin_amdgcn_sched_barrier(0);

@@ -75,6 +75,17 @@ static inline bool ssde_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
   asm volatile("global_load_lds_dwordx4 %0, off offset:%1" : : "v"(gptr), "n"(imm) :)
 #endif
 
+// An LDS address the compiler must treat as one opaque 32-bit register (so that constant distances from it become the
+// immediate offsets of ds_read / ds_write instead of one address register and one add per access).
+typedef __attribute__((address_space(3))) const float ssde_lds_cfloat;
+typedef float ssde_f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const ssde_f32x2 ssde_lds_cfloat2;
+typedef __attribute__((address_space(3))) float ssde_lds_float;
+typedef __attribute__((address_space(3))) ssde_f32x2 ssde_lds_float2;
+#ifndef SSDE_OPAQUE_VGPR
+#define SSDE_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
+#endif
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, which hipcc lowers
 // to s_waitcnt vmcnt(0) whenever an LDS-DMA (or any global load) is in flight: a full memory latency exposed at every
 // barrier.  This form waits for the wave's own LDS operations (lgkmcnt(0)), pins the compiler's ordering of memory
@@ -138,7 +149,7 @@ __device__ __forceinline__ float4 ssde_pro_apply(float4 v, float mu, float rs, c
     v.w = (v.w - mu) * rs * gam.w + bet.w;
   }
   if (p.silu) { v.x = ssde_silu(v.x); v.y = ssde_silu(v.y); v.z = ssde_silu(v.z); v.w = ssde_silu(v.w); }
-  if (p.drop) {
+  if (__builtin_expect(p.drop, 0)) {      // unlikely: keeps the hash out of the staging loops of inference launches
     v.x *= ssde_keep(elem0, p); v.y *= ssde_keep(elem0 + 1u, p);
     v.z *= ssde_keep(elem0 + 2u, p); v.w *= ssde_keep(elem0 + 3u, p);
   }
