@@ -149,7 +149,9 @@ __device__ __forceinline__ float4 ssde_pro_apply(float4 v, float mu, float rs, c
     v.w = (v.w - mu) * rs * gam.w + bet.w;
   }
   if (p.silu) { v.x = ssde_silu(v.x); v.y = ssde_silu(v.y); v.z = ssde_silu(v.z); v.w = ssde_silu(v.w); }
-  if (__builtin_expect(p.drop, 0)) {      // unlikely: keeps the hash out of the staging loops of inference launches
+  // unlikely: the four hashes stay behind a wave-uniform branch, out of line of the inference staging loops (a version
+  // with two separate template instantiations behind the branch cost conv_wino.hip 2-5 %, profiles/r2_ab_prologue_split.txt)
+  if (__builtin_expect(p.drop, 0)) {
     v.x *= ssde_keep(elem0, p); v.y *= ssde_keep(elem0 + 1u, p);
     v.z *= ssde_keep(elem0 + 2u, p); v.w *= ssde_keep(elem0 + 3u, p);
   }

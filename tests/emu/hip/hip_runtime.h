@@ -148,6 +148,7 @@ static inline void emu_global_load_lds(const void* g, __attribute__((address_spa
 // the product issues the copy through inline assembly (ssde_common.h); the emulator substitutes its model of the instruction
 #define SSDE_GLDS16_OFF(gptr, lds_wave_base, imm) emu_global_load_lds((const void*)(gptr), (__attribute__((address_space(3))) void*)(lds_wave_base), 16, (imm))
 #define SSDE_OPAQUE_VGPR(x) ((void)0)
+#define __builtin_amdgcn_readfirstlane(x) (x)      /* only used on wave-uniform values */
 #define SSDE_GLDS16_OFF_SAME_BASE(gptr, lds_wave_base, imm) SSDE_GLDS16_OFF(gptr, lds_wave_base, imm)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
