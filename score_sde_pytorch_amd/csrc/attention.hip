@@ -27,7 +27,8 @@ constexpr int kLDC = 36;         // channel-chunk row stride (32 + 4)
 constexpr int kLDP = 260;        // score / V row stride (256 + 4)
 constexpr int kTileFloats = kQB * kLDP;                 // the 64 x L tile
 constexpr int kStageFloats = (kQB + kLMax) * kLDC;      // Q/K chunk staging (phase 1); >= 32 * kLDP (phase 3)
-constexpr int kAttnLdsFloats = kQB * kLDP + 32 * kLDP;  // forward: staging aliases the tile in phase 1
+constexpr int kFwdVch = 8;                              // V tokens per chunk of the forward kernel
+constexpr int kAttnLdsFloats = kQB * kLDP + kFwdVch * kLDP;  // forward: Q/K staging aliases the tile in phase 1; 75 KB: two workgroups per CU
 constexpr int kBwdLdsFloats = kTileFloats + kStageFloats + 3 * kLMax;
 
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
@@ -99,6 +100,9 @@ __device__ __forceinline__ void gemm_nt(const float* __restrict__ A, int a_valid
 }
 
 // out[64 x C] = out_scale * Ps[64 x Lp] * Bm[L x C]   (Bm token-major rows, row stride ldb, rows >= b_valid zero)
+// VCH = tokens of V staged per chunk (a multiple of 8): 32 in the backward kernels; 8 in the forward kernel, whose LDS
+// footprint (64 x 260 score tile + the chunk) then lets two workgroups share a CU.
+template <int VCH = 32>
 __device__ __forceinline__ void gemm_pv(const float* Ps, int Lp, const float* __restrict__ Bm, int b_valid, size_t ldb, int C,
                                         float* Vs, float* __restrict__ out, size_t ldo, int out_valid, float out_scale) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -108,39 +112,40 @@ __device__ __forceinline__ void gemm_pv(const float* Ps, int Lp, const float* __
     const int Cw = min(256, C - cp);
     const int cb = wave * 64;
     zero_acc(acc);
-    // 32-token chunk of V: up to 8 float4 per thread, prefetched into registers during the MFMAs of the previous chunk
+    // VCH-token chunk of V: up to VCH / 4 float4 per thread, prefetched into registers during the MFMAs of the previous chunk
+    constexpr int NIT = VCH / 4;
     const int f4n = Cw >> 2;
-    int vrow[8], vf[8];
+    int vrow[NIT], vf[NIT];
     {
       int row = tid / f4n, ff = tid - row * f4n;
       const int dr = 256 / f4n, df = 256 - dr * f4n;
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
+      for (int it = 0; it < NIT; ++it) {
         vrow[it] = row; vf[it] = ff;
         row += dr; ff += df;
         if (ff >= f4n) { ff -= f4n; ++row; }
       }
     }
-    float4 rv[8];
+    float4 rv[NIT];
     auto load_chunk = [&](int k0) {
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
+      for (int it = 0; it < NIT; ++it) {
         const int tok = k0 + vrow[it];
         const float4 v = *reinterpret_cast<const float4*>(Bm + (size_t)max(min(tok, b_valid - 1), 0) * ldb + cp + vf[it] * 4);
-        rv[it] = (vrow[it] < 32 && tok < b_valid) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        rv[it] = (vrow[it] < VCH && tok < b_valid) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     };
     load_chunk(0);
-    for (int k0 = 0; k0 < Lp; k0 += 32) {
+    for (int k0 = 0; k0 < Lp; k0 += VCH) {
       __syncthreads();
 #pragma unroll
-      for (int it = 0; it < 8; ++it)
-        if (vrow[it] < 32) *reinterpret_cast<float4*>(Vs + vrow[it] * kLDP + vf[it] * 4) = rv[it];
+      for (int it = 0; it < NIT; ++it)
+        if (vrow[it] < VCH) *reinterpret_cast<float4*>(Vs + vrow[it] * kLDP + vf[it] * 4) = rv[it];
       __syncthreads();
-      if (k0 + 32 < Lp) load_chunk(k0 + 32);
+      if (k0 + VCH < Lp) load_chunk(k0 + VCH);
       if (cb < Cw) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < VCH / 8; ++kk) {
           float4 af[2];
           float bf[2][4];
 #pragma unroll
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
   float* Qs = smem;                       // [64][36]
   float* Ks = smem + kQB * kLDC;          // [256][36]
   float* Ps = smem;                       // [64][260]   (after step 1)
-  float* Vs = smem + kQB * kLDP;          // [32][260]
+  float* Vs = smem + kQB * kLDP;          // [kFwdVch][260]
   const int n = blockIdx.y, q0 = blockIdx.x * kQB;
   const int C3 = 3 * C;
   const float* base = qkv + (size_t)n * L * C3;
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
   __syncthreads();
   float m, l;
   softmax_rows(Ps, L, &m, &l);
-  gemm_pv(Ps, Lp, base + 2 * C, L, C3, C, Vs, dst + ((size_t)n * L + q0) * C, C, L - q0, 1.0f);
+  gemm_pv<kFwdVch>(Ps, Lp, base + 2 * C, L, C3, C, Vs, dst + ((size_t)n * L + q0) * C, C, L - q0, 1.0f);
 }
 
 // ---- backward A: dQ (and the per-row softmax statistics + D for kernel B) ----
