@@ -624,7 +624,9 @@ class Lowering:
         n_tiles = -(-c_out // 64)
         if mode != "3" and legal4 and h >= 16 and w >= 16 and -(-(self.n * h * w) // 512) * n_tiles >= 256:
             return 4
-        return 2 if legal2 and -(-(self.n * h * w) // 256) * n_tiles >= 192 else 0
+        # tools/heuristic_sweep.py (profiles/r2_heuristic_sweep.txt): F(4x4,3x3) wins from 256 of its workgroups, F(2x2,3x3)
+        # over the direct kernel from 128 of its own (by 2-6 %; at 64 the direct kernel is 1.5x faster)
+        return 2 if legal2 and -(-(self.n * h * w) // 256) * n_tiles >= 128 else 0
 
     def upfirdn(self, src, n_ch, h_in, w_in, taps, up=1, down=1, pad=(0, 0), name="fir"):
         kh, kw = taps.shape
