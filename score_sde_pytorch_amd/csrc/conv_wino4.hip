@@ -85,7 +85,16 @@ namespace {
 
 constexpr int kThreads = 512;
 constexpr int kPos = 36, kTiles = 32, kKc = 4;
-constexpr int kVP = kTiles * kKc + 16;               // floats per position of V: 128 + 16, so that the 6 lines x 8 items of a
+// LDS paddings, A/B-timed (profiles/r2_wino4_ab_lds_padding.txt): a V pitch of 128 + 24 (second transform pass free of bank
+// conflicts instead of the first) and raw channel-pair planes 32 banks apart are both neutral: 35 % of the LDS cycles are
+// bank conflicts (PMC), but the LDS is active only a third of the time
+#ifndef SSDE_W4_VPAD
+#define SSDE_W4_VPAD 16
+#endif
+#ifndef SSDE_W4_RAWPAD
+#define SSDE_W4_RAWPAD 0
+#endif
+constexpr int kVP = kTiles * kKc + SSDE_W4_VPAD;               // floats per position of V: 128 + 16, so that the 6 lines x 8 items of a
                                                     // wave's transform writes (b64) spread over all banks
 constexpr int kVFloats = kPos * kVP;                // one V stage
 constexpr int kUFloats = kPos * 64 * kKc;           // 9216: one U stage
@@ -156,7 +165,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
   const int IMGS = kTiles >> (p.lTWt + p.lTHt);
   const int HWd = 4 * TWt + 2, HH = 4 * THt + 2;
   const int halo_px = IMGS * HH * HWd;
-  const int raw_stride = 4 * halo_px;          // floats per raw buffer
+  // floats between the two channel-pair planes of a raw buffer: with SSDE_W4_RAWPAD the planes are 32 banks apart (the 48
+  // lanes of a transform read touch 4 tiles x 6 columns of BOTH planes; columns shared by neighbouring tiles are the same
+  // address, but planes 8 banks apart collided)
+  const int raw_plane = SSDE_W4_RAWPAD ? ((2 * halo_px + 63) & ~63) + 32 : 2 * halo_px;
+  const int raw_stride = 2 * raw_plane;        // floats per raw buffer
   const int img0 = (mt / p.tiles_per_img) * IMGS;
   const int trem = mt % p.tiles_per_img;
   const int ty = trem / p.tiles_x, tx = trem % p.tiles_x;
@@ -247,13 +260,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
         v = ssde_pro_apply(rv[it], mu, rs, gam, bet, (uint32_t)goff[it] * (uint32_t)Ctot + (uint32_t)c_cur, pro);
       const int q = tid + it * kThreads;
       *reinterpret_cast<float2*>(rw + q * 2) = make_float2(v.x, v.y);
-      *reinterpret_cast<float2*>(rw + (halo_px + q) * 2) = make_float2(v.z, v.w);
+      *reinterpret_cast<float2*>(rw + raw_plane + q * 2) = make_float2(v.z, v.w);
     }
   };
   // B^T d B in two 1-D passes over the 6x6 tile, the second in place: pass 1 thread = (column x), pass 2 thread = (row y)
   auto pass1 = [&](const float* rw, float* Vn) {
     if (t_line < 6) {
-      const float* rp = rw + (t_pair * halo_px + t_base + t_line) * 2;
+      const float* rp = rw + t_pair * raw_plane + (t_base + t_line) * 2;
       float2 d[6], o[6];
 #pragma unroll
       for (int a = 0; a < 6; ++a) d[a] = *reinterpret_cast<const float2*>(rp + a * HWd * 2);
@@ -356,7 +369,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
         bf[j] = *(ssde_lds_cfloat2*)(ua + 4 * j * (64 * 4));
       }
       if (tl_ok) {
-        const float* rp = rawb + nxt * raw_stride + (t_pair * halo_px + t_base + t_line) * 2;
+        const float* rp = rawb + nxt * raw_stride + t_pair * raw_plane + (t_base + t_line) * 2;
 #pragma unroll
         for (int a = 0; a < 6; ++a) { const float2 q = *reinterpret_cast<const float2*>(rp + a * HWd * 2); td[a].x = q.x; td[a].y = q.y; }
       }
@@ -561,7 +574,8 @@ int ssde_conv_wino4_launch(const ssde_conv_args* a, void* stream, int* lds_out) 
   }
   const int halo_px = imgs * (4 * tht + 2) * (4 * twt + 2);
   SSDE_REQUIRE(halo_px <= kMaxRaw * kThreads, "conv(winograd 4x4): halo of %d pixels exceeds the staging plan", halo_px);
-  int lds = (2 * kVFloats + 2 * kUFloats + 2 * 4 * halo_px) * 4;
+  const int raw_plane = SSDE_W4_RAWPAD ? ((2 * halo_px + 63) & ~63) + 32 : 2 * halo_px;
+  int lds = (2 * kVFloats + 2 * kUFloats + 2 * 2 * raw_plane) * 4;
   if (gn) lds += (2 * imgs * s.gn_groups + 2 * (s.c0 + s.c1)) * 4;
   const int lds_epi = kPos * 16 * kLdm * 4;
   if (lds < lds_epi) lds = lds_epi;
