@@ -83,7 +83,18 @@ extern "C" int ssde_debug_w4_trace(void* buf) {
 
 namespace {
 
-constexpr int kThreads = 512;
+// waves per workgroup: 8 (two per SIMD, 9 positions x one 32x32 block = 144 accumulator registers each) or 12 (three per
+// SIMD, 6 positions = 96 accumulators, 168 registers per lane).  12 is correct and 11-25 % SLOWER
+// (profiles/r2_wino4_ab_12_waves.txt): the stalls of this kernel are not latencies a third wave would cover, and the
+// output transform spills at 168 registers
+#ifndef SSDE_W4_WAVES
+#define SSDE_W4_WAVES 8
+#endif
+constexpr int kWaves = SSDE_W4_WAVES;
+constexpr int kThreads = kWaves * 64;
+constexpr int kNP = 72 / kWaves;                   // positions per wave
+constexpr int kPS = kWaves / 2;                    // wave (q, h) owns positions q + kPS * j
+constexpr int kEpiThreads = 512;                   // threads of the output transform and of the shared epilogue
 constexpr int kPos = 36, kTiles = 32, kKc = 4;
 // LDS paddings, A/B-timed (profiles/r2_wino4_ab_lds_padding.txt): a V pitch of 128 + 24 (second transform pass free of bank
 // conflicts instead of the first) and raw channel-pair planes 32 banks apart are both neutral: 35 % of the LDS cycles are
@@ -141,7 +152,7 @@ __device__ __forceinline__ void bt6(const ssde_f32x2 (&d)[6], ssde_f32x2 (&o)[6]
 }
 
 template <bool kGn>
-__global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Params p) {
+__global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const Wino4Params p) {
   SSDE_LDS(smem);
   float* Vb = smem;                            // [2][kVFloats]
   float* Ub = smem + 2 * kVFloats;             // [2][kUFloats]
@@ -203,7 +214,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
   // ---- transform plan: a wave owns 8 of the 64 items (tile, channel pair) with all their 6 lines: lane = line * 8 + item
   // (48 lanes), so that pass 2 reads what the SAME wave wrote in pass 1 -- LDS executes a wave's operations in order, and
   // no workgroup barrier is needed between the passes ----
-  const int t_line = lane >> 3, t_tile = (wave * 8 + (lane & 7)) >> 1, t_pair = lane & 1;
+#if SSDE_W4_WAVES == 8
+  const int t_items = 8, t_item0 = wave * 8;
+#else
+  const int t_items = wave < 4 ? 6 : 5, t_item0 = wave < 4 ? 6 * wave : 24 + 5 * (wave - 4);     // 4 x 6 + 8 x 5 = 64 items
+#endif
+  const int t_line = lane >> 3, t_item = t_item0 + (lane & 7);
+  const bool t_ok = t_line < 6 && (lane & 7) < t_items;
+  const int t_tile = (t_ok ? t_item : 0) >> 1, t_pair = (t_ok ? t_item : 0) & 1;
   int t_base;
   {
     const int il = t_tile >> (p.lTWt + p.lTHt);
@@ -265,7 +283,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
   };
   // B^T d B in two 1-D passes over the 6x6 tile, the second in place: pass 1 thread = (column x), pass 2 thread = (row y)
   auto pass1 = [&](const float* rw, float* Vn) {
-    if (t_line < 6) {
+    if (t_ok) {
       const float* rp = rw + t_pair * raw_plane + (t_base + t_line) * 2;
       float2 d[6], o[6];
 #pragma unroll
@@ -276,7 +294,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
     }
   };
   auto pass2 = [&](float* Vn) {
-    if (t_line < 6) {
+    if (t_ok) {
       float* vp = Vn + (t_line * 6) * kVP + t_vcol;
       float2 d[6], o[6];
 #pragma unroll
@@ -289,6 +307,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
   // weights of stage st: the host packed them as the LDS image (36 KB per stage), moved by LDS-DMA: a contiguous run of
   // 5 (waves 0-3) or 4 pieces of 1 KB per wave, one base and immediate offsets -2048 .. +2048
   auto dma_weights = [&](int st, float* Un) {
+#if SSDE_W4_WAVES == 8
     const int p0 = wave < 4 ? 5 * wave : 20 + 4 * (wave - 4);
     const float* gsrc = p.wpk + ((size_t)st * p.n_tiles + nt) * kUFloats + (p0 + 2) * 256 + lane * 4;
     float* ldst = Un + (p0 + 2) * 256;
@@ -297,12 +316,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
     SSDE_GLDS16_OFF(gsrc, ldst, 0);
     SSDE_GLDS16_OFF(gsrc, ldst, 1024);
     if (wave < 4) SSDE_GLDS16_OFF(gsrc, ldst, 2048);
+#else
+    const float* gsrc = p.wpk + ((size_t)st * p.n_tiles + nt) * kUFloats + (3 * wave + 1) * 256 + lane * 4;
+    float* ldst = Un + (3 * wave + 1) * 256;
+    SSDE_GLDS16_OFF(gsrc, ldst, -1024);
+    SSDE_GLDS16_OFF(gsrc, ldst, 0);
+    SSDE_GLDS16_OFF(gsrc, ldst, 1024);
+#endif
   };
 
   const int wq = wave >> 1, wh = wave & 1;      // this wave's positions wq + 4 j and its 32-cout half
-  f32x16 acc[9];
+  f32x16 acc[kNP];
 #pragma unroll
-  for (int j = 0; j < 9; ++j)
+  for (int j = 0; j < kNP; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   const int a_off = li * 4 + 2 * lh, b_off = (wh * 32 + li) * 4 + 2 * lh;
@@ -334,7 +360,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       // the transform plan) | positions 4,5 | pass-2 arithmetic and writes | positions 6-8.  A wave issues in order, and
       // an MFMA only occupies the matrix pipe: the LDS round trips and the VMEM issue stalls pass while the wave's own
       // MFMAs execute.  One barrier per stage.
-      const bool tl_ok = has1 && t_line < 6;
+      const bool tl_ok = has1 && t_ok;
       ssde_f32x2 td[6], to[6];
       ssde_lds_float* tw = (ssde_lds_float*)(Vn + t_line * kVP + t_vcol);            // pass-1 column of this lane
       ssde_lds_float* vp = (ssde_lds_float*)(Vn + (t_line * 6) * kVP + t_vcol);      // pass-2 row of this lane
@@ -346,17 +372,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       // M0 (the LDS base of the wave's run of pieces) is written with the first piece only
 #define SSDE_W4_WPIECE(K, IMM)                                                                          \
       do {                                                                                               \
-        if (has1 && ((K) < 4 || wave < 4)) {                                                             \
+        if (has1 && ((K) < kPieces - 1 || wave < 4 || kWaves == 12)) {                                    \
           if ((K) == 0) SSDE_GLDS16_OFF(dsrc, ddst, IMM);                                                \
           else SSDE_GLDS16_OFF_SAME_BASE(dsrc, ddst, IMM);                                               \
         }                                                                                                \
       } while (0)
 #else
-#define SSDE_W4_WPIECE(K, IMM) do { if (has1 && ((K) < 4 || wave < 4)) SSDE_GLDS16_OFF(dsrc, ddst, IMM); } while (0)
+#define SSDE_W4_WPIECE(K, IMM) do { if (has1 && ((K) < kPieces - 1 || wave < 4 || kWaves == 12)) SSDE_GLDS16_OFF(dsrc, ddst, IMM); } while (0)
 #endif
-      const int dp0 = wave < 4 ? 5 * wave : 20 + 4 * (wave - 4);
-      const float* dsrc = p.wpk + ((size_t)min(st + 1, nst - 1) * p.n_tiles + nt) * kUFloats + (dp0 + 2) * 256 + lane * 4;
-      float* ddst = Un + (dp0 + 2) * 256;
+      constexpr int kPieces = kWaves == 8 ? 5 : 3;           // weight pieces per wave (8 waves: 4 for waves 4-7)
+      const int dp0 = kWaves == 8 ? (wave < 4 ? 5 * wave : 20 + 4 * (wave - 4)) : 3 * wave;
+      constexpr int kMid = kWaves == 8 ? 2 : 1;              // the piece the immediate offsets are relative to
+      const float* dsrc = p.wpk + ((size_t)min(st + 1, nst - 1) * p.n_tiles + nt) * kUFloats + (dp0 + kMid) * 256 + lane * 4;
+      float* ddst = Un + (dp0 + kMid) * 256;
       // one fragment base per operand, opaque to the compiler: the 9 positions are immediate offsets of the ds_read (left
       // alone, hipcc kept a VGPR and a 3-operand add per position and operand: 18 VALU per stage and 16 registers)
       ssde_lds_cfloat* va = (ssde_lds_cfloat*)(Vc + wq * kVP + a_off);
@@ -365,8 +393,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       SSDE_OPAQUE_VGPR(ua);
 #pragma unroll
       for (int j = 0; j < SSDE_W4_PF; ++j) {
-        af[j] = *(ssde_lds_cfloat2*)(va + 4 * j * kVP);
-        bf[j] = *(ssde_lds_cfloat2*)(ua + 4 * j * (64 * 4));
+        af[j] = *(ssde_lds_cfloat2*)(va + kPS * j * kVP);
+        bf[j] = *(ssde_lds_cfloat2*)(ua + kPS * j * (64 * 4));
       }
       if (tl_ok) {
         const float* rp = rawb + nxt * raw_stride + t_pair * raw_plane + (t_base + t_line) * 2;
@@ -376,16 +404,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       __builtin_amdgcn_sched_barrier(0);
 #define SSDE_W4_POS(J)                                                                                          \
       do {                                                                                                         \
-        if ((J) + SSDE_W4_PF < 9) {                                                                                \
+        if ((J) + SSDE_W4_PF < kNP) {                                                                                \
           af[((J) + SSDE_W4_PF) % (SSDE_W4_PF + 1)] =                                                              \
-              *(ssde_lds_cfloat2*)(va + 4 * ((J) + SSDE_W4_PF) * kVP);                                             \
+              *(ssde_lds_cfloat2*)(va + kPS * ((J) + SSDE_W4_PF) * kVP);                                           \
           bf[((J) + SSDE_W4_PF) % (SSDE_W4_PF + 1)] =                                                              \
-              *(ssde_lds_cfloat2*)(ua + 4 * ((J) + SSDE_W4_PF) * (64 * 4));                                        \
+              *(ssde_lds_cfloat2*)(ua + kPS * ((J) + SSDE_W4_PF) * (64 * 4));                                      \
         }                                                                                                          \
         acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(J) % (SSDE_W4_PF + 1)].x, bf[(J) % (SSDE_W4_PF + 1)].x, acc[J], 0, 0, 0); \
         acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(J) % (SSDE_W4_PF + 1)].y, bf[(J) % (SSDE_W4_PF + 1)].y, acc[J], 0, 0, 0); \
         __builtin_amdgcn_sched_barrier(0);                                                                         \
       } while (0)
+#if SSDE_W4_WAVES == 8
       SSDE_W4_POS(0);
       if (has2) load_piece(st + 2, 0);
       SSDE_W4_WPIECE(0, -2048);
@@ -428,6 +457,43 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
       SSDE_W4_POS(6);
       SSDE_W4_POS(7);
       SSDE_W4_POS(8);
+#else
+      SSDE_W4_POS(0);
+      if (has2) load_piece(st + 2, 0);
+      SSDE_W4_WPIECE(0, -1024);
+      __builtin_amdgcn_sched_barrier(0);
+      SSDE_W4_POS(1);
+      if (has2) load_piece(st + 2, 1);
+      SSDE_W4_WPIECE(1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tl_ok) {
+        SSDE_W4_HI();
+        bt6(td, to);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) *(ssde_lds_float2*)(tw + a * 6 * kVP) = to[a];
+        SSDE_W4_LO();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      SSDE_W4_POS(2);
+      SSDE_W4_WPIECE(2, 1024);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tl_ok) {
+#pragma unroll
+        for (int b = 0; b < 6; ++b) td[b] = *(ssde_lds_float2*)(vp + b * kVP);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      SSDE_W4_POS(3);
+      if (tl_ok) {
+        SSDE_W4_HI();
+        bt6(td, to);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) *(ssde_lds_float2*)(vp + b * kVP) = to[b];
+        SSDE_W4_LO();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      SSDE_W4_POS(4);
+      SSDE_W4_POS(5);
+#endif
 #undef SSDE_W4_POS
 #undef SSDE_W4_WPIECE
       if (st < 8) SSDE_TR(8 + st * 10 + 5);
@@ -454,17 +520,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
   // round holds IMGS / 2 whole images (IMGS >= 2: 16 / (tiles per image) images per round)
   const int gn_base = !p.gn_part ? -1 : (IMGS == 1 ? (img0 * p.tiles_per_img + trem) * 2 : img0);
   const int rpi_log2 = IMGS > 2 ? 8 - (4 - p.lTWt - p.lTHt) : 30;             // rows per image in a round: 256 / (IMGS / 2)
-  const int e_tl = tid >> 5, e_cp = tid & 31;
+  const bool e_on = tid < kEpiThreads;                                       // waves 8-11 (if any) only hand over products
+  const int e_tl = e_on ? tid >> 5 : 0, e_cp = tid & 31;
   float* park = smem;                                                         // [256][kLdt], aliases the products
 #pragma unroll
   for (int rnd = 0; rnd < 2; ++rnd) {
 #pragma unroll
-    for (int j = 0; j < 9; ++j)
+    for (int j = 0; j < kNP; ++j)
 #pragma unroll
       for (int r8 = 0; r8 < 8; ++r8) {
         const int r = rnd * 8 + r8;
         const int tl = (r & 3) + 4 * lh + 8 * ((r >> 2) & 1);
-        smem[((wq + 4 * j) * 16 + tl) * kLdm + wh * 32 + li] = acc[j][r];
+        smem[((wq + kPS * j) * 16 + tl) * kLdm + wh * 32 + li] = acc[j][r];
       }
     if (rnd == 0) SSDE_TR(100);
     __syncthreads();
@@ -503,16 +570,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4_kernel(const Wino4Para
     if (rnd == 0) SSDE_TR(102);
     __syncthreads();                           // every thread has read its products: the parked tile may overwrite them
     if (rnd == 0) SSDE_TR(103);
+    if (e_on) {
 #pragma unroll
-    for (int dy = 0; dy < 4; ++dy)
+      for (int dy = 0; dy < 4; ++dy)
 #pragma unroll
-      for (int dx = 0; dx < 4; ++dx)
-        *reinterpret_cast<float2*>(park + (e_tl * 16 + dy * 4 + dx) * kLdt + 2 * e_cp) = y[dy][dx];
+        for (int dx = 0; dx < 4; ++dx)
+          *reinterpret_cast<float2*>(park + (e_tl * 16 + dy * 4 + dx) * kLdt + 2 * e_cp) = y[dy][dx];
+    }
     if (rnd == 0) SSDE_TR(104);
     __syncthreads();
     if (rnd == 0) SSDE_TR(105);
     const int gn_entry = gn_base < 0 ? -1 : (IMGS == 1 ? gn_base + rnd : gn_base + rnd * (IMGS >> 1));
-    ssde_store_tile<256, 64, kThreads, 4, 0>(park, kLdt, n0, e, [&](int row, size_t& pix, int& img) {
+    if (tid < kEpiThreads) ssde_store_tile<256, 64, kEpiThreads, 4, 0>(park, kLdt, n0, e, [&](int row, size_t& pix, int& img) {
       const int tile = rnd * 16 + (row >> 4), dy = (row >> 2) & 3, dx = row & 3;
       const int il = tile >> (p.lTWt + p.lTHt);
       const int tr = (tile >> p.lTWt) & (THt - 1), tc = tile & (TWt - 1);
@@ -569,7 +638,7 @@ int ssde_conv_wino4_launch(const ssde_conv_args* a, void* stream, int* lds_out) 
   const bool gn_ok = a->c_out % 4 == 0 && (imgs == 1 || (p.tiles_per_img == 1 && imgs <= 8));
   SSDE_REQUIRE(!a->gn_part || gn_ok, "conv(winograd 4x4): GroupNorm partials not available for this tiling");
   if (lds_out && stream == reinterpret_cast<void*>(1)) {
-    *lds_out = gn_ok ? (imgs == 1 ? 2 * p.tiles_per_img : 1) * (kThreads / 64) : 0;
+    *lds_out = gn_ok ? (imgs == 1 ? 2 * p.tiles_per_img : 1) * (kEpiThreads / 64) : 0;
     return SSDE_OK;
   }
   const int halo_px = imgs * (4 * tht + 2) * (4 * twt + 2);
