@@ -37,7 +37,8 @@
 //   v4  this file: one barrier per stage (wave-local transform items), fragment reads 3 positions ahead: 223-277 TF/s,
 //       19-26 % over conv_wino.hip from 16x16 maps up; v5 (waves 4-7 stage BEFORE their MFMAs, waves 0-3 after) was 3 %
 //       slower; the weights through registers (global_load_dwordx4 + ds_write_b128) instead of LDS-DMA: 123-141 TF/s;
-//       the halo as 32 bytes per pixel every second stage instead of 16 every stage: 183-222 TF/s
+//       the halo as 32 bytes per pixel every second stage instead of 16 every stage: 183-222 TF/s; all weight pieces of
+//       a wave issued with its first two positions instead of one per position: 5 % slower
 // rocprofv3 counters at 128 -> 128 channels, 32x32 (tools/w4_pmc.sh): matrix pipe 39 % busy (conv_wino.hip: 58 %, on
 // 1.78x more matrix work), waves 30 % parked (waitcnt / barrier), 41 % issue-stalled, VALU 14 %, LDS active 34 % of the
 // time with 35 % of it bank conflicts.
