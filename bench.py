@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: PC-sampler throughput of NCSN++ cont. VE-SDE on CIFAR-10 (BASELINE configs[1]).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under the line below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -473,6 +473,24 @@ def cpu_baseline(args, cfg, model, sd, R, N):
     return out
 
 
+def _self_launch(n):
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print("bench.py: --gpus %d but only %d GPU(s) are visible" % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] self-launch: %s" % " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 _T0 = time.perf_counter()
 
 
@@ -486,9 +504,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs the MI355X (the HIP path has no CPU fallback)"
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU over
+        # RCCL (the same command line the driver uses); rank 0 of that job prints the JSON line on our stdout
+        raise SystemExit(_self_launch(args.gpus))
+    assert args.gpus == world, "--gpus %d under a launcher with WORLD_SIZE=%d" % (args.gpus, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None

@@ -561,8 +561,9 @@ __global__ __launch_bounds__(256) void pack_wino3_kernel(const ssde_pack_desc* _
 }
 
 // Winograd F(4x4,3x3): U = G g G^T with the 6x3 G of conv_wino4.hip, stored as its LDS image
-// [ceil(cin/4)][ceil(cout/64)][36][64][4].  One thread = one (cout, cin): it reads the 3x3 filter once and writes its 36
-// positions (consecutive lanes = the 4 channels of consecutive couts: 1 KB runs per position).  The products are formed in
+// [ceil(cin/4)][ceil(cout/64)][8 waves (q, h)][9 positions q + 4 j][32 couts of half h][4].  One thread = one (cout, cin):
+// it reads the 3x3 filter once and writes its 36 positions (consecutive lanes = the 4 channels of consecutive couts: 512 B
+// runs per position).  The products are formed in
 // fp64 and rounded once, like the host packing (engine.pack_wino4_weight).
 __global__ __launch_bounds__(256) void pack_wino4_kernel(const ssde_pack_desc* __restrict__ table) {
   const ssde_pack_desc d = table[blockIdx.y];
@@ -588,7 +589,11 @@ __global__ __launch_bounds__(256) void pack_wino4_kernel(const ssde_pack_desc* _
     for (int a = 0; a < 6; ++a)
 #pragma unroll
       for (int b = 0; b < 6; ++b)
-        d.dst[((r * 36 + a * 6 + b) * 64 + cs) * 4 + e] = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
+      {
+        const int pos = a * 6 + b, wv = (pos & 3) * 2 + (cs >> 5);
+        d.dst[(((r * 8 + wv) * 9 + (pos >> 2)) * 32 + (cs & 31)) * 4 + e] =
+            (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
+      }
   }
 }
 

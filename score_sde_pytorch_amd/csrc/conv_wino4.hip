@@ -70,8 +70,9 @@ extern "C" int ssde_debug_w4_trace(void* buf) {
 #ifndef SSDE_W4_PRIO
 #define SSDE_W4_PRIO 1
 #endif
-#ifndef SSDE_W4_M0ONCE
-#define SSDE_W4_M0ONCE 1
+// 1: the two waves of a SIMD run their halo prologue at opposite ends of a stage (see the stage body)
+#ifndef SSDE_W4_STAGGER
+#define SSDE_W4_STAGGER 1
 #endif
 #if SSDE_W4_PRIO
 #define SSDE_W4_HI() __builtin_amdgcn_s_setprio(2)
@@ -84,14 +85,10 @@ extern "C" int ssde_debug_w4_trace(void* buf) {
 
 namespace {
 
-// waves per workgroup: 8 (two per SIMD, 9 positions x one 32x32 block = 144 accumulator registers each) or 12 (three per
-// SIMD, 6 positions = 96 accumulators, 168 registers per lane).  12 is correct and 11-25 % SLOWER
-// (profiles/r2_wino4_ab_12_waves.txt): the stalls of this kernel are not latencies a third wave would cover, and the
-// output transform spills at 168 registers
-#ifndef SSDE_W4_WAVES
-#define SSDE_W4_WAVES 8
-#endif
-constexpr int kWaves = SSDE_W4_WAVES;
+// 8 waves per workgroup, two per SIMD: 9 positions x one 32x32 block = 144 accumulator registers each.  (12 waves, three per
+// SIMD at 96 accumulators, measured 11-25 % slower -- profiles/r2_wino4_ab_12_waves.txt: the stalls of this kernel are not
+// latencies a third wave would cover, and the output transform spilled at 168 registers; the variant is no longer built.)
+constexpr int kWaves = 8;
 constexpr int kThreads = kWaves * 64;
 constexpr int kNP = 72 / kWaves;                   // positions per wave
 constexpr int kPS = kWaves / 2;                    // wave (q, h) owns positions q + kPS * j
@@ -110,13 +107,15 @@ constexpr int kVP = kTiles * kKc + SSDE_W4_VPAD;               // floats per pos
                                                     // wave's transform writes (b64) spread over all banks
 constexpr int kVFloats = kPos * kVP;                // one V stage
 constexpr int kUFloats = kPos * 64 * kKc;           // 9216: one U stage
+constexpr int kURegion = kNP * 32 * kKc;            // 1152: the floats of a stage only wave (q, h) reads: [9 positions][32 couts][4]
+static_assert(SSDE_W4_VPAD >= 16, "lanes 48-63 of the transform write the padding columns of V");
 constexpr int kMaxRaw = 2;                          // float4 halo items per thread per stage (halo <= 1024 pixels)
 constexpr int kLdm = 66;                            // row pitch of the product exchange [pos][16 tiles][64 couts]
 constexpr int kLdt = 68;                            // row pitch of the parked output tile [256 pixels][64 couts]
 
 struct Wino4Params {
   ssde_src src;
-  const float* wpk;        // [ceil(C/4)][n_tiles][36][64][4] (LDS image per stage)
+  const float* wpk;        // [ceil(C/4)][n_tiles][8 waves][9][32][4] (LDS image per stage, a wave's 4.5 KB contiguous)
   int N, H, W, Cout;
   int lTWt, lTHt;          // log2 tiles per patch row / column
   int tiles_x, tiles_per_img, m_tiles, n_tiles;
@@ -142,7 +141,28 @@ __device__ __forceinline__ void bt6(const float2 (&d)[6], float2 (&o)[6]) {
   }
 }
 
+// -DSSDE_W4_SCALAR_BT=1 (A/B only, built with -fno-slp-vectorize): the same arithmetic as scalar v_fma_f32 / v_add_f32
+// instead of packed v_pk_* (MI355X_MICROARCH.md prices packed f32 VALU beside bf16 MFMAs as an anti-lever; beside fp32
+// MFMAs, which share the VALU datapath, it measured neutral: profiles/r3_wino4_ab.txt)
+#ifndef SSDE_W4_SCALAR_BT
+#define SSDE_W4_SCALAR_BT 0
+#endif
 __device__ __forceinline__ void bt6(const ssde_f32x2 (&d)[6], ssde_f32x2 (&o)[6]) {
+#if SSDE_W4_SCALAR_BT
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    float d0 = d[0][e], d1 = d[1][e], d2 = d[2][e], d3 = d[3][e], d4 = d[4][e], d5 = d[5][e];
+    asm volatile("" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5));    // keeps the halves apart (no SLP re-packing)
+    const float t1 = d4 - 4.f * d2, t2 = d3 - 4.f * d1, t3 = d4 - d2, t4 = d3 - d1;
+    o[0][e] = 4.f * d0 - 5.f * d2 + d4;
+    o[1][e] = t1 + t2;
+    o[2][e] = t1 - t2;
+    o[3][e] = t3 + 2.f * t4;
+    o[4][e] = t3 - 2.f * t4;
+    o[5][e] = 4.f * d1 - 5.f * d3 + d5;
+  }
+  return;
+#endif
   const ssde_f32x2 t1 = d[4] - 4.f * d[2], t2 = d[3] - 4.f * d[1], t3 = d[4] - d[2], t4 = d[3] - d[1];
   o[0] = 4.f * d[0] - 5.f * d[2] + d[4];
   o[1] = t1 + t2;
@@ -156,7 +176,7 @@ template <bool kGn>
 __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const Wino4Params p) {
   SSDE_LDS(smem);
   float* Vb = smem;                            // [2][kVFloats]
-  float* Ub = smem + 2 * kVFloats;             // [2][kUFloats]
+  float* Ub = smem + 2 * kVFloats;             // [2][8 waves][9 positions][32 couts][4]: a wave reads only its own region
   float* rawb = Ub + 2 * kUFloats;             // [2][2 pairs][halo_px][2], then the GroupNorm tables
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
@@ -195,8 +215,11 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
   const int cpg = kGn ? Ctot / s.gn_groups : 1;
   const float inv_cpg = 1.0f / (float)cpg;
 
-  // ---- raw staging plan: item = halo pixel (its 4 channels of the stage are one float4) ----
+  // ---- raw staging plan: item = halo pixel (its 4 channels of the stage are one float4).  The byte offset of the pixel in
+  // either source is a 32-bit VGPR, the channel offset of a stage rides in the scalar base (global_load ... v, s[:]): no
+  // vector address arithmetic per stage (the launcher checks that a source is smaller than 4 GB) ----
   int goff[kMaxRaw], gil[kMaxRaw];
+  uint32_t voff0[kMaxRaw], voff1[kMaxRaw];
 #pragma unroll
   for (int it = 0; it < kMaxRaw; ++it) {
     const int q = tid + it * kThreads;
@@ -211,25 +234,28 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
       goff[it] = inb ? (img * p.H + iy) * p.W + ix : -1;
       gil[it] = inb ? il * (kGn ? s.gn_groups : 0) : 0;
     }
+    const uint32_t px = (uint32_t)(goff[it] >= 0 ? goff[it] : 0);      // outside the image: a clamped, valid address
+    voff0[it] = px * (uint32_t)s.c0 * 4u;
+    voff1[it] = px * (uint32_t)s.c1 * 4u;
   }
-  // ---- transform plan: a wave owns 8 of the 64 items (tile, channel pair) with all their 6 lines: lane = line * 8 + item
-  // (48 lanes), so that pass 2 reads what the SAME wave wrote in pass 1 -- LDS executes a wave's operations in order, and
-  // no workgroup barrier is needed between the passes ----
-#if SSDE_W4_WAVES == 8
-  const int t_items = 8, t_item0 = wave * 8;
-#else
-  const int t_items = wave < 4 ? 6 : 5, t_item0 = wave < 4 ? 6 * wave : 24 + 5 * (wave - 4);     // 4 x 6 + 8 x 5 = 64 items
-#endif
-  const int t_line = lane >> 3, t_item = t_item0 + (lane & 7);
-  const bool t_ok = t_line < 6 && (lane & 7) < t_items;
-  const int t_tile = (t_ok ? t_item : 0) >> 1, t_pair = (t_ok ? t_item : 0) & 1;
+  // ---- transform plan: a wave owns 8 of the 64 items (tile, channel pair) with all their 6 lines: lane = line * 8 + item,
+  // so that pass 2 reads what the SAME wave wrote in pass 1 -- LDS executes a wave's operations in order, and no workgroup
+  // barrier is needed between the passes.  Lanes 48-63 repeat lines 0 and 1 of the same items into the padding columns of V
+  // (128 .. 143, never read by a fragment): every lane runs the same straight-line code, no exec-masked branch in the
+  // stage body (hipcc's waitcnt insertion is exact only in straight-line code) ----
+  const int t_line6 = lane >> 3;                          // 0..7
+  const bool t_real = t_line6 < 6;
+  const int t_line = t_real ? t_line6 : t_line6 - 6;
+  const int t_item = wave * 8 + (lane & 7);
+  const int t_tile = t_item >> 1, t_pair = t_item & 1;
   int t_base;
   {
     const int il = t_tile >> (p.lTWt + p.lTHt);
     const int tr = (t_tile >> p.lTWt) & (THt - 1), tc = t_tile & (TWt - 1);
     t_base = (il * HH + 4 * tr) * HWd + 4 * tc;
   }
-  const int t_vcol = t_tile * 4 + t_pair * 2;
+  const int t_vcol = t_real ? t_tile * 4 + t_pair * 2 : kTiles * kKc + (lane & 7) * 2;
+  const int t_rawoff = t_pair * raw_plane + (t_base + t_line) * 2;
 
   // GroupNorm tables in LDS: (mean, rstd) of every (tile image, group), gamma and beta of every channel
   float* gn_tab = rawb + 2 * raw_stride;       // [IMGS][groups][2]
@@ -243,25 +269,18 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
     for (int q = tid; q < Ctot; q += kThreads) { gb_tab[q] = s.gn_gamma[q]; gb_tab[Ctot + q] = s.gn_beta[q]; }
   }
 
-  float4 rv[kMaxRaw];
-  int c_cur = 0;
-  // branch-free global loads of stage st (items outside the image read a clamped, valid address and are zeroed below)
-  const float* ld_bp = nullptr; bool ld_second = false;
-  auto load_piece = [&](int st, int k) {
-    if (k == 0) {
-      const int c_base = st * 4;
-      c_cur = c_base;
-      ld_second = c_base >= s.c0;
-      ld_bp = (ld_second ? s.p1 : s.p0) + (ld_second ? c_base - s.c0 : c_base);
-    }
-    rv[k] = *reinterpret_cast<const float4*>(ld_bp + (size_t)(goff[k] >= 0 ? goff[k] : 0) * (ld_second ? s.c1 : s.c0));
+  // halo loads of stage st: opaque to hipcc (SSDE_GLOAD16), their vmcnt accounting is the stage body's
+  ssde_f32x4 rv[kMaxRaw];
+  auto load_piece = [&](int st, int k) __attribute__((always_inline)) {
+    const int c_base = st * 4;
+    const bool second = c_base >= s.c0;
+    const float* sb = second ? s.p1 + (c_base - s.c0) : s.p0 + c_base;
+    const uint32_t vo = second ? voff1[k] : voff0[k];
+    SSDE_GLOAD16(rv[k], vo, sb);
   };
-  auto load_raw = [&](int st) {
-#pragma unroll
-    for (int k = 0; k < kMaxRaw; ++k) load_piece(st, k);
-  };
-  // prologue + raw LDS store (channel-pair major)
-  auto store_raw = [&](float* rw) {
+  // prologue + raw LDS store (channel-pair major) of the halo in rv = stage st
+  auto store_raw = [&](float* rw, int st) __attribute__((always_inline)) {
+    const int c_cur = st * 4;
     float4 gam = make_float4(1.f, 1.f, 1.f, 1.f), bet = make_float4(0.f, 0.f, 0.f, 0.f);
     int g = 0;
     if (kGn) {
@@ -276,237 +295,245 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
       if (kGn) { const float2 mr = *reinterpret_cast<const float2*>(gn_tab + 2 * (gil[it] + g)); mu = mr.x; rs = mr.y; }
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (goff[it] >= 0)
-        v = ssde_pro_apply(rv[it], mu, rs, gam, bet, (uint32_t)goff[it] * (uint32_t)Ctot + (uint32_t)c_cur, pro);
+        v = ssde_pro_apply(make_float4(rv[it].x, rv[it].y, rv[it].z, rv[it].w), mu, rs, gam, bet,
+                           (uint32_t)goff[it] * (uint32_t)Ctot + (uint32_t)c_cur, pro);
       const int q = tid + it * kThreads;
       *reinterpret_cast<float2*>(rw + q * 2) = make_float2(v.x, v.y);
       *reinterpret_cast<float2*>(rw + raw_plane + q * 2) = make_float2(v.z, v.w);
     }
   };
-  // B^T d B in two 1-D passes over the 6x6 tile, the second in place: pass 1 thread = (column x), pass 2 thread = (row y)
+  // B^T d B in two 1-D passes over the 6x6 tile, the second in place: pass 1 lane = (column x), pass 2 lane = (row y)
   auto pass1 = [&](const float* rw, float* Vn) {
-    if (t_ok) {
-      const float* rp = rw + t_pair * raw_plane + (t_base + t_line) * 2;
-      float2 d[6], o[6];
+    const float* rp = rw + t_rawoff;
+    float2 d[6], o[6];
 #pragma unroll
-      for (int a = 0; a < 6; ++a) d[a] = *reinterpret_cast<const float2*>(rp + a * HWd * 2);
-      bt6(d, o);
+    for (int a = 0; a < 6; ++a) d[a] = *reinterpret_cast<const float2*>(rp + a * HWd * 2);
+    bt6(d, o);
 #pragma unroll
-      for (int a = 0; a < 6; ++a) *reinterpret_cast<float2*>(Vn + (a * 6 + t_line) * kVP + t_vcol) = o[a];
-    }
+    for (int a = 0; a < 6; ++a) *reinterpret_cast<float2*>(Vn + (a * 6 + t_line) * kVP + t_vcol) = o[a];
   };
   auto pass2 = [&](float* Vn) {
-    if (t_ok) {
-      float* vp = Vn + (t_line * 6) * kVP + t_vcol;
-      float2 d[6], o[6];
+    float* vp = Vn + (t_line * 6) * kVP + t_vcol;
+    float2 d[6], o[6];
 #pragma unroll
-      for (int b = 0; b < 6; ++b) d[b] = *reinterpret_cast<const float2*>(vp + b * kVP);
-      bt6(d, o);
+    for (int b = 0; b < 6; ++b) d[b] = *reinterpret_cast<const float2*>(vp + b * kVP);
+    bt6(d, o);
 #pragma unroll
-      for (int b = 0; b < 6; ++b) *reinterpret_cast<float2*>(vp + b * kVP) = o[b];
-    }
+    for (int b = 0; b < 6; ++b) *reinterpret_cast<float2*>(vp + b * kVP) = o[b];
   };
-  // weights of stage st: the host packed them as the LDS image (36 KB per stage), moved by LDS-DMA: a contiguous run of
-  // 5 (waves 0-3) or 4 pieces of 1 KB per wave, one base and immediate offsets -2048 .. +2048
-  auto dma_weights = [&](int st, float* Un) {
-#if SSDE_W4_WAVES == 8
-    const int p0 = wave < 4 ? 5 * wave : 20 + 4 * (wave - 4);
-    const float* gsrc = p.wpk + ((size_t)st * p.n_tiles + nt) * kUFloats + (p0 + 2) * 256 + lane * 4;
-    float* ldst = Un + (p0 + 2) * 256;
-    SSDE_GLDS16_OFF(gsrc, ldst, -2048);
-    SSDE_GLDS16_OFF(gsrc, ldst, -1024);
-    SSDE_GLDS16_OFF(gsrc, ldst, 0);
-    SSDE_GLDS16_OFF(gsrc, ldst, 1024);
-    if (wave < 4) SSDE_GLDS16_OFF(gsrc, ldst, 2048);
-#else
-    const float* gsrc = p.wpk + ((size_t)st * p.n_tiles + nt) * kUFloats + (3 * wave + 1) * 256 + lane * 4;
-    float* ldst = Un + (3 * wave + 1) * 256;
-    SSDE_GLDS16_OFF(gsrc, ldst, -1024);
-    SSDE_GLDS16_OFF(gsrc, ldst, 0);
-    SSDE_GLDS16_OFF(gsrc, ldst, 1024);
-#endif
-  };
+  // Weights of a stage: the host packed them as the LDS image (36 KB per stage) in the order [wave][position j][32 couts][4]:
+  // wave (q, h) moves -- and is the only reader of -- the 9 x 512 B of its positions q + 4 j and its cout half h, as 4.5
+  // LDS-DMA pieces of 1 KB (the last one on lanes 0-31).  No other wave waits for these bytes: the wave counts its own
+  // pieces with vmcnt right before the fragment read that needs them, and the stage barrier carries no vmcnt(0).
+  // One scalar base per stage, the lane's bytes as a constant 32-bit offset, the pieces as immediates -2048 .. +2048.
+  const uint32_t w_voff = (uint32_t)((wave * kURegion + 2 * 256 + lane * 4) * 4);
+  auto w_base = [&](int st) { return p.wpk + ((size_t)st * p.n_tiles + nt) * kUFloats; };
+  auto w_ldst = [&](float* Un) { return Un + wave * kURegion + 2 * 256; };
 
-  const int wq = wave >> 1, wh = wave & 1;      // this wave's positions wq + 4 j and its 32-cout half
+  const int wq = wave >> 1;                     // this wave's positions wq + 4 j (its cout half is wave & 1)
   f32x16 acc[kNP];
 #pragma unroll
   for (int j = 0; j < kNP; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  const int a_off = li * 4 + 2 * lh, b_off = (wh * 32 + li) * 4 + 2 * lh;
-  // ---- pipeline fill ----
+  const int a_off = li * 4 + 2 * lh, b_off = wave * kURegion + li * 4 + 2 * lh;
+
+  // ---- pipeline fill.  Leaves what every stage expects on entry: V[cur] transformed, the wave's weight pieces of the stage
+  // issued, raw[nxt] = the activated halo of stage st + 1, rv = the halo of stage st + 2 ----
   SSDE_TR(1);
-  load_raw(0);
-  dma_weights(0, Ub);
+  {
+    const float* wb = w_base(0);
+    float* ld = w_ldst(Ub);
+    SSDE_GLDS16_S(w_voff, wb, ld, -2048);
+    SSDE_GLDS16_S_SAME_BASE(w_voff, wb, ld, -1024);
+    SSDE_GLDS16_S_SAME_BASE(w_voff, wb, ld, 0);
+    SSDE_GLDS16_S_SAME_BASE(w_voff, wb, ld, 1024);
+    SSDE_GLDS16_S_SAME_BASE_LO32(w_voff, wb, ld, 2048);
+  }
+#pragma unroll
+  for (int k = 0; k < kMaxRaw; ++k) load_piece(0, k);
   __syncthreads();                             // publishes the GroupNorm tables
-  store_raw(rawb);
-  if (nst > 1) load_raw(1);
+  SSDE_WAIT_VMCNT_FOR(0, rv[0], rv[1]);
+  store_raw(rawb, 0);
+  if (nst > 1) {
+#pragma unroll
+    for (int k = 0; k < kMaxRaw; ++k) load_piece(1, k);
+  }
   SSDE_LDS_BARRIER();
   pass1(rawb, Vb);
-  SSDE_LDS_BARRIER();
+  SSDE_LDS_BARRIER();                          // (a wave's lanes run in lockstep: only the test emulator's fibers need this one)
   pass2(Vb);
-  if (nst > 1) store_raw(rawb + raw_stride);
-  SSDE_WAIT_VMCNT(0);
+  SSDE_WAIT_VMCNT_FOR(0, rv[0], rv[1]);        // unconditional: every path from a halo load to its use passes a counted wait
+  if (nst > 1) store_raw(rawb + raw_stride, 1);
+  // group Y (waves 4-7, the second wave of every SIMD, SSDE_W4_STAGGER): activates and stores its halo at the END of a
+  // stage instead of at the head, see below
+  const bool grp_y = SSDE_W4_STAGGER && wave >= 4;
+  if (nst > 2 && !grp_y) {
+#pragma unroll
+    for (int k = 0; k < kMaxRaw; ++k) load_piece(2, k);
+  }
+  SSDE_WAIT_VMCNT_FOR(0, rv[0], rv[1]);
   SSDE_LDS_BARRIER();
   SSDE_TR(2);
 
-  for (int st = 0; st < nst; ++st) {
+  // ---- one stage.  HAS1: a stage st + 1 exists (its weights are fetched and its input transformed here), HAS2: the halo of
+  // stage st + 2 is activated and stored, HASL: a halo is fetched (group X: that of stage st + 3, stored at the head of the
+  // next stage; group Y: that of stage st + 2, stored at the end of this one).  Compile-time flags: the main loop runs the
+  // all-true body, the last stages are peeled, and the body has no branch.
+  //
+  //   head     own weight pieces 0, 1 landed | fragment reads of positions 0..2 | pass-1 reads | X: prologue of rv -> raw[cur]
+  //   slot j   fragment reads of position j + 3 | 2 MFMAs of position j | ONE vector-memory instruction (slots 0..6:
+  //            P0' H0' P1' H1' P2' P3' P4' -- as a burst in slots 0-1 the halo loads and the first pieces queued behind each
+  //            other in the address path: 1500 cycles for two positions, tools/wino4_trace.py / profiles/r3_wino4_trace_a.txt)
+  //            after slot 1: pass-1 arithmetic and writes; after 3: pass-2 reads; after 5: pass-2 arithmetic and writes
+  //   tail     Y: prologue of rv -> raw[cur] | LDS-only barrier
+  // X and Y are the two waves of a SIMD: while X runs the prologue (VALU: GroupNorm, SiLU -- two quarter-rate
+  // transcendentals per element) Y already issues MFMAs, and Y's prologue runs beside X's last positions.  With every wave
+  // doing the same thing at the same time each phase was bound by ITS resource while the matrix pipe idled.
+  //
+  // VMEM queue of a wave (in issue order; P = weight piece of this stage, ' = of the next, H = halo load):
+  //   on entry           [P0 H0 P1 H1 P2 P3 P4]  (Y: the H are done)   vmcnt(3): pieces 0, 1 (positions 0..3) and X's rv
+  //   slot 1 (pos 4, 5)  [P2 P3 P4 P0']                                 piece 2 <=> vmcnt(2 + HAS1)
+  //   slot 3 (pos 6, 7)  [P3 P4 P0' H0' P1']                            piece 3 <=> vmcnt(1 + 2 HAS1 + HASL)
+  //   slot 5 (pos 8)     [P4 P0' H0' P1' H1' P2']                       piece 4 <=> vmcnt(3 HAS1 + 2 HASL)
+  //   Y's tail           [P0' H0' P1' H1' P2' P3' P4']                  rv      <=> vmcnt(3 HAS1)
+  // (fragment reads run SSDE_W4_PF = 3 positions ahead, so the read of position j + 3 is what a slot's count protects) ----
+  static_assert(SSDE_W4_PF == 3 && kWaves == 8, "the vmcnt counts of the stage body assume reads 3 positions ahead");
+  auto stage = [&](auto H1, auto H2, auto HL, auto GY, const int st) __attribute__((always_inline)) {
+    constexpr bool has1 = decltype(H1)::value, has2 = decltype(H2)::value, hasl = decltype(HL)::value, gy = decltype(GY)::value;
+    constexpr int n1 = has1 ? 1 : 0, nl = hasl ? 1 : 0;
+    const int st_l = gy ? st + 2 : st + 3;              // the stage whose halo this stage fetches
     const int cur = st & 1, nxt = cur ^ 1;
     const float* Vc = Vb + cur * kVFloats;
     const float* Uc = Ub + cur * kUFloats;
     float* Vn = Vb + nxt * kVFloats;
-    const bool has1 = st + 1 < nst, has2 = st + 2 < nst;
-    {
-      // One wave's stage: 6 LDS reads of transform pass 1 | positions 0,1 (+ halo loads, weight pieces) | pass-1 arithmetic
-      // and 6 LDS writes | positions 2,3 (+ weight pieces) | pass-2 reads of the wave's OWN pass-1 lines (no barrier, see
-      // the transform plan) | positions 4,5 | pass-2 arithmetic and writes | positions 6-8.  A wave issues in order, and
-      // an MFMA only occupies the matrix pipe: the LDS round trips and the VMEM issue stalls pass while the wave's own
-      // MFMAs execute.  One barrier per stage.
-      const bool tl_ok = has1 && t_ok;
-      ssde_f32x2 td[6], to[6];
-      ssde_lds_float* tw = (ssde_lds_float*)(Vn + t_line * kVP + t_vcol);            // pass-1 column of this lane
-      ssde_lds_float* vp = (ssde_lds_float*)(Vn + (t_line * 6) * kVP + t_vcol);      // pass-2 row of this lane
-      SSDE_OPAQUE_VGPR(tw);
-      SSDE_OPAQUE_VGPR(vp);
-      ssde_f32x2 af[SSDE_W4_PF + 1], bf[SSDE_W4_PF + 1];
-      float* Un = Ub + nxt * kUFloats;
-#if SSDE_W4_M0ONCE
-      // M0 (the LDS base of the wave's run of pieces) is written with the first piece only
-#define SSDE_W4_WPIECE(K, IMM)                                                                          \
-      do {                                                                                               \
-        if (has1 && ((K) < kPieces - 1 || wave < 4 || kWaves == 12)) {                                    \
-          if ((K) == 0) SSDE_GLDS16_OFF(dsrc, ddst, IMM);                                                \
-          else SSDE_GLDS16_OFF_SAME_BASE(dsrc, ddst, IMM);                                               \
-        }                                                                                                \
-      } while (0)
-#else
-#define SSDE_W4_WPIECE(K, IMM) do { if (has1 && ((K) < kPieces - 1 || wave < 4 || kWaves == 12)) SSDE_GLDS16_OFF(dsrc, ddst, IMM); } while (0)
-#endif
-      constexpr int kPieces = kWaves == 8 ? 5 : 3;           // weight pieces per wave (8 waves: 4 for waves 4-7)
-      const int dp0 = kWaves == 8 ? (wave < 4 ? 5 * wave : 20 + 4 * (wave - 4)) : 3 * wave;
-      constexpr int kMid = kWaves == 8 ? 2 : 1;              // the piece the immediate offsets are relative to
-      const float* dsrc = p.wpk + ((size_t)min(st + 1, nst - 1) * p.n_tiles + nt) * kUFloats + (dp0 + kMid) * 256 + lane * 4;
-      float* ddst = Un + (dp0 + kMid) * 256;
-      // one fragment base per operand, opaque to the compiler: the 9 positions are immediate offsets of the ds_read (left
-      // alone, hipcc kept a VGPR and a 3-operand add per position and operand: 18 VALU per stage and 16 registers)
-      ssde_lds_cfloat* va = (ssde_lds_cfloat*)(Vc + wq * kVP + a_off);
-      ssde_lds_cfloat* ua = (ssde_lds_cfloat*)(Uc + wq * (64 * 4) + b_off);
-      SSDE_OPAQUE_VGPR(va);
-      SSDE_OPAQUE_VGPR(ua);
+    ssde_f32x2 td[6], to[6];
+    ssde_lds_float* tw = (ssde_lds_float*)(Vn + t_line * kVP + t_vcol);            // pass-1 column of this lane
+    ssde_lds_float* vp = (ssde_lds_float*)(Vn + (t_line * 6) * kVP + t_vcol);      // pass-2 row of this lane
+    SSDE_OPAQUE_VGPR(tw);
+    SSDE_OPAQUE_VGPR(vp);
+    ssde_f32x2 af[SSDE_W4_PF + 1], bf[SSDE_W4_PF + 1];
+    const float* wb = w_base(has1 ? st + 1 : st);
+    float* wl = w_ldst(Ub + nxt * kUFloats);
+    // one fragment base per operand, opaque to the compiler: the 9 positions are immediate offsets of the ds_read (left
+    // alone, hipcc kept a VGPR and a 3-operand add per position and operand: 18 VALU per stage and 16 registers)
+    ssde_lds_cfloat* va = (ssde_lds_cfloat*)(Vc + wq * kVP + a_off);
+    ssde_lds_cfloat* ua = (ssde_lds_cfloat*)(Uc + b_off);
+    SSDE_OPAQUE_VGPR(va);
+    SSDE_OPAQUE_VGPR(ua);
+    // ---- head ----
+    if (has2 && !gy) SSDE_WAIT_VMCNT_FOR(3, rv[0], rv[1]); else SSDE_WAIT_VMCNT_FENCE(3);
 #pragma unroll
-      for (int j = 0; j < SSDE_W4_PF; ++j) {
-        af[j] = *(ssde_lds_cfloat2*)(va + kPS * j * kVP);
-        bf[j] = *(ssde_lds_cfloat2*)(ua + kPS * j * (64 * 4));
-      }
-      if (tl_ok) {
-        const float* rp = rawb + nxt * raw_stride + t_pair * raw_plane + (t_base + t_line) * 2;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) { const float2 q = *reinterpret_cast<const float2*>(rp + a * HWd * 2); td[a].x = q.x; td[a].y = q.y; }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#define SSDE_W4_POS(J)                                                                                          \
-      do {                                                                                                         \
-        if ((J) + SSDE_W4_PF < kNP) {                                                                                \
-          af[((J) + SSDE_W4_PF) % (SSDE_W4_PF + 1)] =                                                              \
-              *(ssde_lds_cfloat2*)(va + kPS * ((J) + SSDE_W4_PF) * kVP);                                           \
-          bf[((J) + SSDE_W4_PF) % (SSDE_W4_PF + 1)] =                                                              \
-              *(ssde_lds_cfloat2*)(ua + kPS * ((J) + SSDE_W4_PF) * (64 * 4));                                      \
-        }                                                                                                          \
-        acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(J) % (SSDE_W4_PF + 1)].x, bf[(J) % (SSDE_W4_PF + 1)].x, acc[J], 0, 0, 0); \
-        acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(J) % (SSDE_W4_PF + 1)].y, bf[(J) % (SSDE_W4_PF + 1)].y, acc[J], 0, 0, 0); \
-        __builtin_amdgcn_sched_barrier(0);                                                                         \
-      } while (0)
-#if SSDE_W4_WAVES == 8
-      SSDE_W4_POS(0);
-      if (has2) load_piece(st + 2, 0);
-      SSDE_W4_WPIECE(0, -2048);
-      __builtin_amdgcn_sched_barrier(0);
-      SSDE_W4_POS(1);
-      if (has2) load_piece(st + 2, 1);
-      SSDE_W4_WPIECE(1, -1024);
-      __builtin_amdgcn_sched_barrier(0);
-      if (tl_ok) {
-        SSDE_W4_HI();
-        bt6(td, to);
-#pragma unroll
-        for (int a = 0; a < 6; ++a) *(ssde_lds_float2*)(tw + a * 6 * kVP) = to[a];
-        SSDE_W4_LO();
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      SSDE_W4_POS(2);
-      SSDE_W4_WPIECE(2, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      SSDE_W4_POS(3);
-      SSDE_W4_WPIECE(3, 1024);
-      __builtin_amdgcn_sched_barrier(0);
-      if (tl_ok) {
-#pragma unroll
-        for (int b = 0; b < 6; ++b) td[b] = *(ssde_lds_float2*)(vp + b * kVP);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      SSDE_W4_POS(4);
-      SSDE_W4_WPIECE(4, 2048);
-      __builtin_amdgcn_sched_barrier(0);
-      SSDE_W4_POS(5);
-      if (tl_ok) {
-        SSDE_W4_HI();
-        bt6(td, to);
-#pragma unroll
-        for (int b = 0; b < 6; ++b) *(ssde_lds_float2*)(vp + b * kVP) = to[b];
-        SSDE_W4_LO();
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      SSDE_W4_POS(6);
-      SSDE_W4_POS(7);
-      SSDE_W4_POS(8);
-#else
-      SSDE_W4_POS(0);
-      if (has2) load_piece(st + 2, 0);
-      SSDE_W4_WPIECE(0, -1024);
-      __builtin_amdgcn_sched_barrier(0);
-      SSDE_W4_POS(1);
-      if (has2) load_piece(st + 2, 1);
-      SSDE_W4_WPIECE(1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (tl_ok) {
-        SSDE_W4_HI();
-        bt6(td, to);
-#pragma unroll
-        for (int a = 0; a < 6; ++a) *(ssde_lds_float2*)(tw + a * 6 * kVP) = to[a];
-        SSDE_W4_LO();
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      SSDE_W4_POS(2);
-      SSDE_W4_WPIECE(2, 1024);
-      __builtin_amdgcn_sched_barrier(0);
-      if (tl_ok) {
-#pragma unroll
-        for (int b = 0; b < 6; ++b) td[b] = *(ssde_lds_float2*)(vp + b * kVP);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      SSDE_W4_POS(3);
-      if (tl_ok) {
-        SSDE_W4_HI();
-        bt6(td, to);
-#pragma unroll
-        for (int b = 0; b < 6; ++b) *(ssde_lds_float2*)(vp + b * kVP) = to[b];
-        SSDE_W4_LO();
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      SSDE_W4_POS(4);
-      SSDE_W4_POS(5);
-#endif
-#undef SSDE_W4_POS
-#undef SSDE_W4_WPIECE
-      if (st < 8) SSDE_TR(8 + st * 10 + 5);
+    for (int j = 0; j < SSDE_W4_PF; ++j) {
+      af[j] = *(ssde_lds_cfloat2*)(va + kPS * j * kVP);
+      bf[j] = *(ssde_lds_cfloat2*)(ua + j * 128);
     }
-    SSDE_W4_HI();
-    if (has2) store_raw(rawb + cur * raw_stride);
-    SSDE_W4_LO();
+    if (has1) {
+      const float* rp = rawb + nxt * raw_stride + t_rawoff;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) { const float2 q = *reinterpret_cast<const float2*>(rp + a * HWd * 2); td[a].x = q.x; td[a].y = q.y; }
+    }
+    if (has2 && !gy) {
+      SSDE_W4_HI();
+      store_raw(rawb + cur * raw_stride, st + 2);
+      SSDE_W4_LO();
+    }
+    if (st < 8) SSDE_TR(8 + st * 10 + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#define SSDE_W4_POS(J)                                                                                          \
+    do {                                                                                                         \
+      if ((J) + SSDE_W4_PF < kNP) {                                                                                \
+        af[((J) + SSDE_W4_PF) % (SSDE_W4_PF + 1)] =                                                              \
+            *(ssde_lds_cfloat2*)(va + kPS * ((J) + SSDE_W4_PF) * kVP);                                           \
+        bf[((J) + SSDE_W4_PF) % (SSDE_W4_PF + 1)] =                                                              \
+            *(ssde_lds_cfloat2*)(ua + ((J) + SSDE_W4_PF) * 128);                                                 \
+      }                                                                                                          \
+      acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(J) % (SSDE_W4_PF + 1)].x, bf[(J) % (SSDE_W4_PF + 1)].x, acc[J], 0, 0, 0); \
+      acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(J) % (SSDE_W4_PF + 1)].y, bf[(J) % (SSDE_W4_PF + 1)].y, acc[J], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                                                         \
+    } while (0)
+    // ---- slots ----
+    SSDE_W4_POS(0);
+    if (has1) SSDE_GLDS16_S(w_voff, wb, wl, -2048);
+    __builtin_amdgcn_sched_barrier(0);
+    SSDE_WAIT_VMCNT_FENCE(2 + n1);
+    SSDE_W4_POS(1);
+    if (hasl) load_piece(st_l, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (st < 8) SSDE_TR(8 + st * 10 + 2);
+    if (has1) {
+      SSDE_W4_HI();
+      bt6(td, to);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) *(ssde_lds_float2*)(tw + a * 6 * kVP) = to[a];
+      SSDE_W4_LO();
+    }
+    if (st < 8) SSDE_TR(8 + st * 10 + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    SSDE_W4_POS(2);
+    if (has1) SSDE_GLDS16_S_SAME_BASE(w_voff, wb, wl, -1024);
+    __builtin_amdgcn_sched_barrier(0);
+    SSDE_WAIT_VMCNT_FENCE(1 + 2 * n1 + nl);
+    SSDE_W4_POS(3);
+    if (hasl) load_piece(st_l, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (st < 8) SSDE_TR(8 + st * 10 + 4);
+    if (has1) {
+#pragma unroll
+      for (int b = 0; b < 6; ++b) td[b] = *(ssde_lds_float2*)(vp + b * kVP);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SSDE_W4_POS(4);
+    if (has1) SSDE_GLDS16_S_SAME_BASE(w_voff, wb, wl, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    SSDE_WAIT_VMCNT_FENCE(3 * n1 + 2 * nl);
+    SSDE_W4_POS(5);
+    if (has1) SSDE_GLDS16_S_SAME_BASE(w_voff, wb, wl, 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    if (has1) {
+      SSDE_W4_HI();
+      bt6(td, to);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) *(ssde_lds_float2*)(vp + b * kVP) = to[b];
+      SSDE_W4_LO();
+    }
+    if (st < 8) SSDE_TR(8 + st * 10 + 5);
+    __builtin_amdgcn_sched_barrier(0);
+    SSDE_W4_POS(6);
+    if (has1) SSDE_GLDS16_S_SAME_BASE_LO32(w_voff, wb, wl, 2048);
+    __builtin_amdgcn_sched_barrier(0);
+    SSDE_W4_POS(7);
+    SSDE_W4_POS(8);
+#undef SSDE_W4_POS
     if (st < 8) SSDE_TR(8 + st * 10 + 6);
-    SSDE_WAIT_VMCNT(0);
-    if (st < 8) SSDE_TR(8 + st * 10 + 7);
+    if (has2 && gy) {
+      SSDE_WAIT_VMCNT_FOR(3 * n1, rv[0], rv[1]);
+      SSDE_W4_HI();
+      store_raw(rawb + cur * raw_stride, st + 2);
+      SSDE_W4_LO();
+    }
     SSDE_LDS_BARRIER();
     if (st < 8) SSDE_TR(8 + st * 10 + 8);
+  };
+  {
+    using T = std::true_type; using F = std::false_type;
+    // (written so that the stage that consumes the halo in flight is the only successor of the stage that fetched it: the
+    //  registers of an asm load are not protected by hipcc on a path it merely cannot rule out, tests/test_isa_guards.py)
+    int st = 0;
+    if (!grp_y) {
+      if (nst >= 3) {
+        for (; st + 3 < nst; ++st) stage(T{}, T{}, T{}, F{}, st);
+        stage(T{}, T{}, F{}, F{}, st); ++st;
+        stage(T{}, F{}, F{}, F{}, st); ++st;
+      } else if (nst == 2) {
+        stage(T{}, F{}, F{}, F{}, st); ++st;
+      }
+      stage(F{}, F{}, F{}, F{}, st);
+    } else {
+      for (; st + 2 < nst; ++st) stage(T{}, T{}, T{}, T{}, st);
+      if (nst >= 2) { stage(T{}, F{}, F{}, T{}, st); ++st; }
+      stage(F{}, F{}, F{}, T{}, st);
+    }
   }
   SSDE_TR(3);
 
@@ -522,6 +549,7 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
   const int gn_base = !p.gn_part ? -1 : (IMGS == 1 ? (img0 * p.tiles_per_img + trem) * 2 : img0);
   const int rpi_log2 = IMGS > 2 ? 8 - (4 - p.lTWt - p.lTHt) : 30;             // rows per image in a round: 256 / (IMGS / 2)
   const bool e_on = tid < kEpiThreads;                                       // waves 8-11 (if any) only hand over products
+  const int wh = wave & 1;
   const int e_tl = e_on ? tid >> 5 : 0, e_cp = tid & 31;
   float* park = smem;                                                         // [256][kLdt], aliases the products
 #pragma unroll
@@ -618,6 +646,9 @@ int ssde_conv_wino4_launch(const ssde_conv_args* a, void* stream, int* lds_out) 
     SSDE_REQUIRE(s.gn_mean && s.gn_rstd && s.gn_gamma && s.gn_beta, "conv(winograd 4x4): GroupNorm pointers missing");
   }
   SSDE_REQUIRE(s.drop_thresh == 0 || s.drop_seed, "conv(winograd 4x4): dropout seed pointer missing");
+  // the halo loads address a source as scalar base + 32-bit byte offset
+  SSDE_REQUIRE((unsigned long long)a->n * a->h_in * a->w_in * (unsigned)(s.c0 > s.c1 ? s.c0 : s.c1) * 4ull < (1ull << 32),
+               "conv(winograd 4x4): a source of 4 GB or more is not addressable by this kernel");
   Wino4Params p;
   p.src = s; p.wpk = a->w_main;
   p.N = a->n; p.H = a->h_out; p.W = a->w_out; p.Cout = a->c_out;

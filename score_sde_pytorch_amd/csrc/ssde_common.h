@@ -75,6 +75,42 @@ static inline bool ssde_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
   asm volatile("global_load_lds_dwordx4 %0, off offset:%1" : : "v"(gptr), "n"(imm) :)
 #endif
 
+// The scalar-base forms: the lane's global address is sbase (SGPR pair, wave-uniform) + voff (32-bit VGPR byte offset) +
+// imm -- a stream that advances by a wave-uniform stride needs no vector address arithmetic at all.  _LO32 issues the
+// piece on lanes 0-31 only (a run of 512 bytes): exec is narrowed and restored inside the statement.
+#ifndef SSDE_GLDS16_S
+#define SSDE_GLDS16_S(voff, sbase, lds_wave_base, imm)                                                                   \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"                               \
+               :                                                                                                          \
+               : "s"(__builtin_amdgcn_readfirstlane(                                                                      \
+                     (int)(uintptr_t)(__attribute__((address_space(3))) void*)(lds_wave_base))),                          \
+                 "v"(voff), "s"(sbase), "n"(imm)                                                                          \
+               :)
+#define SSDE_GLDS16_S_SAME_BASE(voff, sbase, lds_wave_base, imm) \
+  asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(voff), "s"(sbase), "n"(imm) :)
+#define SSDE_GLDS16_S_SAME_BASE_LO32(voff, sbase, lds_wave_base, imm)                                                    \
+  do {                                                                                                                    \
+    unsigned long long ssde_exec_save_;                                                                                   \
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_hi, 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3\n\t"          \
+                 "s_mov_b64 exec, %0"                                                                                     \
+                 : "=&s"(ssde_exec_save_)                                                                                 \
+                 : "v"(voff), "s"(sbase), "n"(imm)                                                                        \
+                 :);                                                                                                      \
+  } while (0)
+#endif
+
+// A 16-byte global load whose completion hipcc does not track (asm): the kernel counts it with SSDE_WAIT_VMCNT_FOR itself,
+// next to its LDS-DMA pieces.  (A load hipcc knows about gets `s_waitcnt vmcnt(n)` with n = the loads hipcc knows to be
+// younger -- it cannot see the asm LDS-DMA pieces issued after it, so every use waited for ALL of them.)
+// SSDE_WAIT_VMCNT_FOR(n, a, b) is the wait that "defines" the destinations a, b for the compiler: nothing may read them
+// between the load and this statement (tests/test_isa_guards.py checks the emitted ISA for a stray copy).
+typedef float ssde_f32x4 __attribute__((ext_vector_type(4)));
+#ifndef SSDE_GLOAD16
+#define SSDE_GLOAD16(dst, voff, sbase) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) :)
+#define SSDE_WAIT_VMCNT_FOR(n, a, b) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(n) : "memory")
+#define SSDE_WAIT_VMCNT_FENCE(n) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(n) : "memory")
+#endif
+
 // An LDS address the compiler must treat as one opaque 32-bit register (so that constant distances from it become the
 // immediate offsets of ds_read / ds_write instead of one address register and one add per access).
 typedef __attribute__((address_space(3))) const float ssde_lds_cfloat;

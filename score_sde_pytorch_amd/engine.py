@@ -300,14 +300,16 @@ _WINO4_G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6
 
 def pack_wino4_weight(w):
     """[Cout, Cin, 3, 3] -> Winograd F(4x4,3x3) weights U = G g G^T (formed in fp64, stored in fp32) arranged as the LDS
-    image conv_wino4.hip reads: [ceil(Cin/4)][ceil(Cout/64)][36 positions][64 couts][4 channels]."""
+    image conv_wino4.hip reads: [ceil(Cin/4)][ceil(Cout/64)][8 waves][9][32 couts][4 channels] -- wave (q, h) of a workgroup
+    owns the transform positions q + 4 j (j = 0..8) and the cout half h of the 64-cout tile, and its 4.5 KB are contiguous."""
     cout, cin = w.shape[0], w.shape[1]
     G = _WINO4_G.to(w.device)
     u = torch.einsum("ak,ockl,bl->ocab", G, w.detach().to(torch.float64), G).to(torch.float32)     # [Cout, Cin, 6, 6]
     c4, nt = (cin + 3) // 4, (cout + 63) // 64
     full = torch.zeros(nt * 64, c4 * 4, 36, dtype=torch.float32, device=w.device)
     full[:cout, :cin] = u.reshape(cout, cin, 36)
-    return full.reshape(nt, 64, c4, 4, 36).permute(2, 0, 4, 1, 3).contiguous()     # [c4, nt, pos, co, e]
+    # [nt, h, cl, c4, e, j, q] -> [c4, nt, q, h, j, cl, e]   (pos = 4 j + q, cout = 64 nt + 32 h + cl)
+    return full.reshape(nt, 2, 32, c4, 4, 9, 4).permute(3, 0, 6, 1, 5, 2, 4).contiguous()
 
 
 def pack_matrix(w):

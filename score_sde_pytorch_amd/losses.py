@@ -218,6 +218,18 @@ class FusedTrainStep:
         import torch.distributed as dist
         return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
+    def _exchanges(self):
+        """Is the gradient exchange on?  Data parallel (world > 1); SSDE_FORCE_GRAD_EXCHANGE=1 also turns it on in a
+        one-rank process group, so that the bucketed RCCL path and its stream ordering run on a single GPU
+        (tests/test_train_gpu.py).  skip_exchange: bench.py times the step without it."""
+        import os
+        import torch.distributed as dist
+        if getattr(self, "skip_exchange", False):
+            return False
+        if self._world() > 1:
+            return True
+        return os.environ.get("SSDE_FORCE_GRAD_EXCHANGE", "0") == "1" and dist.is_available() and dist.is_initialized()
+
     def _optimizer_program(self, optimizer, ema):
         m, v = optimizer.flatten_like(self.flat)
         ema_buf = ema.flatten_like(self.flat) if ema is not None else None
@@ -276,7 +288,7 @@ class FusedTrainStep:
         self._head[1].run()
         self._pending = []
         if spec["train"]:
-            if self._world() > 1 and not getattr(self, "skip_exchange", False):
+            if self._exchanges():
                 # data parallel: ~32 MB buckets of the flat gradient are all-reduced (RCCL, its own stream) as soon as the
                 # backward ops that finalise them are enqueued, overlapping the rest of the backward program
                 import torch.distributed as dist
@@ -300,8 +312,7 @@ class FusedTrainStep:
 
     def optimizer_step(self, optimizer, ema, step, hyper):
         import torch.distributed as dist
-        # skip_exchange: bench.py times the step without the gradient all-reduce to report how much of it is exposed
-        if self._world() > 1 and not getattr(self, "skip_exchange", False):     # gradients were pre-scaled by 1/world in the loss head
+        if self._exchanges():     # gradients were pre-scaled by 1/world in the loss head
             if getattr(self, "_pending", None):
                 for work in self._pending:           # bucketed all-reduces started during the backward program
                     work.wait()

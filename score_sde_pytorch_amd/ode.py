@@ -206,6 +206,11 @@ class FusedDrift:
         eng = self.unet
         eng.weights.refresh()
         eng.cond.tensor[: self.shape[0]].fill_(float(label))
+        if eng.sig is not eng.cond:
+            # discrete-label (positional embedding) VE model with scale_by_sigma: the output is divided by
+            # sigmas[labels.long()] (ncsnpp.py:245,377-379) -- the same table lookup UNetEngine.load_inputs does
+            idx = int(label.reshape(-1)[0])
+            eng.sig.tensor[: self.shape[0]].fill_(float(eng.model.sigmas[idx]))
         if self.vp_like:
             eng.std.tensor[: self.shape[0]].fill_(float(std))
         eng.program.run()

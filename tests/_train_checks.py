@@ -643,6 +643,100 @@ def check_ode_sampler(dev, denoise):
     assert rel_err(x, torch.from_numpy(gold[tag + "_samples"])) < 1e-3
 
 
+def check_fused_drift_discrete_ve(dev):
+    """ode.FusedDrift on a discrete-label VE model (positional embedding + scale_by_sigma, e.g. the reference's
+    ve/cifar10_ncsnpp): the probability-flow ODE always asks for continuous labels (sampling.py:431), so the network sees
+    labels = sigma(t) and divides its output by sigmas[labels.long()] (ncsnpp.py:245,377-379).  The fused right-hand
+    side has to fill that separate per-sample sigma buffer of the U-Net program itself (round-2 advisor finding: it stayed
+    zero and the score was inf / NaN).  Compared with the CPU oracle's drift (oracle/ode_oracle.py:19-22)."""
+    from score_sde_pytorch_amd.models import utils as mutils
+    from score_sde_pytorch_amd import sde_lib, ode
+    from oracle import ode_oracle, sampler_oracle
+    cfg = small_cfg("ncsnpp")
+    cfg.model.embedding_type = "positional"
+    cfg.model.fourier_scale = 16
+    cfg.training.continuous = False
+    assert cfg.model.scale_by_sigma
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    sd = dict(_util.load_seeded(model, seed=1)); sd["sigmas"] = model.sigmas.clone()
+    model = model.to(dev).eval()
+    kw = dict(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=cfg.model.num_scales)
+    sde = sde_lib.VESDE(**kw)
+    R, Bn = cfg.data.image_size, 3
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(Bn, 3, R, R, generator=g) * 4.0
+    rhs = ode.FusedDrift(model, sde, x.shape, torch.device(dev))
+    assert rhs.unet.sig is not rhs.unet.cond
+    for t in (0.9, 0.45):
+        rhs.x32.copy_(x.reshape(-1).to(dev))
+        out = torch.full((x.numel(),), float("nan"), dtype=torch.float64, device=dev)
+        rhs(t, None, out=out)
+        with torch.no_grad():
+            ref = ode_oracle.drift(cfg, sd, sampler_oracle.make_sde("vesde", **kw), x, torch.ones(Bn) * t)
+        got = out.reshape(x.shape).to("cpu", torch.float32)
+        assert torch.isfinite(got).all()
+        assert rel_err(got, ref) < 1e-4, (t, rel_err(got, ref))
+
+
+def check_forced_exchange_one_rank(dev, backend, monkeypatch):
+    """The data-parallel path on ONE GPU: a world-size-1 `nccl` (= RCCL) process group with the exchange forced on
+    (SSDE_FORCE_GRAD_EXCHANGE=1) drives TrainEngine.run_backward_bucketed -> dist.all_reduce(flat.grad[lo:hi],
+    async_op=True) per bucket -> work.wait() before the fused optimizer, i.e. the stream ordering between the
+    ctypes-launched backward segments (torch's current stream) and RCCL's own stream (losses.py, the reference's
+    nn.DataParallel at models/utils.py:93 is what it replaces).  A one-rank SUM is the identity and the 1/world factor is 1,
+    so three steps must be BIT-identical to the same three steps without the exchange; small buckets so that many
+    collectives are in flight while the backward program is still being enqueued."""
+    import socket
+    import torch.distributed as dist
+    from score_sde_pytorch_amd.models import utils as mutils, ema as ema_mod
+    from score_sde_pytorch_amd import losses, sde_lib
+    cfg = _util.small_config("ncsnpp")
+    cfg.model.dropout = 0.1
+    sde = sde_lib.VESDE(cfg.model.sigma_min, cfg.model.sigma_max, cfg.model.num_scales)
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.rand(4, 3, 16, 16, generator=g), torch.rand(4, generator=g) * 0.9 + 0.05, torch.randn(4, 3, 16, 16, generator=g))
+               for _ in range(3)]
+
+    def run():
+        torch.manual_seed(0)
+        model = mutils.get_model("ncsnpp")(cfg)
+        _util.load_seeded(model, seed=1)
+        model = model.to(dev)
+        opt = losses.get_optimizer(cfg, model.parameters())
+        ema = ema_mod.ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate)
+        optimize_fn = losses.optimization_manager(cfg)
+        step_fn = losses.get_step_fn(sde, train=True, optimize_fn=optimize_fn, continuous=True)
+        state = dict(optimizer=opt, model=model, ema=ema, step=0)
+        fs = step_fn.fused_for(state, torch.zeros(4, 3, 16, 16, device=dev))
+        ls, buckets = [], 0
+        for i, (b, t, z) in enumerate(batches):
+            ls.append(float(fs.loss_and_grads(b.to(dev), t=t.to(dev), z=z.to(dev), seed=11 + i)))
+            buckets = max(buckets, len(fs._pending))
+            fs.optimizer_step(opt, ema, state["step"], optimize_fn.ssde_hyper)
+            state["step"] += 1
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        return ls, fs.flat.data.clone(), fs.flat.grad.clone(), buckets
+
+    ref_loss, ref_p, ref_g, nb0 = run()
+    assert nb0 == 0
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    monkeypatch.setenv("SSDE_FORCE_GRAD_EXCHANGE", "1")
+    monkeypatch.setenv("SSDE_GRAD_BUCKET_MB", "0.05")
+    kw = dict(device_id=torch.device("cuda", torch.cuda.current_device())) if backend == "nccl" else {}
+    dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, **kw)
+    try:
+        loss, p, gr, nb = run()
+    finally:
+        dist.destroy_process_group()
+    assert nb >= 4, nb                          # several async all-reduces were in flight behind the backward program
+    assert loss == ref_loss
+    assert torch.equal(gr, ref_g) and torch.equal(p, ref_p)
+
+
 def check_checkpoint_and_ema_swap(dev, tmp_path):
     """utils.save_checkpoint / restore_checkpoint (reference utils.py:7-28) around the fused step, the EMA
     store / copy_to / restore swap (models/ema.py:53-89) on the flat buffers, and weight re-packing of an inference

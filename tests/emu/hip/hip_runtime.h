@@ -148,6 +148,15 @@ static inline void emu_global_load_lds(const void* g, __attribute__((address_spa
 // the product issues the copy through inline assembly (ssde_common.h); the emulator substitutes its model of the instruction
 #define SSDE_GLDS16_OFF(gptr, lds_wave_base, imm) emu_global_load_lds((const void*)(gptr), (__attribute__((address_space(3))) void*)(lds_wave_base), 16, (imm))
 #define SSDE_OPAQUE_VGPR(x) ((void)0)
+// scalar-base forms and the asm global load of ssde_common.h (the copies are synchronous here, the waits are no-ops)
+#define SSDE_GLDS16_S(voff, sbase, lds_wave_base, imm) \
+  emu_global_load_lds((const char*)(sbase) + (voff), (__attribute__((address_space(3))) void*)(lds_wave_base), 16, (imm))
+#define SSDE_GLDS16_S_SAME_BASE(voff, sbase, lds_wave_base, imm) SSDE_GLDS16_S(voff, sbase, lds_wave_base, imm)
+#define SSDE_GLDS16_S_SAME_BASE_LO32(voff, sbase, lds_wave_base, imm) \
+  do { if (emu::cur->lane < 32) SSDE_GLDS16_S(voff, sbase, lds_wave_base, imm); } while (0)
+#define SSDE_GLOAD16(dst, voff, sbase) memcpy(&(dst), (const char*)(sbase) + (voff), 16)
+#define SSDE_WAIT_VMCNT_FOR(n, a, b) ((void)0)
+#define SSDE_WAIT_VMCNT_FENCE(n) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)      /* only used on wave-uniform values */
 #define SSDE_GLDS16_OFF_SAME_BASE(gptr, lds_wave_base, imm) SSDE_GLDS16_OFF(gptr, lds_wave_base, imm)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

@@ -36,6 +36,15 @@ def test_conv3x3_winograd_f4x4():
     T.check_conv_winograd4("cpu", big=False)
 
 
+def test_fused_ode_drift_on_a_discrete_label_ve_model():
+    T.check_fused_drift_discrete_ve("cpu")
+
+
+def test_bucketed_gradient_exchange_over_a_one_rank_group(monkeypatch):
+    """the same check tests/test_train_gpu.py runs over RCCL, here over gloo on the emulator's host tensors"""
+    T.check_forced_exchange_one_rank("cpu", "gloo", monkeypatch)
+
+
 def test_conv_reduction_split_over_two_workgroups(monkeypatch):
     T.check_conv_split_reduction("cpu", monkeypatch, n=5)
 

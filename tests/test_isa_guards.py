@@ -45,7 +45,7 @@ def _main_loop(body):
         if m and labels.get(m.group(1), i) < i:
             lo = labels[m.group(1)]
             n = sum("v_mfma" in x for x in lines[lo:i])
-            if n >= max(8, total // 4) and (best is None or i - lo < best[1] - best[0]):
+            if n >= 8 and (best is None or i - lo < best[1] - best[0]):
                 best = (lo, i)
     assert best is not None
     return lines[best[0]:best[1] + 1]
@@ -63,3 +63,49 @@ def test_winograd_kernels_own_m0_and_keep_scratch_out_of_the_loop(src, kernel, t
         assert not scratch, (sym, scratch[:4])
     spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", isa)]
     assert max(spills) <= 16, spills
+
+
+def _regs(text):
+    """VGPR numbers an operand string mentions: v7, v[4:7]"""
+    out = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", text):
+        if m.group(3) is not None:
+            out.add(int(m.group(3)))
+        else:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def test_asm_halo_loads_are_not_read_before_their_counted_wait(tmp_path):
+    """conv_wino4.hip issues its halo loads from inline asm (SSDE_GLOAD16) and counts them with its own s_waitcnt
+    (SSDE_WAIT_VMCNT_FOR): hipcc does not know the destination registers are in flight, so a copy or a spill of them
+    between the load and the wait would move stale data.  Walk every path from each such load to the first
+    `s_waitcnt vmcnt(n)`, n <= 3 (the stage head / the fill waits), and require that no instruction on the way names
+    the destination registers."""
+    isa = _isa("conv_wino4.hip", tmp_path)
+    for sym, body in _kernels(isa, "conv_wino4_kernel"):
+        lines = [l.split(";")[0].rstrip() for l in body.split("\n")]
+        labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"(\.LBB\d+_\d+):", l)] if m}
+        loads = [i for i, l in enumerate(lines) if re.match(r"\s+global_load_dwordx4 v\[\d+:\d+\], v\d+, s\[", l)]
+        assert len(loads) >= 4, (sym, len(loads))
+        for i in loads:
+            dst = _regs(re.match(r"\s+global_load_dwordx4 (v\[\d+:\d+\])", lines[i]).group(1))
+            seen, todo = set(), [i + 1]
+            while todo:
+                j = todo.pop()
+                while j < len(lines) and j not in seen:
+                    seen.add(j)
+                    l = lines[j].strip()
+                    m = re.match(r"s_waitcnt vmcnt\((\d+)\)", l)
+                    if m and int(m.group(1)) <= 3:
+                        break
+                    if l and not l.startswith(".") and not l.endswith(":"):
+                        ops = l.split(None, 1)[1] if " " in l else ""
+                        assert not (_regs(ops) & dst), (sym, lines[i].strip(), l)
+                        b = re.match(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", l)
+                        if b:
+                            todo.append(labels[b.group(1)])
+                            if l.startswith("s_branch"):
+                                break
+                        assert not l.startswith("s_endpgm"), (sym, lines[i].strip(), "reached the end without a wait")
+                    j += 1

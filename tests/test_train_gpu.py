@@ -112,5 +112,13 @@ def test_ode_sampler_matches_reference_fixture(denoise):
     T.check_ode_sampler("cuda", denoise)
 
 
+def test_fused_ode_drift_on_a_discrete_label_ve_model():
+    T.check_fused_drift_discrete_ve("cuda")
+
+
 def test_checkpoint_roundtrip_and_ema_swap(tmp_path):
     T.check_checkpoint_and_ema_swap("cuda", tmp_path)
+
+
+def test_bucketed_gradient_exchange_over_a_one_rank_rccl_group(monkeypatch):
+    T.check_forced_exchange_one_rank("cuda", "nccl", monkeypatch)

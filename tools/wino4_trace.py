@@ -40,10 +40,9 @@ def main():
             for st in range(8):
                 b = 8 + st * 10
                 prev = 2 if st == 0 else b - 2
-                print("   st%d: weights %d loads %d | pass1 %d | mfma(5) %d | barrier %d | pass2 %d | mfma(4) %d | store_raw %d | vmcnt %d | barrier %d"
-                      % (st, d(prev, b + 9), d(b + 9, b), d(b, b + 1), d(b + 1, b + 2), d(b + 2, b + 3), d(b + 3, b + 4), d(b + 4, b + 5), d(b + 5, b + 6),
-                         d(b + 6, b + 7), d(b + 7, b + 8)))
-
+                print("   st%d: head (waits, reads, prologue) %d | slots 0-1 %d | pass 1 %d | slots 2-3 %d | slots 4-5 + pass 2 %d | slots 6-8 %d | barrier %d"
+                      % (st, d(prev, b + 1), d(b + 1, b + 2), d(b + 2, b + 3), d(b + 3, b + 4), d(b + 4, b + 5), d(b + 5, b + 6),
+                         d(b + 6, b + 8)))
 
 if __name__ == "__main__":
     main()
