@@ -65,9 +65,11 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the compact ffhq256 / subvp_ode measurements")
     ap.add_argument("--dump-ops", type=str, default="")
     ap.add_argument("--no-train", action="store_true", help="skip the DSM training-step measurement")
-    ap.add_argument("--workload", default="cifar10", choices=["cifar10", "ffhq256", "subvp_ode"],
+    ap.add_argument("--workload", default="cifar10", choices=["cifar10", "ffhq256", "subvp_ode", "subvp_likelihood"],
                     help="cifar10 = BASELINE configs[1] (the headline line); ffhq256 = configs[3] (NCSN++ 256x256, N=2000, batch "
-                         "16/GPU); subvp_ode = configs[4] (DDPM++ sub-VP, probability-flow ODE sampler with RK45; 1 step = 1 solve)")
+                         "16/GPU); subvp_ode = configs[4] (DDPM++ sub-VP, probability-flow ODE sampler with RK45; 1 step = 1 solve); "
+                         "subvp_likelihood = configs[4]'s likelihood.py solve at rtol = atol = 1e-5")
+    ap.add_argument("--likelihood-tol", type=float, default=1e-3, help="rtol = atol of the likelihood solve inside the default run")
     ap.add_argument("--train-batch", type=int, default=128)
     ap.add_argument("--train-steps", type=int, default=0, help="timed training steps (0: same as --steps, capped at 10)")
     ap.add_argument("--dump-train-ops", type=str, default="")
@@ -396,6 +398,40 @@ def bench_ode_compact(args, dev, dist, world, rank):
                         "random-init weights (the NFE of a trained network differs)" % B}
 
 
+def bench_likelihood(args, dev, dist, world, rank, tol=1e-5, batch=256):
+    """BASELINE configs[4]'s other half (likelihood.py:69-111): bits/dim of a batch by the probability-flow ODE with the
+    Hutchinson-Skilling divergence, RK45, the state [x | delta log p] resident on the device; every evaluation = one U-Net
+    forward + one input-gradient (vector-Jacobian) pass as ONE captured program (ode.FusedLikelihoodRhs).  Synthetic data
+    U[-1, 1) (the sub-VP configs centre their data), random-init weights: the NFE of a trained network differs."""
+    import _util
+    from score_sde_pytorch_amd import sde_lib, likelihood
+    from score_sde_pytorch_amd.models import utils as mutils
+    cfg = _util.cfgs.get_config("subvp/cifar10_ddpmpp_continuous")
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    _util.load_seeded(model, seed=1)
+    model = model.to(dev).eval()
+    B, R = batch, cfg.data.image_size
+    sde = sde_lib.subVPSDE(beta_min=cfg.model.beta_min, beta_max=cfg.model.beta_max, N=cfg.model.num_scales)
+    inv = lambda v: (v + 1.) / 2.                                    # noqa: E731  (datasets.get_data_inverse_scaler, centered data)
+    lik = likelihood.get_likelihood_fn(sde, inv, rtol=tol, atol=tol, eps=1e-5)
+    warm = likelihood.get_likelihood_fn(sde, inv, rtol=0.5, atol=0.5, eps=0.9)     # same SDE object: warms the cached program / graph
+    torch.manual_seed(4321 + rank)
+    data = torch.rand(B, 3, R, R, device=dev) * 2 - 1
+    warm(model, data)
+    sync_all = _sync_factory(dev, dist)
+    sync_all()
+    t0 = time.perf_counter()
+    bpd, z, nfe = lik(model, data)
+    sync_all()
+    dt = _max_over_ranks(time.perf_counter() - t0, dev, dist)
+    return {"metric": "likelihood_images_per_sec", "value": world * B / dt, "unit": "images/s", "nfe": int(nfe),
+            "ms_per_nfe": dt / max(int(nfe), 1) * 1e3, "seconds_per_solve": dt, "batch_per_gpu": B, "bpd_mean": float(bpd.mean()),
+            "bpd_finite": bool(torch.isfinite(bpd).all()), "path": lik.last_path, "rtol_atol": tol,
+            "workload": "configs/subvp/cifar10_ddpmpp_continuous likelihood.get_likelihood_fn (RK45 rtol=atol=%g, eps=1e-5, Rademacher "
+                        "probe), batch %d/GPU; 1 evaluation = U-Net forward + input-gradient pass" % (tol, B)}
+
+
 def cpu_baseline(args, cfg, model, sd, R, N):
     """The CPU oracle (torch-CPU port of the reference path, the same ATen ops the reference runs on CPU) on this box's host
     cores: K whole PC iterations at the config batch (up to K=5, bounded by --cpu-seconds), extrapolated to N
@@ -527,6 +563,15 @@ def main():
 
     if args.workload == "subvp_ode":
         return bench_ode(args, dev, dist, world, rank)
+    if args.workload == "subvp_likelihood":
+        r = bench_likelihood(args, dev, dist, world, rank, tol=1e-5, batch=256 if args.batch == 256 else args.batch)
+        r.update(n_gpus=world, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32 (f64 integrator state)", data="synthetic",
+                 steps=1, warmup=1, ms_per_step=r["seconds_per_solve"] * 1e3, config={"workload": r.pop("workload")})
+        if rank == 0:
+            print(json.dumps(r))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.workload == "ffhq256":
         cfg_name = "ve/ffhq_256_ncsnpp_continuous"
         if args.batch == 256:
@@ -623,8 +668,13 @@ def main():
         del e3, m3
         torch.cuda.empty_cache()
         extra["subvp_ode"] = bench_ode_compact(args, dev, dist, world, rank)
-        out["extra"] = extra
         _phase("subvp_ode done")
+        torch.cuda.empty_cache()
+        # the likelihood of the same config at a LOOSER tolerance in the default run (the solve at the config's 1e-5 takes
+        # minutes: `--workload subvp_likelihood`); ms_per_nfe is what carries over
+        extra["subvp_likelihood"] = bench_likelihood(args, dev, dist, world, rank, tol=args.likelihood_tol)
+        out["extra"] = extra
+        _phase("subvp_likelihood done")
 
     if rank == 0:
         print(json.dumps(out))

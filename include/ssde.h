@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSDE_ABI_VERSION 4   /* 4: SSDE_TILE_WINOGRAD4, SSDE_PACK_WINO4 (plans lowered with them need this library) */
+#define SSDE_ABI_VERSION 5   /* 5: SSDE_PACK_WINO4 image re-ordered per wave (plan blobs of version 4 carry the old image), ODE ops in programs */
 
 /* ---- prologue applied to a source tensor while it is staged into LDS ---- */
 enum {
@@ -366,14 +366,31 @@ typedef struct ssde_axpy_args {   /* dst = (acc ? dst : 0) + alpha * x, optional
 typedef struct ssde_rk_coefs { double v[7]; } ssde_rk_coefs;
 typedef struct ssde_rk_combine_args {     /* dst = y + sum_{j < terms} coef[j] * K[j]   (coef = a_sj * h); dst32 = (float)dst or NULL */
   const double* y; const double* k; int64_t n; int32_t terms; int32_t _pad0; ssde_rk_coefs coef; double* dst; float* dst32;
+  int64_t n32;                             /* elements of dst32 (0 = n): the likelihood state is [x | delta log p], only x feeds the U-Net */
 } ssde_rk_combine_args;
 typedef struct ssde_rk_error_args {       /* out[0] = sqrt(mean(((sum_j coef[j] K[j]) / (atol + max(|y|,|y_new|) rtol))^2)), coef = E_j * h */
   const double* y; const double* y_new; const double* k; int64_t n; ssde_rk_coefs coef; double atol, rtol;
   double* partial; int32_t partial_len; int32_t _pad0; double* out;
 } ssde_rk_error_args;
+/* Per-evaluation scalars of an ODE right-hand side, in DEVICE memory, so that one captured hipGraph (fill labels ->
+ * U-Net program -> drift [-> input-gradient program -> divergence]) serves every evaluation of an adaptive solve: the
+ * host uploads this record (24 bytes) before each replay.  label / std are read by SSDE_OP_FILL (tab = &rec.label, ...). */
+typedef struct ssde_ode_dyn {
+  float label, std;                        /* network label and marginal std of this evaluation (models/utils.py:147-166) */
+  float a, g2;                             /* drift coefficient f(x, t) = a x and g(t)^2 (sde_lib.py:61-64, 119-123, 171-176) */
+  double* dst;                             /* the integrator's slope row this evaluation fills */
+} ssde_ode_dyn;
 typedef struct ssde_pf_drift_args {       /* dst = (double)(a * x - (g2 * score) * 0.5) in fp32, RSDE.sde with probability_flow (sde_lib.py:93-97) */
   const float* x; const float* score; double* dst; int64_t numel; float a, g2;
+  const ssde_ode_dyn* dyn;                 /* non-NULL: a, g2 and dst come from this device record */
 } ssde_pf_drift_args;
+/* Hutchinson-Skilling divergence of the probability-flow drift (likelihood.py:26-37, 59-67):
+ *   dst[dst_off + b] = sum_i (a eps_i - 0.5 g2 gx_i) eps_i,   gx = (d score / d x)^T eps  (the input-gradient program's result)
+ * i.e. eps^T (d drift / d x) eps for drift = a x - g2 score / 2; one workgroup per sample, fixed summation order. */
+typedef struct ssde_hutch_div_args {
+  const float* gx; const float* eps; double* dst; int64_t dst_off; int32_t n; int32_t per; float a, g2;
+  const ssde_ode_dyn* dyn;                 /* non-NULL: a, g2 and dst come from this device record */
+} ssde_hutch_div_args;
 
 /* ---- single-op launch entry points ------------------------------------------ */
 int ssde_conv2d(const ssde_conv_args* a, void* stream);
@@ -398,6 +415,7 @@ int ssde_project_update(const ssde_project_args* a, void* stream);
 int ssde_rk_combine(const ssde_rk_combine_args* a, void* stream);
 int ssde_rk_error_norm(const ssde_rk_error_args* a, void* stream);
 int ssde_pf_drift(const ssde_pf_drift_args* a, void* stream);
+int ssde_hutch_div(const ssde_hutch_div_args* a, void* stream);
 int ssde_conv_wgrad(const ssde_wgrad_args* a, void* stream);
 int ssde_colsum(const ssde_colsum_args* a, void* stream);
 int ssde_gn_bwd_reduce(const ssde_gn_bwd_reduce_args* a, void* stream);
@@ -422,7 +440,7 @@ enum {
   SSDE_OP_WGRAD = 15, SSDE_OP_COLSUM = 16, SSDE_OP_GN_BWD_REDUCE = 17, SSDE_OP_PROLOGUE_BWD = 18,
   SSDE_OP_ATTN_BWD = 19, SSDE_OP_PERTURB = 20, SSDE_OP_DSM_LOSS = 21, SSDE_OP_SUMSQ_FLAT = 22,
   SSDE_OP_ADAM = 23, SSDE_OP_MEMSET = 24, SSDE_OP_AXPY = 25, SSDE_OP_PACK = 26, SSDE_OP_PROJECT = 27,
-  SSDE_OP_GN_FINALIZE = 28
+  SSDE_OP_GN_FINALIZE = 28, SSDE_OP_PF_DRIFT = 29, SSDE_OP_HUTCH_DIV = 30
 };
 typedef struct ssde_op {
   int32_t kind; int32_t flops_class;   /* flops_class: free tag echoed by timing */
@@ -436,6 +454,7 @@ typedef struct ssde_op {
     ssde_attn_bwd_args attn_bwd; ssde_perturb_args perturb; ssde_dsm_loss_args dsm_loss;
     ssde_sumsq_flat_args sumsq_flat; ssde_adam_args adam; ssde_memset_args memset; ssde_axpy_args axpy;
     ssde_pack_args pack; ssde_project_args project; ssde_gn_finalize_args gn_fin;
+    ssde_pf_drift_args pf_drift; ssde_hutch_div_args hutch_div;
   } u;
 } ssde_op;
 

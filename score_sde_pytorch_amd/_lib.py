@@ -10,14 +10,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SSDE_LIB_PATH: developer switch for A/B timing of kernel variants built by _build.build_variant (tools/ab_bench.sh)
 LIB_PATH = os.environ.get("SSDE_LIB_PATH") or os.path.join(_HERE, "libssde_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_SILU = 0, 1, 2, 3
 TILE_AUTO, TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32, TILE_WINOGRAD, TILE_WINOGRAD4 = 0, 1, 2, 3, 4, 5, 6
 (OP_CONV, OP_GN_STATS, OP_UPFIRDN, OP_ATTN, OP_EMBED, OP_TO_NHWC, OP_TO_NCHW, OP_BIAS_ACT, OP_SUMSQ,
  OP_RANDN, OP_LANGEVIN, OP_PREDICTOR, OP_FILL, OP_STEP_INC, OP_WGRAD, OP_COLSUM, OP_GN_BWD_REDUCE, OP_PROLOGUE_BWD,
  OP_ATTN_BWD, OP_PERTURB, OP_DSM_LOSS, OP_SUMSQ_FLAT, OP_ADAM, OP_MEMSET, OP_AXPY, OP_PACK, OP_PROJECT,
- OP_GN_FINALIZE) = range(1, 29)
+ OP_GN_FINALIZE, OP_PF_DRIFT, OP_HUTCH_DIV) = range(1, 31)
 PACK_CONV3, PACK_WINO3, PACK_MATRIX, PACK_VECTOR, PACK_WINO4 = 1, 2, 3, 4, 5
 
 _fp = C.c_void_p  # device pointers are passed as integers
@@ -48,7 +48,7 @@ class GnStatsArgs(C.Structure):
 
 class RkCombineArgs(C.Structure):
     _fields_ = [("y", _fp), ("k", _fp), ("n", C.c_int64), ("terms", C.c_int32), ("_pad0", C.c_int32), ("coef", C.c_double * 7),
-                ("dst", _fp), ("dst32", _fp)]
+                ("dst", _fp), ("dst32", _fp), ("n32", C.c_int64)]
 
 
 class RkErrorArgs(C.Structure):
@@ -57,7 +57,17 @@ class RkErrorArgs(C.Structure):
 
 
 class PfDriftArgs(C.Structure):
-    _fields_ = [("x", _fp), ("score", _fp), ("dst", _fp), ("numel", C.c_int64), ("a", C.c_float), ("g2", C.c_float)]
+    _fields_ = [("x", _fp), ("score", _fp), ("dst", _fp), ("numel", C.c_int64), ("a", C.c_float), ("g2", C.c_float), ("dyn", _fp)]
+
+
+class OdeDyn(C.Structure):
+    """per-evaluation scalars of an ODE right-hand side (device record, include/ssde.h: ssde_ode_dyn)"""
+    _fields_ = [("label", C.c_float), ("std", C.c_float), ("a", C.c_float), ("g2", C.c_float), ("dst", _fp)]
+
+
+class HutchDivArgs(C.Structure):
+    _fields_ = [("gx", _fp), ("eps", _fp), ("dst", _fp), ("dst_off", C.c_int64), ("n", C.c_int32), ("per", C.c_int32),
+                ("a", C.c_float), ("g2", C.c_float), ("dyn", _fp)]
 
 
 class GnFinalizeArgs(C.Structure):
@@ -206,7 +216,8 @@ class _OpUnion(C.Union):
                 ("wgrad", WgradArgs), ("colsum", ColsumArgs), ("gn_bwd", GnBwdReduceArgs), ("pro_bwd", PrologueBwdArgs),
                 ("attn_bwd", AttnBwdArgs), ("perturb", PerturbArgs), ("dsm_loss", DsmLossArgs),
                 ("sumsq_flat", SumsqFlatArgs), ("adam", AdamArgs), ("memset", MemsetArgs), ("axpy", AxpyArgs),
-                ("pack", PackArgs), ("project", ProjectArgs), ("gn_fin", GnFinalizeArgs)]
+                ("pack", PackArgs), ("project", ProjectArgs), ("gn_fin", GnFinalizeArgs),
+                ("pf_drift", PfDriftArgs), ("hutch_div", HutchDivArgs)]
 
 
 class Op(C.Structure):
@@ -219,7 +230,7 @@ _UNION_FIELD = {OP_CONV: "conv", OP_GN_STATS: "gn", OP_UPFIRDN: "fir", OP_ATTN: 
                 OP_STEP_INC: "step_inc", OP_WGRAD: "wgrad", OP_COLSUM: "colsum", OP_GN_BWD_REDUCE: "gn_bwd",
                 OP_PROLOGUE_BWD: "pro_bwd", OP_ATTN_BWD: "attn_bwd", OP_PERTURB: "perturb", OP_DSM_LOSS: "dsm_loss",
                 OP_SUMSQ_FLAT: "sumsq_flat", OP_ADAM: "adam", OP_MEMSET: "memset", OP_AXPY: "axpy", OP_PACK: "pack", OP_PROJECT: "project",
-                OP_GN_FINALIZE: "gn_fin"}
+                OP_GN_FINALIZE: "gn_fin", OP_PF_DRIFT: "pf_drift", OP_HUTCH_DIV: "hutch_div"}
 
 EXPORTS = ["ssde_conv2d", "ssde_groupnorm_stats", "ssde_upfirdn2d", "ssde_attention", "ssde_embed", "ssde_to_nhwc",
            "ssde_to_nchw", "ssde_fused_bias_act", "ssde_sumsq", "ssde_randn", "ssde_langevin_update",
@@ -228,7 +239,7 @@ EXPORTS = ["ssde_conv2d", "ssde_groupnorm_stats", "ssde_upfirdn2d", "ssde_attent
            "ssde_abi_version", "ssde_sizeof_op", "ssde_last_error", "ssde_conv_lds_bytes",
            "ssde_conv_wgrad", "ssde_colsum", "ssde_gn_bwd_reduce", "ssde_prologue_bwd", "ssde_attention_bwd",
            "ssde_perturb", "ssde_dsm_loss", "ssde_sumsq_flat", "ssde_adam_clip_ema", "ssde_memset", "ssde_axpy",
-           "ssde_wgrad_scratch_floats", "ssde_pack_weights", "ssde_project_update", "ssde_gn_finalize", "ssde_conv_gn_slices", "ssde_rk_combine", "ssde_rk_error_norm", "ssde_pf_drift",
+           "ssde_wgrad_scratch_floats", "ssde_pack_weights", "ssde_project_update", "ssde_gn_finalize", "ssde_conv_gn_slices", "ssde_rk_combine", "ssde_rk_error_norm", "ssde_pf_drift", "ssde_hutch_div",
            # plan-level entry points (csrc/plan.hip; argument types: plan_export.bind)
            "ssde_plan_load", "ssde_plan_load_file", "ssde_plan_destroy", "ssde_plan_info", "ssde_plan_param",
            "ssde_plan_refresh_weights", "ssde_unet_forward", "ssde_pc_reset", "ssde_pc_run", "ssde_pc_state"]
@@ -261,7 +272,7 @@ def bind(lib):
                       ("ssde_attention_bwd", AttnBwdArgs), ("ssde_perturb", PerturbArgs), ("ssde_dsm_loss", DsmLossArgs),
                       ("ssde_sumsq_flat", SumsqFlatArgs), ("ssde_adam_clip_ema", AdamArgs), ("ssde_memset", MemsetArgs),
                       ("ssde_axpy", AxpyArgs), ("ssde_pack_weights", PackArgs), ("ssde_project_update", ProjectArgs),
-                      ("ssde_gn_finalize", GnFinalizeArgs), ("ssde_rk_combine", RkCombineArgs),
+                      ("ssde_gn_finalize", GnFinalizeArgs), ("ssde_rk_combine", RkCombineArgs), ("ssde_hutch_div", HutchDivArgs),
                       ("ssde_rk_error_norm", RkErrorArgs), ("ssde_pf_drift", PfDriftArgs)]:
         getattr(lib, name).argtypes = [C.POINTER(typ), C.c_void_p]
     lib.ssde_conv_lds_bytes.argtypes = [C.POINTER(ConvArgs)]

@@ -70,9 +70,20 @@ extern "C" int ssde_debug_w4_trace(void* buf) {
 #ifndef SSDE_W4_PRIO
 #define SSDE_W4_PRIO 1
 #endif
-// 1: the two waves of a SIMD run their halo prologue at opposite ends of a stage (see the stage body)
+// 1: the two waves of a SIMD run their halo prologue at opposite ends of a stage (see the stage body); measured neutral
+// (profiles/r3_wino4_ab.txt: a VALU instruction of one wave waits out the running 64-cycle MFMA of the other, so the head of
+// the wave that overlaps took 2100 cycles instead of 1500), kept as a switch
 #ifndef SSDE_W4_STAGGER
-#define SSDE_W4_STAGGER 1
+#define SSDE_W4_STAGGER 0
+#endif
+// 1: a stage head reads the GroupNorm tables before its fragment / transform reads
+#ifndef SSDE_W4_GNFIRST
+#define SSDE_W4_GNFIRST 1
+#endif
+// rows of the output tile a thread has in flight in the second round of the shared epilogue (residual loads issued before
+// the first use; the first round still holds half of the accumulators and keeps 4)
+#ifndef SSDE_W4_EPI_BATCH
+#define SSDE_W4_EPI_BATCH 8
 #endif
 #if SSDE_W4_PRIO
 #define SSDE_W4_HI() __builtin_amdgcn_s_setprio(2)
@@ -260,15 +271,6 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
   // GroupNorm tables in LDS: (mean, rstd) of every (tile image, group), gamma and beta of every channel
   float* gn_tab = rawb + 2 * raw_stride;       // [IMGS][groups][2]
   float* gb_tab = gn_tab + 2 * IMGS * (kGn ? s.gn_groups : 0);   // [2][Ctot]
-  if (kGn) {
-    for (int q = tid; q < IMGS * s.gn_groups; q += kThreads) {
-      const int il = q / s.gn_groups, img = img0 + il < p.N ? img0 + il : 0;
-      const int gi = img * s.gn_groups + (q - il * s.gn_groups);
-      *reinterpret_cast<float2*>(gn_tab + 2 * q) = make_float2(s.gn_mean[gi], s.gn_rstd[gi]);
-    }
-    for (int q = tid; q < Ctot; q += kThreads) { gb_tab[q] = s.gn_gamma[q]; gb_tab[Ctot + q] = s.gn_beta[q]; }
-  }
-
   // halo loads of stage st: opaque to hipcc (SSDE_GLOAD16), their vmcnt accounting is the stage body's
   ssde_f32x4 rv[kMaxRaw];
   auto load_piece = [&](int st, int k) __attribute__((always_inline)) {
@@ -278,30 +280,40 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
     const uint32_t vo = second ? voff1[k] : voff0[k];
     SSDE_GLOAD16(rv[k], vo, sb);
   };
-  // prologue + raw LDS store (channel-pair major) of the halo in rv = stage st
-  auto store_raw = [&](float* rw, int st) __attribute__((always_inline)) {
-    const int c_cur = st * 4;
-    float4 gam = make_float4(1.f, 1.f, 1.f, 1.f), bet = make_float4(0.f, 0.f, 0.f, 0.f);
-    int g = 0;
+  // prologue + raw LDS store (channel-pair major) of the halo in rv = stage st, in two steps so that a stage can put the few
+  // LDS reads of the GroupNorm tables AHEAD of its burst of fragment / transform reads (LDS returns in order: the prologue
+  // arithmetic then starts when 4 reads have come back instead of 16)
+  struct GnRegs { float4 gam, bet; float2 mr[kMaxRaw]; };
+  auto gn_fetch = [&](int st) __attribute__((always_inline)) {
+    GnRegs r;
+    r.gam = make_float4(1.f, 1.f, 1.f, 1.f); r.bet = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int it = 0; it < kMaxRaw; ++it) r.mr[it] = make_float2(0.f, 1.f);
     if (kGn) {
-      gam = *reinterpret_cast<const float4*>(gb_tab + c_cur);
-      bet = *reinterpret_cast<const float4*>(gb_tab + Ctot + c_cur);
-      g = (int)(((float)c_cur + 0.5f) * inv_cpg);          // c_cur / cpg, exact for these small integers
+      const int c_cur = st * 4;
+      r.gam = *reinterpret_cast<const float4*>(gb_tab + c_cur);
+      r.bet = *reinterpret_cast<const float4*>(gb_tab + Ctot + c_cur);
+      const int g = (int)(((float)c_cur + 0.5f) * inv_cpg);          // c_cur / cpg, exact for these small integers
+#pragma unroll
+      for (int it = 0; it < kMaxRaw; ++it) r.mr[it] = *reinterpret_cast<const float2*>(gn_tab + 2 * (gil[it] + g));   // (item 1 of most lanes: entry 0)
     }
+    return r;
+  };
+  auto store_raw_with = [&](float* rw, int st, const GnRegs& r) __attribute__((always_inline)) {
+    const int c_cur = st * 4;
 #pragma unroll
     for (int it = 0; it < kMaxRaw; ++it) {
       if (goff[it] == -2) continue;
-      float mu = 0.f, rs = 1.f;
-      if (kGn) { const float2 mr = *reinterpret_cast<const float2*>(gn_tab + 2 * (gil[it] + g)); mu = mr.x; rs = mr.y; }
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (goff[it] >= 0)
-        v = ssde_pro_apply(make_float4(rv[it].x, rv[it].y, rv[it].z, rv[it].w), mu, rs, gam, bet,
+        v = ssde_pro_apply(make_float4(rv[it].x, rv[it].y, rv[it].z, rv[it].w), r.mr[it].x, r.mr[it].y, r.gam, r.bet,
                            (uint32_t)goff[it] * (uint32_t)Ctot + (uint32_t)c_cur, pro);
       const int q = tid + it * kThreads;
       *reinterpret_cast<float2*>(rw + q * 2) = make_float2(v.x, v.y);
       *reinterpret_cast<float2*>(rw + raw_plane + q * 2) = make_float2(v.z, v.w);
     }
   };
+  auto store_raw = [&](float* rw, int st) __attribute__((always_inline)) { store_raw_with(rw, st, gn_fetch(st)); };
   // B^T d B in two 1-D passes over the 6x6 tile, the second in place: pass 1 lane = (column x), pass 2 lane = (row y)
   auto pass1 = [&](const float* rw, float* Vn) {
     const float* rp = rw + t_rawoff;
@@ -352,6 +364,15 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
   }
 #pragma unroll
   for (int k = 0; k < kMaxRaw; ++k) load_piece(0, k);
+  // (the table loads below are issued behind the weight pieces and the halo of stage 0: one memory latency for all of them)
+  if (kGn) {
+    for (int q = tid; q < IMGS * s.gn_groups; q += kThreads) {
+      const int il = q / s.gn_groups, img = img0 + il < p.N ? img0 + il : 0;
+      const int gi = img * s.gn_groups + (q - il * s.gn_groups);
+      *reinterpret_cast<float2*>(gn_tab + 2 * q) = make_float2(s.gn_mean[gi], s.gn_rstd[gi]);
+    }
+    for (int q = tid; q < Ctot; q += kThreads) { gb_tab[q] = s.gn_gamma[q]; gb_tab[Ctot + q] = s.gn_beta[q]; }
+  }
   __syncthreads();                             // publishes the GroupNorm tables
   SSDE_WAIT_VMCNT_FOR(0, rv[0], rv[1]);
   store_raw(rawb, 0);
@@ -422,6 +443,8 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
     SSDE_OPAQUE_VGPR(va);
     SSDE_OPAQUE_VGPR(ua);
     // ---- head ----
+    GnRegs gnr;
+    if (has2 && !gy && SSDE_W4_GNFIRST) gnr = gn_fetch(st + 2);        // (tables: no dependence on the weight pieces)
     if (has2 && !gy) SSDE_WAIT_VMCNT_FOR(3, rv[0], rv[1]); else SSDE_WAIT_VMCNT_FENCE(3);
 #pragma unroll
     for (int j = 0; j < SSDE_W4_PF; ++j) {
@@ -435,7 +458,8 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
     }
     if (has2 && !gy) {
       SSDE_W4_HI();
-      store_raw(rawb + cur * raw_stride, st + 2);
+      if (SSDE_W4_GNFIRST) store_raw_with(rawb + cur * raw_stride, st + 2, gnr);
+      else store_raw(rawb + cur * raw_stride, st + 2);
       SSDE_W4_LO();
     }
     if (st < 8) SSDE_TR(8 + st * 10 + 1);
@@ -610,7 +634,7 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
     __syncthreads();
     if (rnd == 0) SSDE_TR(105);
     const int gn_entry = gn_base < 0 ? -1 : (IMGS == 1 ? gn_base + rnd : gn_base + rnd * (IMGS >> 1));
-    if (tid < kEpiThreads) ssde_store_tile<256, 64, kEpiThreads, 4, 0>(park, kLdt, n0, e, [&](int row, size_t& pix, int& img) {
+    auto pixfn = [&](int row, size_t& pix, int& img) {
       const int tile = rnd * 16 + (row >> 4), dy = (row >> 2) & 3, dx = row & 3;
       const int il = tile >> (p.lTWt + p.lTHt);
       const int tr = (tile >> p.lTWt) & (THt - 1), tc = tile & (TWt - 1);
@@ -619,7 +643,11 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
       if (img >= p.N || oy >= p.H || ox >= p.W) return false;
       pix = ((size_t)img * p.H + oy) * p.W + ox;
       return true;
-    }, gn_entry, rpi_log2, IMGS == 1 ? p.N * p.tiles_per_img * 2 : p.N);
+    };
+    const int gn_max = IMGS == 1 ? p.N * p.tiles_per_img * 2 : p.N;
+    // round 1 has no accumulators left: all 8 rows of a thread (residual loads) in flight instead of 4
+    if (rnd == 0) ssde_store_tile<256, 64, kEpiThreads, 4, 0>(park, kLdt, n0, e, pixfn, gn_entry, rpi_log2, gn_max);
+    else ssde_store_tile<256, 64, kEpiThreads, SSDE_W4_EPI_BATCH, 0>(park, kLdt, n0, e, pixfn, gn_entry, rpi_log2, gn_max);
     if (rnd == 0) SSDE_TR(106);
     if (rnd == 0) { __syncthreads(); SSDE_TR(4); }
   }

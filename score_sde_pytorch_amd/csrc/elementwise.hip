@@ -307,14 +307,14 @@ extern "C" int ssde_sumsq(const ssde_sumsq_args* a, void* stream) {
 // casts the state to float32 per evaluation, models/utils.py:186-188), one launch + a fixed-order finish form scipy's
 // RMS error norm -- the only scalar the host reads per step.
 __global__ __launch_bounds__(256) void rk_combine_kernel(const double* __restrict__ y, const double* __restrict__ k, size_t n, int terms,
-                                                         ssde_rk_coefs c, double* __restrict__ dst, float* __restrict__ dst32) {
+                                                         ssde_rk_coefs c, double* __restrict__ dst, float* __restrict__ dst32, size_t n32) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     // scipy: dy = np.dot(K[:s].T, a[:s]) * h ; y + dy   -- here a_j * h is folded on the host, summed j = 0, 1, ...
     double dy = 0.0;
     for (int j = 0; j < terms; ++j) dy += k[(size_t)j * n + i] * c.v[j];
     const double v = y[i] + dy;
     dst[i] = v;
-    if (dst32) dst32[i] = (float)v;
+    if (dst32 && i < n32) dst32[i] = (float)v;
   }
 }
 
@@ -349,7 +349,8 @@ __global__ void rk_error_finish_kernel(const double* __restrict__ partial, int b
 //   drift = f(x, t) - g(t)^2 * score * 0.5,  f = a(t) * x  (a = -beta(t)/2 for VP / sub-VP, 0 for VE)
 // evaluated in fp32 in the reference's operation order (no contraction), widened to the integrator's fp64.
 __global__ __launch_bounds__(256) void pf_drift_kernel(const float* __restrict__ x, const float* __restrict__ score, double* __restrict__ dst,
-                                                       size_t numel, float a, float g2) {
+                                                       size_t numel, float a, float g2, const ssde_ode_dyn* __restrict__ dyn) {
+  if (dyn) { a = dyn->a; g2 = dyn->g2; dst = dyn->dst; }
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (size_t)gridDim.x * blockDim.x) {
     const float f = __fmul_rn(a, x[i]);
     const float d = __fmul_rn(__fmul_rn(g2, score[i]), 0.5f);
@@ -357,10 +358,33 @@ __global__ __launch_bounds__(256) void pf_drift_kernel(const float* __restrict__
   }
 }
 
+// eps^T (d drift / d x) eps per sample (likelihood.py:29-35: grad of sum(drift * eps) wrt x, times eps, summed over the
+// image): the cotangent of the input-gradient program is eps itself, so gx = J_score^T eps and the drift's own factors
+// (a for the linear part, -g2/2 for the score part, sde_lib.py:93-97) are applied here.  fp32 terms as the reference,
+// summed in fp64 in a fixed order (thread-strided partials, wave shuffles, 4 waves in order).
+__global__ __launch_bounds__(256) void hutch_div_kernel(const float* __restrict__ gx, const float* __restrict__ eps, double* __restrict__ dst,
+                                                        long long dst_off, int per, float a, float g2, const ssde_ode_dyn* __restrict__ dyn) {
+  SSDE_LDS(smem);
+  double* red = reinterpret_cast<double*>(smem);      // [4]
+  if (dyn) { a = dyn->a; g2 = dyn->g2; dst = dyn->dst; }
+  const size_t base = (size_t)blockIdx.x * per;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < per; i += 256) {
+    const float e = eps[base + i];
+    const float t = __fsub_rn(__fmul_rn(a, e), __fmul_rn(__fmul_rn(g2, gx[base + i]), 0.5f));
+    acc += (double)__fmul_rn(t, e);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) dst[dst_off + blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
 extern "C" int ssde_rk_combine(const ssde_rk_combine_args* a, void* stream) {
   SSDE_REQUIRE(a && a->y && a->dst && a->n > 0 && a->terms >= 0 && a->terms <= 7 && (a->terms == 0 || a->k), "rk_combine: bad args");
   hipLaunchKernelGGL(rk_combine_kernel, dim3(grid_for((size_t)a->n)), dim3(256), 0, static_cast<hipStream_t>(stream), a->y, a->k, (size_t)a->n,
-                     a->terms, a->coef, a->dst, a->dst32);
+                     a->terms, a->coef, a->dst, a->dst32, a->n32 > 0 ? (size_t)a->n32 : (size_t)a->n);
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;
 }
@@ -378,9 +402,17 @@ extern "C" int ssde_rk_error_norm(const ssde_rk_error_args* a, void* stream) {
 }
 
 extern "C" int ssde_pf_drift(const ssde_pf_drift_args* a, void* stream) {
-  SSDE_REQUIRE(a && a->x && a->score && a->dst && a->numel > 0, "pf_drift: bad args");
+  SSDE_REQUIRE(a && a->x && a->score && (a->dst || a->dyn) && a->numel > 0, "pf_drift: bad args");
   hipLaunchKernelGGL(pf_drift_kernel, dim3(grid_for((size_t)a->numel)), dim3(256), 0, static_cast<hipStream_t>(stream), a->x, a->score, a->dst,
-                     (size_t)a->numel, a->a, a->g2);
+                     (size_t)a->numel, a->a, a->g2, a->dyn);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}
+
+extern "C" int ssde_hutch_div(const ssde_hutch_div_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->gx && a->eps && (a->dst || a->dyn) && a->n > 0 && a->per > 0 && a->dst_off >= 0, "hutch_div: bad args");
+  hipLaunchKernelGGL(hutch_div_kernel, dim3(a->n), dim3(256), 64, static_cast<hipStream_t>(stream), a->gx, a->eps, a->dst,
+                     (long long)a->dst_off, a->per, a->a, a->g2, a->dyn);
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;
 }

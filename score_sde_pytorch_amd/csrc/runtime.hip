@@ -46,6 +46,8 @@ static int run_one(const ssde_op& op, void* stream) {
     case SSDE_OP_AXPY: return ssde_axpy(&op.u.axpy, stream);
     case SSDE_OP_PACK: return ssde_pack_weights(&op.u.pack, stream);
     case SSDE_OP_GN_FINALIZE: return ssde_gn_finalize(&op.u.gn_fin, stream);
+    case SSDE_OP_PF_DRIFT: return ssde_pf_drift(&op.u.pf_drift, stream);
+    case SSDE_OP_HUTCH_DIV: return ssde_hutch_div(&op.u.hutch_div, stream);
   }
   ssde_set_error("program: unknown op kind %d", op.kind);
   return SSDE_EINVAL;

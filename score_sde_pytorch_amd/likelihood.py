@@ -1,7 +1,10 @@
 """Bits/dim by the probability-flow ODE with a Hutchinson-Skilling divergence estimate (drop-in for the reference's
 likelihood.py:26-113: `get_div_fn`, `get_likelihood_fn`, same arguments and return values).
 
-The drift and its vector-Jacobian product run on the HIP forward / backward programs through the autograd bridge
+For an NCSNpp model and a stock SDE the whole right-hand side -- drift and eps^T (d drift / d x) eps -- is ONE device
+program per evaluation (ode.FusedLikelihoodRhs: forward program, drift kernel, input-gradient program with the probe as
+the cotangent, per-sample divergence kernel; captured into a hipGraph).  Other models / SDEs go through `get_div_fn`
+below: the drift and its vector-Jacobian product run on the HIP forward / backward programs through the autograd bridge
 (autograd.py).  Only d drift / d x is needed, so the parameters are frozen for the duration of a call: the backward
 program is then lowered without its weight-gradient kernels (backward.TrainEngine(param_grads=False)).
 The augmented state [x (B*D values) | accumulated log-density change (B values)] is one fp64 tensor; with method='RK45'
@@ -57,19 +60,32 @@ def get_likelihood_fn(sde, inverse_scaler, hutchinson_type='Rademacher', rtol=1e
         batch, dims = data.shape[0], data[0].numel()
         with torch.no_grad(), _frozen(model):
             probe = _probe(data, hutchinson_type)
-            score_fn = mutils.get_score_fn(sde, model, train=False, continuous=True)
-            flow = sde.reverse(score_fn, probability_flow=True)          # the probability-flow ODE as a reverse SDE
-
-            def drift(x, t):
-                return flow.sde(x, t)[0]
-            divergence = get_div_fn(drift)
-
-            def rhs(t, y):                                                # d/dt [x, delta log p] = [drift, div drift]
-                x = y[: batch * dims].reshape(data.shape).to(torch.float32)
-                vec_t = torch.full((batch,), float(t), device=x.device)
-                return torch.cat([drift(x, vec_t).reshape(-1), divergence(x, vec_t, probe)]).to(torch.float64)
-
             y0 = torch.cat([data.reshape(-1), data.new_zeros(batch)]).to(torch.float64)
+            if method == 'RK45' and ode.FusedLikelihoodRhs.applies(model, sde, data):
+                # the whole right-hand side as one device program per evaluation (ode.FusedLikelihoodRhs): no torch
+                # arithmetic, no autograd graph, no dtype round trips between U-Net evaluations
+                cache = model.__dict__.setdefault("_ode_rhs", {})      # shared by every likelihood_fn of this SDE object
+                key = ("likelihood", id(sde), tuple(data.shape), data.device.index)
+                rhs = cache.get(key)
+                if rhs is None:
+                    rhs = cache[key] = ode.FusedLikelihoodRhs(model, sde, data.shape, probe, data.device)
+                else:
+                    rhs.set_probe(probe)
+                likelihood_fn.last_path = "fused"
+            else:
+                score_fn = mutils.get_score_fn(sde, model, train=False, continuous=True)
+                flow = sde.reverse(score_fn, probability_flow=True)          # the probability-flow ODE as a reverse SDE
+
+                def drift(x, t):
+                    return flow.sde(x, t)[0]
+                divergence = get_div_fn(drift)
+
+                def rhs(t, y):                                                # d/dt [x, delta log p] = [drift, div drift]
+                    x = y[: batch * dims].reshape(data.shape).to(torch.float32)
+                    vec_t = torch.full((batch,), float(t), device=x.device)
+                    return torch.cat([drift(x, vec_t).reshape(-1), divergence(x, vec_t, probe)]).to(torch.float64)
+                likelihood_fn.last_path = "generic"
+
             y1, nfe = ode.integrate_ode(rhs, (eps, sde.T), y0, rtol, atol, method)
             z = y1[: batch * dims].reshape(data.shape).to(torch.float32)
             delta_logp = y1[batch * dims:].to(torch.float32)
@@ -78,4 +94,5 @@ def get_likelihood_fn(sde, inverse_scaler, hutchinson_type='Rademacher', rtol=1e
             bpd = nats / (math.log(2.) * dims) + (7. - inverse_scaler(-1.))
             return bpd, z, nfe
 
+    likelihood_fn.last_path = None
     return likelihood_fn

@@ -64,9 +64,9 @@ class _HipStages:
     argument together with its fp32 copy -- written straight into the U-Net's input buffer when the right-hand side is
     the fused drift (FusedDrift) -- and the error norm comes back as ONE scalar per step."""
 
-    def __init__(self, n, like, x32=None):
+    def __init__(self, n, like, x32=None, n32=0):
         from . import _lib as L
-        self.L, self.lib, self.n = L, L.load(), n
+        self.L, self.lib, self.n, self.n32 = L, L.load(), n, int(n32)
         self.K = torch.empty(7, n, dtype=torch.float64, device=like.device)
         self.partial = torch.empty(1024, dtype=torch.float64, device=like.device)
         self.out = torch.empty(1, dtype=torch.float64, device=like.device)
@@ -82,6 +82,7 @@ class _HipStages:
         terms = max([j + 1 for j, c in enumerate(coefs) if c != 0.0], default=0)
         a.y, a.k, a.n, a.terms, a.dst = y.data_ptr(), self.K.data_ptr(), self.n, terms, dst.data_ptr()
         a.dst32 = self.x32.data_ptr() if self.x32 is not None else None
+        a.n32 = self.n32
         for j in range(terms):
             a.coef[j] = coefs[j]
         self.L.check(self.lib.ssde_rk_combine(C.byref(a), self._stream()), "ssde_rk_combine")
@@ -169,22 +170,95 @@ def _once(fun, stages, t, yy, in_place):
     return out
 
 
-class FusedDrift:
-    """Right-hand side of the probability-flow ODE for an NCSNpp model and a stock SDE, without torch arithmetic:
-    drift = f(x, t) - g(t)^2 score(x, t) / 2 (sde_lib.py:93-97 with probability_flow=True; score_fn models/utils.py:129-178).
-    The integrator's combine kernel writes the fp32 state straight into the U-Net program's input buffer, the program
-    runs (score head included: -h / std for VP / sub-VP), ssde_pf_drift forms the fp64 slope.  Per-evaluation scalars
-    (label, std, drift coefficient, g^2) are computed on the host with the SDE's own fp32 torch expressions."""
+class _FusedRhs:
+    """Common part of the fused right-hand sides: the per-evaluation scalars live in a 24-byte DEVICE record
+    (include/ssde.h: ssde_ode_dyn -- label, std, drift coefficient, g^2, the slope row to fill), uploaded before every
+    evaluation, and every launch of an evaluation is an op of ONE program that reads them from there.  On the GPU that
+    program is captured into a hipGraph once and replayed per evaluation (SSDE_ODE_GRAPH=0: launched op by op): an
+    adaptive solve is ~500 evaluations of ~230 (sampler) to ~1100 (likelihood) launches each."""
     writes_out = True
+    _RING = 32
 
-    def __init__(self, model, sde, shape, device):
-        from . import engine as E, sde_lib
-        self.sde, self.shape = sde, tuple(shape)
-        self.vp_like = isinstance(sde, (sde_lib.VPSDE, sde_lib.subVPSDE))
-        self.unet = E.UNetEngine(model, shape[0], shape[2], shape[3], device, vp_score=self.vp_like)
-        self.n = int(torch.tensor(self.shape).prod())
-        self.x32 = self.unet.x_in.tensor[: self.n]
+    def _init_dyn(self, device):
+        import os
+        self.device = torch.device(device)
+        self.dyn = torch.zeros(24, dtype=torch.uint8, device=self.device)
+        on_gpu = self.device.type == "cuda"
+        self._host = [torch.zeros(24, dtype=torch.uint8).pin_memory() if on_gpu else torch.zeros(24, dtype=torch.uint8)
+                      for _ in range(self._RING if on_gpu else 1)]
+        self._slot = 0
+        self.use_graph = on_gpu and os.environ.get("SSDE_ODE_GRAPH", "1") != "0"
+        self.graph_stream = torch.cuda.Stream(device=self.device) if self.use_graph else None
         self.nfev = 0
+        self.last_path = None
+
+    def _scalars(self, t):
+        """(label, std, a, g2) with the SDE's own fp32 torch expressions (f(x, t) is linear in x: a = f(1, t))."""
+        sde = self.sde
+        tv = torch.full((1,), float(t), dtype=torch.float32)
+        one = torch.ones(1, 1, 1, 1)
+        drift1, diffusion = sde.sde(one, tv)
+        std = sde.marginal_prob(torch.zeros(1, 1, 1, 1), tv)[1]
+        label = tv * 999 if self.vp_like else std                         # models/utils.py:147-166 (continuous labels)
+        eng = self.unet
+        second = float(std)
+        if eng.sig is not eng.cond:
+            # discrete-label (positional embedding) VE model with scale_by_sigma: the output is divided by
+            # sigmas[labels.long()] (ncsnpp.py:245,377-379) -- the same table lookup UNetEngine.load_inputs does; the
+            # value rides in the record's `std` slot (a VE network has no std head)
+            second = float(eng.model.sigmas[int(label.reshape(-1)[0])])
+        return float(label), second, float(drift1.reshape(-1)[0]), float((diffusion ** 2).reshape(-1)[0])
+
+    def _upload(self, t, out):
+        import struct
+        label, second, a, g2 = self._scalars(t)
+        h = self._host[self._slot % len(self._host)]
+        self._slot += 1
+        import numpy as np
+        h.numpy()[:] = np.frombuffer(struct.pack("<ffffQ", label, second, a, g2, out.data_ptr()), dtype=np.uint8)
+        self.dyn.copy_(h, non_blocking=True)
+
+    def _head_ops(self, emit):
+        from . import _lib as L
+        eng, n = self.unet, self.shape[0]
+        p = self.dyn.data_ptr()
+        emit(L.OP_FILL, L.FillArgs, dst=eng.cond.tensor, tab=p, step_ptr=None, n=n)
+        if eng.sig is not eng.cond:
+            emit(L.OP_FILL, L.FillArgs, dst=eng.sig.tensor, tab=p + 4, step_ptr=None, n=n)
+        if self.vp_like:
+            emit(L.OP_FILL, L.FillArgs, dst=eng.std.tensor, tab=p + 4, step_ptr=None, n=n)
+
+    def _build(self, assemble):
+        import ctypes as C
+        from . import _lib as L, engine as E
+        ops = []
+
+        def emit(kind, struct_cls, **fields):
+            a = struct_cls()
+            for k, v in fields.items():
+                setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+            ops.append(L.make_op(kind, a))
+        assemble(emit, ops)
+        self.program = E.Program(L.op_array(ops), [E.FC_OTHER] * len(ops), [0.0] * len(ops), self)
+
+    def __call__(self, t, y, out):
+        self.unet.weights.refresh()
+        self._upload(t, out)
+        if self.use_graph:
+            cur = torch.cuda.current_stream()
+            s = cur if cur.cuda_stream != 0 else self.graph_stream      # (capture needs a non-default stream)
+            if s is not cur:
+                s.wait_stream(cur)
+            if self.program._graph is None:
+                self.program.capture(s)
+            self.program.replay(s)
+            if s is not cur:
+                cur.wait_stream(s)
+            self.last_path = "graph"
+        else:
+            self.program.run()
+            self.last_path = "eager"
+        self.nfev += 1
 
     @staticmethod
     def applies(model, sde, x):
@@ -194,31 +268,63 @@ class FusedDrift:
             return False
         return not (type(sde) is not sde_lib.VESDE and model.config.model.scale_by_sigma)
 
-    def __call__(self, t, y, out):
-        import ctypes as C
-        from . import _lib as L, hipops
-        sde = self.sde
-        tv = torch.full((1,), float(t), dtype=torch.float32)
-        one = torch.ones(1, 1, 1, 1)
-        drift1, diffusion = sde.sde(one, tv)                              # f(x, t) is linear in x: coefficient = f(1, t)
-        std = sde.marginal_prob(torch.zeros(1, 1, 1, 1), tv)[1]
-        label = tv * 999 if self.vp_like else std                         # models/utils.py:147-166 (continuous labels)
-        eng = self.unet
-        eng.weights.refresh()
-        eng.cond.tensor[: self.shape[0]].fill_(float(label))
-        if eng.sig is not eng.cond:
-            # discrete-label (positional embedding) VE model with scale_by_sigma: the output is divided by
-            # sigmas[labels.long()] (ncsnpp.py:245,377-379) -- the same table lookup UNetEngine.load_inputs does
-            idx = int(label.reshape(-1)[0])
-            eng.sig.tensor[: self.shape[0]].fill_(float(eng.model.sigmas[idx]))
-        if self.vp_like:
-            eng.std.tensor[: self.shape[0]].fill_(float(std))
-        eng.program.run()
-        a = L.PfDriftArgs()
-        a.x, a.score, a.dst, a.numel = self.x32.data_ptr(), eng.out.tensor.data_ptr(), out.data_ptr(), self.n
-        a.a, a.g2 = float(drift1.reshape(-1)[0]), float((diffusion ** 2).reshape(-1)[0])
-        L.check(L.load().ssde_pf_drift(C.byref(a), hipops._stream()), "ssde_pf_drift")
-        self.nfev += 1
+
+class FusedDrift(_FusedRhs):
+    """Right-hand side of the probability-flow ODE for an NCSNpp model and a stock SDE, without torch arithmetic:
+    drift = f(x, t) - g(t)^2 score(x, t) / 2 (sde_lib.py:93-97 with probability_flow=True; score_fn models/utils.py:129-178).
+    The integrator's combine kernel writes the fp32 state straight into the U-Net program's input buffer, the program
+    runs (score head included: -h / std for VP / sub-VP), ssde_pf_drift forms the fp64 slope."""
+
+    def __init__(self, model, sde, shape, device):
+        from . import engine as E, sde_lib, _lib as L
+        self.sde, self.shape = sde, tuple(shape)
+        self.vp_like = isinstance(sde, (sde_lib.VPSDE, sde_lib.subVPSDE))
+        self.unet = E.UNetEngine(model, shape[0], shape[2], shape[3], device, vp_score=self.vp_like)
+        self.n = int(torch.tensor(self.shape).prod())
+        self.x32, self.n32 = self.unet.x_in.tensor[: self.n], self.n
+        self._init_dyn(device)
+
+        def assemble(emit, ops):
+            self._head_ops(emit)
+            ops.extend(self.unet.program.ops[i] for i in range(self.unet.program.n))
+            emit(L.OP_PF_DRIFT, L.PfDriftArgs, x=self.x32, score=self.unet.out.tensor, dst=None, numel=self.n, a=0.0, g2=0.0,
+                 dyn=self.dyn)
+        self._build(assemble)
+
+
+class FusedLikelihoodRhs(_FusedRhs):
+    """Right-hand side of the likelihood ODE (likelihood.py:59-67): d/dt [x, delta log p] = [drift, eps^T (d drift / d x) eps]
+    with the Hutchinson-Skilling probe eps fixed for the whole solve (likelihood.py:76-81).  One program per evaluation:
+    labels -> U-Net forward (activations resident) -> drift -> input-gradient program with the probe as the cotangent
+    (backward.TrainEngine without weight-gradient kernels) -> per-sample divergence (ssde_hutch_div).  The reference gets
+    the same vector-Jacobian product from torch.autograd.grad (likelihood.py:29-35)."""
+
+    def __init__(self, model, sde, shape, probe, device):
+        from . import backward as B, sde_lib, _lib as L
+        self.sde, self.shape = sde, tuple(shape)
+        self.vp_like = isinstance(sde, (sde_lib.VPSDE, sde_lib.subVPSDE))
+        eng = self.unet = B.TrainEngine(model, shape[0], shape[2], shape[3], device, vp_score=self.vp_like, input_grad=True,
+                                        dropout=False, param_grads=False)
+        self.n = int(torch.tensor(self.shape).prod())
+        self.per = self.n // self.shape[0]
+        self.x32, self.n32 = eng.x_in.tensor[: self.n], self.n
+        self.eps = probe.detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+        eng.gout.tensor[: self.n].copy_(self.eps)        # the cotangent never changes: d(sum(score * eps)) / d score = eps
+        self._init_dyn(device)
+
+        def assemble(emit, ops):
+            self._head_ops(emit)
+            ops.extend(eng.program.ops[i] for i in range(eng.n_fwd))
+            emit(L.OP_PF_DRIFT, L.PfDriftArgs, x=self.x32, score=eng.out.tensor, dst=None, numel=self.n, a=0.0, g2=0.0, dyn=self.dyn)
+            ops.extend(eng.program.ops[i] for i in range(eng.n_fwd, eng.program.n))
+            emit(L.OP_HUTCH_DIV, L.HutchDivArgs, gx=eng.gx.tensor, eps=self.eps, dst=None, dst_off=self.n, n=self.shape[0],
+                 per=self.per, a=0.0, g2=0.0, dyn=self.dyn)
+        self._build(assemble)
+
+    def set_probe(self, probe):
+        """a new Hutchinson probe for the next solve (the reference draws one per likelihood_fn call, likelihood.py:76-81)"""
+        self.eps.copy_(probe.detach().to(self.eps.device, torch.float32).reshape(-1))
+        self.unet.gout.tensor[: self.n].copy_(self.eps)
 
 
 def solve_host(fun, t_span, y0, rtol=1e-5, atol=1e-5, method="RK45"):
@@ -242,8 +348,18 @@ def integrate_ode(fun, t_span, y0, rtol, atol, method):
     A right-hand side with `writes_out` (FusedDrift) gets the fp32 copy of every stage argument written into its input."""
     import os
     if method == "RK45" and y0.is_cuda and os.environ.get("SSDE_HOST_ODE", "0") != "1":
-        stages = _HipStages(y0.numel(), y0, x32=getattr(fun, "x32", None))
-        return solve_rk45(fun, t_span, y0, rtol=rtol, atol=atol, stages=stages)
+        side = getattr(fun, "graph_stream", None)
+        if side is None:
+            stages = _HipStages(y0.numel(), y0, x32=getattr(fun, "x32", None), n32=getattr(fun, "n32", 0))
+            return solve_rk45(fun, t_span, y0, rtol=rtol, atol=atol, stages=stages)
+        # graph-captured right-hand side: the whole solve (stage kernels, graph replays, the one scalar read per step)
+        # runs on the side stream the graph was captured on
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            stages = _HipStages(y0.numel(), y0, x32=getattr(fun, "x32", None), n32=getattr(fun, "n32", 0))
+            res = solve_rk45(fun, t_span, y0, rtol=rtol, atol=atol, stages=stages)
+        torch.cuda.current_stream().wait_stream(side)
+        return res
     if getattr(fun, "writes_out", False):
         inner = fun
 

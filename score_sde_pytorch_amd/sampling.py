@@ -322,8 +322,6 @@ def get_ode_sampler(sde, shape, inverse_scaler, denoise=False, rtol=1e-5, atol=1
         score_fn = get_score_fn(sde, model, train=False, continuous=True)
         return sde.reverse(score_fn, probability_flow=True).sde(x, t)[0]
 
-    fused_rhs = {}
-
     def ode_sampler(model, z=None):
         from . import ode
         with torch.no_grad():
@@ -331,10 +329,14 @@ def get_ode_sampler(sde, shape, inverse_scaler, denoise=False, rtol=1e-5, atol=1
 
             if ode.FusedDrift.applies(model, sde, x):
                 # stock SDE + NCSNpp: stage arithmetic, U-Net program and drift are all HIP launches, no torch arithmetic
-                key = id(model)
-                rhs = fused_rhs.get(key)
+                # cached on the model (not in this closure): every sampler built for the same SDE object, shape and
+                # device shares the lowered program, its packed weights and its captured graph (the rhs keeps `sde` alive,
+                # so the id cannot be recycled)
+                cache = model.__dict__.setdefault("_ode_rhs", {})
+                key = ("drift", id(sde), tuple(shape), x.device.index)
+                rhs = cache.get(key)
                 if rhs is None:
-                    rhs = fused_rhs[key] = ode.FusedDrift(model, sde, shape, x.device)
+                    rhs = cache[key] = ode.FusedDrift(model, sde, shape, x.device)
                 ode_sampler.last_path = "fused"
             else:
                 def rhs(t, y):

@@ -599,10 +599,11 @@ def check_likelihood(dev):
     real = torch.randint_like
     torch.randint_like = lambda t, low=0, high=2, **kw: ((epsilon + 1.) / 2.).to(t.device)
     try:
-        bpd, z, nfe = likelihood.get_likelihood_fn(sde, inv, rtol=case["rtol"], atol=case["atol"], eps=case["lik_eps"])(
-            model, data.to(dev))
+        lik = likelihood.get_likelihood_fn(sde, inv, rtol=case["rtol"], atol=case["atol"], eps=case["lik_eps"])
+        bpd, z, nfe = lik(model, data.to(dev))
     finally:
         torch.randint_like = real
+    assert dev == "cpu" or lik.last_path == "fused"       # ode.FusedLikelihoodRhs: one device program per evaluation
     # (a) one evaluation of the augmented right-hand side at a fixed point (reference closures likelihood.py:26-37,59-67)
     drift_fn = lambda xx, tt: sde.reverse(mutils.get_score_fn(sde, model, train=False, continuous=True),     # noqa: E731
                                           probability_flow=True).sde(xx, tt)[0]
@@ -621,6 +622,39 @@ def check_likelihood(dev):
     assert torch.isfinite(bpd).all() and torch.isfinite(z).all()
     assert rel_err(bpd, torch.from_numpy(gold["lik_bpd"])) < 1e-3, (bpd, gold["lik_bpd"])
     assert rel_err(z, torch.from_numpy(gold["lik_z"])) < 5e-2
+
+
+def check_fused_likelihood_rhs(dev):
+    """ode.FusedLikelihoodRhs: one evaluation of d/dt [x, delta log p] as a single device program (forward, drift kernel,
+    input-gradient program seeded with the Hutchinson probe, per-sample divergence kernel) against the REFERENCE's
+    right-hand side stored in tests/golden/ode_small.npz (`rhs_drift`, `rhs_div`: likelihood.py:29-35,59-67 evaluated by
+    oracle/gen_golden_ode.py at t_probe), then a second evaluation at another time to show that the per-evaluation
+    scalars really come from the device record (same program, new record)."""
+    from score_sde_pytorch_amd import ode
+    from oracle import ode_oracle, sampler_oracle
+    gold = np.load(os.path.join(_util.GOLDEN, "ode_small.npz"))
+    case = _util.ODE_CASE
+    cfg, model, sde = _ode_case_model(dev)
+    _, data, epsilon = _util.ode_case_inputs()
+    rhs = ode.FusedLikelihoodRhs(model, sde, data.shape, epsilon, torch.device(dev))
+    n, Bn = data.numel(), data.shape[0]
+    scale = float(np.prod(data.shape[1:]))
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    osde = sampler_oracle.make_sde("subvpsde", **case["sde_kwargs"])
+    for t in (case["t_probe"], 0.37):
+        rhs.x32.copy_(data.reshape(-1).to(dev))
+        out = torch.full((n + Bn,), float("nan"), dtype=torch.float64, device=dev)
+        rhs(t, None, out=out)
+        got_d = out[:n].reshape(data.shape).to("cpu", torch.float32)
+        got_v = out[n:].to("cpu", torch.float32)
+        if t == case["t_probe"]:
+            ref_d, ref_v = torch.from_numpy(gold["rhs_drift"]), torch.from_numpy(gold["rhs_div"])
+        else:
+            ref_d, ref_v = ode_oracle.rhs_augmented(cfg, sd, osde, data, torch.ones(Bn) * t, epsilon)
+        assert rel_err(got_d, ref_d) < 1e-4, (t, rel_err(got_d, ref_d))
+        # eps^T J eps is a sum of 768 terms of mixed sign: compare on the scale of the number of terms
+        assert float((got_v - ref_v).abs().max()) / scale < 1e-4, (t, got_v, ref_v)
+    assert rhs.last_path == ("graph" if dev != "cpu" else "eager")
 
 
 def check_ode_sampler(dev, denoise):

@@ -4,7 +4,8 @@ differs from the one the small-batch tests exercise):
 
   configs[1]  CIFAR-10 NCSN++ forward at batch 256, and one whole predictor-corrector iteration at batch 256
   configs[2]  CIFAR-10 NCSN++ training: all 571 parameter gradients + the input gradient at batch 128
-  configs[3]  FFHQ-256 NCSN++ forward at batch 16
+  configs[3]  FFHQ-256 NCSN++ forward at batch 16, and one whole PC iteration at batch 16 (sigma_max 348, snr 0.075)
+  configs[4]  CIFAR-10 DDPM++ (sub-VP) forward at batch 256
 
 each against the CPU oracle (oracle/unet_oracle.py, sampler_oracle.py -- pinned bit-exactly to the reference by
 tests/golden/, see test_oracle_golden.py).  The network treats samples independently (GroupNorm statistics are
@@ -147,6 +148,62 @@ def test_ffhq256_forward_batch16():
     with torch.no_grad():
         y = model(x.cuda(), sig.cuda())
     ref = _oracle_forward(cfg, sd, x, sig, 4)
+    assert torch.isfinite(y).all()
+    assert rel_err(y, ref) < 1e-4, rel_err(y, ref)
+    per = (y.cpu() - ref).reshape(B, -1).abs().max(dim=1)[0] / ref.reshape(B, -1).abs().max(dim=1)[0]
+    assert float(per.max()) < 2e-4, float(per.max())
+
+
+def test_ffhq256_pc_iteration_batch16():
+    """configs[3]'s sampler step at its own settings (configs/ve/ffhq_256_ncsnpp_continuous.py: sigma_max 348, snr 0.075,
+    N = 2000, reverse diffusion + Langevin, batch 16 per GPU): one whole iteration -- two U-Net evaluations on 256x256
+    maps, 94 % of their 3x3 FLOPs on the F(4x4,3x3) kernel, the Langevin step size from the 16-sample batch mean --
+    against the CPU oracle, on north_star's two yardsticks."""
+    from oracle import sampler_oracle
+    from score_sde_pytorch_amd import sde_lib, sampling
+    cfg = _util.cfgs.get_config("ve/ffhq_256_ncsnpp_continuous")
+    model, sd = _model(cfg)
+    B, N, R = 16, 2000, 256
+    smax, snr = float(cfg.model.sigma_max), float(cfg.sampling.snr)
+    assert abs(smax - 348.0) < 1e-6 and abs(snr - 0.075) < 1e-9
+    kw = dict(sigma_min=cfg.model.sigma_min, sigma_max=smax, N=N)
+    sde = sde_lib.VESDE(**kw)
+    g = torch.Generator().manual_seed(2000)
+    x_T = torch.randn(B, 3, R, R, generator=g) * smax
+    noises = torch.randn(1, 2, B, 3, R, R, generator=g)
+    sampler = sampling.get_pc_sampler(sde, (B, 3, R, R), sampling.ReverseDiffusionPredictor, sampling.LangevinCorrector,
+                                      lambda v: v, snr=snr, n_steps=1, probability_flow=False, continuous=True,
+                                      denoise=False, eps=1e-5, device="cuda")
+    out, _ = sampler(model, x_init=x_T, noises=noises, max_steps=1)
+    assert sampler.last_path == "fused-eager"
+    wino, direct = _kernel_mix(sampler.engine.unet)
+    assert wino >= 40, (wino, direct)
+    ref = sampler_oracle.pc_sample(cfg, sd, "vesde", kw, x_T, noises, snr=snr, n_steps=1, eps=1e-5, denoise=False, max_steps=1)
+    r = ref["x_steps"][0]
+    mse = float(((out.cpu().double() - r.double()) ** 2).mean())
+    assert mse <= 1e-8 * float(r.abs().max()) ** 2, mse
+    assert rel_err(out, r) < 2e-4
+    s = sampler.engine.unet.output_view()
+    norm = float(torch.norm(s.reshape(B, -1), dim=-1).mean())
+    assert abs(norm - ref["score_norms"][1]) / ref["score_norms"][1] < 1e-4
+
+
+def test_ddpmpp_forward_batch256():
+    """configs[4]'s network (configs/subvp/cifar10_ddpmpp_continuous.py: DDPM++ -- positional time embedding, plain
+    average-pool / nearest resampling instead of FIR, labels t * 999) at the batch the ODE bench runs, under the production
+    kernel heuristic (F(4x4,3x3) on the 32x32 and 16x16 layers); its reference goldens are batch <= 9."""
+    cfg = _util.cfgs.get_config("subvp/cifar10_ddpmpp_continuous")
+    model, sd = _model(cfg)
+    B = 256
+    g = torch.Generator().manual_seed(4)
+    t = torch.rand(B, generator=g) * (1 - 1e-3) + 1e-3
+    x = torch.randn(B, 3, 32, 32, generator=g)
+    labels = t * 999                                           # models/utils.py:147-150 (continuous VP / sub-VP labels)
+    with torch.no_grad():
+        y = model(x.cuda(), labels.cuda())
+    ref = _oracle_forward(cfg, sd, x, labels, 64)
+    wino, direct = _kernel_mix(next(iter(model._engines.values())))
+    assert wino >= 40, (wino, direct)
     assert torch.isfinite(y).all()
     assert rel_err(y, ref) < 1e-4, rel_err(y, ref)
     per = (y.cpu() - ref).reshape(B, -1).abs().max(dim=1)[0] / ref.reshape(B, -1).abs().max(dim=1)[0]

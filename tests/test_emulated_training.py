@@ -36,6 +36,10 @@ def test_conv3x3_winograd_f4x4():
     T.check_conv_winograd4("cpu", big=False)
 
 
+def test_fused_likelihood_right_hand_side():
+    T.check_fused_likelihood_rhs("cpu")
+
+
 def test_fused_ode_drift_on_a_discrete_label_ve_model():
     T.check_fused_drift_discrete_ve("cpu")
 

@@ -112,6 +112,10 @@ def test_ode_sampler_matches_reference_fixture(denoise):
     T.check_ode_sampler("cuda", denoise)
 
 
+def test_fused_likelihood_right_hand_side():
+    T.check_fused_likelihood_rhs("cuda")
+
+
 def test_fused_ode_drift_on_a_discrete_label_ve_model():
     T.check_fused_drift_discrete_ve("cuda")
 
