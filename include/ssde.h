@@ -479,9 +479,14 @@ int ssde_graph_destroy(void* graph);
 enum { SSDE_REGION_ZERO = 0,    /* activations, I/O, sampler state: zero-initialised                      */
        SSDE_REGION_CONST = 1 }; /* initial contents in the blob: packed weights, parameters, tables       */
 enum { SSDE_RELOC_OP = 0, SSDE_RELOC_REFRESH_OP = 1, SSDE_RELOC_REGION = 2 };
-enum { SSDE_PLAN_UNET = 0, SSDE_PLAN_PC = 1 };
+enum { SSDE_PLAN_UNET = 0, SSDE_PLAN_PC = 1, SSDE_PLAN_TRAIN = 2 };
 enum { SSDE_IO_X = 0, SSDE_IO_COND = 1, SSDE_IO_SIGMA = 2, SSDE_IO_STD = 3, SSDE_IO_OUT = 4, SSDE_IO_XMEAN = 5,
-       SSDE_IO_STEP = 6, SSDE_IO_SEED = 7 };
+       SSDE_IO_STEP = 6, SSDE_IO_SEED = 7,
+       /* training plans (losses.FusedTrainStep): clean batch, noise, per-sample mean coefficient / std / g^2, scalar loss,
+        * the 12-float hyper-parameter record of ssde_adam_clip_ema, the dropout seed word, d loss / d out, d loss / d x,
+        * the flat gradient and the flat parameter buffer (reference layouts, state_dict order) */
+       SSDE_IO_BATCH = 8, SSDE_IO_Z = 9, SSDE_IO_A = 10, SSDE_IO_S = 11, SSDE_IO_G2 = 12, SSDE_IO_LOSS = 13, SSDE_IO_HYPER = 14,
+       SSDE_IO_DROP_SEED = 15, SSDE_IO_GOUT = 16, SSDE_IO_GX = 17, SSDE_IO_GRAD = 18, SSDE_IO_PARAMS = 19, SSDE_IO_SLOTS = 24 };
 typedef struct ssde_plan_header {
   char magic[8];                /* "SSDEPLN1" */
   int32_t abi_version, sizeof_op;
@@ -490,7 +495,10 @@ typedef struct ssde_plan_header {
   int32_t batch, channels, height, width;
   int32_t nfe_per_iteration;    /* sampler plans: U-Net evaluations per PC iteration; else 1 */
   int32_t sde_steps;            /* sampler plans: N (length of the step tables) */
-  int32_t io[8];                /* region ids by SSDE_IO_*; -1 = absent */
+  int32_t io[SSDE_IO_SLOTS];    /* region ids by SSDE_IO_*; -1 = absent */
+  int32_t seg[4];               /* training plans: first op of the forward / loss head / backward / optimizer segments
+                                   (ops [0, seg[0]) perturb the batch: losses.py:84-88) */
+  int64_t n_flat;               /* training plans: floats of the flat parameter / gradient buffers */
   int64_t data_bytes;
 } ssde_plan_header;
 typedef struct ssde_plan_region { int64_t bytes; int64_t data_offset; int32_t kind; int32_t _pad0; char name[32]; } ssde_plan_region;
@@ -518,6 +526,27 @@ int ssde_unet_forward(ssde_plan* p, const float* x, const float* cond, const flo
 /* replaces pc_sampler's loop (sampling.py:390-409): load the prior sample, run iterations, read the state */
 int ssde_pc_reset(ssde_plan* p, const float* x_T, uint64_t seed, void* stream);
 int ssde_pc_run(ssde_plan* p, int32_t n_iterations, int32_t use_graph, void* stream);
+/* ---- training plans (SSDE_PLAN_TRAIN, exported from losses.FusedTrainStep by plan_export.export_train_plan) ----
+ * replaces step_fn (losses.py:179-208) for one optimisation step of the denoising score matching loss: perturb the batch
+ * (x_t = a[n] batch + s[n] z, losses.py:84-88), forward, loss head + d loss / d score, backward, gradient clipping + Adam +
+ * EMA (losses.py:41-51, models/ema.py:46-51), re-pack of the kernel-layout weights.  All tensors are DEVICE pointers:
+ * batch, z [B,C,H,W]; a, s, labels [B] (mean coefficient, marginal std and network label of every sample's t -- the
+ * host evaluates sde.marginal_prob, a handful of scalars); g2 [B] or NULL (likelihood weighting); loss_out: 1 float or
+ * NULL.  `hyper` is a HOST pointer to 9 floats: lr, beta1, beta2, eps, weight_decay, grad_clip, 1 - beta1^t,
+ * sqrt(1 - beta2^t), 1 - ema_decay. */
+int ssde_train_step(ssde_plan* p, const float* batch, const float* z, const float* a, const float* s, const float* labels,
+                    const float* g2, const float* hyper, uint32_t dropout_seed, float* loss_out, void* stream);
+/* the two halves of autograd through the network on a training plan: out = model(x, cond) in train mode (activations
+ * stay resident, dropout masks from `dropout_seed`), then the vector-Jacobian products of d loss / d out = dout:
+ * dx [B,C,H,W] (plans exported with the input gradient; else pass NULL) and dparams = the flat parameter gradient
+ * (n_flat floats, reference layouts in state_dict order; NULL to leave it in the plan).  Replaces loss.backward()
+ * (losses.py:196) for hosts that bring their own loss. */
+int ssde_train_forward(ssde_plan* p, const float* x, const float* cond, const float* sigma, const float* std_, uint32_t dropout_seed,
+                       float* out, void* stream);
+int ssde_unet_backward(ssde_plan* p, const float* dout, float* dx, float* dparams, void* stream);
+/* device-to-device copy between an I/O region of the plan (SSDE_IO_*) and the caller's buffer: to_plan = 0 reads the region
+ * (e.g. SSDE_IO_PARAMS: the flat parameter buffer after training steps), 1 writes it */
+int ssde_plan_copy_io(ssde_plan* p, int32_t slot, void* buf, int64_t bytes, int32_t to_plan, void* stream);
 int ssde_pc_state(ssde_plan* p, float* x, float* x_mean, void* stream);
 
 int ssde_abi_version(void);

@@ -242,7 +242,8 @@ EXPORTS = ["ssde_conv2d", "ssde_groupnorm_stats", "ssde_upfirdn2d", "ssde_attent
            "ssde_wgrad_scratch_floats", "ssde_pack_weights", "ssde_project_update", "ssde_gn_finalize", "ssde_conv_gn_slices", "ssde_rk_combine", "ssde_rk_error_norm", "ssde_pf_drift", "ssde_hutch_div",
            # plan-level entry points (csrc/plan.hip; argument types: plan_export.bind)
            "ssde_plan_load", "ssde_plan_load_file", "ssde_plan_destroy", "ssde_plan_info", "ssde_plan_param",
-           "ssde_plan_refresh_weights", "ssde_unet_forward", "ssde_pc_reset", "ssde_pc_run", "ssde_pc_state"]
+           "ssde_plan_refresh_weights", "ssde_unet_forward", "ssde_pc_reset", "ssde_pc_run", "ssde_pc_state",
+           "ssde_train_step", "ssde_train_forward", "ssde_unet_backward", "ssde_plan_copy_io"]
 
 _lib = None
 

@@ -240,3 +240,93 @@ extern "C" int ssde_pc_state(ssde_plan* p, float* x, float* x_mean, void* stream
   if (x_mean) SSDE_HIP_CHECK(hipMemcpyAsync(x_mean, region_ptr(p, h.io[SSDE_IO_XMEAN]), img, hipMemcpyDeviceToDevice, st));
   return SSDE_OK;
 }
+
+// ---- training plans (losses.FusedTrainStep: perturb | forward | loss head | backward | clip + Adam + EMA) ----
+namespace {
+int run_segment(ssde_plan* p, int lo, int hi, void* stream) {
+  SSDE_REQUIRE(0 <= lo && lo <= hi && hi <= (int)p->ops.size(), "plan: bad segment [%d, %d)", lo, hi);
+  return ssde_program_run(p->ops.data() + lo, hi - lo, stream);
+}
+// host scalars of a call (dropout seed word, hyper-parameters) are copied from the caller's memory: the stream is
+// synchronised before returning to the caller's frame
+int set_seed(ssde_plan* p, const int32_t* seed_word, hipStream_t st) {
+  if (p->hdr.io[SSDE_IO_DROP_SEED] < 0) return SSDE_OK;              // a plan lowered without dropout
+  SSDE_HIP_CHECK(hipMemcpyAsync(region_ptr(p, p->hdr.io[SSDE_IO_DROP_SEED]), seed_word, sizeof(int32_t), hipMemcpyHostToDevice, st));
+  return SSDE_OK;
+}
+}  // namespace
+
+extern "C" int ssde_train_step(ssde_plan* p, const float* batch, const float* z, const float* a, const float* s, const float* labels,
+                               const float* g2, const float* hyper, uint32_t dropout_seed, float* loss_out, void* stream) {
+  SSDE_REQUIRE(p && p->hdr.kind == SSDE_PLAN_TRAIN && p->hdr.seg[3] > 0, "train_step: not a training plan with an optimizer segment");
+  SSDE_REQUIRE(hyper, "train_step: null hyper-parameters");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const ssde_plan_header& h = p->hdr;
+  const size_t img = (size_t)h.batch * h.channels * h.height * h.width * sizeof(float), vec = (size_t)h.batch * sizeof(float);
+  if (int rc = copy_in(p, SSDE_IO_BATCH, batch, img, st)) return rc;
+  if (int rc = copy_in(p, SSDE_IO_Z, z, img, st)) return rc;
+  if (int rc = copy_in(p, SSDE_IO_A, a, vec, st)) return rc;
+  if (int rc = copy_in(p, SSDE_IO_S, s, vec, st)) return rc;
+  if (int rc = copy_in(p, SSDE_IO_COND, labels, vec, st)) return rc;
+  if (h.io[SSDE_IO_STD] >= 0)                                         // VP score head: score = -h / std (models/utils.py:159)
+    if (int rc = copy_in(p, SSDE_IO_STD, s, vec, st)) return rc;
+  if (h.io[SSDE_IO_G2] >= 0 && g2)
+    if (int rc = copy_in(p, SSDE_IO_G2, g2, vec, st)) return rc;
+  SSDE_REQUIRE(region_ptr(p, h.io[SSDE_IO_HYPER]), "train_step: plan has no hyper-parameter record");
+  SSDE_HIP_CHECK(hipMemcpyAsync(region_ptr(p, h.io[SSDE_IO_HYPER]), hyper, 9 * sizeof(float), hipMemcpyHostToDevice, st));
+  const int32_t seed_word = (int32_t)(dropout_seed & 0x7FFFFFFFu);
+  if (int rc = set_seed(p, &seed_word, st)) return rc;
+  SSDE_HIP_CHECK(hipStreamSynchronize(st));                           // `hyper` and `seed_word` are the caller's / this frame's
+  if (int rc = run_segment(p, 0, (int)p->ops.size(), stream)) return rc;
+  if (int rc = ssde_plan_refresh_weights(p, stream)) return rc;       // packed copies follow the in-place parameter update
+  if (loss_out) SSDE_HIP_CHECK(hipMemcpyAsync(loss_out, region_ptr(p, h.io[SSDE_IO_LOSS]), sizeof(float), hipMemcpyDeviceToDevice, st));
+  return SSDE_OK;
+}
+
+extern "C" int ssde_train_forward(ssde_plan* p, const float* x, const float* cond, const float* sigma, const float* std_,
+                                  uint32_t dropout_seed, float* out, void* stream) {
+  SSDE_REQUIRE(p && p->hdr.kind == SSDE_PLAN_TRAIN, "train_forward: not a training plan");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const ssde_plan_header& h = p->hdr;
+  const size_t img = (size_t)h.batch * h.channels * h.height * h.width * sizeof(float), vec = (size_t)h.batch * sizeof(float);
+  if (int rc = copy_in(p, SSDE_IO_X, x, img, st)) return rc;
+  if (int rc = copy_in(p, SSDE_IO_COND, cond, vec, st)) return rc;
+  if (h.io[SSDE_IO_SIGMA] >= 0 && h.io[SSDE_IO_SIGMA] != h.io[SSDE_IO_COND])
+    if (int rc = copy_in(p, SSDE_IO_SIGMA, sigma, vec, st)) return rc;
+  if (h.io[SSDE_IO_STD] >= 0)
+    if (int rc = copy_in(p, SSDE_IO_STD, std_, vec, st)) return rc;
+  const int32_t seed_word = (int32_t)(dropout_seed & 0x7FFFFFFFu);
+  if (int rc = set_seed(p, &seed_word, st)) return rc;
+  SSDE_HIP_CHECK(hipStreamSynchronize(st));
+  if (int rc = run_segment(p, h.seg[0], h.seg[1], stream)) return rc;
+  if (out) SSDE_HIP_CHECK(hipMemcpyAsync(out, region_ptr(p, h.io[SSDE_IO_OUT]), img, hipMemcpyDeviceToDevice, st));
+  return SSDE_OK;
+}
+
+extern "C" int ssde_unet_backward(ssde_plan* p, const float* dout, float* dx, float* dparams, void* stream) {
+  SSDE_REQUIRE(p && p->hdr.kind == SSDE_PLAN_TRAIN && dout, "unet_backward: not a training plan / null cotangent");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const ssde_plan_header& h = p->hdr;
+  const size_t img = (size_t)h.batch * h.channels * h.height * h.width * sizeof(float);
+  if (int rc = copy_in(p, SSDE_IO_GOUT, dout, img, st)) return rc;
+  if (int rc = run_segment(p, h.seg[2], h.seg[3] > 0 ? h.seg[3] : (int)p->ops.size(), stream)) return rc;
+  if (dx) {
+    SSDE_REQUIRE(region_ptr(p, h.io[SSDE_IO_GX]), "unet_backward: the plan was exported without the input gradient");
+    SSDE_HIP_CHECK(hipMemcpyAsync(dx, region_ptr(p, h.io[SSDE_IO_GX]), img, hipMemcpyDeviceToDevice, st));
+  }
+  if (dparams) {
+    SSDE_REQUIRE(region_ptr(p, h.io[SSDE_IO_GRAD]) && h.n_flat > 0, "unet_backward: the plan carries no parameter gradients");
+    SSDE_HIP_CHECK(hipMemcpyAsync(dparams, region_ptr(p, h.io[SSDE_IO_GRAD]), (size_t)h.n_flat * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  return SSDE_OK;
+}
+
+extern "C" int ssde_plan_copy_io(ssde_plan* p, int32_t slot, void* buf, int64_t bytes, int32_t to_plan, void* stream) {
+  SSDE_REQUIRE(p && buf && slot >= 0 && slot < SSDE_IO_SLOTS && bytes >= 0, "plan_copy_io: bad args");
+  void* reg = region_ptr(p, p->hdr.io[slot]);
+  SSDE_REQUIRE(reg, "plan_copy_io: the plan has no I/O slot %d", slot);
+  SSDE_REQUIRE(bytes <= p->regions[p->hdr.io[slot]].bytes, "plan_copy_io: %lld bytes exceed slot %d (%lld)", (long long)bytes, slot,
+               (long long)p->regions[p->hdr.io[slot]].bytes);
+  SSDE_HIP_CHECK(hipMemcpyAsync(to_plan ? reg : buf, to_plan ? buf : reg, (size_t)bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+  return SSDE_OK;
+}

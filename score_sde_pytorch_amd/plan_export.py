@@ -25,8 +25,10 @@ from . import _lib as L
 MAGIC = b"SSDEPLN1"
 REGION_ZERO, REGION_CONST = 0, 1
 RELOC_OP, RELOC_REFRESH_OP, RELOC_REGION = 0, 1, 2
-PLAN_UNET, PLAN_PC = 0, 1
+PLAN_UNET, PLAN_PC, PLAN_TRAIN = 0, 1, 2
 IO_X, IO_COND, IO_SIGMA, IO_STD, IO_OUT, IO_XMEAN, IO_STEP, IO_SEED = range(8)
+(IO_BATCH, IO_Z, IO_A, IO_S, IO_G2, IO_LOSS, IO_HYPER, IO_DROP_SEED, IO_GOUT, IO_GX, IO_GRAD, IO_PARAMS) = range(8, 20)
+IO_SLOTS = 24
 
 
 class PlanHeader(C.Structure):
@@ -34,7 +36,8 @@ class PlanHeader(C.Structure):
                 ("n_regions", C.c_int32), ("n_ops", C.c_int32), ("n_refresh_ops", C.c_int32), ("n_relocs", C.c_int32),
                 ("n_params", C.c_int32), ("kind", C.c_int32),
                 ("batch", C.c_int32), ("channels", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
-                ("nfe_per_iteration", C.c_int32), ("sde_steps", C.c_int32), ("io", C.c_int32 * 8), ("data_bytes", C.c_int64)]
+                ("nfe_per_iteration", C.c_int32), ("sde_steps", C.c_int32), ("io", C.c_int32 * IO_SLOTS), ("seg", C.c_int32 * 4),
+                ("n_flat", C.c_int64), ("data_bytes", C.c_int64)]
 
 
 class PlanRegion(C.Structure):
@@ -127,7 +130,7 @@ def _collect_unet(regions, eng):
         regions.add(raw, REGION_CONST, "packtab%d" % i)
 
 
-def _emit(kind, regions, ops, n_ops, eng_unet, model, io_tensors, batch, shape, nfe, sde_steps):
+def _emit(kind, regions, ops, n_ops, eng_unet, model, io_tensors, batch, shape, nfe, sde_steps, seg=(0, 0, 0, 0), n_flat=0):
     regions.freeze()
     relocs = []
     op_bytes = bytearray()
@@ -194,7 +197,10 @@ def _emit(kind, regions, ops, n_ops, eng_unet, model, io_tensors, batch, shape, 
     hdr.kind, hdr.batch = kind, batch
     hdr.channels, hdr.height, hdr.width = shape
     hdr.nfe_per_iteration, hdr.sde_steps = nfe, sde_steps
-    for slot in range(8):
+    for k in range(4):
+        hdr.seg[k] = int(seg[k])
+    hdr.n_flat = int(n_flat)
+    for slot in range(IO_SLOTS):
         t = io_tensors.get(slot)
         hdr.io[slot] = -1
         if t is not None:
@@ -252,6 +258,56 @@ def export_pc_plan(sampler, with_rng=True):
     return _emit(PLAN_PC, regions, prog.ops, prog.n, eng, sampler.model, io, B, (Cc, H, W), sampler.nfe_per_step(), sampler.sde.N)
 
 
+def export_train_plan(fs, optimizer=None, ema=None):
+    """losses.FusedTrainStep -> blob for ssde_train_step / ssde_train_forward / ssde_unet_backward.
+
+    One op array: [perturb | forward | loss head | backward | clip + Adam + EMA]; the segment starts go into the
+    header.  The flat parameter buffer (the parameters are views into it), the flat gradient, Adam's moments and the EMA
+    shadow are regions of their own; moments and shadow carry their CURRENT contents, so a plan exported mid-run resumes.
+    Without `optimizer` the plan stops after the backward segment (hosts that bring their own optimizer read the flat
+    gradient through ssde_unet_backward)."""
+    eng = fs.eng
+    eng.weights.refresh()
+    regions = _Regions()
+    _collect_unet(regions, eng)
+    regions.add(fs.flat.data, REGION_CONST, "flat_params")
+    regions.add(fs.flat.grad, REGION_ZERO, "flat_grad")
+    for name in ("z", "batch", "a", "s", "g2", "losses", "loss", "hyper", "gnorm", "partial"):
+        regions.add(getattr(fs, name), REGION_ZERO, name)
+    head_ops = lambda prog: [prog.ops[i] for i in range(prog.n)]                 # noqa: E731
+    ops = head_ops(fs._head[0])
+    seg0 = len(ops)
+    ops += [eng.program.ops[i] for i in range(eng.n_fwd)]
+    seg1 = len(ops)
+    ops += head_ops(fs._head[1])
+    seg2 = len(ops)
+    ops += [eng.program.ops[i] for i in range(eng.n_fwd, eng.program.n)]
+    seg3 = 0
+    if optimizer is not None:
+        m, v = optimizer.flatten_like(fs.flat)
+        regions.add(m, REGION_CONST, "adam_m")
+        regions.add(v, REGION_CONST, "adam_v")
+        if ema is not None:
+            regions.add(ema.flatten_like(fs.flat), REGION_CONST, "ema")
+        seg3 = len(ops)
+        ops += head_ops(fs._optimizer_program(optimizer, ema))
+    io = {IO_X: eng.x_in.tensor, IO_COND: eng.cond.tensor, IO_OUT: eng.out.tensor, IO_BATCH: fs.batch, IO_Z: fs.z, IO_A: fs.a,
+          IO_S: fs.s, IO_LOSS: fs.loss, IO_HYPER: fs.hyper, IO_GOUT: eng.gout.tensor, IO_GRAD: fs.flat.grad, IO_PARAMS: fs.flat.data}
+    if fs.spec["likelihood_weighting"]:
+        io[IO_G2] = fs.g2
+    if eng.sig is not eng.cond:
+        io[IO_SIGMA] = eng.sig.tensor
+    if eng.std is not None:
+        io[IO_STD] = eng.std.tensor
+    if eng.drop_seed is not None:
+        io[IO_DROP_SEED] = eng.drop_seed
+    if eng.gx is not None:
+        io[IO_GX] = eng.gx.tensor
+    arr = L.op_array(ops)
+    return _emit(PLAN_TRAIN, regions, arr, len(ops), eng, fs.model, io, eng.n, (eng.channels, eng.h, eng.w), 1, 0,
+                 seg=(seg0, seg1, seg2, seg3), n_flat=fs.flat.numel)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # ctypes binding of the plan entry points (what a C host calls; used by the tests and by tools)
 def bind(lib):
@@ -265,6 +321,10 @@ def bind(lib):
     lib.ssde_pc_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.ssde_pc_run.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.ssde_pc_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ssde_train_step.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.POINTER(C.c_float), C.c_uint32, C.c_void_p, C.c_void_p]
+    lib.ssde_train_forward.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_uint32, C.c_void_p, C.c_void_p]
+    lib.ssde_unet_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ssde_plan_copy_io.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
     return lib
 
 
@@ -291,6 +351,36 @@ class LoadedPlan:
         out = torch.empty_like(x)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
         L.check(self.lib.ssde_unet_forward(self.handle, p(x), p(cond), p(sigma), p(std), p(out), C.c_void_p(stream or 0)), "ssde_unet_forward")
+        return out
+
+    def train_step(self, batch, z, a, s, labels, hyper9, seed, g2=None, stream=None):
+        """one optimisation step through the C entry point; returns the loss as a 1-element tensor on the inputs' device"""
+        loss = torch.zeros(1, dtype=torch.float32, device=batch.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+        hy = (C.c_float * 9)(*[float(v) for v in hyper9])
+        L.check(self.lib.ssde_train_step(self.handle, p(batch), p(z), p(a), p(s), p(labels), p(g2), hy, int(seed) & 0xFFFFFFFF, p(loss),
+                                         C.c_void_p(stream or 0)), "ssde_train_step")
+        return loss
+
+    def train_forward(self, x, cond, seed=0, sigma=None, std=None, stream=None):
+        out = torch.empty_like(x)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+        L.check(self.lib.ssde_train_forward(self.handle, p(x), p(cond), p(sigma), p(std), int(seed) & 0xFFFFFFFF, p(out),
+                                            C.c_void_p(stream or 0)), "ssde_train_forward")
+        return out
+
+    def unet_backward(self, dout, want_dx=False, stream=None):
+        dx = torch.empty_like(dout) if want_dx else None
+        dparams = torch.empty(int(self.header.n_flat), dtype=torch.float32, device=dout.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+        L.check(self.lib.ssde_unet_backward(self.handle, p(dout), p(dx), p(dparams), C.c_void_p(stream or 0)), "ssde_unet_backward")
+        return dx, dparams
+
+    def read_io(self, slot, like):
+        """the first like.numel() elements of an I/O region, as a tensor shaped / typed / placed like `like`"""
+        out = torch.empty_like(like)
+        L.check(self.lib.ssde_plan_copy_io(self.handle, int(slot), C.c_void_p(out.data_ptr()), out.numel() * out.element_size(), 0,
+                                           C.c_void_p(0)), "ssde_plan_copy_io")
         return out
 
     def close(self):

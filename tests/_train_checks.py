@@ -771,6 +771,105 @@ def check_forced_exchange_one_rank(dev, backend, monkeypatch):
     assert torch.equal(gr, ref_g) and torch.equal(p, ref_p)
 
 
+def _train_plan_case(dev, dropout):
+    from score_sde_pytorch_amd.models import utils as mutils, ema as ema_mod
+    from score_sde_pytorch_amd import losses, sde_lib
+    cfg = small_cfg("ncsnpp")
+    cfg.model.dropout = dropout
+    cfg.optim.warmup = 0
+    sde = sde_lib.VESDE(cfg.model.sigma_min, cfg.model.sigma_max, cfg.model.num_scales)
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    sd = dict(_util.load_seeded(model, seed=1)); sd["sigmas"] = model.sigmas.clone()
+    model = model.to(dev)
+    opt = losses.get_optimizer(cfg, model.parameters())
+    ema = ema_mod.ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate)
+    optimize_fn = losses.optimization_manager(cfg)
+    step_fn = losses.get_step_fn(sde, train=True, optimize_fn=optimize_fn, reduce_mean=False, continuous=True)
+    state = dict(optimizer=opt, model=model, ema=ema, step=0)
+    R, Bn = cfg.data.image_size, 3
+    fs = step_fn.fused_for(state, torch.zeros(Bn, 3, R, R, device=dev))
+    return cfg, sd, sde, model, opt, ema, optimize_fn, state, fs, R, Bn
+
+
+def check_train_plan(dev, tmp_path=None, c_host=None):
+    """SURVEY 8(b)'s training entries of the plan-level C ABI (csrc/plan.hip): a losses.FusedTrainStep exported with
+    plan_export.export_train_plan and driven through ssde_train_step reproduces the Python-driven fused step (same kernels,
+    same order: loss and every parameter bit for bit over two steps, Adam moments and EMA carried inside the plan);
+    ssde_train_forward + ssde_unet_backward return the forward output and ALL parameter gradients of the network, compared
+    with torch autograd through the CPU oracle (= the reference's loss.backward(), losses.py:196).
+    c_host: optional callable(blob_path, files, loss_ref) that runs tests/c_host/plan_host.c in `train` mode."""
+    from score_sde_pytorch_amd import plan_export
+    # ---- (1) whole optimisation steps
+    cfg, sd, sde, model, opt, ema, optimize_fn, state, fs, R, Bn = _train_plan_case(dev, dropout=0.1)
+    blob = plan_export.export_train_plan(fs, opt, ema)
+    g = torch.Generator().manual_seed(21)
+    steps = [(torch.rand(Bn, 3, R, R, generator=g), torch.rand(Bn, generator=g) * 0.9 + 0.05, torch.randn(Bn, 3, R, R, generator=g))
+             for _ in range(2)]
+    ref_loss, hypers, coefs = [], [], []
+    for i, (b, t, z) in enumerate(steps):
+        ref_loss.append(float(fs.loss_and_grads(b.to(dev), t=t.to(dev), z=z.to(dev), seed=40 + i)))
+        coefs.append((fs.a.clone(), fs.s.clone(), fs.eng.cond.tensor[:Bn].clone()))
+        fs.optimizer_step(opt, ema, state["step"], optimize_fn.ssde_hyper)
+        state["step"] += 1
+        hypers.append(fs.hyper.detach().cpu()[:9].tolist())
+    ref_params = fs.flat.data.clone()
+    plan = plan_export.LoadedPlan(blob)
+    assert plan.header.kind == plan_export.PLAN_TRAIN and plan.header.n_flat == fs.flat.numel and plan.header.seg[3] > plan.header.seg[2]
+    for i, (b, t, z) in enumerate(steps):
+        a_, s_, lab = coefs[i]
+        loss = plan.train_step(b.to(dev), z.to(dev), a_, s_, lab, hypers[i], 40 + i)
+        assert abs(float(loss) - ref_loss[i]) <= (0.0 if dev != "cpu" else 1e-6 * abs(ref_loss[i])), (i, float(loss), ref_loss[i])
+    got = plan.read_io(plan_export.IO_PARAMS, ref_params)
+    if dev != "cpu":
+        assert torch.equal(got, ref_params), float((got - ref_params).abs().max())
+    else:
+        # on the emulator's host tensors the Python path re-packs the Winograd weights with the torch packers after a step
+        # (WeightStore.refresh: device re-pack only on the GPU) while the plan always uses ssde_pack_weights: G g G^T in
+        # another summation order, a last-bit difference in the packed weights of the second step
+        assert rel_err(got, ref_params) < 1e-5
+    plan.close()
+    if c_host is not None:
+        files = {}
+        b, t, z = steps[0]
+        a_, s_, lab = coefs[0]
+        for name, v in (("batch", b), ("z", z), ("a", a_), ("s", s_), ("labels", lab), ("hyper", torch.tensor(hypers[0]))):
+            files[name] = os.path.join(str(tmp_path), name + ".f32")
+            np.ascontiguousarray(v.detach().cpu().numpy(), dtype=np.float32).tofile(files[name])
+        blob_path = os.path.join(str(tmp_path), "train.blob")
+        open(blob_path, "wb").write(blob)
+        c_host(blob_path, files, 40, ref_loss[0])
+    # ---- (2) forward + all gradients through the plan, against autograd over the oracle (no dropout)
+    cfg, sd, sde, model, opt, ema, optimize_fn, state, fs, R, Bn = _train_plan_case(dev, dropout=0.0)
+    plan = plan_export.LoadedPlan(plan_export.export_train_plan(fs))          # no optimizer segment
+    assert plan.header.seg[3] == 0
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(Bn, 3, R, R, generator=g) * 2
+    cond = torch.exp(torch.rand(Bn, generator=g) * 4 - 2)
+    gout = torch.randn(Bn, 3, R, R, generator=g)
+    y_ref, _, gref = oracle_grads(cfg, sd, x, cond, gout)
+    y = plan.train_forward(x.to(dev), cond.to(dev))
+    assert rel_err(y, y_ref) < 1e-4
+    _, dparams = plan.unet_backward(gout.to(dev))
+    worst = 0.0
+    checked = 0
+    for name, p in model.named_parameters():
+        if not p.requires_grad:                      # (the Fourier frequencies are not trained: ncsnpp.py:60-64 / layerspp.py:35)
+            continue
+        o, n = fs.flat.index[id(p)]
+        checked += 1
+        gv, gr = dparams[o:o + n].view(p.shape).cpu(), gref[name]
+        scale = float(gr.abs().max())
+        if scale < 1e-4:
+            assert float((gv - gr).abs().max()) < 1e-4, name
+            continue
+        worst = max(worst, rel_err(gv, gr))
+        assert rel_err(gv, gr) < TOL_GRAD, (name, rel_err(gv, gr))
+    assert checked >= 100
+    plan.close()
+    return worst
+
+
 def check_checkpoint_and_ema_swap(dev, tmp_path):
     """utils.save_checkpoint / restore_checkpoint (reference utils.py:7-28) around the fused step, the EMA
     store / copy_to / restore swap (models/ema.py:53-89) on the flat buffers, and weight re-packing of an inference

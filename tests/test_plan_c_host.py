@@ -152,3 +152,43 @@ def test_sampler_plan_through_c_abi_matches_python_sampler():
         st.synchronize()
         assert torch.equal(out.cpu(), ref.cpu()), use_graph
     plan.close()
+
+
+def _c_host_train(exe):
+    def run(blob_path, files, seed, loss_ref):
+        cmd = [exe, "train", blob_path] + [files[k] for k in ("batch", "z", "a", "s", "labels", "hyper")] + [str(seed), repr(loss_ref), "1e-6"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+        assert "plan_host train:" in r.stdout
+    return run
+
+
+def test_training_plan_through_c_abi_on_emulator(tmp_path):
+    """ssde_train_step / ssde_train_forward / ssde_unet_backward (include/ssde.h) on exported training plans: Python binding
+    and the plain-C host, kernels on the emulator"""
+    import emu
+    import _train_checks as T
+    if not emu.available():
+        pytest.skip("emulator needs x86-64 + ROCm's clang++")
+    emu_lib = emu.build_emu.build()
+    exe = str(tmp_path / "plan_host_emu")
+    r = subprocess.run(["gcc", "-O1", "-std=c11", "-DHOST_IS_DEVICE", "-I", INC, SRC, "-o", exe, emu_lib, "-lm",
+                        "-Wl,-rpath," + os.path.dirname(emu_lib)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    with emu.emulated():
+        worst = T.check_train_plan("cpu", tmp_path, c_host=_c_host_train(exe))
+    assert worst < T.TOL_GRAD
+
+
+@pytest.mark.gpu
+def test_training_plan_through_c_abi_on_gpu(tmp_path):
+    import _train_checks as T
+    from score_sde_pytorch_amd import _lib as L
+    exe = str(tmp_path / "plan_host")
+    libdir = os.path.dirname(L.LIB_PATH)
+    r = subprocess.run(["gcc", "-O1", "-std=c11", "-I", INC, "-I", "/opt/rocm/include", SRC, "-o", exe, L.LIB_PATH,
+                        "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    worst = T.check_train_plan("cuda", tmp_path, c_host=_c_host_train(exe))
+    assert worst < T.TOL_GRAD
