@@ -614,6 +614,10 @@ def main():
                 # 1024 SIMDs; rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs
                 mfma_busy = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * m["GRBM_GUI_ACTIVE"] / 8.0)
             out["config"]["pmc_source"] = os.path.basename(summ)
+            # the counters describe the kernels as they were when the profile was taken: flag them when a source changed since
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import summarize_profile
+            out["config"]["pmc_stale"] = prof.get("csrc_sha256") != summarize_profile.csrc_sha()
         except Exception:
             pass
         n3 = int(roof["conv3"].sum())

@@ -17,31 +17,42 @@
 //   wave (q, h) = 9 positions {q, q+4, ..} x (32 tiles x 32 couts) on v_mfma_f32_32x32x2_f32: a lane's ds_read_b64 is
 //   the channel pair (2k, 2k+1), k = lane >> 5 = the MFMA k index, one read of each operand feeds two MFMAs; all 64
 //   lanes of a fragment read are 512 contiguous bytes (no bank conflicts)
-// V, U and raw are double buffered, ONE LDS-only barrier per stage: a wave transforms 8 of the 64 (tile, channel pair)
-// items with all their 6 lines, so the second 1-D pass reads what the same wave wrote in the first.  Every wave runs the
-// same program; its halo loads, its 4-5 weight DMA pieces and the LDS round trips of the two transform passes ride
-// between its 18 MFMAs (an MFMA only occupies the matrix pipe; the wave keeps issuing).
+// V and raw are double buffered, ONE LDS-only barrier per stage: a wave transforms 8 of the 64 (tile, channel pair) items
+// with all their 6 lines, so the second 1-D pass reads what the same wave wrote in the first.  Every wave runs the same
+// program; its halo loads, its weight DMA pieces and the LDS round trips of the two transform passes ride between its 18
+// MFMAs (an MFMA only occupies the matrix pipe; the wave keeps issuing).
 // The 36 positions of an output live in 4 waves, so the workgroup exchanges the products through LDS -- 16 tiles (half of
 // every wave's accumulators) at a time, M[pos][16 tiles][64 couts] = 150 KB -- every thread applies A^T M A to one
 // (tile, cout pair), and the result goes through the shared coalesced epilogue (ssde_store_tile: bias, temb addend,
 // residual, scale, GroupNorm partials).
 //
-// Measured on the MI355X at batch 256 (profiles/r2_wino4_*.txt, tools/conv_bench.py, tools/wino4_trace.py):
-//   v1  all waves in program order (issue, pass 1, MFMA, barrier, pass 2, MFMA, staging), exchange per 32-cout half
-//       150-234 TF/s direct-equivalent; the exchange kept 144 accumulators live (81 scratch stores per lane, 105 k cycles
-//       of epilogue per workgroup) and the 36 DMA pieces + halo loads stalled ~2000 cycles at the top of every stage
-//   v2  ping-pong roles as conv_wino.hip (waves 0-3 MFMA + DMA | waves 4-7 staging, then swapped): SLOWER, 114-164 TF/s
-//       -- four waves carry all the staging of a stage that has only 1152 matrix cycles per wave
-//       (tools/experiments/conv_wino4_pingpong.patch)
-//   v3  16-tile exchange rounds (epilogue 30 k cycles), issues and LDS round trips between the MFMAs: 217-268 TF/s
-//   v4  this file: one barrier per stage (wave-local transform items), fragment reads 3 positions ahead: 223-277 TF/s,
-//       19-26 % over conv_wino.hip from 16x16 maps up; v5 (waves 4-7 stage BEFORE their MFMAs, waves 0-3 after) was 3 %
-//       slower; the weights through registers (global_load_dwordx4 + ds_write_b128) instead of LDS-DMA: 123-141 TF/s;
-//       the halo as 32 bytes per pixel every second stage instead of 16 every stage: 183-222 TF/s; all weight pieces of
-//       a wave issued with its first two positions instead of one per position: 5 % slower
-// rocprofv3 counters at 128 -> 128 channels, 32x32 (tools/w4_pmc.sh): matrix pipe 39 % busy (conv_wino.hip: 58 %, on
-// 1.78x more matrix work), waves 30 % parked (waitcnt / barrier), 41 % issue-stalled, VALU 14 %, LDS active 34 % of the
-// time with 35 % of it bank conflicts.
+// Round 3 (profiles/r3_wino4_*.txt; every figure a same-box A/B against the round-2 kernel built as a variant library):
+//   * U is PRIVATE per wave: the packed image of a stage is ordered [wave][position j][32 couts][4], wave (q, h) moves its
+//     own 4.5 KB by LDS-DMA and is their only reader.  The stage barrier therefore carries no vmcnt(0) any more (it cost
+//     400-570 cycles per stage: the last piece landed ~1500 cycles after its issue); a wave counts its own pieces with
+//     vmcnt right before the fragment read that needs them.  The halo loads are issued from inline asm as well, so that
+//     hipcc's waitcnt insertion (which cannot see the asm DMA pieces behind them) does not turn every use into vmcnt(0).
+//   * The halo prologue (GroupNorm, SiLU, dropout -> raw) moved from the END of a stage to the HEAD of the next one (one
+//     stage more of load latency covered, nothing between the last MFMA and the barrier), with the GroupNorm table reads
+//     ahead of the head's burst of fragment / transform reads.
+//   * The stage body is branch-free: flags are template parameters, the last three stages are peeled, lanes 48-63 of the
+//     transforms work on padding columns.  hipcc's waitcnt counts are exact only in straight-line code (with the exec-masked
+//     transform blocks every MFMA waited for the transform's LDS writes as well).
+//   * One vector-memory instruction per position slot (as a burst in slots 0-1 they queued behind each other: 1500 cycles
+//     for two positions); addressing by scalar base + 32-bit lane offset (no vector address arithmetic per stage).
+//   Together +7 .. +10 % per layer (241-315 TF/s direct-equivalent with GroupNorm + SiLU, 240-333 without).
+//   Measured and NOT adopted: the transform as scalar v_fma_f32 instead of packed v_pk_* (neutral, -DSSDE_W4_SCALAR_BT=1);
+//   the two waves of a SIMD running their prologue at opposite ends of the stage (neutral: a VALU instruction of one wave
+//   waits out the 64-cycle MFMA the other has in the pipe, its head took 2100 cycles instead of 1500); the MFMAs of the
+//   last three positions issued after the barrier inside the next head, fragments carried in registers (2-3 % slower: the
+//   head grew by exactly the matrix cycles it gained -- LDS burst latency, VALU and fp32 MFMA time ADD on a SIMD).
+//   Where a stage's ~4400 cycles go (s_memtime, tools/wino4_trace.py): 2304 are MFMAs of the SIMD's two waves, ~950 VALU
+//   (prologue 2 x 130-260, transforms 2 x 120, bookkeeping), the rest LDS / VMEM issue latency that nothing overlaps
+//   because all eight waves are in the same phase (one barrier per stage, double buffers: no wave may run ahead).
+// Note on the PMC figure: under rocprofv3 --pmc this kernel runs 26 % slower than unprofiled (408 vs 323 us per launch in
+// the same process, profiles/r3_profile_summary.json vs r3_kernel_stats_rocprofv3.csv), so SQ_VALU_MFMA_BUSY_CYCLES /
+// GRBM_GUI_ACTIVE reads 0.40 both before and after this round's changes, while the cycle trace of an unprofiled launch
+// (128 -> 128 channels: 73.7 k matrix cycles of 145 k per workgroup) gives 0.51, and 0.55-0.58 for the 256 / 512-channel layers.
 #include "ssde_common.h"
 #include <type_traits>
 

@@ -49,8 +49,20 @@ def pmc(out, counter_dir):
     return {k: {c: {"sum": v[0], "dispatches": v[1], "avg": v[0] / max(v[1], 1)} for c, v in cs.items()} for k, cs in acc.items()}
 
 
+def csrc_sha():
+    """sha256 over the kernel sources the counters were collected on: bench.py compares it with the sources it runs and
+    marks the PMC figures `pmc_stale` when a kernel changed after the profile was taken"""
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "score_sde_pytorch_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def main(out, dst):
-    res = {"kernel_stats": kernel_stats(out)}
+    res = {"csrc_sha256": csrc_sha(), "kernel_stats": kernel_stats(out)}
     fetch, write, mfma = pmc(out, "pmc_FETCH_SIZE"), pmc(out, "pmc_WRITE_SIZE"), pmc(out, "pmc_MFMA")
     traffic = {}
     for k in set(fetch) | set(write):
