@@ -20,6 +20,9 @@ int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out);
 bool ssde_wgrad_wino_wants(const ssde_wgrad_args* a);                                // wgrad_wino.hip
 int64_t ssde_wgrad_wino_scratch_floats(const ssde_wgrad_args* a);
 int ssde_wgrad_wino_launch(const ssde_wgrad_args* a, void* stream);
+bool ssde_wgrad_wino4_wants(const ssde_wgrad_args* a);                               // wgrad_wino4.hip (asked first)
+int64_t ssde_wgrad_wino4_scratch_floats(const ssde_wgrad_args* a);
+int ssde_wgrad_wino4_launch(const ssde_wgrad_args* a, void* stream);
 
 #define SSDE_REQUIRE(cond, ...)            \
   do {                                     \

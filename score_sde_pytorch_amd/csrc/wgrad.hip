@@ -335,6 +335,7 @@ int make_plan(const ssde_wgrad_args* a, WgPlan* pl) {
 }  // namespace
 
 extern "C" int64_t ssde_wgrad_scratch_floats(const ssde_wgrad_args* a) {
+  if (a && ssde_wgrad_wino4_wants(a)) return ssde_wgrad_wino4_scratch_floats(a);    // Winograd F(4x4,3x3): wgrad_wino4.hip
   if (a && ssde_wgrad_wino_wants(a)) return ssde_wgrad_wino_scratch_floats(a);      // Winograd F(2x2,3x3): wgrad_wino.hip
   WgPlan pl;
   if (int rc = make_plan(a, &pl)) return rc;
@@ -342,6 +343,7 @@ extern "C" int64_t ssde_wgrad_scratch_floats(const ssde_wgrad_args* a) {
 }
 
 extern "C" int ssde_conv_wgrad(const ssde_wgrad_args* a, void* stream) {
+  if (a && ssde_wgrad_wino4_wants(a)) return ssde_wgrad_wino4_launch(a, stream);
   if (a && ssde_wgrad_wino_wants(a)) return ssde_wgrad_wino_launch(a, stream);
   WgPlan pl;
   if (int rc = make_plan(a, &pl)) return rc;

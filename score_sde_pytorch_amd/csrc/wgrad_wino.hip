@@ -347,13 +347,9 @@ __global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const WwParams p
   }
 }
 
-bool winograd_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("SSDE_WGRAD_WINOGRAD");
-    v = (e && e[0] == '0') ? 0 : 1;
-  }
-  return v == 1;
+bool winograd_enabled() {                          // SSDE_WGRAD_WINOGRAD=0: the direct kernel everywhere (read per call)
+  const char* e = getenv("SSDE_WGRAD_WINOGRAD");
+  return !(e && e[0] == '0');
 }
 
 }  // namespace

@@ -172,11 +172,18 @@ def test_conv1x1_gemm_kernel(ops, n, h, c1, c2, cout, pro, extras):
 # (n, h, w, cin1, cin2, cout, prologue, dropout): shapes that take the Winograd weight-gradient kernel (wgrad_wino.hip:
 # 3x3 / stride 1 / pad 1, h % 4 == 0, w % 8 == 0, channels % 64 == 0), with a virtual concat, every prologue, dropout
 WGRAD_WINO_CASES = [(1, 8, 8, 64, 0, 64, 0, 0.0), (2, 8, 16, 64, 0, 128, 3, 0.0), (3, 4, 8, 64, 64, 64, 2, 0.0),
-                    (1, 16, 16, 128, 0, 64, 1, 0.0), (2, 8, 8, 64, 0, 64, 2, 0.25)]
+                    (1, 16, 16, 128, 0, 64, 1, 0.0), (2, 8, 8, 64, 0, 64, 2, 0.25),
+                    # F(4x4,3x3) only (wgrad_wino4.hip: maps that are multiples of 8, 32-cout blocks): one chunk, several chunks
+                    # per image with a ragged split (5 chunks over splits), a virtual concat, dropout
+                    (1, 8, 8, 64, 0, 32, 0, 0.0), (5, 16, 8, 64, 64, 96, 2, 0.0), (3, 8, 24, 128, 0, 32, 2, 0.3)]
 
 
+@pytest.mark.parametrize("wmode", ["4", "2"])
 @pytest.mark.parametrize("n,h,w,c1,c2,cout,pro,drop", WGRAD_WINO_CASES)
-def test_wgrad_winograd_kernel(ops, n, h, w, c1, c2, cout, pro, drop):
+def test_wgrad_winograd_kernel(ops, n, h, w, c1, c2, cout, pro, drop, wmode, monkeypatch):
+    # SSDE_WGRAD_WINOGRAD: "4" = F(4x4,3x3) (wgrad_wino4.hip) where it is legal, F(2x2,3x3) elsewhere; "2" = F(2x2,3x3) only
+    # (channel counts the latter does not take fall to the direct kernel: still checked against autograd)
+    monkeypatch.setenv("SSDE_WGRAD_WINOGRAD", wmode)
     g = torch.Generator().manual_seed(n * 100 + cout + c1)
     xa = torch.randn(n, c1, h, w, generator=g)
     xb = torch.randn(n, c2, h, w, generator=g) if c2 else None
