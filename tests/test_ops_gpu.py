@@ -326,15 +326,16 @@ def test_conv1x1_gemm_kernel(n, h, c1, c2, cout, pro, extras):
 # 3x3 / stride 1 / pad 1, h % 4 == 0, w % 8 == 0, channels % 64 == 0), with a virtual concat, every prologue, dropout
 WGRAD_WINO_CASES = [(1, 8, 8, 64, 0, 64, 0, 0.0), (2, 8, 16, 64, 0, 128, 3, 0.0), (3, 4, 8, 64, 64, 64, 2, 0.0),
                     (1, 16, 16, 128, 0, 64, 1, 0.0), (2, 8, 8, 64, 0, 64, 2, 0.25),
-                    # F(4x4,3x3) only (wgrad_wino4.hip: maps that are multiples of 8, 32-cout blocks): one chunk, several chunks
-                    # per image with a ragged split (5 chunks over splits), a virtual concat, dropout
-                    (1, 8, 8, 64, 0, 32, 0, 0.0), (5, 16, 8, 64, 64, 96, 2, 0.0), (3, 8, 24, 128, 0, 32, 2, 0.3)]
+                    # F(4x4,3x3) only (wgrad_wino4.hip: maps that are multiples of 4, channels multiples of 32): channel
+                    # blocks that do not fill the 128 x 128 GEMM tile, a ragged last K stage, a virtual concat, dropout
+                    (1, 8, 8, 64, 0, 32, 0, 0.0), (5, 16, 8, 64, 64, 96, 2, 0.0), (3, 8, 24, 128, 0, 32, 2, 0.3),
+                    (2, 12, 8, 160, 0, 160, 3, 0.0)]
 
 
-@pytest.mark.parametrize("wmode", ["4", "2"])
+@pytest.mark.parametrize("wmode", ["44", "2"])
 @pytest.mark.parametrize("n,h,w,c1,c2,cout,pro,drop", WGRAD_WINO_CASES)
 def test_wgrad_winograd_kernel(n, h, w, c1, c2, cout, pro, drop, wmode, monkeypatch):
-    # SSDE_WGRAD_WINOGRAD: "4" = F(4x4,3x3) (wgrad_wino4.hip) where it is legal, F(2x2,3x3) elsewhere; "2" = F(2x2,3x3) only
+    # SSDE_WGRAD_WINOGRAD: "44" = F(4x4,3x3) (wgrad_wino4.hip) wherever it is legal, F(2x2,3x3) elsewhere; "2" = F(2x2,3x3) only
     # (channel counts the latter does not take fall to the direct kernel: still checked against autograd)
     monkeypatch.setenv("SSDE_WGRAD_WINOGRAD", wmode)
     ops = _ops()
