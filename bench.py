@@ -148,6 +148,10 @@ def bench_train(args, cfg, dev, dist, world, rank, sync_all):
                         ("backward_elementwise", B.FC_BWD), ("other", E.FC_OTHER)]:
             m = cls == c
             by[name] = {"launches": int(m.sum()), "ms": float(ms[m].sum()), "gflop": float(fl[m].sum()) / 1e9}
+            if name in ("backward_elementwise", "groupnorm_stats", "upfirdn") and by[name]["ms"] > 0:
+                # HBM-bound classes: algorithmic bytes of the op list over the HIP-event time, against the 8 TB/s peak
+                gb = float(sum(op_bytes(eng.program.ops[i]) for i in np.nonzero(m)[0])) / 1e9
+                by[name].update(bound="hbm", gb=gb, achieved_tbs=gb / by[name]["ms"], frac=gb / by[name]["ms"] / PEAK_HBM_TBS)
         out["fwd_ms_events"] = float(ms[idx < eng.n_fwd].sum())
         out["bwd_ms_events"] = float(ms[idx >= eng.n_fwd].sum())
         out["by_class"] = by
@@ -259,6 +263,30 @@ def op_bytes(op):
         return 20.0 * op.u.langevin.n * op.u.langevin.per
     if k == L.OP_PREDICTOR:
         return 20.0 * op.u.predictor.numel
+    if k == L.OP_GN_FINALIZE:                     # the producers' partial statistics: (mean, M2, count) per slice and channel quad
+        a = op.u.gn_fin
+        return 12.0 * a.n * (a.slices0 * (a.c0 // 4) + a.slices1 * (a.c1 // 4))
+    # backward, element-wise class: GroupNorm / SiLU / dropout backward = read x, read d(act), write (or accumulate) dx;
+    # its statistics pass = read x, read d(act); bias gradients = one read of the gradient; layout changes = read + write
+    if k == L.OP_PROLOGUE_BWD:
+        a = op.u.pro_bwd
+        c = a.src.c0 + a.src.c1
+        return 4.0 * a.n * a.hw * c * (3 + (1 if (a.acc0 or a.acc1) else 0))
+    if k == L.OP_GN_BWD_REDUCE:
+        a = op.u.gn_bwd
+        return 8.0 * a.n * a.hw * (a.src.c0 + a.src.c1)
+    if k == L.OP_COLSUM:
+        return 4.0 * op.u.colsum.n * op.u.colsum.hw * op.u.colsum.c
+    if k == L.OP_TO_NHWC:
+        a = op.u.to_nhwc
+        return 4.0 * a.n * a.h * a.w * (a.c + a.c_pad)
+    if k == L.OP_TO_NCHW:
+        a = op.u.to_nchw
+        return 4.0 * a.n * a.h * a.w * (a.c + a.c_src)
+    if k == L.OP_MEMSET:
+        return float(op.u.memset.bytes)
+    if k == L.OP_AXPY:
+        return 12.0 * op.u.axpy.numel
     return 0.0
 
 

@@ -207,6 +207,16 @@ typedef struct ssde_predictor_args {
   const float* coef; const int32_t* step_ptr;
   int64_t numel;
 } ssde_predictor_args;
+typedef struct ssde_sample_update_args {
+  /* One predictor / corrector update with PER-SAMPLE coefficients (the generic path of sampling.py, where `t` may differ per
+   * sample and the score comes from any model):   x_mean = a[n] x + b[n] y ;   x_out = x_mean + c[n] z
+   * fp32, one rounding per product and per sum (the reference's separate torch multiply / add kernels).  a == NULL: 1;
+   * y == NULL: no second term; z == NULL: x_out = x_mean.  Covers Euler-Maruyama (sampling.py:181-187: y = drift, b = dt,
+   * c = g sqrt(-dt)), reverse diffusion (:195-200: y = f, b = -1, c = G), ancestral sampling (:213-239), Langevin and
+   * annealed Langevin steps (:262-282, :300-319: y = score, b = step size, c = sqrt(2 step size)). */
+  const float* x; const float* y; const float* z; const float* a; const float* b; const float* c;
+  float* x_mean; float* x_out; int32_t n; int32_t per;
+} ssde_sample_update_args;
 typedef struct ssde_fill_args {   /* dst[i] = tab[*step_ptr] (vec_t / labels of the current step, sampling.py:405) */
   float* dst; const float* tab; const int32_t* step_ptr; int32_t n; int32_t _pad0;
 } ssde_fill_args;
@@ -409,6 +419,7 @@ int ssde_sumsq(const ssde_sumsq_args* a, void* stream);
 int ssde_randn(const ssde_randn_args* a, void* stream);
 int ssde_langevin_update(const ssde_langevin_args* a, void* stream);
 int ssde_predictor_update(const ssde_predictor_args* a, void* stream);
+int ssde_sample_update(const ssde_sample_update_args* a, void* stream);
 int ssde_fill_from_table(const ssde_fill_args* a, void* stream);
 int ssde_step_inc(const ssde_step_inc_args* a, void* stream);
 int ssde_project_update(const ssde_project_args* a, void* stream);

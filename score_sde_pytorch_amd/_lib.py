@@ -128,6 +128,11 @@ class PredictorArgs(C.Structure):
                 ("numel", C.c_int64)]
 
 
+class SampleUpdateArgs(C.Structure):
+    _fields_ = [("x", _fp), ("y", _fp), ("z", _fp), ("a", _fp), ("b", _fp), ("c", _fp), ("x_mean", _fp), ("x_out", _fp),
+                ("n", C.c_int32), ("per", C.c_int32)]
+
+
 class FillArgs(C.Structure):
     _fields_ = [("dst", _fp), ("tab", _fp), ("step_ptr", _fp), ("n", C.c_int32), ("_pad0", C.c_int32)]
 
@@ -239,7 +244,7 @@ EXPORTS = ["ssde_conv2d", "ssde_groupnorm_stats", "ssde_upfirdn2d", "ssde_attent
            "ssde_abi_version", "ssde_sizeof_op", "ssde_last_error", "ssde_conv_lds_bytes",
            "ssde_conv_wgrad", "ssde_colsum", "ssde_gn_bwd_reduce", "ssde_prologue_bwd", "ssde_attention_bwd",
            "ssde_perturb", "ssde_dsm_loss", "ssde_sumsq_flat", "ssde_adam_clip_ema", "ssde_memset", "ssde_axpy",
-           "ssde_wgrad_scratch_floats", "ssde_pack_weights", "ssde_project_update", "ssde_gn_finalize", "ssde_conv_gn_slices", "ssde_rk_combine", "ssde_rk_error_norm", "ssde_pf_drift", "ssde_hutch_div",
+           "ssde_wgrad_scratch_floats", "ssde_pack_weights", "ssde_project_update", "ssde_gn_finalize", "ssde_conv_gn_slices", "ssde_rk_combine", "ssde_rk_error_norm", "ssde_pf_drift", "ssde_hutch_div", "ssde_sample_update",
            # plan-level entry points (csrc/plan.hip; argument types: plan_export.bind)
            "ssde_plan_load", "ssde_plan_load_file", "ssde_plan_destroy", "ssde_plan_info", "ssde_plan_param",
            "ssde_plan_refresh_weights", "ssde_unet_forward", "ssde_pc_reset", "ssde_pc_run", "ssde_pc_state",
@@ -273,7 +278,7 @@ def bind(lib):
                       ("ssde_attention_bwd", AttnBwdArgs), ("ssde_perturb", PerturbArgs), ("ssde_dsm_loss", DsmLossArgs),
                       ("ssde_sumsq_flat", SumsqFlatArgs), ("ssde_adam_clip_ema", AdamArgs), ("ssde_memset", MemsetArgs),
                       ("ssde_axpy", AxpyArgs), ("ssde_pack_weights", PackArgs), ("ssde_project_update", ProjectArgs),
-                      ("ssde_gn_finalize", GnFinalizeArgs), ("ssde_rk_combine", RkCombineArgs), ("ssde_hutch_div", HutchDivArgs),
+                      ("ssde_gn_finalize", GnFinalizeArgs), ("ssde_rk_combine", RkCombineArgs), ("ssde_hutch_div", HutchDivArgs), ("ssde_sample_update", SampleUpdateArgs),
                       ("ssde_rk_error_norm", RkErrorArgs), ("ssde_pf_drift", PfDriftArgs)]:
         getattr(lib, name).argtypes = [C.POINTER(typ), C.c_void_p]
     lib.ssde_conv_lds_bytes.argtypes = [C.POINTER(ConvArgs)]

@@ -517,15 +517,8 @@ template <int WM, int WN, int TM, int TN, int BKC3 = 8>
 int launch_cfg(ConvPlan& pl, hipStream_t st) {
   dim3 grid(pl.grid), block(kThreads);
   if (pl.kp.ksplit == 2) {
-    // a fresh run of slots per launch: launches in flight on different streams (or captured into different graphs)
-    // never share a pair unless more than kSyncSlots pairs are dealt in between
-    static std::atomic<unsigned> cursor{0};
-    const unsigned need = (unsigned)(pl.kp.g.m_tiles * pl.kp.g.n_tiles);
-    unsigned at = cursor.fetch_add(need) % kSyncSlots;
-    if (at + need > kSyncSlots) at = 0;
-    unsigned* base = nullptr;
-    SSDE_HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_conv_sync)));
-    pl.kp.sync = base + 2 * (size_t)at;
+    pl.kp.sync = ssde_conv_sync_slots(pl.kp.g.m_tiles * pl.kp.g.n_tiles);
+    SSDE_REQUIRE(pl.kp.sync, "conv: no hand-over slots for a split reduction");
   }
 #define SSDE_CONV_LAUNCH(H3, H1)                                                                     \
   do {                                                                                               \
@@ -547,6 +540,19 @@ int launch_cfg(ConvPlan& pl, hipStream_t st) {
 }
 
 }  // namespace
+
+// A fresh run of (ticket, ready) pairs for a launch that splits its reduction (this file and conv_wino4.hip): launches in
+// flight on different streams (or captured into different graphs) never share a pair unless more than kSyncSlots pairs are
+// dealt in between.  nullptr: more pairs asked for than a launch may take.
+unsigned* ssde_conv_sync_slots(int need) {
+  static std::atomic<unsigned> cursor{0};
+  if (need <= 0 || need > kSyncSlots / 4) return nullptr;
+  unsigned at = cursor.fetch_add((unsigned)need) % kSyncSlots;
+  if (at + (unsigned)need > (unsigned)kSyncSlots) at = 0;
+  unsigned* base = nullptr;
+  if (hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_conv_sync)) != hipSuccess) return nullptr;
+  return base + 2 * (size_t)at;
+}
 
 extern "C" int ssde_conv2d(const ssde_conv_args* a, void* stream) {
   if (a && a->tile == SSDE_TILE_WINOGRAD) return ssde_conv_wino_launch(a, stream, nullptr);

@@ -146,6 +146,10 @@ struct Wino4Params {
   float scale;
   float* dst;
   float* gn_part;
+  int ksplit;              // 1, 2 or 4 workgroups per tile, each reducing its share of the channel stages (the kernel's kKs)
+  unsigned* sync;          // ksplit > 1: this launch's (shares started, shares handed over) pairs, one per tile, from
+                           // conv_mfma.hip's g_conv_sync (zero before and after)
+  int ticket_off;          // float index of the hand-over ticket in LDS (behind everything else)
 };
 
 // 1-D input transform (one column / row of B^T d, B^T rows: [4,0,-5,0,1,0] [0,-4,-4,1,1,0] [0,4,-4,-1,1,0]
@@ -194,8 +198,14 @@ __device__ __forceinline__ void bt6(const ssde_f32x2 (&d)[6], ssde_f32x2 (&o)[6]
   o[5] = 4.f * d[1] - 5.f * d[3] + d[5];
 }
 
-template <bool kGn>
+// kKs = 2 or 4: that many workgroups per tile, each reducing its share of the channel stages (own instantiations: the
+// hand-over costs the epilogue registers, and the unsplit kernel is the one the big layers run).  The shares are dealt in
+// the order the workgroups START (an atomic counter per tile, as a decoupled look-back scan numbers its blocks): share k
+// only ever waits for shares < k, which are resident or done -- no assumption about the dispatch order -- and the sums are
+// formed in the fixed order ((s0 + s1) + s2) + s3, so the result does not depend on who arrived when.
+template <bool kGn, int kKs>
 __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const Wino4Params p) {
+  constexpr bool kSplit = kKs > 1;
   SSDE_LDS(smem);
   float* Vb = smem;                            // [2][kVFloats]
   float* Ub = smem + 2 * kVFloats;             // [2][8 waves][9 positions][32 couts][4]: a wave reads only its own region
@@ -207,7 +217,8 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
   const int bid = blockIdx.x;
   const int xcd = bid & 7, l = bid >> 3;
   const int nt = l % p.n_tiles;
-  const int mt = (l / p.n_tiles) * 8 + xcd;
+                                                             // (the kKs workgroups of a tile: same XCD, 8 * n_tiles blocks apart)
+  const int mt = (l / (p.n_tiles * kKs)) * 8 + xcd;
 #ifdef SSDE_W4_TRACE
   const bool tr_on = lane == 0 && (wave == 0 || wave == 7) && bid == 0 && g_w4_trace != nullptr;
   const int tr_base = (wave == 0 ? 0 : 1) * 128;
@@ -231,7 +242,13 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
 
   const ssde_src& s = p.src;
   const int Ctot = s.c0 + s.c1;
-  const int nst = (Ctot + 3) >> 2;
+  const int nst_all = (Ctot + 3) >> 2;
+  // this workgroup's share of the reduction: stages st_off .. st_off + nst (`st` below counts from 0: LDS buffer parity and
+  // the peeled last stages go by the local count, channels and weights by st + st_off)
+  unsigned* sy = kSplit ? p.sync + 2 * ((size_t)mt * p.n_tiles + nt) : nullptr;
+  int* ticket = reinterpret_cast<int*>(smem + p.ticket_off);
+  if (kSplit && tid == 0) *ticket = (int)atomicAdd(sy, 1u);       // (read after the index set-up below)
+  int ks = 0, st_off = 0, nst = nst_all;
   SsdePro pro = ssde_pro_decode(s);
   pro.gn = kGn;
   const int cpg = kGn ? Ctot / s.gn_groups : 1;
@@ -285,7 +302,7 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
   // halo loads of stage st: opaque to hipcc (SSDE_GLOAD16), their vmcnt accounting is the stage body's
   ssde_f32x4 rv[kMaxRaw];
   auto load_piece = [&](int st, int k) __attribute__((always_inline)) {
-    const int c_base = st * 4;
+    const int c_base = (st + st_off) * 4;
     const bool second = c_base >= s.c0;
     const float* sb = second ? s.p1 + (c_base - s.c0) : s.p0 + c_base;
     const uint32_t vo = second ? voff1[k] : voff0[k];
@@ -301,7 +318,7 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
 #pragma unroll
     for (int it = 0; it < kMaxRaw; ++it) r.mr[it] = make_float2(0.f, 1.f);
     if (kGn) {
-      const int c_cur = st * 4;
+      const int c_cur = (st + st_off) * 4;
       r.gam = *reinterpret_cast<const float4*>(gb_tab + c_cur);
       r.bet = *reinterpret_cast<const float4*>(gb_tab + Ctot + c_cur);
       const int g = (int)(((float)c_cur + 0.5f) * inv_cpg);          // c_cur / cpg, exact for these small integers
@@ -311,7 +328,7 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
     return r;
   };
   auto store_raw_with = [&](float* rw, int st, const GnRegs& r) __attribute__((always_inline)) {
-    const int c_cur = st * 4;
+    const int c_cur = (st + st_off) * 4;
 #pragma unroll
     for (int it = 0; it < kMaxRaw; ++it) {
       if (goff[it] == -2) continue;
@@ -350,7 +367,7 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
   // pieces with vmcnt right before the fragment read that needs them, and the stage barrier carries no vmcnt(0).
   // One scalar base per stage, the lane's bytes as a constant 32-bit offset, the pieces as immediates -2048 .. +2048.
   const uint32_t w_voff = (uint32_t)((wave * kURegion + 2 * 256 + lane * 4) * 4);
-  auto w_base = [&](int st) { return p.wpk + ((size_t)st * p.n_tiles + nt) * kUFloats; };
+  auto w_base = [&](int st) { return p.wpk + ((size_t)(st + st_off) * p.n_tiles + nt) * kUFloats; };
   auto w_ldst = [&](float* Un) { return Un + wave * kURegion + 2 * 256; };
 
   const int wq = wave >> 1;                     // this wave's positions wq + 4 j (its cout half is wave & 1)
@@ -361,6 +378,12 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   const int a_off = li * 4 + 2 * lh, b_off = wave * kURegion + li * 4 + 2 * lh;
 
+  if constexpr (kSplit) {
+    __syncthreads();
+    ks = __builtin_amdgcn_readfirstlane(*ticket);
+    st_off = nst_all * ks / kKs;
+    nst = nst_all * (ks + 1) / kKs - st_off;
+  }
   // ---- pipeline fill.  Leaves what every stage expects on entry: V[cur] transformed, the wave's weight pieces of the stage
   // issued, raw[nxt] = the activated halo of stage st + 1, rv = the halo of stage st + 2 ----
   SSDE_TR(1);
@@ -587,6 +610,8 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
   const int wh = wave & 1;
   const int e_tl = e_on ? tid >> 5 : 0, e_cp = tid & 31;
   float* park = smem;                                                         // [256][kLdt], aliases the products
+  // split reduction: share 0 leaves its raw 4x4 outputs in the tile's own part of dst, shares 1 .. kKs - 2 add theirs to
+  // them in turn, the last share adds its own and runs the epilogue.  sy[1] counts the shares that have handed over.
 #pragma unroll
   for (int rnd = 0; rnd < 2; ++rnd) {
 #pragma unroll
@@ -656,6 +681,73 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
       return true;
     };
     const int gn_max = IMGS == 1 ? p.N * p.tiles_per_img * 2 : p.N;
+    if constexpr (kSplit) {
+      const bool first = ks == 0, last = ks == kKs - 1;
+      // The sums travel as agent-scope dword accesses, coherent at the device level by themselves (no __threadfence():
+      // that is a write-back of the whole L2 per workgroup, conv_mfma.hip)
+      if (!first && rnd == 0) {
+        if (tid == 0)
+          while (__hip_atomic_load(sy + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)ks) __builtin_amdgcn_s_sleep(4);
+        __syncthreads();
+      }
+      // (4 float4 of a thread at a time: round 0 still holds half of the accumulators)
+      constexpr int kIters = 256 * 16 / kThreads, kBatch = 4;
+#pragma unroll
+      for (int ib = 0; ib < kIters; ib += kBatch) {
+        float* tp[kBatch];
+        float* dp[kBatch];
+#pragma unroll
+        for (int it = 0; it < kBatch; ++it) {
+          const int q = tid + (ib + it) * kThreads;
+          const int row = q >> 4, j = (q & 15) * 4;
+          size_t pix; int img;
+          const bool ok = pixfn(row, pix, img) && n0 + j < p.Cout;       // c_out % 4 == 0 on this path
+          tp[it] = park + row * kLdt + j;
+          dp[it] = ok ? p.dst + pix * p.Cout + n0 + j : nullptr;
+        }
+        float o[kBatch][4];
+        if (!first) {
+          // the batch's loads in flight before the first add
+#pragma unroll
+          for (int it = 0; it < kBatch; ++it)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              o[it][k] = dp[it] ? __hip_atomic_load(dp[it] + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+          for (int it = 0; it < kBatch; ++it)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[it][k] += tp[it][k];            // (sum so far) + own share
+        } else {
+#pragma unroll
+          for (int it = 0; it < kBatch; ++it)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[it][k] = tp[it][k];
+        }
+        if (last) {
+#pragma unroll
+          for (int it = 0; it < kBatch; ++it)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tp[it][k] = o[it][k];
+        } else {
+#pragma unroll
+          for (int it = 0; it < kBatch; ++it)
+            if (dp[it]) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) __hip_atomic_store(dp[it] + k, o[it][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+      }
+      if (!last) {
+        if (rnd == 0) { __syncthreads(); continue; }                     // (park is refilled by round 1)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0);      // every store of this thread is acknowledged ...
+        __syncthreads();                    // ... and every thread's
+        if (tid == 0) atomicAdd(sy + 1, 1u);
+        return;
+      }
+      __syncthreads();
+      if (rnd == 1 && tid == 0) { sy[0] = 0u; sy[1] = 0u; }              // ready for the next launch that is dealt these slots
+    }
     // round 1 has no accumulators left: all 8 rows of a thread (residual loads) in flight instead of 4
     if (rnd == 0) ssde_store_tile<256, 64, kEpiThreads, 4, 0>(park, kLdt, n0, e, pixfn, gn_entry, rpi_log2, gn_max);
     else ssde_store_tile<256, 64, kEpiThreads, SSDE_W4_EPI_BATCH, 0>(park, kLdt, n0, e, pixfn, gn_entry, rpi_log2, gn_max);
@@ -668,6 +760,17 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
 int pow2_floor(int v) { int q = 1; while (q * 2 <= v) q *= 2; return q; }
 
 }  // namespace
+
+// over how many workgroups per tile (1, 2 or 4) a launch of `wgs` tiles over `ctot` input channels splits its reduction: up
+// to 256 workgroups, at least 16 channel stages each (engine.py picks this kernel for 8x8 maps only where the split fills
+// the chip -- same rule there).  SSDE_CONV_KSPLIT=0 switches it off (read per call: the tests compare both forms).
+int ssde_conv_wino4_splits(int wgs, int ctot, int c_out) {
+  const char* se = getenv("SSDE_CONV_KSPLIT");
+  if ((se && atoi(se) == 0) || c_out % 4 != 0) return 1;
+  if (wgs <= 64 && ctot >= 256) return 4;
+  if (wgs <= 128 && ctot >= 128) return 2;
+  return 1;
+}
 
 // stream == (void*)1 with lds_out: plan-only query of the GroupNorm slices per image (conv_mfma.hip, ssde_conv_gn_slices)
 int ssde_conv_wino4_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
@@ -719,17 +822,33 @@ int ssde_conv_wino4_launch(const ssde_conv_args* a, void* stream, int* lds_out) 
   if (gn) lds += (2 * imgs * s.gn_groups + 2 * (s.c0 + s.c1)) * 4;
   const int lds_epi = kPos * 16 * kLdm * 4;
   if (lds < lds_epi) lds = lds_epi;
+  p.ticket_off = lds / 4;
+  lds += 16;
   SSDE_REQUIRE(lds <= 160 * 1024, "conv(winograd 4x4): %d bytes of LDS", lds);
   if (lds_out) { *lds_out = lds; return SSDE_OK; }
-  static std::atomic<bool> attr_set{false};   // once, before any stream capture
-  if (!attr_set) {
-    SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
-  const dim3 grid(ssde_cdiv(p.m_tiles, 8) * 8 * p.n_tiles);
-  if (gn) hipLaunchKernelGGL(conv_wino4_kernel<true>, grid, dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
-  else hipLaunchKernelGGL(conv_wino4_kernel<false>, grid, dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
+  // Split the reduction when the launch would leave half of the CUs or more without a workgroup (8x8 maps at batch 256:
+  // 128 tiles of 8 images x 64 couts)
+  const int wgs = ssde_cdiv(p.m_tiles, 8) * 8 * p.n_tiles;
+  p.ksplit = a->resid != a->dst ? ssde_conv_wino4_splits(wgs, s.c0 + s.c1, a->c_out) : 1;
+  p.sync = p.ksplit > 1 ? ssde_conv_sync_slots(p.m_tiles * p.n_tiles) : nullptr;
+  if (!p.sync) p.ksplit = 1;
+  const dim3 grid(wgs * p.ksplit);
+  auto go = [&](auto kfn, std::atomic<bool>& attr_set) {
+    if (!attr_set) {                            // once per instantiation, before any stream capture
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return false;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
+    return true;
+  };
+  static std::atomic<bool> set[2][3];
+  const int si = p.ksplit == 4 ? 2 : p.ksplit == 2 ? 1 : 0;
+  const bool ok = gn ? (si == 2 ? go(conv_wino4_kernel<true, 4>, set[1][2]) : si == 1 ? go(conv_wino4_kernel<true, 2>, set[1][1])
+                                                                                     : go(conv_wino4_kernel<true, 1>, set[1][0]))
+                     : (si == 2 ? go(conv_wino4_kernel<false, 4>, set[0][2]) : si == 1 ? go(conv_wino4_kernel<false, 2>, set[0][1])
+                                                                                      : go(conv_wino4_kernel<false, 1>, set[0][0]));
+  SSDE_REQUIRE(ok, "conv(winograd 4x4): hipFuncSetAttribute failed");
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;
 }

@@ -179,6 +179,19 @@ __global__ __launch_bounds__(256) void predictor_kernel(float* __restrict__ x, f
   }
 }
 
+// the same update with per-sample coefficient vectors (ssde_sample_update: the generic path of sampling.py)
+__global__ __launch_bounds__(256) void sample_update_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                                            const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                            float* __restrict__ x_mean, float* __restrict__ x_out, int per, size_t numel) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / (size_t)per;
+    float xm = a ? __fmul_rn(a[n], x[i]) : x[i];
+    if (y) xm = __fadd_rn(xm, __fmul_rn(b[n], y[i]));
+    x_mean[i] = xm;
+    x_out[i] = z ? __fadd_rn(xm, __fmul_rn(c[n], z[i])) : xm;
+  }
+}
+
 // ---- controllable-generation projection (controllable_generation.py:44-52, 136-144) ------
 // Elementwise form (inpainting): x = x (1 - mask) + (m D + z s) mask ; x_mean = x (1 - mask) + m D mask.
 __global__ __launch_bounds__(256) void project_kernel(float* __restrict__ x, float* __restrict__ x_mean,
@@ -442,6 +455,16 @@ extern "C" int ssde_predictor_update(const ssde_predictor_args* a, void* stream)
   SSDE_REQUIRE(a && a->x && a->x_mean && a->score && a->coef && a->numel > 0, "predictor: bad args");
   hipLaunchKernelGGL(predictor_kernel, dim3(grid_for((size_t)a->numel)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      a->x, a->x_mean, a->score, a->noise, a->coef, a->step_ptr, (size_t)a->numel);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}
+
+extern "C" int ssde_sample_update(const ssde_sample_update_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->x && a->x_mean && a->x_out && a->n > 0 && a->per > 0, "sample_update: bad args");
+  SSDE_REQUIRE((!a->y || a->b) && (!a->z || a->c), "sample_update: a tensor term needs its coefficient vector");
+  const size_t numel = (size_t)a->n * a->per;
+  hipLaunchKernelGGL(sample_update_kernel, dim3(grid_for(numel)), dim3(256), 0, static_cast<hipStream_t>(stream), a->x, a->y, a->z, a->a,
+                     a->b, a->c, a->x_mean, a->x_out, a->per, numel);
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;
 }

@@ -17,6 +17,8 @@ int ssde_conv_wino_launch(const ssde_conv_args* a, void* stream, int* lds_out);
 int ssde_conv_wino4_launch(const ssde_conv_args* a, void* stream, int* lds_out);   // conv_wino4.hip, same forms
 bool ssde_conv1x1_wants(const ssde_conv_args* a);                                    // conv1x1.hip
 int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out);
+unsigned* ssde_conv_sync_slots(int need);                                            // conv_mfma.hip
+int ssde_conv_wino4_splits(int wgs, int ctot, int c_out);                           // conv_wino4.hip
 bool ssde_wgrad_wino_wants(const ssde_wgrad_args* a);                                // wgrad_wino.hip
 int64_t ssde_wgrad_wino_scratch_floats(const ssde_wgrad_args* a);
 int ssde_wgrad_wino_launch(const ssde_wgrad_args* a, void* stream);

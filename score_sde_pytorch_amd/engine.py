@@ -115,6 +115,10 @@ class ProgramBuilder:
     def finalize(self):
         """Liveness-planned storage + ctypes op array."""
         bufs = {}
+        # FIR pairs are fused into the FIRST spec's launch (dst2): the partner's destination is written at spec i, one
+        # spec before its own -- its lifetime must start there, or the allocator could hand it a block that spec i still
+        # reads (round-2 advisor finding: safe only by the accident of block sizes)
+        fused_fir = _fir_pairs(self.specs)
         for i, (_, fields, _, _) in enumerate(self.specs):
             def mark(b, i=i):
                 if b.first is None:
@@ -122,6 +126,8 @@ class ProgramBuilder:
                 b.last = i
                 bufs[id(b)] = b
             _walk_refs(fields, mark)
+            if fused_fir.get(i) is not None:
+                _walk_refs({"dst2": fused_fir[i]}, mark)
         by_first, by_last = {}, {}
         for b in bufs.values():
             by_first.setdefault(b.first, []).append(b)
@@ -151,7 +157,6 @@ class ProgramBuilder:
         self.blocks = blocks
         self.arena_bytes = sum(t.numel() for t in blocks) * _FLT
         ops, classes, flops, starts = [], [], [], []
-        fused_fir = _fir_pairs(self.specs)
         for si, (kind, fields, fclass, fl) in enumerate(self.specs):
             starts.append(len(ops))
             if si in fused_fir:
@@ -182,7 +187,10 @@ def _fir_pairs(specs):
         (k0, f0, _, _), (k1, f1, _, _) = specs[i], specs[i + 1]
         if k0 != L.OP_UPFIRDN or k1 != L.OP_UPFIRDN or i in out:
             continue
-        if f0["src"]["p0"] is not f1["src"]["p0"] or f0["src"]["pro_mode"] == L.PRO_NONE or f1["src"]["pro_mode"] != L.PRO_NONE:
+        s0, s1 = f0["src"], f1["src"]
+        if s0["p0"] is not s1["p0"] or s0["p1"] is not s1["p1"] or s0["c0"] != s1["c0"] or s0["c1"] != s1["c1"]:
+            continue
+        if s0["pro_mode"] == L.PRO_NONE or s1["pro_mode"] != L.PRO_NONE or f0["dst"] is f1["dst"]:
             continue
         if f0.get("accumulate") or f1.get("accumulate") or any(f0[k] != f1[k] for k in same):
             continue
@@ -608,7 +616,8 @@ class Lowering:
         to cover the 256 CUs (F(2x2,3x3): 64 tiles x 64 couts per workgroup -- measured x1.2-1.5 over the direct kernel
         from 8x8 up at batch 256, x0.5 at 4x4 where only 64 workgroups exist).  F(4x4,3x3) does 1.78x less matrix work
         again and is 15-23 % faster than F(2x2,3x3) from 16x16 maps up (profiles/r2_wino4_v3_interleaved.txt); its
-        workgroups cover 32 tiles = 512 pixels, so 8x8 maps at batch 256 would give 128 of them and stay on F(2x2,3x3).
+        workgroups cover 32 tiles = 512 pixels, so 8x8 maps at batch 256 give 128 of them: taken only where the kernel splits its
+        reduction over two workgroups per tile (below), F(2x2,3x3) otherwise.
         Rounding: ~5x coarser than the direct form, 2.5e-6 .. 1.3e-5 on the whole network against the 1e-4 the parity
         tests allow (tools/experiments/wino43_error_budget.py).
         SSDE_WINOGRAD: 0 = direct (bitwise fmaf-chain) kernel everywhere, 1 = this heuristic (default), 2 = F(2x2,3x3)
@@ -625,6 +634,15 @@ class Lowering:
             return 2 if legal2 else 0
         n_tiles = -(-c_out // 64)
         if mode != "3" and legal4 and h >= 16 and w >= 16 and -(-(self.n * h * w) // 512) * n_tiles >= 256:
+            return 4
+        # Fewer tiles than that (8x8 maps at batch 256: 128 tiles of 8 images x 64 couts): the kernel splits its reduction
+        # over 2 or 4 workgroups per tile (conv_wino4.hip, ssde_conv_wino4_splits -- the same rule), taken where that
+        # fills the chip
+        wgs4 = -(-(-(-(self.n * h * w) // 512)) // 8) * 8 * n_tiles
+        splits = 1
+        if c_out % 4 == 0 and os.environ.get("SSDE_CONV_KSPLIT", "1") != "0":
+            splits = 4 if wgs4 <= 64 and c_in >= 256 else 2 if wgs4 <= 128 and c_in >= 128 else 1
+        if mode != "3" and legal4 and splits > 1 and wgs4 * splits >= int(os.environ.get("SSDE_W4_SPLIT_MIN_WGS", "192")):
             return 4
         # tools/heuristic_sweep.py (profiles/r2_heuristic_sweep.txt): F(4x4,3x3) wins from 256 of its workgroups, F(2x2,3x3)
         # over the direct kernel from 128 of its own (by 2-6 %; at 64 the direct kernel is 1.5x faster)

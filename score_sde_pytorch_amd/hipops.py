@@ -292,6 +292,23 @@ def attention_bwd(qkv, o, d_o, channels):
     return dqkv
 
 
+def sample_update(x, y=None, b=None, z=None, c=None, a=None):
+    """x_mean = a[n] x + b[n] y ; x_out = x_mean + c[n] z with per-sample coefficient vectors (ssde_sample_update): the
+    arithmetic of one predictor / corrector update of the generic sampler path.  Returns (x_out, x_mean)."""
+    _need_cuda(x)
+    x = x.contiguous()
+    n, per = x.shape[0], x[0].numel()
+    vec = lambda v: None if v is None else torch.as_tensor(v, dtype=torch.float32, device=x.device).expand(n).contiguous()   # noqa: E731
+    ten = lambda t: None if t is None else t.to(torch.float32).contiguous()                                                   # noqa: E731
+    y, z, a, b, c = ten(y), ten(z), vec(a), vec(b), vec(c)
+    x_mean, x_out = torch.empty_like(x), torch.empty_like(x)
+    args = L.SampleUpdateArgs()
+    args.x, args.y, args.z, args.a, args.b, args.c = _p(x), _p(y), _p(z), _p(a), _p(b), _p(c)
+    args.x_mean, args.x_out, args.n, args.per = _p(x_mean), _p(x_out), n, per
+    L.check(L.load().ssde_sample_update(C.byref(args), _stream()), "ssde_sample_update")
+    return x_out, x_mean
+
+
 def dsm_loss(score, z, s, g2=None, reduce_mean=False, likelihood_weighting=False, want_grad=True, grad_scale=1.0):
     _need_cuda(score, z, s)
     n = score.shape[0]

@@ -84,25 +84,44 @@ def optimization_manager(config):
     return optimize_fn
 
 
+class _DsmHead(torch.autograd.Function):
+    """mean_n [ reduce_i (score * s + z)^2 ]  (or the likelihood-weighted form  reduce_i (score + z / s)^2 * g2)  as ONE
+    libssde_hip kernel pair (ssde_dsm_loss); its gradient w.r.t. `score` is produced by the same launch.  This is the
+    loss head of the three reference closures (losses.py:77-101, 104-125, 128-148) for models the fused step cannot
+    lower: the model itself still runs under torch autograd, the head does not."""
+
+    @staticmethod
+    def forward(ctx, score, z, s, g2, reduce_mean, likelihood_weighting):
+        from . import hipops
+        loss, _, dscore = hipops.dsm_loss(score.detach().float().contiguous(), z.float().contiguous(), s.float().contiguous(),
+                                          None if g2 is None else g2.float().contiguous(), reduce_mean=reduce_mean,
+                                          likelihood_weighting=likelihood_weighting, want_grad=True)
+        ctx.save_for_backward(dscore)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad):
+        (dscore,) = ctx.saved_tensors
+        return dscore * grad, None, None, None, None, None
+
+
+def _perturb(x, z, s, a=None):
+    """a[n] * x + s[n] * z  (ssde_perturb)."""
+    from . import hipops
+    return hipops.perturb(x.float().contiguous(), z.float().contiguous(), s.float().contiguous(),
+                          None if a is None else a.float().contiguous())
+
+
 def get_sde_loss_fn(sde, train, reduce_mean=True, continuous=True, likelihood_weighting=True, eps=1e-5):
     """Continuous-time denoising score matching loss (losses.py:55-101)."""
-    reduce_op = torch.mean if reduce_mean else lambda *args, **kwargs: 0.5 * torch.sum(*args, **kwargs)
-
     def loss_fn(model, batch):
         score_fn = mutils.get_score_fn(sde, model, train=train, continuous=continuous)
         t = torch.rand(batch.shape[0], device=batch.device) * (sde.T - eps) + eps
         z = torch.randn_like(batch)
         mean, std = sde.marginal_prob(batch, t)
-        perturbed_data = mean + std[:, None, None, None] * z
-        score = score_fn(perturbed_data, t)
-        if not likelihood_weighting:
-            losses = torch.square(score * std[:, None, None, None] + z)
-            losses = reduce_op(losses.reshape(losses.shape[0], -1), dim=-1)
-        else:
-            g2 = sde.sde(torch.zeros_like(batch), t)[1] ** 2
-            losses = torch.square(score + z / std[:, None, None, None])
-            losses = reduce_op(losses.reshape(losses.shape[0], -1), dim=-1) * g2
-        return torch.mean(losses)
+        score = score_fn(_perturb(mean, z, std), t)                      # mean + std[:, None, None, None] * z
+        g2 = sde.sde(torch.zeros_like(batch), t)[1] ** 2 if likelihood_weighting else None
+        return _DsmHead.apply(score, z, std, g2, reduce_mean, likelihood_weighting)
 
     loss_fn.ssde_spec = dict(kind="sde", sde=sde, train=train, reduce_mean=reduce_mean, continuous=continuous,
                              likelihood_weighting=likelihood_weighting, eps=eps)
@@ -113,19 +132,15 @@ def get_smld_loss_fn(vesde, train, reduce_mean=False):
     """Legacy discrete SMLD (NCSN) loss (losses.py:104-125)."""
     assert isinstance(vesde, VESDE), "SMLD training only works for VESDEs."
     smld_sigma_array = torch.flip(vesde.discrete_sigmas, dims=(0,))
-    reduce_op = torch.mean if reduce_mean else lambda *args, **kwargs: 0.5 * torch.sum(*args, **kwargs)
 
     def loss_fn(model, batch):
         model_fn = mutils.get_model_fn(model, train=train)
         labels = torch.randint(0, vesde.N, (batch.shape[0],), device=batch.device)
         sigmas = smld_sigma_array.to(batch.device)[labels]
-        noise = torch.randn_like(batch) * sigmas[:, None, None, None]
-        perturbed_data = noise + batch
-        score = model_fn(perturbed_data, labels)
-        target = -noise / (sigmas ** 2)[:, None, None, None]
-        losses = torch.square(score - target)
-        losses = reduce_op(losses.reshape(losses.shape[0], -1), dim=-1) * sigmas ** 2
-        return torch.mean(losses)
+        z = torch.randn_like(batch)
+        score = model_fn(_perturb(batch, z, sigmas), labels)             # batch + sigma * z
+        # (score - target)^2 * sigma^2 with target = -z / sigma  is  (score * sigma + z)^2
+        return _DsmHead.apply(score, z, sigmas, None, reduce_mean, False)
 
     # (score - target)^2 sigma^2 with target = -z / sigma is (score sigma + z)^2: the DSM head with std = sigma[labels]
     loss_fn.ssde_spec = dict(kind="smld", sde=vesde, train=train, reduce_mean=reduce_mean, continuous=False,
@@ -136,20 +151,16 @@ def get_smld_loss_fn(vesde, train, reduce_mean=False):
 def get_ddpm_loss_fn(vpsde, train, reduce_mean=True):
     """Legacy discrete DDPM loss (losses.py:128-148)."""
     assert isinstance(vpsde, VPSDE), "DDPM training only works for VPSDEs."
-    reduce_op = torch.mean if reduce_mean else lambda *args, **kwargs: 0.5 * torch.sum(*args, **kwargs)
 
     def loss_fn(model, batch):
         model_fn = mutils.get_model_fn(model, train=train)
         labels = torch.randint(0, vpsde.N, (batch.shape[0],), device=batch.device)
-        sqrt_alphas_cumprod = vpsde.sqrt_alphas_cumprod.to(batch.device)
-        sqrt_1m_alphas_cumprod = vpsde.sqrt_1m_alphas_cumprod.to(batch.device)
-        noise = torch.randn_like(batch)
-        perturbed_data = sqrt_alphas_cumprod[labels, None, None, None] * batch + \
-            sqrt_1m_alphas_cumprod[labels, None, None, None] * noise
-        score = model_fn(perturbed_data, labels)
-        losses = torch.square(score - noise)
-        losses = reduce_op(losses.reshape(losses.shape[0], -1), dim=-1)
-        return torch.mean(losses)
+        a = vpsde.sqrt_alphas_cumprod.to(batch.device)[labels]
+        s = vpsde.sqrt_1m_alphas_cumprod.to(batch.device)[labels]
+        z = torch.randn_like(batch)
+        eps_theta = model_fn(_perturb(batch, z, s, a), labels)           # sqrt(abar) * batch + sqrt(1 - abar) * z
+        # (eps_theta - z)^2 = (eps_theta * (-1) + z)^2: the same head with s = -1
+        return _DsmHead.apply(eps_theta, z, -torch.ones_like(s), None, reduce_mean, False)
 
     # (eps_theta - z)^2 is (score std + z)^2 for the VP score head score = -eps_theta / std, std = sqrt(1 - alpha_bar)[labels]
     loss_fn.ssde_spec = dict(kind="ddpm", sde=vpsde, train=train, reduce_mean=reduce_mean, continuous=False,

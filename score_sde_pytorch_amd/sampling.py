@@ -106,16 +106,23 @@ class Corrector(abc.ABC):
         pass
 
 
+def _apply(x, y=None, b=None, z=None, c=None, a=None):
+    """x_mean = a[n] x + b[n] y ; x = x_mean + c[n] z as ONE launch of ssde_sample_update (per-sample coefficients, the
+    reference's fp32 rounding per product and sum).  This is the arithmetic of every stock update below when it runs in
+    the GENERIC loop -- a user-registered subclass, a model other than NCSNpp, per-sample times; the stock classes on an
+    NCSNpp model never get here (pc_engine.FusedPCSampler runs whole iterations as one program)."""
+    from . import hipops
+    return hipops.sample_update(x, y=y, b=b, z=z, c=c, a=a)
+
+
 @register_predictor(name='euler_maruyama')
 class EulerMaruyamaPredictor(Predictor):
     """x <- x + drift dt + g sqrt(-dt) z with dt = -1/N (sampling.py:176-187)."""
 
     def update_fn(self, x, t):
         dt = -1. / self.rsde.N
-        z = torch.randn_like(x)
         drift, diffusion = self.rsde.sde(x, t)
-        x_mean = x + drift * dt
-        return x_mean + _b(diffusion) * np.sqrt(-dt) * z, x_mean
+        return _apply(x, y=drift, b=dt, z=torch.randn_like(x), c=diffusion * np.sqrt(-dt))
 
 
 @register_predictor(name='reverse_diffusion')
@@ -124,9 +131,7 @@ class ReverseDiffusionPredictor(Predictor):
 
     def update_fn(self, x, t):
         f, G = self.rsde.discretize(x, t)
-        z = torch.randn_like(x)
-        x_mean = x - f
-        return x_mean + _b(G) * z, x_mean
+        return _apply(x, y=f, b=-1.0, z=torch.randn_like(x), c=G)
 
 
 @register_predictor(name='ancestral_sampling')
@@ -145,18 +150,17 @@ class AncestralSamplingPredictor(Predictor):
         table = sde.discrete_sigmas.to(t.device)
         sigma = table[idx]
         prev = torch.where(idx == 0, torch.zeros_like(t), table[idx - 1])
-        score = self.score_fn(x, t)
-        x_mean = x + score * _b(sigma ** 2 - prev ** 2)
-        std = torch.sqrt((prev ** 2 * (sigma ** 2 - prev ** 2)) / (sigma ** 2))
-        return x_mean + _b(std) * torch.randn_like(x), x_mean
+        gap = sigma ** 2 - prev ** 2                                        # variance removed by this step
+        std = torch.sqrt((prev ** 2 * gap) / (sigma ** 2))
+        return _apply(x, y=self.score_fn(x, t), b=gap, z=torch.randn_like(x), c=std)
 
     def vpsde_update_fn(self, x, t):
         sde = self.sde
         idx = (t * (sde.N - 1) / sde.T).long()
         beta = sde.discrete_betas.to(t.device)[idx]
-        score = self.score_fn(x, t)
-        x_mean = (x + _b(beta) * score) / _b(torch.sqrt(1. - beta))
-        return x_mean + _b(torch.sqrt(beta)) * torch.randn_like(x), x_mean
+        # (x + beta score) / sqrt(1 - beta) as a x + b score with the division folded into the coefficients
+        inv = 1. / torch.sqrt(1. - beta)
+        return _apply(x, y=self.score_fn(x, t), a=inv, b=beta * inv, z=torch.randn_like(x), c=torch.sqrt(beta))
 
     def update_fn(self, x, t):
         if isinstance(self.sde, sde_lib.VESDE):
@@ -184,6 +188,10 @@ def _langevin_alpha(sde, t):
     return torch.ones_like(t)
 
 
+def _batch_mean_norm(v):
+    return torch.norm(v.reshape(v.shape[0], -1), dim=-1).mean()
+
+
 @register_corrector(name='langevin')
 class LangevinCorrector(Corrector):
     """Langevin MCMC with the step size set from BATCH-MEAN norms (sampling.py:253-282)."""
@@ -198,11 +206,8 @@ class LangevinCorrector(Corrector):
         for _ in range(self.n_steps):
             grad = self.score_fn(x, t)
             noise = torch.randn_like(x)
-            grad_norm = torch.norm(grad.reshape(grad.shape[0], -1), dim=-1).mean()
-            noise_norm = torch.norm(noise.reshape(noise.shape[0], -1), dim=-1).mean()
-            step_size = (self.snr * noise_norm / grad_norm) ** 2 * 2 * alpha
-            x_mean = x + _b(step_size) * grad
-            x = x_mean + _b(torch.sqrt(step_size * 2)) * noise
+            step = (self.snr * _batch_mean_norm(noise) / _batch_mean_norm(grad)) ** 2 * 2 * alpha      # [B]
+            x, x_mean = _apply(x, y=grad, b=step, z=noise, c=torch.sqrt(step * 2))
         return x, x_mean
 
 
@@ -215,15 +220,10 @@ class AnnealedLangevinDynamics(Corrector):
         _check_corrector_sde(sde)
 
     def update_fn(self, x, t):
-        alpha = _langevin_alpha(self.sde, t)
-        std = self.sde.marginal_prob(x, t)[1]
+        step = (self.snr * self.sde.marginal_prob(x, t)[1]) ** 2 * 2 * _langevin_alpha(self.sde, t)  # [B]
         x_mean = x
         for _ in range(self.n_steps):
-            grad = self.score_fn(x, t)
-            noise = torch.randn_like(x)
-            step_size = (self.snr * std) ** 2 * 2 * alpha
-            x_mean = x + _b(step_size) * grad
-            x = x_mean + noise * _b(torch.sqrt(step_size * 2))
+            x, x_mean = _apply(x, y=self.score_fn(x, t), b=step, z=torch.randn_like(x), c=torch.sqrt(step * 2))
         return x, x_mean
 
 

@@ -870,6 +870,84 @@ def check_train_plan(dev, tmp_path=None, c_host=None):
     return worst
 
 
+def check_generic_loss_closures(dev):
+    """losses.get_sde_loss_fn / get_smld_loss_fn / get_ddpm_loss_fn on a model the fused step cannot lower (a plain
+    torch module): perturbation and loss head run as libssde_hip kernels (ssde_perturb, ssde_dsm_loss) under a custom
+    autograd function.  Loss value and parameter gradients against the reference's formulas (losses.py:77-101, 104-125,
+    128-148) written out in torch on the same RNG draws."""
+    from score_sde_pytorch_amd import losses, sde_lib
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = torch.nn.Conv2d(3, 8, 3, padding=1)
+            self.c2 = torch.nn.Conv2d(8, 3, 3, padding=1)
+
+        def forward(self, x, labels):
+            h = F.silu(self.c1(x)) * (1.0 + 0.01 * torch.log1p(labels.float().abs()))[:, None, None, None]
+            return self.c2(h)
+
+    torch.manual_seed(3)
+    model = Tiny().to(dev)
+    batch = torch.randn(4, 3, 8, 8, device=dev)
+    bc = lambda v: v[:, None, None, None]                                                            # noqa: E731
+
+    def ref_sde(sde, reduce_mean, lw, eps=1e-5):
+        t = torch.rand(batch.shape[0], device=dev) * (sde.T - eps) + eps
+        z = torch.randn_like(batch)
+        mean, std = sde.marginal_prob(batch, t)
+        xt = mean + bc(std) * z
+        if isinstance(sde, sde_lib.VESDE):
+            score = model(xt, sde.marginal_prob(torch.zeros_like(xt), t)[1])
+        else:
+            score = -model(xt, t * 999) / bc(std)
+        red = (lambda v: v.flatten(1).mean(1)) if reduce_mean else (lambda v: 0.5 * v.flatten(1).sum(1))
+        if lw:
+            g2 = sde.sde(torch.zeros_like(batch), t)[1] ** 2
+            return (red((score + z / bc(std)) ** 2) * g2).mean()
+        return red((score * bc(std) + z) ** 2).mean()
+
+    def ref_smld(sde, reduce_mean):
+        labels = torch.randint(0, sde.N, (batch.shape[0],), device=dev)
+        sig = torch.flip(sde.discrete_sigmas, dims=(0,)).to(dev)[labels]
+        z = torch.randn_like(batch)
+        score = model(batch + bc(sig) * z, labels)
+        red = (lambda v: v.flatten(1).mean(1)) if reduce_mean else (lambda v: 0.5 * v.flatten(1).sum(1))
+        return (red((score + z / bc(sig)) ** 2) * sig ** 2).mean()
+
+    def ref_ddpm(sde, reduce_mean):
+        labels = torch.randint(0, sde.N, (batch.shape[0],), device=dev)
+        a, s = sde.sqrt_alphas_cumprod.to(dev)[labels], sde.sqrt_1m_alphas_cumprod.to(dev)[labels]
+        z = torch.randn_like(batch)
+        out = model(bc(a) * batch + bc(s) * z, labels)
+        red = (lambda v: v.flatten(1).mean(1)) if reduce_mean else (lambda v: 0.5 * v.flatten(1).sum(1))
+        return red((out - z) ** 2).mean()
+
+    ve, vp, sub = sde_lib.VESDE(N=50), sde_lib.VPSDE(N=50), sde_lib.subVPSDE(N=50)
+    cases = [
+        (losses.get_sde_loss_fn(ve, True, reduce_mean=False, likelihood_weighting=False), lambda: ref_sde(ve, False, False)),
+        (losses.get_sde_loss_fn(vp, True, reduce_mean=True, likelihood_weighting=False), lambda: ref_sde(vp, True, False)),
+        (losses.get_sde_loss_fn(sub, True, reduce_mean=False, likelihood_weighting=True), lambda: ref_sde(sub, False, True)),
+        (losses.get_sde_loss_fn(vp, True, reduce_mean=True, likelihood_weighting=True), lambda: ref_sde(vp, True, True)),
+        (losses.get_smld_loss_fn(ve, True, reduce_mean=False), lambda: ref_smld(ve, False)),
+        (losses.get_smld_loss_fn(ve, True, reduce_mean=True), lambda: ref_smld(ve, True)),
+        (losses.get_ddpm_loss_fn(vp, True, reduce_mean=True), lambda: ref_ddpm(vp, True)),
+        (losses.get_ddpm_loss_fn(vp, True, reduce_mean=False), lambda: ref_ddpm(vp, False)),
+    ]
+    for i, (fn, ref) in enumerate(cases):
+        got = []
+        for f in (lambda: fn(model, batch), ref):
+            torch.manual_seed(100 + i)
+            model.zero_grad(set_to_none=True)
+            loss = f()
+            loss.backward()
+            got.append((loss.detach().clone(), [p.grad.detach().clone() for p in model.parameters()]))
+        (l1, g1), (l0, g0) = got
+        assert l1.shape == () and abs(float(l1) - float(l0)) <= 2e-5 * abs(float(l0)), (i, float(l1), float(l0))
+        for a, b in zip(g1, g0):
+            assert rel_err(a, b) < 2e-5, (i, rel_err(a, b))
+
+
 def check_checkpoint_and_ema_swap(dev, tmp_path):
     """utils.save_checkpoint / restore_checkpoint (reference utils.py:7-28) around the fused step, the EMA
     store / copy_to / restore swap (models/ema.py:53-89) on the flat buffers, and weight re-packing of an inference
@@ -1035,17 +1113,24 @@ def check_conv_winograd4(dev, big=False):
     from score_sde_pytorch_amd.engine import pack_wino4_weight
     lib = L.load()
     g = torch.Generator().manual_seed(2)
-    plain = [(1, 8, 64, 16), (2, 32, 64, 8), (3, 16, 96, 8), (1, 12, 128, 32)]
+    # (>= 128 / 256 input channels and few workgroups: the reduction is split over two / four workgroups per tile, checked
+    # both ways)
+    plain = [(1, 8, 64, 16), (2, 32, 64, 8), (3, 16, 96, 8), (1, 12, 128, 32), (3, 128, 64, 8), (9, 132, 72, 8), (2, 260, 96, 8)]
     if big:
         plain += [(16, 128, 128, 32), (9, 256, 256, 16), (20, 256, 256, 8), (2, 128, 128, 64)]
     for (n, cin, cout, h) in plain:
         x = torch.randn(n, cin, h, h, generator=g)
         w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
         b = torch.randn(cout, generator=g)
-        y = ops.conv2d(x.permute(0, 2, 3, 1).contiguous().to(dev), w.to(dev), b.to(dev), tile=L.TILE_WINOGRAD4)
         ref = F.conv2d(x, w, b, padding=1)
-        assert _util.rel_err(y.cpu().permute(0, 3, 1, 2), ref) < 2e-5, (n, cin, cout, h)
-    fused = [(5, 32, 16, 64, 16), (9, 64, 0, 96, 8), (3, 24, 32, 128, 32)]
+        for ksplit in (("1", "0") if cin >= 128 else ("1",)):
+            os.environ["SSDE_CONV_KSPLIT"] = ksplit
+            try:
+                y = ops.conv2d(x.permute(0, 2, 3, 1).contiguous().to(dev), w.to(dev), b.to(dev), tile=L.TILE_WINOGRAD4)
+            finally:
+                del os.environ["SSDE_CONV_KSPLIT"]
+            assert _util.rel_err(y.cpu().permute(0, 3, 1, 2), ref) < 2e-5, (n, cin, cout, h, ksplit)
+    fused = [(5, 32, 16, 64, 16), (9, 64, 0, 96, 8), (3, 24, 32, 128, 32), (10, 96, 32, 64, 8), (4, 192, 64, 64, 8)]
     if big:
         fused += [(12, 128, 128, 128, 32), (10, 256, 256, 256, 16)]
     for (n, c0, c1, cout, h) in fused:

@@ -108,3 +108,7 @@ def test_input_gradient_only_program():
 
 def test_checkpoint_roundtrip_and_ema_swap(tmp_path):
     T.check_checkpoint_and_ema_swap("cpu", tmp_path)
+
+
+def test_generic_loss_closures_run_the_hip_loss_head():
+    T.check_generic_loss_closures("cpu")

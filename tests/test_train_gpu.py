@@ -126,3 +126,7 @@ def test_checkpoint_roundtrip_and_ema_swap(tmp_path):
 
 def test_bucketed_gradient_exchange_over_a_one_rank_rccl_group(monkeypatch):
     T.check_forced_exchange_one_rank("cuda", "nccl", monkeypatch)
+
+
+def test_generic_loss_closures_run_the_hip_loss_head():
+    T.check_generic_loss_closures("cuda")

@@ -49,7 +49,9 @@ def time_conv(n, cin, cout, h, tile, gn=False, reps=5, resid=False):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     shapes = [(128, 128, 32), (256, 128, 32), (256, 256, 16), (512, 256, 16), (256, 256, 8), (384, 128, 32)]
-    if os.environ.get("CONV_BENCH_SMALL"):
+    if os.environ.get("CONV_BENCH_SHAPES"):          # "cin,cout,h;cin,cout,h;..."
+        shapes = [tuple(int(v) for v in t.split(",")) for t in os.environ["CONV_BENCH_SHAPES"].split(";")]
+    elif os.environ.get("CONV_BENCH_SMALL"):
         shapes = [(256, 256, 4), (512, 256, 4), (128, 256, 8), (256, 256, 8)]
     for cin, cout, h in shapes:
         for gn in ((0, 1, 2, 3) if os.environ.get("CONV_BENCH_PROLOGUES") else (0, 1)):   # 1 GN+SiLU, 2 GN, 3 SiLU
