@@ -616,8 +616,7 @@ class Lowering:
         to cover the 256 CUs (F(2x2,3x3): 64 tiles x 64 couts per workgroup -- measured x1.2-1.5 over the direct kernel
         from 8x8 up at batch 256, x0.5 at 4x4 where only 64 workgroups exist).  F(4x4,3x3) does 1.78x less matrix work
         again and is 15-23 % faster than F(2x2,3x3) from 16x16 maps up (profiles/r2_wino4_v3_interleaved.txt); its
-        workgroups cover 32 tiles = 512 pixels, so 8x8 maps at batch 256 give 128 of them: taken only where the kernel splits its
-        reduction over two workgroups per tile (below), F(2x2,3x3) otherwise.
+        workgroups cover 32 tiles = 512 pixels, so 8x8 maps at batch 256 give 128 of them and stay on F(2x2,3x3) (see below).
         Rounding: ~5x coarser than the direct form, 2.5e-6 .. 1.3e-5 on the whole network against the 1e-4 the parity
         tests allow (tools/experiments/wino43_error_budget.py).
         SSDE_WINOGRAD: 0 = direct (bitwise fmaf-chain) kernel everywhere, 1 = this heuristic (default), 2 = F(2x2,3x3)
@@ -636,14 +635,17 @@ class Lowering:
         if mode != "3" and legal4 and h >= 16 and w >= 16 and -(-(self.n * h * w) // 512) * n_tiles >= 256:
             return 4
         # Fewer tiles than that (8x8 maps at batch 256: 128 tiles of 8 images x 64 couts): the kernel splits its reduction
-        # over 2 or 4 workgroups per tile (conv_wino4.hip, ssde_conv_wino4_splits -- the same rule), taken where that
-        # fills the chip
-        wgs4 = -(-(-(-(self.n * h * w) // 512)) // 8) * 8 * n_tiles
-        splits = 1
-        if c_out % 4 == 0 and os.environ.get("SSDE_CONV_KSPLIT", "1") != "0":
-            splits = 4 if wgs4 <= 64 and c_in >= 256 else 2 if wgs4 <= 128 and c_in >= 128 else 1
-        if mode != "3" and legal4 and splits > 1 and wgs4 * splits >= int(os.environ.get("SSDE_W4_SPLIT_MIN_WGS", "192")):
-            return 4
+        # over 2 or 4 workgroups per tile (conv_wino4.hip, ssde_conv_wino4_splits -- the same rule).  Measured
+        # (profiles/r3_wino4_split_reduction_ab.txt): 17-40 % over the unsplit kernel, but only level with F(2x2,3x3) on
+        # 8x8 maps at batch 256 and 128 (0.123 / 0.184 ms against 0.110 / 0.190 ms; the PC iteration 58.1 against 57.0 ms),
+        # so the heuristic takes it only on request: SSDE_W4_SPLIT_MIN_WGS=<workgroups after the split, e.g. 192>
+        if mode != "3" and legal4 and "SSDE_W4_SPLIT_MIN_WGS" in os.environ:
+            wgs4 = -(-(-(-(self.n * h * w) // 512)) // 8) * 8 * n_tiles
+            splits = 1
+            if c_out % 4 == 0 and os.environ.get("SSDE_CONV_KSPLIT", "1") != "0":
+                splits = 4 if wgs4 <= 64 and c_in >= 256 else 2 if wgs4 <= 128 and c_in >= 128 else 1
+            if splits > 1 and wgs4 * splits >= int(os.environ["SSDE_W4_SPLIT_MIN_WGS"]):
+                return 4
         # tools/heuristic_sweep.py (profiles/r2_heuristic_sweep.txt): F(4x4,3x3) wins from 256 of its workgroups, F(2x2,3x3)
         # over the direct kernel from 128 of its own (by 2-6 %; at 64 the direct kernel is 1.5x faster)
         return 2 if legal2 and -(-(self.n * h * w) // 256) * n_tiles >= 128 else 0
