@@ -562,6 +562,27 @@ def _phase(msg):
     print("[bench %7.1f s] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
 
+def mfma_probe(dev, iters=20000, reps=5):
+    """TFLOP/s of back-to-back fp32 MFMAs on every SIMD (the C ABI's diagnostic ssde_mfma_probe), best of `reps`."""
+    import ctypes as C
+    from score_sde_pytorch_amd import _lib as L
+    lib = L.load()
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    sink = torch.zeros(64, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    lib.ssde_mfma_probe.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    L.check(lib.ssde_mfma_probe(cus, 200, sink.data_ptr(), st), "ssde_mfma_probe")
+    best = 0.0
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(lib.ssde_mfma_probe(cus, iters, sink.data_ptr(), st), "ssde_mfma_probe")
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, cus * 4 * iters * 8 * 4096.0 / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+    return best
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -663,6 +684,17 @@ def main():
                     "traffic(_algorithmic) = bytes per %s launch (PMC / op list)" % roof["dominant"],
             "unet_eval_ms_eager_events": float(roof["ms"].sum()),
             "by_class": roof["by_class"]}
+        # what the matrix pipe of THIS device sustains: every SIMD issuing back-to-back fp32 MFMAs on register operands
+        # (ssde_mfma_probe), ~5 ms per timed launch.  `peak` above stays the data-sheet figure (2.4 GHz); under load the
+        # device settles on a lower clock, and the fractions against the sustained rate are reported beside it.
+        try:
+            sustained = mfma_probe(dev)
+            out["roofline"]["sustained_mfma_probe"] = {
+                "tflops": sustained, "implied_clock_ghz": sustained / PEAK_FP32_MFMA_TFLOPS * 2.4,
+                "frac_of_sustained": roof["achieved_exec"] / sustained,
+                "note": "ssde_mfma_probe: 1 wave per SIMD, 8 independent v_mfma_f32_32x32x2_f32 chains, no LDS / memory traffic"}
+        except Exception as exc:                                 # diagnostic only
+            out["roofline"]["sustained_mfma_probe"] = {"error": repr(exc)}
         if args.dump_ops:
             up, ms, cls, fl = eng.unet.program, roof["ms"], roof["cls"], roof["fl"]
             rows = []

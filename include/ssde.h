@@ -565,6 +565,12 @@ int ssde_sizeof_op(void);             /* lets the ctypes mirror verify its layou
 const char* ssde_last_error(void);
 int ssde_conv_lds_bytes(const ssde_conv_args* a);   /* diagnostic: LDS a launch would use */
 int64_t ssde_wgrad_scratch_floats(const ssde_wgrad_args* a);   /* scratch the preferred split needs (0: none), < 0: error */
+/* diagnostic: `workgroups` workgroups of 4 waves (pass the CU count: one wave per SIMD) issue `iters` x 8 back-to-back
+ * v_mfma_f32_32x32x2_f32 on register operands (nothing else: no LDS, no memory).  Timed by the caller,
+ * workgroups x 4 x iters x 8 x 4096 FLOP / t is the fp32 matrix rate this device SUSTAINS at the clock it settles on
+ * under load -- bench.py reports it beside the 157.3 TFLOP/s data-sheet peak (2.4 GHz) the roofline fractions are quoted
+ * against.  sink: at least 64 floats (never written). */
+int ssde_mfma_probe(int32_t workgroups, int32_t iters, float* sink, void* stream);
 
 #ifdef __cplusplus
 }

@@ -244,7 +244,7 @@ EXPORTS = ["ssde_conv2d", "ssde_groupnorm_stats", "ssde_upfirdn2d", "ssde_attent
            "ssde_abi_version", "ssde_sizeof_op", "ssde_last_error", "ssde_conv_lds_bytes",
            "ssde_conv_wgrad", "ssde_colsum", "ssde_gn_bwd_reduce", "ssde_prologue_bwd", "ssde_attention_bwd",
            "ssde_perturb", "ssde_dsm_loss", "ssde_sumsq_flat", "ssde_adam_clip_ema", "ssde_memset", "ssde_axpy",
-           "ssde_wgrad_scratch_floats", "ssde_pack_weights", "ssde_project_update", "ssde_gn_finalize", "ssde_conv_gn_slices", "ssde_rk_combine", "ssde_rk_error_norm", "ssde_pf_drift", "ssde_hutch_div", "ssde_sample_update",
+           "ssde_wgrad_scratch_floats", "ssde_pack_weights", "ssde_project_update", "ssde_gn_finalize", "ssde_conv_gn_slices", "ssde_rk_combine", "ssde_rk_error_norm", "ssde_pf_drift", "ssde_hutch_div", "ssde_sample_update", "ssde_mfma_probe",
            # plan-level entry points (csrc/plan.hip; argument types: plan_export.bind)
            "ssde_plan_load", "ssde_plan_load_file", "ssde_plan_destroy", "ssde_plan_info", "ssde_plan_param",
            "ssde_plan_refresh_weights", "ssde_unet_forward", "ssde_pc_reset", "ssde_pc_run", "ssde_pc_state",

@@ -16,6 +16,33 @@ extern "C" const char* ssde_last_error(void) { return g_err; }
 extern "C" int ssde_abi_version(void) { return SSDE_ABI_VERSION; }
 extern "C" int ssde_sizeof_op(void) { return (int)sizeof(ssde_op); }
 
+// ---- ssde_mfma_probe: the matrix rate the device sustains (see include/ssde.h) ----
+typedef float probe_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void mfma_probe_kernel(int iters, float* sink) {
+  probe_f32x16 acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const float a = 1.0f + (float)(threadIdx.x & 7) * 0.125f, b = 0.5f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);   // 8 independent chains
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t += acc[j][0];
+  if (t == -1.f) sink[threadIdx.x & 63] = t;          // never true: keeps the chains alive
+}
+
+extern "C" int ssde_mfma_probe(int32_t workgroups, int32_t iters, float* sink, void* stream) {
+  SSDE_REQUIRE(workgroups > 0 && iters > 0 && sink, "mfma_probe: bad args");
+  // a workgroup is 4 waves = one wave per SIMD of the CU it lands on
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(workgroups), dim3(256), 0, static_cast<hipStream_t>(stream), iters, sink);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}
+
 static int run_one(const ssde_op& op, void* stream) {
   switch (op.kind) {
     case SSDE_OP_CONV: return ssde_conv2d(&op.u.conv, stream);
