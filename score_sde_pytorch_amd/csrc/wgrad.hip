@@ -19,6 +19,7 @@
 // conflict-free ds_read_b32 of 32 consecutive floats and the halo is re-used by all 9 taps.
 // dw is written in the REFERENCE layout (OIHW, or [in][out] for NIN with transpose_out).
 #include "ssde_common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -39,6 +40,7 @@ struct WgParams {
   float scale;
   float* dw;
   float* scratch;
+  int rows, rows_per_split;    // wgrad1x1_gemm_kernel: pixels in total / per split (a multiple of its 16-row stage)
 };
 
 template <int KS, int CO_B, int CI_B>
@@ -219,6 +221,146 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(const WgParams p) {
         }
 }
 
+// ---- 1x1 / NIN / Linear weight gradients as a software-pipelined GEMM ------------------------------------------------
+// dw[co, ci] = sum_m g[m, co] * pro(src)[m, ci] over the pixels m of the whole batch: both operands are K-major rows of
+// channels exactly as they lie in memory.  wgrad_kernel<1, 2, 2> above stages a 64-pixel chunk, waits, multiplies, waits
+// (44-54 TF/s: the load latency of every chunk is exposed); here a stage is 16 pixels, double buffered in LDS, and the
+// next stage's rows are fetched into registers -- prologue applied there -- while the MFMAs of the current one run (the
+// schedule of wgrad_wino4.hip's wgrad4_gemm_kernel).  Workgroup = 4 waves = 128 co x 128 ci, wave = a 64 x 64 quadrant;
+// splits over pixel ranges, slabs in wgrad_reduce_kernel<1, 128, 128>'s layout (the same reduction follows).
+constexpr int kG1BK = 16, kG1LDP = 128 + 4;                    // LDS row pitch: rows 4 banks apart
+constexpr int kG1Stage = 2 * kG1BK * kG1LDP;                   // floats of one LDS stage (g rows, then source rows)
+
+__global__ __launch_bounds__(kThreads, 4) void wgrad1x1_gemm_kernel(const WgParams p) {
+  SSDE_LDS(smem);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int ntiles = p.co_tiles * p.ci_tiles;
+  const int xcd = blockIdx.x & 7, lin = blockIdx.x >> 3;       // the tiles of one pixel split share an XCD (one L2)
+  const int tile = lin % ntiles, split = (lin / ntiles) * 8 + xcd;
+  if (split >= p.splits) return;
+  const int co0 = (tile / p.ci_tiles) * 128, ci0 = (tile % p.ci_tiles) * 128;
+  const int k0 = split * p.rows_per_split;
+  const int k1 = min(p.rows, k0 + p.rows_per_split);
+  const int nst = (k1 - k0 + kG1BK - 1) / kG1BK;
+  const int hw = p.Hout * p.Wout;
+
+  const ssde_src& s = p.src;
+  const SsdePro pro = ssde_pro_decode(s);
+  const int cpg = pro.gn ? p.Ctot / s.gn_groups : 1;
+  // staging: thread = rows r0, r0 + 8 of a stage, channel quad q4 of both operands
+  const int q4 = (tid & 31) * 4, r0 = tid >> 5;
+  const bool zc_ok = co0 + q4 < p.Cout && p.g_off + co0 + q4 + 4 <= p.g_ld;
+  const int ch = ci0 + q4;
+  const bool vc_ok = ch < p.Ctot;
+  const bool second = ch >= s.c0;
+  const float* vbase = second ? s.p1 + (ch - s.c0) : s.p0 + ch;
+  const int vld = second ? s.c1 : s.c0;
+  float4 gam = make_float4(1.f, 1.f, 1.f, 1.f), bet = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (pro.gn && vc_ok) {
+    gam = *reinterpret_cast<const float4*>(s.gn_gamma + ch);
+    bet = *reinterpret_cast<const float4*>(s.gn_beta + ch);
+  }
+  const int grp = pro.gn && vc_ok ? ch / cpg : 0;
+  float4 zv[2], vv[2];
+  auto load_stage = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = k0 + st * kG1BK + r0 + i * 8;
+      const bool ok = m < k1;
+      const size_t row = (size_t)(ok ? m : k0);
+      zv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      vv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok && zc_ok) zv[i] = *reinterpret_cast<const float4*>(p.g + row * p.g_ld + p.g_off + co0 + q4);
+      if (ok && vc_ok) {
+        float4 x = *reinterpret_cast<const float4*>(vbase + row * vld);
+        float mu = 0.f, rs = 1.f;
+        if (pro.gn) {
+          const int gi = (int)(row / (size_t)hw) * s.gn_groups + grp;
+          mu = s.gn_mean[gi]; rs = s.gn_rstd[gi];
+        }
+        vv[i] = ssde_pro_apply(x, mu, rs, gam, bet, (uint32_t)row * (uint32_t)p.Ctot + (uint32_t)ch, pro);
+      }
+    }
+  };
+  auto store_stage = [&](float* buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<float4*>(buf + (r0 + i * 8) * kG1LDP + q4) = zv[i];
+      *reinterpret_cast<float4*>(buf + (kG1BK + r0 + i * 8) * kG1LDP + q4) = vv[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int aoff = lh * kG1LDP + wm0 + li, boff = (kG1BK + lh) * kG1LDP + wn0 + li;
+
+  load_stage(0);
+  store_stage(smem);
+  __syncthreads();
+  for (int st = 0; st < nst; ++st) {
+    const float* cur = smem + (st & 1) * kG1Stage;
+    const bool has_next = st + 1 < nst;
+    if (has_next) load_stage(st + 1);
+    float af[2][2], bf[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) af[0][a] = cur[aoff + a * 32];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) bf[0][c] = cur[boff + c * 32];
+#pragma unroll
+    for (int kk = 0; kk < kG1BK / 2; ++kk) {
+      const int w = kk & 1;
+      if (kk + 1 < kG1BK / 2) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) af[w ^ 1][a] = cur[aoff + (kk + 1) * 2 * kG1LDP + a * 32];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) bf[w ^ 1][c] = cur[boff + (kk + 1) * 2 * kG1LDP + c * 32];
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][a], bf[w][c], acc[a][c], 0, 0, 0);
+    }
+    if (has_next) store_stage(smem + ((st + 1) & 1) * kG1Stage);
+    __syncthreads();
+  }
+
+  // lane owns input channel ci (column), 16 output channels (rows) per block -- as wgrad_kernel's epilogue
+  if (p.splits == 1) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int ci = ci0 + wn0 + c * 32 + li;
+      if (ci >= p.cin_store) continue;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (co >= p.Cout) continue;
+          const size_t idx = p.transpose_out ? (size_t)ci * p.Cout + co : (size_t)co * p.cin_store + ci;
+          p.dw[idx] += acc[a][c][r] * p.scale;
+        }
+    }
+    return;
+  }
+  float* slab = p.scratch + ((size_t)split * ntiles + tile) * (size_t)(128 * 128);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int col = wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        slab[(size_t)col * 128 + wn0 + c * 32 + li] = acc[a][c][r];
+      }
+}
+
 // dw[co, ci, tap] += scale * sum_splits slab[split][tile][tap][co_l][ci_l]; thread = one (tile, tap, co_l, ci_l)
 template <int T, int BCO, int BCI>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgParams p) {
@@ -270,6 +412,12 @@ int launch(const WgParams& p, int lds_bytes, hipStream_t st) {
 int pow2_floor(int v) { int q = 1; while (q * 2 <= v) q *= 2; return q; }
 
 struct WgPlan { WgParams p; int lds; int64_t slab_floats; int pref_splits; };
+
+// 1x1 / NIN / Linear gradients go to wgrad1x1_gemm_kernel (SSDE_WGRAD_1X1_PIPELINED=0: the chunked kernel, read per call)
+bool pipelined_1x1(const ssde_wgrad_args* a) {
+  const char* e = getenv("SSDE_WGRAD_1X1_PIPELINED");
+  return a->ksize == 1 && (!e || atoi(e) != 0);
+}
 
 int make_plan(const ssde_wgrad_args* a, WgPlan* pl) {
   SSDE_REQUIRE(a && a->ksize != 0, "wgrad: null args");
@@ -325,6 +473,22 @@ int make_plan(const ssde_wgrad_args* a, WgPlan* pl) {
   }
   p.chunks_per_split = ssde_cdiv(p.chunks, splits);
   p.splits = ssde_cdiv(p.chunks, p.chunks_per_split);
+  p.rows = a->n * hw;
+  p.rows_per_split = 0;
+  if (pipelined_1x1(a)) {
+    // the pipelined GEMM: ~768 workgroups (3 of the 4 a CU holds: the sweep in profiles/r3_wgrad1x1_ab.txt peaks at
+    // 768-1024 for every shape of the CIFAR network), at least 8 stages of 16 pixels each
+    const int stages = ssde_cdiv(p.rows, kG1BK);
+    int sp = ssde_cdiv(768, ntiles);
+    if (sp > stages / 8) sp = stages / 8;
+    if (sp < 1) sp = 1;
+    pl->pref_splits = sp;
+    if (a->splits > 0) sp = a->splits;
+    if (sp > stages) sp = stages;
+    if (sp > 1 && a->scratch_floats < pl->slab_floats * sp) { sp = (int)(a->scratch_floats / pl->slab_floats); if (sp < 1) sp = 1; }
+    p.rows_per_split = ssde_cdiv(stages, sp) * kG1BK;
+    p.splits = ssde_cdiv(p.rows, p.rows_per_split);
+  }
   const int ks = a->ksize;
   const int halo = imgs * ((th - 1) * a->stride + ks) * ((tw - 1) * a->stride + ks);
   pl->lds = (px * bco + halo * bci) * 4;
@@ -355,5 +519,17 @@ extern "C" int ssde_conv_wgrad(const ssde_wgrad_args* a, void* stream) {
   SSDE_REQUIRE(pl.p.splits == 1 || a->scratch, "wgrad: scratch missing");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (a->ksize == 3) return launch<3, 1, 1>(pl.p, pl.lds, st);
+  if (pl.p.rows_per_split > 0) {
+    const int ntiles = pl.p.co_tiles * pl.p.ci_tiles;
+    hipLaunchKernelGGL(wgrad1x1_gemm_kernel, dim3(ssde_cdiv(pl.p.splits, 8) * 8 * ntiles), dim3(kThreads), 2 * kG1Stage * 4, st, pl.p);
+    SSDE_LAUNCH_CHECK();
+    if (pl.p.splits > 1) {
+      size_t blocks = ((size_t)128 * 128 * ntiles + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL((wgrad_reduce_kernel<1, 128, 128>), dim3((unsigned)blocks), dim3(256), 0, st, pl.p);
+      SSDE_LAUNCH_CHECK();
+    }
+    return SSDE_OK;
+  }
   return launch<1, 2, 2>(pl.p, pl.lds, st);
 }

@@ -170,6 +170,59 @@ def check_backward_ops(dev):
         assert rel_err(pp, p_ref.detach()) < 1e-6 and rel_err(ema, ema_ref) < 1e-6
 
 
+def check_wgrad_1x1(dev):
+    """1x1 / NIN weight gradients on wgrad1x1_gemm_kernel (software-pipelined, the default) and on the chunked
+    wgrad_kernel<1,2,2> (SSDE_WGRAD_1X1_PIPELINED=0): several (co, ci) tiles, pixel splits with ragged last stages, concatenated
+    sources, GroupNorm (+SiLU) prologue, the regenerated dropout mask, column slices of the gradient and the transposed
+    (NIN) destination -- against torch autograd over the same arithmetic."""
+    from score_sde_pytorch_amd import hipops as ops, _lib as L
+    g = torch.Generator().manual_seed(11)
+    d = lambda t: t.to(dev)                                                                           # noqa: E731
+    cases = [  # n, c0, c1, cout, h, pro, splits, dropout
+        (3, 96, 64, 136, 12, L.PRO_GN_SILU, 0, False),
+        (2, 160, 0, 72, 10, L.PRO_GN, 3, False),
+        (5, 64, 32, 260, 6, L.PRO_NONE, 2, False),
+        (3, 128, 0, 128, 8, L.PRO_GN_SILU, 4, True),
+        (2, 32, 0, 40, 5, L.PRO_SILU, 0, False),
+    ]
+    for (n, c0, c1, cout, h, pro, splits, drop) in cases:
+        C = c0 + c1
+        x = (torch.randn(n, C, h, h, generator=g) * 1.3 + 0.2).requires_grad_()
+        w = (torch.randn(cout, C, generator=g) / np.sqrt(C)).requires_grad_()
+        gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        G = 32 if C % 32 == 0 and (C // 32) % 4 == 0 else C // 4
+        gfull = torch.randn(n, h, h, cout + 8, generator=g)
+        u = x
+        if pro in (L.PRO_GN, L.PRO_GN_SILU):
+            u = F.group_norm(u, G, gamma, beta, 1e-6)
+        if pro in (L.PRO_SILU, L.PRO_GN_SILU):
+            u = F.silu(u)
+        xa = d(nhwc(x.detach()))
+        seed_t, salt, pdrop = torch.tensor([0x1234567], dtype=torch.int32, device=dev), 77, 0.25
+        if drop:
+            thresh = min(int(round(pdrop * 2.0 ** 32)), 2 ** 32 - 1)
+            keep = hash_keep(np.arange(n * h * h * C, dtype=np.uint64), (0x1234567 ^ salt) & 0xFFFFFFFF, thresh, 1.0 / (1.0 - pdrop))
+            u = u * torch.from_numpy(keep.reshape(n, h, h, C)).permute(0, 3, 1, 2)
+        torch.einsum('nchw,oc->nhwo', u, w).backward(gfull[..., 4:4 + cout].contiguous())
+        gn = None
+        if pro in (L.PRO_GN, L.PRO_GN_SILU):
+            mean, rstd = ops.groupnorm_stats(xa, G, 1e-6)
+            gn = (mean, rstd, d(gamma), d(beta), G)
+        x0 = xa[..., :c0].contiguous()
+        x1 = xa[..., c0:].contiguous() if c1 else None
+        for mode in ("1", "0"):
+            os.environ["SSDE_WGRAD_1X1_PIPELINED"] = mode
+            try:
+                for tr in (False, True):
+                    dw = torch.full((C, cout) if tr else (cout, C), 0.5, device=dev)
+                    ops.conv_wgrad(x0, d(gfull), 1, dw, pad=0, x2=x1, pro=pro, gn=gn, g_off=4, c_out=cout, transpose_out=tr, scale=0.5,
+                                   splits=splits, dropout=(pdrop, seed_t, salt) if drop else None)
+                    ref = 0.5 + 0.5 * (w.grad.t() if tr else w.grad)
+                    assert rel_err(dw, ref) < TOL_OP, (n, c0, c1, cout, h, pro, splits, drop, mode, tr)
+            finally:
+                del os.environ["SSDE_WGRAD_1X1_PIPELINED"]
+
+
 def check_upfirdn_tiles(dev):
     """The LDS-staged FIR kernel (channels % 32 == 0, 4x4 taps) in all three modes and their gradient shapes, with
     ragged sizes (partial tiles, odd maps), an asymmetric kernel (flip), the GroupNorm+SiLU prologue applied once in LDS,

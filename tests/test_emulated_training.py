@@ -112,3 +112,7 @@ def test_checkpoint_roundtrip_and_ema_swap(tmp_path):
 
 def test_generic_loss_closures_run_the_hip_loss_head():
     T.check_generic_loss_closures("cpu")
+
+
+def test_1x1_weight_gradients_pipelined_and_chunked():
+    T.check_wgrad_1x1("cpu")

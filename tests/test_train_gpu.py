@@ -130,3 +130,7 @@ def test_bucketed_gradient_exchange_over_a_one_rank_rccl_group(monkeypatch):
 
 def test_generic_loss_closures_run_the_hip_loss_head():
     T.check_generic_loss_closures("cuda")
+
+
+def test_1x1_weight_gradients_pipelined_and_chunked():
+    T.check_wgrad_1x1("cuda")
