@@ -68,8 +68,15 @@ extern "C" int ssde_debug_w4_trace(void* buf) {
   do {                                                                                                    \
     if (tr_on) g_w4_trace[tr_base + (slot)] = __builtin_amdgcn_s_memtime();                               \
   } while (0)
+// the same with the constant 100 MHz counter: (s_memtime delta) / (s_memrealtime delta) x 100 MHz = the shader clock the
+// kernel actually ran at
+#define SSDE_TRR(slot)                                                                                    \
+  do {                                                                                                    \
+    if (tr_on) g_w4_trace[tr_base + (slot)] = __builtin_amdgcn_s_memrealtime();                           \
+  } while (0)
 #else
 #define SSDE_TR(slot) do { } while (0)
+#define SSDE_TRR(slot) do { } while (0)
 #endif
 
 
@@ -224,6 +231,7 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
   const int tr_base = (wave == 0 ? 0 : 1) * 128;
 #endif
   SSDE_TR(0);
+  SSDE_TRR(110);
   if (mt >= p.m_tiles) return;
 
   const int TWt = 1 << p.lTWt, THt = 1 << p.lTHt;
@@ -755,6 +763,7 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
     if (rnd == 0) { __syncthreads(); SSDE_TR(4); }
   }
   SSDE_TR(5);
+  SSDE_TRR(111);
 }
 
 int pow2_floor(int v) { int q = 1; while (q * 2 <= v) q *= 2; return q; }

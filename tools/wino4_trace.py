@@ -33,6 +33,9 @@ def main():
 
             def d(a, b):
                 return int(r[b] - r[a]) if r[a] and r[b] else -1
+            if r[110] and r[111] and r[111] > r[110]:
+                print(" wave %d: shader clock during the workgroup = %.0f MHz (s_memtime %d ticks over %d ticks of the 100 MHz counter)"
+                      % (wv * 7, 100.0 * (r[5] - r[0]) / (r[111] - r[110]), r[5] - r[0], r[111] - r[110]))
             print(" wave %d: setup %d | fill %d | loop %d | epilogue half0 %d half1 %d | total %d"
                   % (wv * 7, d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5), d(0, 5)))
             print("   epilogue half 0: M write %d | sync %d | transform %d | sync %d | park %d | sync %d | store %d | sync %d"
