@@ -191,51 +191,80 @@ struct PbParams {
   int acc0, acc1; float* g0; float* g1;
 };
 
-__global__ __launch_bounds__(256) void prologue_bwd_kernel(const PbParams p) {
+// A thread keeps ONE channel quad for the whole kernel (the launcher makes the grid's thread count a multiple of C/4) and
+// walks pixels px_step apart: gamma / beta / group index / source pointers are loop invariants, the loop body has no
+// 64-bit division (the flat-index form spent more instructions on idx / CL, idx % CL and pix / hw than on the arithmetic),
+// and two pixels are in flight per trip.
+__global__ __launch_bounds__(256) void prologue_bwd_kernel(const PbParams p, const unsigned px_step) {
   const ssde_src& s = p.src;
   const int C = s.c0 + s.c1, CL = C >> 2;
   const SsdePro pro = ssde_pro_decode(s);
   const int cpg = pro.gn ? C / s.gn_groups : 1;
-  const size_t total = (size_t)p.n * p.hw * CL;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int cl = (int)(idx % CL);
-    const size_t pix = idx / CL;
-    const int n = (int)(pix / p.hw);
-    const int ch = cl * 4;
-    const bool first = ch < s.c0;
-    float* gdst = first ? p.g0 : p.g1;
-    if (!gdst) continue;
-    const int Cs = first ? s.c0 : s.c1, cc = first ? ch : ch - s.c0;
-    const float4 dv = *reinterpret_cast<const float4*>(p.dp + pix * p.dp_ld + p.dp_off + ch);
-    float d[4] = {dv.x, dv.y, dv.z, dv.w};
-    if (pro.gn || pro.silu) {
-      const float* xsrc = first ? s.p0 : s.p1;
-      const float4 xv = *reinterpret_cast<const float4*>(xsrc + pix * Cs + cc);
-      const float x[4] = {xv.x, xv.y, xv.z, xv.w};
+  const unsigned gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int cl = (int)(gtid % (unsigned)CL);
+  const unsigned pix0 = gtid / (unsigned)CL, npix = (unsigned)p.n * (unsigned)p.hw;
+  const int ch = cl * 4;
+  const bool first = ch < s.c0;
+  float* gdst = first ? p.g0 : p.g1;
+  if (!gdst) return;
+  const int Cs = first ? s.c0 : s.c1, cc = first ? ch : ch - s.c0;
+  const float* xsrc = (first ? s.p0 : s.p1) + cc;
+  const float* dsrc = p.dp + p.dp_off + ch;
+  const bool acc = first ? p.acc0 : p.acc1;
+  const bool need_x = pro.gn || pro.silu;
+  const int g = ch / cpg;
+  float gm[4] = {1.f, 1.f, 1.f, 1.f}, bt[4] = {0.f, 0.f, 0.f, 0.f};
+  if (pro.gn) {
+    const float4 gam = *reinterpret_cast<const float4*>(s.gn_gamma + ch);
+    const float4 bet = *reinterpret_cast<const float4*>(s.gn_beta + ch);
+    gm[0] = gam.x; gm[1] = gam.y; gm[2] = gam.z; gm[3] = gam.w;
+    bt[0] = bet.x; bt[1] = bet.y; bt[2] = bet.z; bt[3] = bet.w;
+  }
+  constexpr int U = 2;
+  for (unsigned pb = pix0; pb < npix; pb += U * px_step) {
+    float4 dv[U], xv[U], old[U];
+    float mu[U], rs[U], A[U], B[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned pix = pb + u * px_step;
+      ok[u] = pix < npix;
+      const size_t px = ok[u] ? pix : pb;
+      dv[u] = *reinterpret_cast<const float4*>(dsrc + px * p.dp_ld);
+      xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (need_x) xv[u] = *reinterpret_cast<const float4*>(xsrc + px * Cs);
+      old[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (acc) old[u] = *reinterpret_cast<const float4*>(gdst + px * Cs + cc);
+      mu[u] = 0.f; rs[u] = 1.f; A[u] = 0.f; B[u] = 0.f;
       if (pro.gn) {
-        const int g = ch / cpg;
-        const float mu = s.gn_mean[n * s.gn_groups + g], rs = s.gn_rstd[n * s.gn_groups + g];
-        const float A = p.sums[(n * s.gn_groups + g) * 2], B = p.sums[(n * s.gn_groups + g) * 2 + 1];
-        const float4 gam = *reinterpret_cast<const float4*>(s.gn_gamma + ch);
-        const float4 bet = *reinterpret_cast<const float4*>(s.gn_beta + ch);
-        const float gm[4] = {gam.x, gam.y, gam.z, gam.w}, bt[4] = {bet.x, bet.y, bet.z, bet.w};
+        const int gi = (int)((unsigned)px / (unsigned)p.hw) * s.gn_groups + g;
+        mu[u] = s.gn_mean[gi]; rs[u] = s.gn_rstd[gi];
+        A[u] = p.sums[gi * 2]; B[u] = p.sums[gi * 2 + 1];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+      const unsigned pix = pb + u * px_step;
+      float d[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+      const float x[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+      if (pro.gn) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float xh = (x[k] - mu) * rs;
+          const float xh = (x[k] - mu[u]) * rs[u];
           float du = d[k];
           if (pro.silu) du *= ssde_silu_grad(xh * gm[k] + bt[k]);
-          if (pro.drop) du *= ssde_keep((uint32_t)pix * (uint32_t)C + (uint32_t)(ch + k), pro);
-          d[k] = rs * (du * gm[k] - A - xh * B);
+          if (pro.drop) du *= ssde_keep(pix * (uint32_t)C + (uint32_t)(ch + k), pro);
+          d[k] = rs[u] * (du * gm[k] - A[u] - xh * B[u]);
         }
-      } else {
+      } else if (pro.silu) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) d[k] *= ssde_silu_grad(x[k]);
       }
+      float4 r = make_float4(d[0] * p.scale, d[1] * p.scale, d[2] * p.scale, d[3] * p.scale);
+      if (acc) { r.x += old[u].x; r.y += old[u].y; r.z += old[u].z; r.w += old[u].w; }
+      *reinterpret_cast<float4*>(gdst + (size_t)pix * Cs + cc) = r;
     }
-    float4* o = reinterpret_cast<float4*>(gdst + pix * Cs + cc);
-    float4 r = make_float4(d[0] * p.scale, d[1] * p.scale, d[2] * p.scale, d[3] * p.scale);
-    if (first ? p.acc0 : p.acc1) { const float4 old = *o; r.x += old.x; r.y += old.y; r.z += old.z; r.w += old.w; }
-    *o = r;
   }
 }
 
@@ -428,8 +457,17 @@ extern "C" int ssde_prologue_bwd(const ssde_prologue_bwd_args* a, void* stream) 
   SSDE_REQUIRE(a->dp_ld % 4 == 0 && a->dp_off % 4 == 0, "prologue_bwd: dp columns must be 16-byte aligned");
   SSDE_REQUIRE(a->n > 0 && a->hw > 0, "prologue_bwd: bad shape");
   PbParams p{a->src, a->dp, a->dp_ld, a->dp_off, a->n, a->hw, a->sums, a->scale, a->acc0, a->acc1, a->g0, a->g1};
-  const size_t total = (size_t)a->n * a->hw * ((a->src.c0 + a->src.c1) / 4);
-  hipLaunchKernelGGL(prologue_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  const int CL = (a->src.c0 + a->src.c1) / 4;
+  const size_t total = (size_t)a->n * a->hw * CL;
+  SSDE_REQUIRE(CL > 0 && (size_t)a->n * a->hw < (1ull << 31), "prologue_bwd: bad shape");
+  // thread count = a multiple of CL: blocks in steps of CL / gcd(CL, 256)
+  int gcd = CL, b256 = 256;
+  while (b256) { const int t = gcd % b256; gcd = b256; b256 = t; }
+  const unsigned unit = (unsigned)(CL / gcd);
+  unsigned blocks = grid_for(total);
+  blocks = (blocks + unit - 1) / unit * unit;
+  const unsigned px_step = blocks * 256u / (unsigned)CL;
+  hipLaunchKernelGGL(prologue_bwd_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, px_step);
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;
 }

@@ -49,10 +49,12 @@
 //   Where a stage's ~4400 cycles go (s_memtime, tools/wino4_trace.py): 2304 are MFMAs of the SIMD's two waves, ~950 VALU
 //   (prologue 2 x 130-260, transforms 2 x 120, bookkeeping), the rest LDS / VMEM issue latency that nothing overlaps
 //   because all eight waves are in the same phase (one barrier per stage, double buffers: no wave may run ahead).
-// Note on the PMC figure: under rocprofv3 --pmc this kernel runs 26 % slower than unprofiled (408 vs 323 us per launch in
-// the same process, profiles/r3_profile_summary.json vs r3_kernel_stats_rocprofv3.csv), so SQ_VALU_MFMA_BUSY_CYCLES /
-// GRBM_GUI_ACTIVE reads 0.40 both before and after this round's changes, while the cycle trace of an unprofiled launch
-// (128 -> 128 channels: 73.7 k matrix cycles of 145 k per workgroup) gives 0.51, and 0.55-0.58 for the 256 / 512-channel layers.
+// Matrix-pipe occupancy, two ways.  Cycle trace of an unprofiled launch (tools/wino4_trace.py, profiles/r3_wino4_trace_e_*):
+// matrix cycles / workgroup cycles = 0.40 for 128 -> 128 channels (73.7 k of 183 k: loop 146.5 k, fill 9.6 k, epilogue 27 k),
+// 0.46 for 256 -> 256, 0.49 for 512 -> 256; inside the main loop 0.50-0.52.  PMC (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE
+// over all launches of the bench command): 0.40 in round 2 and in round 3 -- under rocprofv3 --pmc the kernel runs 26 %
+// slower than unprofiled (408 vs 323 us per launch in one process), so the ratio understates the unprofiled kernel and moved
+// less than the +7-10 % the same-box A/B shows.  The shader clock inside the kernel (s_memtime / s_memrealtime): 2.09-2.17 GHz.
 #include "ssde_common.h"
 #include <type_traits>
 

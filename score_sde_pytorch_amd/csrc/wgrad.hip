@@ -375,15 +375,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgParams p) {
     const int t = (int)(rem / ((size_t)BCI * BCO));
     const int co = (tile / p.ci_tiles) * BCO + co_l, ci = (tile % p.ci_tiles) * BCI + ci_l;
     if (co >= p.Cout || ci >= p.cin_store) continue;
-    float s0 = 0.f, s1 = 0.f;
+    // eight slabs in flight per thread (two were 2.3 TB/s on the 100-200 slabs of the pipelined 1x1 kernel: a chain of
+    // exposed load latencies); fixed order -> deterministic
+    float sa[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sa[u] = 0.f;
     int sp = 0;
-    for (; sp + 1 < p.splits; sp += 2) {
-      s0 += p.scratch[(size_t)sp * total + idx];
-      s1 += p.scratch[(size_t)(sp + 1) * total + idx];
+    for (; sp + 8 <= p.splits; sp += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p.scratch[(size_t)(sp + u) * total + idx];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sa[u] += v[u];
     }
-    if (sp < p.splits) s0 += p.scratch[(size_t)sp * total + idx];
+    float tail = 0.f;
+    for (; sp < p.splits; ++sp) tail += p.scratch[(size_t)sp * total + idx];
+    const float sum = (((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sa[4] + sa[5]) + (sa[6] + sa[7]))) + tail;
     const size_t o = p.transpose_out ? (size_t)ci * p.Cout + co : ((size_t)co * p.cin_store + ci) * T + t;
-    p.dw[o] += (s0 + s1) * p.scale;
+    p.dw[o] += sum * p.scale;
   }
 }
 
