@@ -161,6 +161,9 @@ static inline void emu_global_load_lds(const void* g, __attribute__((address_spa
 #define SSDE_GLDS16_OFF_SAME_BASE(gptr, lds_wave_base, imm) SSDE_GLDS16_OFF(gptr, lds_wave_base, imm)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
+// timestamps: a counter that advances on every read (a loop that waits for time to pass terminates)
+static inline unsigned long long __builtin_amdgcn_s_memtime() { static unsigned long long t = 0; return t += 1000; }
+static inline unsigned long long __builtin_amdgcn_s_memrealtime() { static unsigned long long t = 0; return t += 50; }
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_sched_barrier(a) ((void)0)
