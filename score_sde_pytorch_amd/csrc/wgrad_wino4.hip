@@ -53,14 +53,16 @@ struct W4Params {
   int N, H, W, Cout, Ctot;
   int tx, ty, T;           // tiles per row / column of an image, tiles in total
   int co_tiles, ci_tiles, splits, k_per_split;
+  int xcd_order;           // 1: the blocks of one (position, split) share an XCD (SSDE_WGRAD4_XCD=0: plain order, A/B only)
   float scale;
   float* dw;
   float* V; float* Z; float* slabs;
 };
 
-// ---- transforms: thread = (tile t, channel c), consecutive threads = consecutive channels: 36 (16) coalesced 4-byte loads
-// and 36 stores in flight per thread.  (Four channels per thread -- 16-byte accesses, 256 registers, two waves per SIMD --
-// measured 5-12 % SLOWER end to end: profiles/r3_wgrad_wino4_ab.txt.) ----
+// ---- transforms: thread = (tile t, VEC channels), consecutive threads = consecutive channels: 36 (16) coalesced loads and 36
+// stores in flight per thread.  VEC = 2 (8-byte accesses, 112-126 registers, four waves per SIMD) is 3-7 % faster per layer
+// than VEC = 1; four channels per thread (16-byte accesses, 256 registers, two waves per SIMD) measured 5-12 % SLOWER end to
+// end: profiles/r3_wgrad_wino4_ab.txt. ----
 // B^T rows [4,0,-5,0,1,0] [0,-4,-4,1,1,0] [0,4,-4,-1,1,0] [0,-2,-1,2,1,0] [0,2,-1,-2,1,0] [0,4,0,-5,0,1]
 __device__ __forceinline__ void bt6(const float (&d)[6], float (&o)[6]) {
   const float t1 = d[4] - 4.f * d[2], t2 = d[3] - 4.f * d[1], t3 = d[4] - d[2], t4 = d[3] - d[1];
@@ -82,27 +84,43 @@ __device__ __forceinline__ void at6(const float (&d)[4], float (&o)[6]) {
   o[5] = d[3];
 }
 
-template <bool kGn>
+// VEC = channels per thread (1, or 2 with 8-byte accesses: SSDE_WGRAD4_XVEC, A/B in profiles/r3_wgrad_wino4_ab.txt)
+template <int VEC> struct XfVec;
+template <> struct XfVec<1> { typedef float type; };
+template <> struct XfVec<2> { typedef float2 type; };
+template <int VEC> __device__ __forceinline__ float xf_get(const typename XfVec<VEC>::type& v, int e);
+template <> __device__ __forceinline__ float xf_get<1>(const float& v, int) { return v; }
+template <> __device__ __forceinline__ float xf_get<2>(const float2& v, int e) { return e ? v.y : v.x; }
+template <int VEC> __device__ __forceinline__ typename XfVec<VEC>::type xf_make(const float (&o)[VEC]);
+template <> __device__ __forceinline__ float xf_make<1>(const float (&o)[1]) { return o[0]; }
+template <> __device__ __forceinline__ float2 xf_make<2>(const float (&o)[2]) { return make_float2(o[0], o[1]); }
+
+template <bool kGn, int VEC>
 __global__ __launch_bounds__(256) void wino4_xform_v_kernel(const W4Params p) {
+  typedef typename XfVec<VEC>::type vec_t;
   const ssde_src& s = p.src;
   SsdePro pro = ssde_pro_decode(s);
   pro.gn = kGn;
   const int cpg = kGn ? p.Ctot / s.gn_groups : 1;
-  const long long total = (long long)p.T * p.Ctot;
+  const int CV = p.Ctot / VEC;
+  const long long total = (long long)p.T * CV;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % p.Ctot), t = (int)(idx / p.Ctot);
+    const int c = (int)(idx % CV) * VEC, t = (int)(idx / CV);
     const int img = t / (p.tx * p.ty), r = t - img * (p.tx * p.ty);
     const int ty = r / p.tx, tx = r - ty * p.tx;
-    const bool second = c >= s.c0;
+    const bool second = c >= s.c0;                    // (c0 % 4 == 0: a pair never straddles the sources)
     const float* base = second ? s.p1 + (c - s.c0) : s.p0 + c;
     const int C = second ? s.c1 : s.c0;
-    float mu = 0.f, rs = 1.f, ga = 1.f, be = 0.f;
+    float mu = 0.f, rs = 1.f, ga[VEC], be[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { ga[e] = 1.f; be[e] = 0.f; }
     if (kGn) {
-      mu = s.gn_mean[img * s.gn_groups + c / cpg];
+      mu = s.gn_mean[img * s.gn_groups + c / cpg];    // (cpg % 4 == 0: a pair lies in one group)
       rs = s.gn_rstd[img * s.gn_groups + c / cpg];
-      ga = s.gn_gamma[c]; be = s.gn_beta[c];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { ga[e] = s.gn_gamma[c + e]; be[e] = s.gn_beta[c + e]; }
     }
-    float v[6][6];
+    float v[VEC][6][6];
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -110,59 +128,86 @@ __global__ __launch_bounds__(256) void wino4_xform_v_kernel(const W4Params p) {
         const int iy = ty * 4 - 1 + a, ix = tx * 4 - 1 + b;
         const bool inb = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         const int pix = (img * p.H + (inb ? iy : 0)) * p.W + (inb ? ix : 0);
-        float x = base[(size_t)pix * C];
-        if (kGn) x = (x - mu) * rs * ga + be;
-        if (pro.silu) x = ssde_silu(x);
-        if (__builtin_expect(pro.drop, 0)) x *= ssde_keep((uint32_t)pix * (uint32_t)p.Ctot + (uint32_t)c, pro);
-        v[a][b] = inb ? x : 0.f;                    // the convolution pads the ACTIVATED tensor with zeros
+        const vec_t xv = *reinterpret_cast<const vec_t*>(base + (size_t)pix * C);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float x = xf_get<VEC>(xv, e);
+          if (kGn) x = (x - mu) * rs * ga[e] + be[e];
+          if (pro.silu) x = ssde_silu(x);
+          if (__builtin_expect(pro.drop, 0)) x *= ssde_keep((uint32_t)pix * (uint32_t)p.Ctot + (uint32_t)(c + e), pro);
+          v[e][a][b] = inb ? x : 0.f;               // the convolution pads the ACTIVATED tensor with zeros
+        }
       }
     // columns (over the rows a of every column b), then rows
 #pragma unroll
-    for (int b = 0; b < 6; ++b) {
-      float d[6], o[6];
+    for (int e = 0; e < VEC; ++e)
 #pragma unroll
-      for (int a = 0; a < 6; ++a) d[a] = v[a][b];
-      bt6(d, o);
+      for (int b = 0; b < 6; ++b) {
+        float d[6], o[6];
 #pragma unroll
-      for (int a = 0; a < 6; ++a) v[a][b] = o[a];
-    }
+        for (int a = 0; a < 6; ++a) d[a] = v[e][a][b];
+        bt6(d, o);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) v[e][a][b] = o[a];
+      }
     float* dst = p.V + (size_t)t * p.Ctot + c;
     const size_t plane = (size_t)p.T * p.Ctot;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      float o[6];
-      bt6(v[a], o);
+      float o[VEC][6];
 #pragma unroll
-      for (int b = 0; b < 6; ++b) dst[(size_t)(a * 6 + b) * plane] = o[b];
+      for (int e = 0; e < VEC; ++e) bt6(v[e][a], o[e]);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        float w[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) w[e] = o[e][b];
+        *reinterpret_cast<vec_t*>(dst + (size_t)(a * 6 + b) * plane) = xf_make<VEC>(w);
+      }
     }
   }
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void wino4_xform_z_kernel(const W4Params p) {
-  const long long total = (long long)p.T * p.Cout;
+  typedef typename XfVec<VEC>::type vec_t;
+  const int CV = p.Cout / VEC;
+  const long long total = (long long)p.T * CV;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx % p.Cout), t = (int)(idx / p.Cout);
+    const int c = (int)(idx % CV) * VEC, t = (int)(idx / CV);
     const int img = t / (p.tx * p.ty), r = t - img * (p.tx * p.ty);
     const int ty = r / p.tx, tx = r - ty * p.tx;
     const float* base = p.g + p.g_off + c + (size_t)((img * p.H + ty * 4) * p.W + tx * 4) * p.g_ld;
-    float tcol[6][4];
+    float tcol[VEC][6][4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      float d[4], o[6];
+      vec_t dv[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) d[a] = base[(size_t)(a * p.W + b) * p.g_ld];
-      at6(d, o);
+      for (int a = 0; a < 4; ++a) dv[a] = *reinterpret_cast<const vec_t*>(base + (size_t)(a * p.W + b) * p.g_ld);
 #pragma unroll
-      for (int a = 0; a < 6; ++a) tcol[a][b] = o[a];
+      for (int e = 0; e < VEC; ++e) {
+        float d[4], o[6];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) d[a] = xf_get<VEC>(dv[a], e);
+        at6(d, o);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) tcol[e][a][b] = o[a];
+      }
     }
     float* dst = p.Z + (size_t)t * p.Cout + c;
     const size_t plane = (size_t)p.T * p.Cout;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      float o[6];
-      at6(tcol[a], o);
+      float o[VEC][6];
 #pragma unroll
-      for (int b = 0; b < 6; ++b) dst[(size_t)(a * 6 + b) * plane] = o[b];
+      for (int e = 0; e < VEC; ++e) at6(tcol[e][a], o[e]);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        float w[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) w[e] = o[e][b];
+        *reinterpret_cast<vec_t*>(dst + (size_t)(a * 6 + b) * plane) = xf_make<VEC>(w);
+      }
     }
   }
 }
@@ -176,12 +221,18 @@ __global__ __launch_bounds__(kGemmThreads, 4) void wgrad4_gemm_kernel(const W4Pa
   SSDE_LDS(smem);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 31, lh = lane >> 5;
-  // block order: the (co, ci) blocks and splits of one position are consecutive (they share the position's operand planes)
-  int b = blockIdx.x;
-  const int ci_t = b % p.ci_tiles; b /= p.ci_tiles;
-  const int co_t = b % p.co_tiles; b /= p.co_tiles;
-  const int split = b % p.splits;
-  const int pos = b / p.splits;
+  // XCD-aware block order: the (co, ci) blocks of one (position, split) read the same rows of both operands, so they run
+  // on ONE XCD (blocks are dealt round-robin over the 8 XCDs, each with its own L2) -- as consecutive blocks they landed on
+  // different XCDs and every operand row was fetched from HBM once per block that uses it (PMC: 469 MB per launch
+  // against 263 MB of operands, profiles/r3_train_pmc.json)
+  const int ntiles = p.co_tiles * p.ci_tiles;
+  const int xcd = blockIdx.x & 7, lin = blockIdx.x >> 3;
+  const int tile = p.xcd_order ? lin % ntiles : (int)blockIdx.x % ntiles;
+  const int grp = p.xcd_order ? (lin / ntiles) * 8 + xcd : (int)blockIdx.x / ntiles;       // (position, split) pair
+  if (grp >= kPos * p.splits) return;
+  const int ci_t = tile % p.ci_tiles, co_t = tile / p.ci_tiles;
+  const int split = grp % p.splits;
+  const int pos = grp / p.splits;
   const int co0 = co_t * BM, ci0 = ci_t * BN;
   const int k0 = split * p.k_per_split;
   const int k1 = min(p.T, k0 + p.k_per_split);
@@ -349,6 +400,7 @@ void plan(const ssde_wgrad_args* a, W4Params* p) {
   p->k_per_split = ssde_cdiv(ssde_cdiv(p->T, splits), BK) * BK;
   p->splits = ssde_cdiv(p->T, p->k_per_split);
   p->scale = a->scale; p->dw = a->dw;
+  { const char* e = getenv("SSDE_WGRAD4_XCD"); p->xcd_order = !(e && e[0] == '0'); }
 }
 
 int64_t scratch_floats(const W4Params& p) {
@@ -367,9 +419,10 @@ bool ssde_wgrad_wino4_wants(const ssde_wgrad_args* a) {
   if (a->c_out % 32 != 0 || Ctot % 32 != 0 || a->cin_store != Ctot) return false;
   if (a->g_ld % 4 != 0 || a->g_off % 4 != 0 || s.c0 % 4 != 0) return false;
   const long long T = (long long)a->n * (a->h_out / 4) * (a->w_out / 4);
-  // where it pays (profiles/r3_wgrad_wino4_ab.txt, batch 128): from 16x16 maps up unless both channel counts are small
-  // (128 -> 128 at 32x32 is a draw), and on 8x8 maps from 512 input channels; the rest stays on the fused F(2x2,3x3) kernel
-  if (m == 4 && !((T >= 1024 && (Ctot > 128 || a->c_out > 128)) || (T >= 512 && Ctot >= 512))) return false;
+  // where it pays (profiles/r3_wgrad_wino4_ab.txt, batch 128): from 16x16 maps up when a channel count exceeds 128, 128 -> 128
+  // from 8192 tiles (32x32 maps at batch 128: +3-4 % since the transforms move two channels per thread), and on 8x8 maps from
+  // 512 input channels; the rest stays on the fused F(2x2,3x3) kernel
+  if (m == 4 && !((T >= 1024 && (Ctot > 128 || a->c_out > 128)) || T >= 8192 || (T >= 512 && Ctot >= 512))) return false;
   return (long long)a->n * a->h_out * a->w_out < (1ll << 30) && T * (Ctot > a->c_out ? Ctot : a->c_out) * kPos < (1ll << 40);
 }
 
@@ -406,13 +459,23 @@ int ssde_wgrad_wino4_launch(const ssde_wgrad_args* a, void* stream) {
   p.slabs = p.Z + (size_t)kPos * p.T * p.Cout;
   hipStream_t st = static_cast<hipStream_t>(stream);
   auto grid_for = [](long long total) { long long b = (total + 255) / 256; return (unsigned)(b > 256 * 32 ? 256 * 32 : (b < 1 ? 1 : b)); };
-  if (gn) hipLaunchKernelGGL(wino4_xform_v_kernel<true>, dim3(grid_for((long long)p.T * p.Ctot)), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(wino4_xform_v_kernel<false>, dim3(grid_for((long long)p.T * p.Ctot)), dim3(256), 0, st, p);
-  SSDE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(wino4_xform_z_kernel, dim3(grid_for((long long)p.T * p.Cout)), dim3(256), 0, st, p);
+  static const int xvec = getenv("SSDE_WGRAD4_XVEC") ? atoi(getenv("SSDE_WGRAD4_XVEC")) : 2;      // channels per transform thread
+  const bool v2 = xvec == 2 && p.Ctot % 2 == 0 && p.Cout % 2 == 0 && s.c0 % 2 == 0 && p.g_ld % 2 == 0 && p.g_off % 2 == 0;
+  const dim3 gv(grid_for((long long)p.T * p.Ctot / (v2 ? 2 : 1))), gz(grid_for((long long)p.T * p.Cout / (v2 ? 2 : 1)));
+  if (v2) {
+    if (gn) hipLaunchKernelGGL((wino4_xform_v_kernel<true, 2>), gv, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((wino4_xform_v_kernel<false, 2>), gv, dim3(256), 0, st, p);
+    SSDE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wino4_xform_z_kernel<2>, gz, dim3(256), 0, st, p);
+  } else {
+    if (gn) hipLaunchKernelGGL((wino4_xform_v_kernel<true, 1>), gv, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((wino4_xform_v_kernel<false, 1>), gv, dim3(256), 0, st, p);
+    SSDE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wino4_xform_z_kernel<1>, gz, dim3(256), 0, st, p);
+  }
   SSDE_LAUNCH_CHECK();
   const int lds = 2 * kStage * 4;
-  hipLaunchKernelGGL(wgrad4_gemm_kernel, dim3(kPos * p.splits * p.co_tiles * p.ci_tiles), dim3(kGemmThreads), lds, st, p);
+  hipLaunchKernelGGL(wgrad4_gemm_kernel, dim3(ssde_cdiv(kPos * p.splits, 8) * 8 * p.co_tiles * p.ci_tiles), dim3(kGemmThreads), lds, st, p);
   SSDE_LAUNCH_CHECK();
   if (p.splits > 1) {
     hipLaunchKernelGGL(wgrad4_sum_splits_kernel, dim3(grid_for((long long)kPos * p.Cout * p.Ctot / 4)), dim3(256), 0, st, p);

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/train_pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --train-steps 2"
+BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras --train-steps 2"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o bench --output-format csv -- $BENCH > $OUT/pmc_$C.log 2>&1
   echo "pmc $C rc=$?"
@@ -20,7 +20,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             for key in ("wgrad_wino_kernel", "wgrad_wino_reduce_kernel", "wgrad_kernel", "wgrad_reduce_kernel", "conv_wino_kernel", "gemm1x1_kernel",
-                        "prologue_bwd_kernel", "gn_bwd_reduce_kernel", "attn_bwd_kv_kernel", "attn_bwd_q_kernel", "adam_kernel", "colsum_kernel"):
+                        "prologue_bwd_kernel", "gn_bwd_reduce_kernel", "attn_bwd_kv_kernel", "attn_bwd_q_kernel", "adam_kernel", "colsum_kernel",
+                        "conv_wino4_kernel", "wino4_xform_v_kernel", "wino4_xform_z_kernel", "wgrad4_gemm_kernel", "wgrad4_sum_splits_kernel",
+                        "wgrad1x1_gemm_kernel", "gn_bwd_finalize_kernel", "conv_mfma_kernel"):
                 if key + "<" in k or key + "(" in k:
                     a = acc[key][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 out = {}
