@@ -332,6 +332,10 @@ def roofline_of(prog, E, L, reps=3):
         elif bound == "hbm" and t > 0:
             row.update(bound="hbm", algorithmic_gb=float(nbytes[m].sum()) / 1e9, achieved_tbs=float(nbytes[m].sum()) / t / 1e12,
                        frac=float(nbytes[m].sum()) / t / 1e12 / PEAK_HBM_TBS)
+        if name == "groupnorm_stats" and row["launches"]:
+            row["note"] = ("launch-bound, not bandwidth-bound: %d ssde_gn_finalize launches of %.1f us merging the producers' partial "
+                           "statistics (the activations are not re-read); the fraction is kept for completeness"
+                           % (row["launches"], row["ms"] * 1e3 / row["launches"]))
         by_class[name] = row
     # PC-update kernels (rocRAND noise, norms, Langevin and predictor updates): HBM-bound, grouped by op kind
     upd = np.array([int(prog.ops[i].kind) in (L.OP_RANDN, L.OP_SUMSQ, L.OP_LANGEVIN, L.OP_PREDICTOR) for i in range(prog.n)])
