@@ -84,6 +84,31 @@ def test_cifar_forward_batch256():
     assert float(per.max()) < 2e-4, float(per.max())
 
 
+def test_cifar_forward_f4x4_split_reduction_batch48(monkeypatch):
+    """F(4x4,3x3) forced on every legal layer at a batch where the 16x16 and 8x8 layers have few tiles: conv_wino4_kernel
+    splits their reduction over 2 or 4 workgroups per tile (shares dealt in start order, sums formed in fixed order).
+    Parity with the oracle, and bit-equality of two evaluations -- the result must not depend on which workgroup arrived
+    when."""
+    monkeypatch.setenv("SSDE_WINOGRAD", "4")
+    cfg = _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous")
+    model, sd = _model(cfg)
+    B = 48
+    g = torch.Generator().manual_seed(48)
+    sig = torch.exp(torch.rand(B, generator=g) * (np.log(50.0) - np.log(0.01)) + np.log(0.01)).float()
+    x = torch.rand(B, 3, 32, 32, generator=g) + sig[:, None, None, None] * torch.randn(B, 3, 32, 32, generator=g)
+    with torch.no_grad():
+        y1 = model(x.cuda(), sig.cuda()).clone()
+        ys = [model(x.cuda(), sig.cuda()).clone() for _ in range(3)]
+    from score_sde_pytorch_amd import _lib as L
+    eng = next(iter(model._engines.values()))
+    n4 = sum(1 for i in range(eng.program.n) if eng.program.ops[i].kind == L.OP_CONV and eng.program.ops[i].u.conv.tile == L.TILE_WINOGRAD4)
+    assert n4 >= 60, n4                                         # 8x8 maps included
+    for y in ys:
+        assert torch.equal(y, y1)
+    ref = _oracle_forward(cfg, sd, x, sig, 48)
+    assert rel_err(y1, ref) < 1e-4, rel_err(y1, ref)
+
+
 def test_cifar_pc_iteration_batch256():
     """one corrector + predictor iteration (2 U-Net evaluations, Langevin batch-mean step size over all 256 samples,
     reverse-diffusion update) with injected noise, at the N=1000 schedule of configs[1]"""
