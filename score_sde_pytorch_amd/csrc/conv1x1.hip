@@ -242,6 +242,184 @@ __global__ __launch_bounds__(kThreads, SSDE_GEMM_OCC) void gemm1x1_kernel(const 
   }
 }
 
+// ---- the same GEMM through the BF16 matrix pipe: exact-fp32 products by a 3-way bf16 split (SSDE_MATRIX=bf16x6) ----------
+// Both operands are split while they are staged (ssde_split3: 5.5 VALU per element, which the BF16 MFMAs -- unlike the
+// fp32 ones -- co-issue with); LDS holds six planes per stage, [piece][128 rows][16 channels] bf16 for the pixel rows and
+// the same for the weight rows: a lane's 16 bytes of a fragment are channels 8 k .. 8 k + 7 (k = lane >> 5) of its row, the 64
+// lanes of a ds_read_b128 cover 1 KB contiguously.  Per 16-channel stage a wave issues 24 MFMAs of 32 cycles (6 terms x its
+// 2 x 2 blocks) on 12 fragment reads: 768 matrix cycles against 2048 of the fp32 kernel for the same channels.
+// 48 KB of LDS (two stages; the half-tile epilogue aliases them): three workgroups per CU.
+constexpr int XBK = 16;
+constexpr int kXPlane = 128 * XBK * 2;              // bytes of one piece plane
+constexpr int kXStage = 6 * kXPlane;                // A pieces 0..2, B pieces 0..2
+
+template <bool kGn>
+__global__ __launch_bounds__(kThreads, 3) void gemm1x1_bf16x6_kernel(const GemmParams p) {
+  SSDE_LDS(smem);
+  char* lds = reinterpret_cast<char*>(smem);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int xcd = blockIdx.x & 7, lin = blockIdx.x >> 3;
+  const int nt = lin % p.n_tiles, mt = (lin / p.n_tiles) * 8 + xcd;
+#ifdef SSDE_GEMM_TRACE
+  const bool gt_on = tid == 0 && blockIdx.x == 0 && g_gemm_trace != nullptr;
+#endif
+  SSDE_GT(0);
+  if (mt >= p.m_tiles) return;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const ssde_src& s = p.src;
+  SsdePro pro = ssde_pro_decode(s);
+  pro.gn = kGn;
+  const int Ctot = s.c0 + s.c1;
+  const int cpg = kGn ? Ctot / s.gn_groups : 1;
+  const int nst = (p.K + XBK - 1) / XBK;
+  const int ncin8 = (p.K + 7) >> 3;
+
+  // staging plan: thread = (rows r0, r0 + 64; channel quad f) of both operands
+  constexpr int NI = 2, RS = 64;
+  const int f = tid & 3, r0 = tid >> 2;
+  int arow[NI], aimg[NI];
+  bool aok[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int m = m0 + r0 + i * RS;
+    aok[i] = m < p.M;
+    arow[i] = aok[i] ? m : 0;
+    aimg[i] = arow[i] / p.HW;
+  }
+  bool bok[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) bok[i] = (n0 + r0 + i * RS) < p.CoutPad;
+  const float* bptr = p.wpk + ((size_t)n0 + r0) * 8 + (f & 1) * 4;
+
+  float4 av[NI], bv[NI];
+  float mu[NI], rs[NI];
+  float4 gam = make_float4(1.f, 1.f, 1.f, 1.f), bet = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool k_ok = false;
+  int c_cur = 0;
+  auto load_stage = [&](int st) {
+    const int c_base = st * XBK;
+    const bool second = c_base >= s.c0;
+    const float* base = second ? s.p1 : s.p0;
+    const int C = second ? s.c1 : s.c0;
+    const int cthr = (second ? c_base - s.c0 : c_base) + f * 4;
+    c_cur = c_base + f * 4;
+    k_ok = c_cur < p.K;
+    const float* ap = base + (k_ok ? cthr : 0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) av[i] = *reinterpret_cast<const float4*>(ap + (size_t)arow[i] * C);
+    const int cin8 = min(st * 2 + (f >> 1), ncin8 - 1);
+    const float* bp = bptr + (size_t)cin8 * p.CoutPad * 8;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) bv[i] = *reinterpret_cast<const float4*>(bp + (bok[i] ? i * RS * 8 : 0));
+    if (kGn) {
+      const int cg = k_ok ? c_cur : 0;
+      gam = *reinterpret_cast<const float4*>(s.gn_gamma + cg);
+      bet = *reinterpret_cast<const float4*>(s.gn_beta + cg);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int gi = aimg[i] * s.gn_groups + cg / cpg;
+        mu[i] = s.gn_mean[gi];
+        rs[i] = s.gn_rstd[gi];
+      }
+    }
+  };
+  auto store_stage = [&](int st, char* buf) {
+    const int cin8 = st * 2 + (f >> 1);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (aok[i] && k_ok)
+        v = ssde_pro_apply(av[i], mu[i], rs[i], gam, bet, (uint32_t)arow[i] * (uint32_t)Ctot + (uint32_t)c_cur, pro);
+      float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bok[i] && cin8 < ncin8) w = bv[i];
+      uint2 q0, q1, q2;
+      char* d = buf + (r0 + i * RS) * (XBK * 2) + f * 8;
+      ssde_split3(v, q0, q1, q2);
+      *reinterpret_cast<uint2*>(d) = q0;
+      *reinterpret_cast<uint2*>(d + kXPlane) = q1;
+      *reinterpret_cast<uint2*>(d + 2 * kXPlane) = q2;
+      ssde_split3(w, q0, q1, q2);
+      *reinterpret_cast<uint2*>(d + 3 * kXPlane) = q0;
+      *reinterpret_cast<uint2*>(d + 4 * kXPlane) = q1;
+      *reinterpret_cast<uint2*>(d + 5 * kXPlane) = q2;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int aoff = (wm0 + li) * (XBK * 2) + lh * 16, boff = 3 * kXPlane + (wn0 + li) * (XBK * 2) + lh * 16;
+
+  SSDE_GT(1);
+  load_stage(0);
+  store_stage(0, lds);
+  __syncthreads();
+  SSDE_GT(2);
+  for (int st = 0; st < nst; ++st) {
+    const char* cur = lds + (st & 1) * kXStage;
+    const bool has_next = st + 1 < nst;
+    if (has_next) load_stage(st + 1);
+    ssde_u32x4 A[2][3], B[2][3];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        A[a][q] = *reinterpret_cast<const ssde_u32x4*>(cur + aoff + q * kXPlane + a * 32 * (XBK * 2));
+        B[a][q] = *reinterpret_cast<const ssde_u32x4*>(cur + boff + q * kXPlane + a * 32 * (XBK * 2));
+      }
+    // term by term over the four blocks: consecutive MFMAs never share an accumulator
+    constexpr int TI[6] = {0, 2, 1, 0, 1, 0}, TJ[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ssde_bf16x8, A[a][TI[t]]),
+                                                              __builtin_bit_cast(ssde_bf16x8, B[b][TJ[t]]), acc[a][b], 0, 0, 0);
+    if (st < 8) SSDE_GT(4 + st * 4);
+    if (has_next) store_stage(st + 1, lds + ((st + 1) & 1) * kXStage);
+    if (st < 8) SSDE_GT(5 + st * 4);
+    __syncthreads();
+    if (st < 8) SSDE_GT(6 + st * 4);
+  }
+  SSDE_GT(40);
+
+  constexpr int LDT = BN + 4;
+  SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, p.Cout, p.gn_part};
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if ((wave >> 1) == half) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            smem[m * LDT + wn0 + b * 32 + li] = acc[a][b][r];
+          }
+    }
+    __syncthreads();
+    ssde_store_tile<64, BN, kThreads, SSDE_GEMM_BATCH>(smem, LDT, n0, e, [&](int row, size_t& pix, int& img) {
+      const int m = m0 + half * 64 + row;
+      if (m >= p.M) return false;
+      pix = (size_t)m;
+      img = m / p.HW;
+      return true;
+    }, p.gn_part ? (p.HW >= 64 ? (m0 >> 6) + half : (m0 + half * 64) / p.HW) : -1, p.HW >= 64 ? 30 : p.lHW, p.gn_entries);
+    SSDE_GT(41 + half * 2);
+    __syncthreads();
+    SSDE_GT(42 + half * 2);
+  }
+}
+
 }  // namespace
 
 // Used by ssde_conv2d for 1x1-only launches it judges large enough (conv_mfma.hip); shapes it does not take stay on the
@@ -275,17 +453,23 @@ int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
   SSDE_REQUIRE(!a->gn_part || gn_ok, "conv1x1: GroupNorm partials need H*W %% 64 == 0 or a power of two in 8..32");
   p.lHW = ssde_ilog2(p.HW);
   p.gn_entries = p.HW >= 64 ? a->n * (p.HW / 64) : a->n;
-  const int lds_ops = 2 * kStage * 4, lds_epi = 64 * (BN + 4) * 4;
+  const bool x6 = ssde_matrix_bf16x6();
+  const int lds_ops = x6 ? 2 * kXStage : 2 * kStage * 4, lds_epi = 64 * (BN + 4) * 4;
   const int lds = lds_ops > lds_epi ? lds_ops : lds_epi;
   if (lds_out) { *lds_out = lds; return SSDE_OK; }
   static std::atomic<bool> attr_set{false};   // once, before any stream capture
   if (!attr_set) {
     SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm1x1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm1x1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm1x1_bf16x6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SSDE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm1x1_bf16x6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   const dim3 grid(ssde_cdiv(p.m_tiles, 8) * 8 * p.n_tiles);
-  if (gn) hipLaunchKernelGGL(gemm1x1_kernel<true>, grid, dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
+  if (x6) {
+    if (gn) hipLaunchKernelGGL(gemm1x1_bf16x6_kernel<true>, grid, dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
+    else hipLaunchKernelGGL(gemm1x1_bf16x6_kernel<false>, grid, dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
+  } else if (gn) hipLaunchKernelGGL(gemm1x1_kernel<true>, grid, dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
   else hipLaunchKernelGGL(gemm1x1_kernel<false>, grid, dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;

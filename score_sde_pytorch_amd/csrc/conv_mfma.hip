@@ -547,8 +547,14 @@ int launch_cfg(ConvPlan& pl, hipStream_t st) {
 unsigned* ssde_conv_sync_slots(int need) {
   static std::atomic<unsigned> cursor{0};
   if (need <= 0 || need > kSyncSlots / 4) return nullptr;
-  unsigned at = cursor.fetch_add((unsigned)need) % kSyncSlots;
-  if (at + (unsigned)need > (unsigned)kSyncSlots) at = 0;
+  // CAS loop: a run that would straddle the end of the table starts at 0 AND moves the cursor behind itself, so the next
+  // caller cannot be dealt [0, need) again (a bare fetch_add left the cursor inside the run just handed out)
+  unsigned cur = cursor.load(std::memory_order_relaxed), at, next;
+  do {
+    at = cur % (unsigned)kSyncSlots;
+    if (at + (unsigned)need > (unsigned)kSyncSlots) at = 0;
+    next = at + (unsigned)need;
+  } while (!cursor.compare_exchange_weak(cur, next, std::memory_order_relaxed));
   unsigned* base = nullptr;
   if (hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_conv_sync)) != hipSuccess) return nullptr;
   return base + 2 * (size_t)at;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <atomic>
 #include "../../include/ssde.h"
 
@@ -329,6 +330,57 @@ __device__ __forceinline__ void ssde_store_tile(float* tile, int ld, int n0, con
       }
     }
   }
+}
+
+// ---- exact fp32 products on the BF16 matrix pipe (SSDE_MATRIX=bf16x6) --------------------------------------------------
+// An fp32 value is the exact sum of three bf16 pieces taken by truncation (8 significand bits each: p0 = the top 16 bits of
+// a, p1 = the top 16 bits of a - p0, p2 = a - p0 - p1, which has at most 8 significant bits left).  a * b = sum_ij a_i b_j
+// with every partial product exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16 (8 x 8 significand bits); the six
+// terms a0b0, a0b1, a1b0, a1b1, a0b2, a2b0 drop a1b2 + a2b1 + a2b2 <= 2^-23 |a b| per product -- the size of the fp32
+// rounding of the product itself -- and cost 6/16 of the fp32 MFMA time (the BF16 pipe runs 16x the fp32 rate and, unlike
+// fp32 MFMAs, co-issues with VALU).  tools/experiments/bf16_split_error_budget.py: the whole CIFAR NCSN++ through this
+// split is as close to fp64 as the fp32 evaluation (profiles/r4_bf16_split_error_budget.txt).
+typedef __bf16 ssde_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned ssde_u32x4 __attribute__((ext_vector_type(4)));
+// (hi's upper half, lo's upper half) as one dword of two bf16: v_perm_b32
+__device__ __forceinline__ uint32_t ssde_pack_hi16(uint32_t lo, uint32_t hi) {
+#ifdef SSDE_EMULATED
+  return (hi & 0xffff0000u) | (lo >> 16);
+#else
+  return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+#endif
+}
+// 4 consecutive channels -> 3 pieces of 4 bf16 (8 bytes each), channel order kept
+__device__ __forceinline__ void ssde_split3(const float4& v, uint2& p0, uint2& p1, uint2& p2) {
+  const float f[4] = {v.x, v.y, v.z, v.w};
+  uint32_t a[4], b[4], c[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = __builtin_bit_cast(uint32_t, f[i]);
+    const float r = f[i] - __builtin_bit_cast(float, a[i] & 0xffff0000u);
+    b[i] = __builtin_bit_cast(uint32_t, r);
+    c[i] = __builtin_bit_cast(uint32_t, r - __builtin_bit_cast(float, b[i] & 0xffff0000u));
+  }
+  p0 = make_uint2(ssde_pack_hi16(a[0], a[1]), ssde_pack_hi16(a[2], a[3]));
+  p1 = make_uint2(ssde_pack_hi16(b[0], b[1]), ssde_pack_hi16(b[2], b[3]));
+  p2 = make_uint2(ssde_pack_hi16(c[0], c[1]), ssde_pack_hi16(c[2], c[3]));
+}
+// the six partial products of one 32x32 block over 16 channels, smallest terms first
+#define SSDE_MFMA_BF16X6(acc, A, B)                                                                                       \
+  do {                                                                                                                     \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ssde_bf16x8, (A)[0]), __builtin_bit_cast(ssde_bf16x8, (B)[2]), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ssde_bf16x8, (A)[2]), __builtin_bit_cast(ssde_bf16x8, (B)[0]), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ssde_bf16x8, (A)[1]), __builtin_bit_cast(ssde_bf16x8, (B)[1]), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ssde_bf16x8, (A)[0]), __builtin_bit_cast(ssde_bf16x8, (B)[1]), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ssde_bf16x8, (A)[1]), __builtin_bit_cast(ssde_bf16x8, (B)[0]), acc, 0, 0, 0); \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ssde_bf16x8, (A)[0]), __builtin_bit_cast(ssde_bf16x8, (B)[0]), acc, 0, 0, 0); \
+  } while (0)
+
+// SSDE_MATRIX (read per call on the host: the tests compare both forms in one process): "bf16x6" routes the contractions
+// that have a split kernel through the BF16 matrix pipe; anything else = the exact-fp32 MFMA kernels
+static inline bool ssde_matrix_bf16x6() {
+  const char* e = getenv("SSDE_MATRIX");
+  return e && e[0] == 'b';
 }
 
 __device__ __forceinline__ float ssde_wave_sum(float v) {

@@ -417,7 +417,12 @@ bool ssde_wgrad_wino4_wants(const ssde_wgrad_args* a) {
   const ssde_src& s = a->src;
   const int Ctot = s.c0 + s.c1;
   if (a->c_out % 32 != 0 || Ctot % 32 != 0 || a->cin_store != Ctot) return false;
-  if (a->g_ld % 4 != 0 || a->g_off % 4 != 0 || s.c0 % 4 != 0) return false;
+  if (a->g_ld % 4 != 0 || a->g_off % 4 != 0 || s.c0 % 4 != 0 || s.c1 % 4 != 0) return false;
+  // what wgrad.hip's make_plan would have checked had it been asked first: the transforms read one (mean, rstd) per channel
+  // quad, and the gradient block must lie inside a row of the parameter's gradient
+  if (a->g_off + a->c_out > a->g_ld) return false;
+  if ((s.pro_mode == SSDE_PRO_GN || s.pro_mode == SSDE_PRO_GN_SILU) &&
+      (s.gn_groups <= 0 || Ctot % s.gn_groups != 0 || (Ctot / s.gn_groups) % 4 != 0)) return false;
   const long long T = (long long)a->n * (a->h_out / 4) * (a->w_out / 4);
   // where it pays (profiles/r3_wgrad_wino4_ab.txt, batch 128): from 16x16 maps up when a channel count exceeds 128, 128 -> 128
   // from 8192 tiles (32x32 maps at batch 128: +3-4 % since the transforms move two channels per thread), and on 8x8 maps from

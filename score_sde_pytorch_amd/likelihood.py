@@ -64,12 +64,10 @@ def get_likelihood_fn(sde, inverse_scaler, hutchinson_type='Rademacher', rtol=1e
             if method == 'RK45' and ode.FusedLikelihoodRhs.applies(model, sde, data):
                 # the whole right-hand side as one device program per evaluation (ode.FusedLikelihoodRhs): no torch
                 # arithmetic, no autograd graph, no dtype round trips between U-Net evaluations
-                cache = model.__dict__.setdefault("_ode_rhs", {})      # shared by every likelihood_fn of this SDE object
+                # shared by every likelihood_fn of this SDE object; a small LRU (ode.rhs_cache_get)
                 key = ("likelihood", id(sde), tuple(data.shape), data.device.index)
-                rhs = cache.get(key)
-                if rhs is None:
-                    rhs = cache[key] = ode.FusedLikelihoodRhs(model, sde, data.shape, probe, data.device)
-                else:
+                rhs, fresh = ode.rhs_cache_get(model, key, lambda: ode.FusedLikelihoodRhs(model, sde, data.shape, probe, data.device))
+                if not fresh:
                     rhs.set_probe(probe)
                 likelihood_fn.last_path = "fused"
             else:

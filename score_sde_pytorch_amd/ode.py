@@ -170,6 +170,21 @@ def _once(fun, stages, t, yy, in_place):
     return out
 
 
+def rhs_cache_get(model, key, make, limit=4):
+    """The fused right-hand sides of a model (lowered program + arena + packed weights + hipGraph each), newest last.
+    Bounded: building samplers / likelihood closures with fresh SDE objects or varying batch shapes evicts the oldest
+    entry (its graph and arena are released with it) instead of growing until the device runs out of memory."""
+    cache = model.__dict__.setdefault("_ode_rhs", {})
+    rhs = cache.pop(key, None)
+    fresh = rhs is None
+    if fresh:
+        rhs = make()
+    cache[key] = rhs                                   # (re-)inserted as the most recently used
+    while len(cache) > limit:
+        cache.pop(next(iter(cache)))
+    return rhs, fresh
+
+
 class _FusedRhs:
     """Common part of the fused right-hand sides: the per-evaluation scalars live in a 24-byte DEVICE record
     (include/ssde.h: ssde_ode_dyn -- label, std, drift coefficient, g^2, the slope row to fill), uploaded before every
@@ -187,6 +202,7 @@ class _FusedRhs:
         self._host = [torch.zeros(24, dtype=torch.uint8).pin_memory() if on_gpu else torch.zeros(24, dtype=torch.uint8)
                       for _ in range(self._RING if on_gpu else 1)]
         self._slot = 0
+        self._slot_events = [None] * len(self._host)     # the copy out of a pinned slot, recorded when it was enqueued
         self.use_graph = on_gpu and os.environ.get("SSDE_ODE_GRAPH", "1") != "0"
         self.graph_stream = torch.cuda.Stream(device=self.device) if self.use_graph else None
         self.nfev = 0
@@ -212,11 +228,20 @@ class _FusedRhs:
     def _upload(self, t, out):
         import struct
         label, second, a, g2 = self._scalars(t)
-        h = self._host[self._slot % len(self._host)]
+        i = self._slot % len(self._host)
+        h = self._host[i]
         self._slot += 1
+        # a driver that enqueues more than _RING evaluations without reading anything back (a fixed-step integrator) must
+        # not overwrite a record whose upload has not executed yet (as losses.FusedTrainStep's hyper ring)
+        if self._slot_events[i] is not None:
+            self._slot_events[i].synchronize()
         import numpy as np
         h.numpy()[:] = np.frombuffer(struct.pack("<ffffQ", label, second, a, g2, out.data_ptr()), dtype=np.uint8)
         self.dyn.copy_(h, non_blocking=True)
+        if self.device.type == "cuda":
+            ev = self._slot_events[i] or torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._slot_events[i] = ev
 
     def _head_ops(self, emit):
         from . import _lib as L

@@ -108,7 +108,7 @@ class Corrector(abc.ABC):
 
 def _apply(x, y=None, b=None, z=None, c=None, a=None):
     """x_mean = a[n] x + b[n] y ; x = x_mean + c[n] z as ONE launch of ssde_sample_update (per-sample coefficients, the
-    reference's fp32 rounding per product and sum).  This is the arithmetic of every stock update below when it runs in
+    reference's fp32 rounding per product and sum, except the VP ancestral rule -- see there).  This is the arithmetic of every stock update below when it runs in
     the GENERIC loop -- a user-registered subclass, a model other than NCSNpp, per-sample times; the stock classes on an
     NCSNpp model never get here (pc_engine.FusedPCSampler runs whole iterations as one program)."""
     from . import hipops
@@ -158,7 +158,10 @@ class AncestralSamplingPredictor(Predictor):
         sde = self.sde
         idx = (t * (sde.N - 1) / sde.T).long()
         beta = sde.discrete_betas.to(t.device)[idx]
-        # (x + beta score) / sqrt(1 - beta) as a x + b score with the division folded into the coefficients
+        # (x + beta score) / sqrt(1 - beta) as a x + b score with the division folded into the coefficients.  NOT bit-faithful
+        # to sampling.py:236 (a reciprocal and two products instead of one sum and one division: differences of an ulp or
+        # two per step) -- the one stock rule whose rounding differs from the reference's operation order; it is covered by
+        # the 1e-4 / 1e-3 variant goldens, not by a bit-equality claim
         inv = 1. / torch.sqrt(1. - beta)
         return _apply(x, y=self.score_fn(x, t), a=inv, b=beta * inv, z=torch.randn_like(x), c=torch.sqrt(beta))
 
@@ -332,11 +335,8 @@ def get_ode_sampler(sde, shape, inverse_scaler, denoise=False, rtol=1e-5, atol=1
                 # cached on the model (not in this closure): every sampler built for the same SDE object, shape and
                 # device shares the lowered program, its packed weights and its captured graph (the rhs keeps `sde` alive,
                 # so the id cannot be recycled)
-                cache = model.__dict__.setdefault("_ode_rhs", {})
                 key = ("drift", id(sde), tuple(shape), x.device.index)
-                rhs = cache.get(key)
-                if rhs is None:
-                    rhs = cache[key] = ode.FusedDrift(model, sde, shape, x.device)
+                rhs, _ = ode.rhs_cache_get(model, key, lambda: ode.FusedDrift(model, sde, shape, x.device))
                 ode_sampler.last_path = "fused"
             else:
                 def rhs(t, y):

@@ -44,6 +44,7 @@ struct alignas(8) float2 { float x, y; };
 struct alignas(16) int4 { int x, y, z, w; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 struct alignas(8) uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
@@ -138,6 +139,33 @@ static inline emu_f32x4 emu_mfma_16x16x4(float a, float b, emu_f32x4 c) {
   }
   return d;
 }
+// v_mfma_f32_32x32x16_bf16: lane l holds A[i = l & 31][k = 8 (l >> 5) .. + 7] and B[k][j = l & 31] as 8 bf16 (element e in the
+// low / high half of dword e / 2); C/D as the 32x32x2 form.  Products of two bf16 are exact in fp32; they are summed into the
+// accumulator one by one in k order (the hardware's internal summation order is not specified: the GPU tests carry the
+// tolerance, this model carries the index math).
+template <class V>
+static inline emu_f32x16 emu_mfma_32x32x16_bf16(V a, V b, emu_f32x16 c) {
+  static_assert(sizeof(V) == 16, "8 bf16 per lane");
+  uint32_t aw[4], bw[4];
+  memcpy(aw, &a, 16); memcpy(bw, &b, 16);
+  const emu::Xchg xa = emu::wave_exchange(aw[0], aw[1], aw[2], aw[3]);      // (copied: the buffer is reused two exchanges on)
+  const emu::Xchg& xb = emu::wave_exchange(bw[0], bw[1], bw[2], bw[3]);
+  const int l = emu::cur->lane, j = l & 31, hi = l >> 5;
+  emu_f32x16 d;
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float v = c[r];
+    for (int kh = 0; kh < 2; ++kh)
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t ua = xa.w[kh * 32 + row][e >> 1], ub = xb.w[kh * 32 + j][e >> 1];
+        const float fa = emu::u2f((e & 1) ? (ua & 0xffff0000u) : (ua << 16)), fb = emu::u2f((e & 1) ? (ub & 0xffff0000u) : (ub << 16));
+        v += fa * fb;
+      }
+    d[r] = v;
+  }
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma_32x32x16_bf16((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_16x16x4((a), (b), (c))
 // LDS-DMA: lane l's `size` bytes land at the wave-uniform LDS base + size * l (executed synchronously here)

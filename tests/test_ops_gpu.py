@@ -292,8 +292,10 @@ GEMM1X1_CASES = [(2, 8, 64, 0, 128, 0, False), (3, 8, 40, 0, 96, 0, True), (1, 1
                  (5, 6, 8, 0, 130, 3, False), (2, 16, 64, 32, 256, 1, True)]
 
 
+@pytest.mark.parametrize("matrix", ["f32", "bf16x6"])     # SSDE_MATRIX: exact-fp32 MFMA / 3-way bf16 split on the BF16 pipe
 @pytest.mark.parametrize("n,h,c1,c2,cout,pro,extras", GEMM1X1_CASES)
-def test_conv1x1_gemm_kernel(n, h, c1, c2, cout, pro, extras):
+def test_conv1x1_gemm_kernel(n, h, c1, c2, cout, pro, extras, matrix, monkeypatch):
+    monkeypatch.setenv("SSDE_MATRIX", matrix)
     ops = _ops()
     g = torch.Generator().manual_seed(n * 1000 + cout)
     xa = torch.randn(n, c1, h, h, generator=g)
