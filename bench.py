@@ -49,7 +49,7 @@ WINOGRAD_FLOP_RATIO = 2.25      # F(2x2,3x3): 16 instead of 36 multiply-adds per
 WINOGRAD4_FLOP_RATIO = 4.0      # F(4x4,3x3): 36 instead of 144 per 4x4 output tile and (ci, co)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -61,7 +61,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=256, help="batch of the CPU-oracle sampler sample (config batch)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads for the CPU baseline (0: min(64, all))")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-work budget per baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=200.0,
+                    help="CPU-work budget per baseline leg (200 s: K=5 PC iterations at batch 256 and 1 + 3 DSM steps at batch 128, BASELINE.md 3)")
     ap.add_argument("--no-extras", action="store_true", help="skip the compact ffhq256 / subvp_ode measurements")
     ap.add_argument("--dump-ops", type=str, default="")
     ap.add_argument("--no-train", action="store_true", help="skip the DSM training-step measurement")
@@ -69,11 +70,20 @@ def parse():
                     help="cifar10 = BASELINE configs[1] (the headline line); ffhq256 = configs[3] (NCSN++ 256x256, N=2000, batch "
                          "16/GPU); subvp_ode = configs[4] (DDPM++ sub-VP, probability-flow ODE sampler with RK45; 1 step = 1 solve); "
                          "subvp_likelihood = configs[4]'s likelihood.py solve at rtol = atol = 1e-5")
-    ap.add_argument("--likelihood-tol", type=float, default=1e-3, help="rtol = atol of the likelihood solve inside the default run")
+    ap.add_argument("--likelihood-tol", type=float, default=1e-5,
+                    help="rtol = atol of the likelihood solve inside the default run (1e-5 = the config's own, likelihood.py:40; ~110 s)")
     ap.add_argument("--train-batch", type=int, default=128)
-    ap.add_argument("--train-steps", type=int, default=0, help="timed training steps (0: same as --steps, capped at 10)")
+    ap.add_argument("--train-steps", type=int, default=100, help="timed training steps (SURVEY 8d: 100), a fresh batch each")
+    ap.add_argument("--train-warmup", type=int, default=20, help="untimed training steps before them (SURVEY 8d: 20)")
     ap.add_argument("--dump-train-ops", type=str, default="")
-    return ap.parse_args()
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for --gpus N > 1: nccl (= RCCL over xGMI, one rank per GPU) or gloo (collectives "
+                         "staged through the host; with --share-device it runs the N > 1 code paths on a single GPU)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rank r uses GPU r %% (visible GPUs): N ranks on fewer GPUs -- a functional run of the multi-rank branches "
+                         "(self-launch, rank census, bucketed gradient exchange, exposed-exchange leg, parameter broadcast), NOT a "
+                         "scaling measurement; needs --dist-backend gloo (RCCL refuses two ranks on one device)")
+    return ap.parse_args(argv)
 
 
 def bench_train(args, cfg, dev, dist, world, rank, sync_all):
@@ -94,16 +104,22 @@ def bench_train(args, cfg, dev, dist, world, rank, sync_all):
                                  continuous=True, likelihood_weighting=cfg.training.likelihood_weighting)
     state = dict(optimizer=opt, model=model, ema=ema, step=0)
     Bt, R = args.train_batch, cfg.data.image_size
+    if dist is not None:
+        # every replica starts from rank 0's parameters (the reference's DataParallel replicates device 0's module,
+        # models/utils.py:93); one broadcast of the flat parameter buffer
+        from score_sde_pytorch_amd import parallel
+        parallel.broadcast_parameters(model)
     torch.manual_seed(100 + rank)
-    batch = torch.rand(Bt, 3, R, R, device=dev)
-    k = args.train_steps or min(args.steps, 10)
-    w = max(1, min(args.warmup, 3))
-    for _ in range(w):
-        loss = step_fn(state, batch)
+    pool = [torch.rand(Bt, 3, R, R, device=dev) for _ in range(8)]       # a fresh batch every step (this rank's shard)
+    batch = pool[0]
+    k = args.train_steps                               # 20 warm-up + 100 timed steps
+    w = args.train_warmup
+    for i in range(w):
+        loss = step_fn(state, pool[i % len(pool)])
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(k):
-        loss = step_fn(state, batch)
+    for i in range(k):
+        loss = step_fn(state, pool[(w + i) % len(pool)])
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -114,16 +130,25 @@ def bench_train(args, cfg, dev, dist, world, rank, sync_all):
     fs = step_fn.fused_for(state, batch)
     eng = fs.eng
     exposed_ms = None
+    replicas_equal = None
     if dist is not None:
+        # data parallel = same parameters everywhere after every step: compare a checksum and the extremes of the flat
+        # parameter buffer across ranks (before the no-exchange leg below, which lets them diverge on purpose)
+        flat = eng.flat.data
+        sig = torch.stack([flat.double().sum(), flat.double().abs().sum(), flat.max().double(), flat.min().double()])
+        lo, hi = sig.clone(), sig.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_equal = bool((lo == hi).all().item())
         # the same steps without the gradient exchange (replicas diverge -- timing only, the last thing this model does):
         # the difference is the part of the bucketed all-reduce that the backward program does not hide
         fs.skip_exchange = True
-        for _ in range(w):
-            step_fn(state, batch)
+        for i in range(min(w, 3)):
+            step_fn(state, pool[i % len(pool)])
         sync_all()
         t0 = time.perf_counter()
-        for _ in range(k):
-            step_fn(state, batch)
+        for i in range(k):
+            step_fn(state, pool[i % len(pool)])
         sync_all()
         dt0 = time.perf_counter() - t0
         t = torch.tensor([dt0], device=dev, dtype=torch.float64)
@@ -136,6 +161,7 @@ def bench_train(args, cfg, dev, dist, world, rank, sync_all):
            "loss": float(loss), "dropout": float(cfg.model.dropout), "path": "fused (losses.FusedTrainStep)",
            "algorithmic_tflops": float(fl.sum()) / sec / 1e12, "gflop_per_image": float(fl.sum()) / Bt / 1e9,
            "grad_allreduce_mb": eng.flat.numel * 4 / 1e6 if world > 1 else 0.0, "allreduce_exposed_ms": exposed_ms,
+           "replicas_bit_identical_after_timed_steps": replicas_equal,
            "arena_gb": eng.b.arena_bytes / 1e9}
     if rank == 0 and not args.no_roofline:
         ms = np.array(eng.program.run_range_timed(0, eng.program.n))
@@ -227,11 +253,15 @@ def bench_ode(args, dev, dist, world, rank):
 
 
 def _sync_factory(dev, dist):
+    on_gpu = torch.device(dev).type == "cuda"           # (the CPU test of the rank logic passes a CPU device)
+
     def sync_all():
-        torch.cuda.synchronize(dev)
+        if on_gpu:
+            torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize(dev)
+            if on_gpu:
+                torch.cuda.synchronize(dev)
     return sync_all
 
 
@@ -502,9 +532,10 @@ def cpu_baseline(args, cfg, model, sd, R, N):
         return time.perf_counter() - t0
     t_probe = cpu_iters(4, 1) / 4                              # warm-up + per-image cost of one iteration
     cb = int(max(4, min(args.cpu_batch, args.cpu_seconds / max(t_probe, 1e-4))))
-    t1 = cpu_iters(cb, 1)
-    k = int(max(1, min(5, (args.cpu_seconds - t1) // max(t1, 1e-3) + 1)))
-    t_k = t1 if k == 1 else cpu_iters(cb, k)
+    # K = 5 whole PC iterations at the config batch when the budget holds them (the default 200 s does on this
+    # host: ~35 s per iteration at batch 256), fewer on a slower host -- ONE timed run
+    k = int(max(1, min(5, args.cpu_seconds // max(t_probe * cb, 1e-3))))
+    t_k = cpu_iters(cb, k)
     out = {"value": cb / (N / k * t_k), "unit": "images/s", "cores": cores, "host_cores_total": total, "kind": "port",
            "sample": "K=%d PC iteration(s) (%d U-Net evaluations) at batch %d with the torch-CPU oracle (oracle/sampler_oracle.py) "
                      "on %d of %d host threads: %.2f s; extrapolated img/s = B / ((N/K) * t_K) with N=%d"
@@ -541,22 +572,54 @@ def cpu_baseline(args, cfg, model, sd, R, N):
     return out
 
 
-def _self_launch(n):
+def _launch_cmd(n, port, argv):
+    """The driver's own command line for N ranks on one node (one rank per GPU, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def _self_launch(n, share_device=False):
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < n:
-        print("bench.py: --gpus %d but only %d GPU(s) are visible" % (n, have), file=sys.stderr)
+    if have < (1 if share_device else n):
+        print("bench.py: --gpus %d but only %d GPU(s) are visible%s" % (n, have, "" if share_device else " (--share-device --dist-backend gloo "
+              "runs the N-rank code paths on fewer GPUs)"), file=sys.stderr)
         return 2
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL across processes)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = _launch_cmd(n, port, sys.argv[1:])
     print("[bench] self-launch: %s" % " ".join(cmd), file=sys.stderr, flush=True)
     return subprocess.call(cmd, env=env)
+
+
+def rank_setup(args, env, n_devices, on_gpu=True):
+    """(world, rank, device index) of this process and its process group (None at world 1): torchrun's RANK / LOCAL_RANK /
+    WORLD_SIZE, one GPU per local rank -- or, with --share-device, GPU local_rank % n_devices.  Ends with an actual collective:
+    every rank contributes 1 and the sum must be the world size."""
+    world = int(env.get("WORLD_SIZE", "1"))
+    rank = int(env.get("RANK", "0"))
+    local_rank = int(env.get("LOCAL_RANK", "0"))
+    assert args.gpus == world, "--gpus %d under a launcher with WORLD_SIZE=%d" % (args.gpus, world)
+    assert not (args.share_device and args.dist_backend == "nccl" and world > n_devices), \
+        "--share-device with more ranks than GPUs needs --dist-backend gloo (RCCL refuses two ranks on one device)"
+    index = local_rank % max(n_devices, 1) if args.share_device else local_rank
+    assert index < max(n_devices, 1), "local rank %d but %d visible GPU(s)" % (local_rank, n_devices)
+    dev = torch.device("cuda", index) if on_gpu else torch.device("cpu")
+    dist, ranks = None, 1
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {"device_id": dev} if args.dist_backend == "nccl" else {}
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world, **kw)
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)                          # an actual collective (RCCL / gloo): every rank contributes 1
+        ranks = int(round(float(one.item())))
+        assert ranks == dist.get_world_size() == world, (ranks, world)
+    return world, rank, dev, dist, ranks
 
 
 _T0 = time.perf_counter()
@@ -589,27 +652,15 @@ def mfma_probe(dev, iters=20000, reps=5):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs the MI355X (the HIP path has no CPU fallback)"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU over
         # RCCL (the same command line the driver uses); rank 0 of that job prints the JSON line on our stdout
-        raise SystemExit(_self_launch(args.gpus))
-    assert args.gpus == world, "--gpus %d under a launcher with WORLD_SIZE=%d" % (args.gpus, world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    rccl_ranks = 1
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        one = torch.ones(1, device=dev)
-        dist.all_reduce(one)                          # an actual collective over RCCL: every rank contributes 1
-        rccl_ranks = int(round(float(one.item())))
-        assert rccl_ranks == dist.get_world_size() == world, (rccl_ranks, world)
+        raise SystemExit(_self_launch(args.gpus, args.share_device))
+    n_dev = torch.cuda.device_count()
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(lr % n_dev if args.share_device else lr)
+    world, rank, dev, dist, rccl_ranks = rank_setup(args, os.environ, n_dev)
 
     import _util
     from score_sde_pytorch_amd import engine as E, _lib as L
@@ -642,7 +693,7 @@ def main():
         "metric": "pc_sampler_images_per_sec", "value": res["value"], "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "rccl_ranks": rccl_ranks,
+        "rccl_ranks": rccl_ranks, "dist_backend": args.dist_backend if world > 1 else None,
         "config": {"workload": res["workload"], "batch_per_gpu": B, "sde_steps": args.sde_steps, "nfe_per_step": res["nfe_per_step"],
                    "path": res["path"], "state_finite": res["state_finite"], "unet_gflop_per_image": res["unet_gflop_per_image"],
                    "end_to_end_tflops": res["end_to_end_tflops"],
@@ -714,6 +765,9 @@ def main():
             with open(args.dump_ops, "w") as f:
                 json.dump(rows, f)
 
+    if args.share_device and world > 1:
+        out["scaling"] = "none: %d ranks share %d GPU(s) over %s -- a functional run of the multi-rank code paths, not a scaling point" \
+            % (world, n_dev, args.dist_backend)
     _phase("sampler + roofline done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, cfg, model, sd, R, args.sde_steps)
@@ -738,8 +792,8 @@ def main():
         extra["subvp_ode"] = bench_ode_compact(args, dev, dist, world, rank)
         _phase("subvp_ode done")
         torch.cuda.empty_cache()
-        # the likelihood of the same config at a LOOSER tolerance in the default run (the solve at the config's 1e-5 takes
-        # minutes: `--workload subvp_likelihood`); ms_per_nfe is what carries over
+        # the likelihood of the same config at the config's own tolerance (rtol = atol = 1e-5, likelihood.py:40: ~1600
+        # evaluations of forward + input gradient, ~110 s); --likelihood-tol loosens it for quick runs
         extra["subvp_likelihood"] = bench_likelihood(args, dev, dist, world, rank, tol=args.likelihood_tol)
         out["extra"] = extra
         _phase("subvp_likelihood done")

@@ -141,6 +141,11 @@ def main():
         traj_x.append(xn.clone())
         return xn, xm
     ref_sampling.shared_predictor_update_fn = spy_pred
+    # ||score|| per function evaluation (batch mean of the per-sample norm) of the REFERENCE run: for the continuous VE
+    # score_fn the score is the network output itself (models/utils.py:166-176), so a forward hook sees it
+    ref_norms = []
+    hook = ref_model.register_forward_hook(
+        lambda mod, inp, outp: ref_norms.append(float(torch.norm(outp.reshape(outp.shape[0], -1), dim=-1).mean())))
     try:
         sampler = ref_sampling.get_pc_sampler(sde, (B, 3, 32, 32), ref_sampling.ReverseDiffusionPredictor,
                                               ref_sampling.LangevinCorrector, lambda v: v, snr=0.16, n_steps=1,
@@ -150,7 +155,8 @@ def main():
     finally:
         torch.randn_like = real_randn_like
         ref_sampling.shared_predictor_update_fn = real_pred
-    assert nfe == 2 * N
+        hook.remove()
+    assert nfe == 2 * N and len(ref_norms) == 2 * N
     out = sampler_oracle.pc_sample(cfg, full_sd, sde_kind="vesde", sde_kwargs=dict(sigma_min=0.01, sigma_max=50, N=N),
                                    x_T=x_T, noises=noises, snr=0.16, n_steps=1, eps=1e-5, denoise=True)
     err = float((out["samples"] - samples_ref).abs().max() / samples_ref.abs().max())
@@ -161,9 +167,12 @@ def main():
     for i in range(N):
         e = float((out["x_steps"][i] - traj_x[i]).abs().max() / traj_x[i].abs().max())
         assert e < 1e-4, (i, e)
+    ne = max(abs(a - b) / b for a, b in zip(out["score_norms"], ref_norms))
+    print("score-norm trajectory oracle-vs-reference rel err %.3g" % ne)
+    assert ne < 1e-5, ne
     # x_T and the noises are regenerated from the seed by the tests (recipe: tests/_util.pc_case_inputs)
     np.savez_compressed(os.path.join(out_dir, "pc_cifar_ncsnpp_n10.npz"), samples=samples_ref.numpy(),
-                        score_norms=np.asarray(out["score_norms"], dtype=np.float64),
+                        score_norms=np.asarray(ref_norms, dtype=np.float64),         # from the reference run (the oracle's agree, below)
                         x_step0=traj_x[0].numpy(), x_step4=traj_x[4].numpy(), x_step9=traj_x[9].numpy())
     print("golden vectors written to", out_dir)
 

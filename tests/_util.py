@@ -79,6 +79,30 @@ def rel_err(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+def per_sample_err(a, b):
+    """max over the batch of (max-abs error of a sample / max-abs of that sample's reference): a sample whose values are small
+    next to the batch maximum cannot hide behind it (rel_err normalises by the maximum of the whole tensor)"""
+    a, b = a.double().cpu().reshape(a.shape[0], -1), b.double().cpu().reshape(b.shape[0], -1)
+    return float(((a - b).abs().amax(1) / (b.abs().amax(1) + 1e-30)).max())
+
+
+# Trajectory yardsticks (VERDICT r3 item 7).  Measured on the MI355X against the reference run: pixel-MSE / max|x|^2 =
+# 1.7e-15 .. 3.8e-15 and max-abs error / max|x| = 3.5e-7 .. 5e-7 at every step (profiles/r3_f4x4_trajectory_error_growth.txt,
+# F(4x4,3x3) kernels, the coarsest-rounding mode).  The bounds sit ~10x above the observed max-abs error; the former
+# 1e-8 max^2 yardstick could not fail (the state is dominated by the prior and the injected noise).
+TRAJ_MSE = 1e-12
+TRAJ_MAXABS = 5e-6
+
+
+def assert_trajectory_close(x, ref, what=""):
+    x, ref = x.double().cpu(), ref.double().cpu()
+    mx = float(ref.abs().max())
+    mse = float(((x - ref) ** 2).mean())
+    assert mse <= TRAJ_MSE * mx ** 2, (what, "pixel MSE / max^2", mse / mx ** 2)
+    err = float((x - ref).abs().max()) / mx
+    assert err <= TRAJ_MAXABS, (what, "max-abs error / max", err)
+
+
 def pc_variant_inputs(name, batch, n_steps, size, sigma_max):
     """x_T and injected noises of one entry of tests/golden/pc_small_variants.npz (oracle/gen_golden_variants.py)"""
     import zlib

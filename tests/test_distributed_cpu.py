@@ -111,3 +111,52 @@ def test_gradient_buckets_are_final_when_announced():
         for lo, hi, snap in seen:
             assert torch.equal(snap, ref[lo:hi]), (lo, hi)
         assert torch.equal(eng.flat.grad, ref)
+
+
+# ---- bench.py's rank logic (the code the driver's N > 1 run enters first), with a CPU device standing in for the GPU ----
+def _bench_rank_worker(rank, world, port, out_dir):
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, _util.ROOT)
+    import bench
+    args = bench.parse(["--gpus", str(world), "--dist-backend", "gloo", "--share-device"])
+    w, r, dev, d, ranks = bench.rank_setup(args, os.environ, n_devices=1, on_gpu=False)     # both ranks on "GPU 0"
+    assert (w, r, ranks) == (world, rank, world) and d is not None
+    sync_all = bench._sync_factory(dev, d)
+    sync_all()
+    # max over ranks of a per-rank wall time (the contract's "take the MAX over ranks")
+    mx = bench._max_over_ranks(1.0 + rank, dev, d)
+    torch.save(dict(mx=mx, rank=r, world=w), os.path.join(out_dir, "bench_rank%d.pt" % rank))
+    sync_all()
+    d.destroy_process_group()
+
+
+def test_bench_rank_setup_two_gloo_ranks_share_one_device(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_bench_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in (0, 1):
+        got = torch.load(os.path.join(str(tmp_path), "bench_rank%d.pt" % r))
+        assert got == dict(mx=2.0, rank=r, world=2)
+
+
+def test_bench_launch_line_and_rank_guards():
+    import sys
+    sys.path.insert(0, _util.ROOT)
+    import bench
+    cmd = bench._launch_cmd(4, 29512, ["--gpus", "4", "--steps", "7"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "7"] and cmd[-5].endswith("bench.py")
+    # world 1: no process group, device 0
+    args = bench.parse([])
+    assert bench.rank_setup(args, {}, n_devices=1, on_gpu=False)[:2] == (1, 0)
+    # a launcher whose world size disagrees with --gpus, a local rank without a GPU, RCCL with two ranks per device
+    with pytest.raises(AssertionError):
+        bench.rank_setup(bench.parse(["--gpus", "2"]), {"WORLD_SIZE": "4"}, n_devices=8, on_gpu=False)
+    with pytest.raises(AssertionError):
+        bench.rank_setup(bench.parse(["--gpus", "2"]), {"WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "1"}, n_devices=1, on_gpu=False)
+    with pytest.raises(AssertionError):
+        bench.rank_setup(bench.parse(["--gpus", "2", "--share-device"]), {"WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "1"}, n_devices=1, on_gpu=False)

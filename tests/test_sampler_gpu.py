@@ -4,7 +4,7 @@ VESDE N=10, reverse_diffusion + langevin, snr 0.16, eps 1e-5, denoise) with INJE
 tests/golden/pc_cifar_ncsnpp_n10.npz.
 
 Stated tolerances (north_star: pixel MSE and score-norm trajectory):
-  pixel MSE per step  <= 1e-8 * max|x|^2     score-norm trajectory <= 1e-4 relative
+  pixel MSE per step  <= 1e-12 * max|x|^2, max-abs error <= 5e-6 max|x| (_util.TRAJ_*)     score-norm trajectory <= 1e-4 relative
 """
 import os
 
@@ -49,15 +49,13 @@ def test_fused_pc_sampler_matches_reference_trajectory(wino, monkeypatch):
     samples, nfe = sampler(model, x_init=x_T, noises=noises)
     assert nfe == 20 and sampler.last_path == "fused-eager"
     ref = torch.from_numpy(gold["samples"])
-    mse = float(((samples.cpu().double() - ref.double()) ** 2).mean())
-    assert mse <= 1e-8 * float(ref.abs().max()) ** 2, mse
-    assert rel_err(samples, ref) < 2e-4
+    _util.assert_trajectory_close(samples, ref, "samples")
     # intermediate states: re-run truncated
     for k, name in [(1, "x_step0"), (5, "x_step4"), (10, "x_step9")]:
         sampler(model, x_init=x_T, noises=noises, max_steps=k)
         x_k = sampler.engine.x.view(8, 3, 32, 32).cpu()
         r = torch.from_numpy(gold[name])
-        assert float(((x_k.double() - r.double()) ** 2).mean()) <= 1e-8 * float(r.abs().max()) ** 2, name
+        _util.assert_trajectory_close(x_k, r, name)
 
 
 @pytest.mark.parametrize("wino", WINO_MODES)
@@ -291,7 +289,7 @@ def test_long_trajectory_error_growth_f4x4(monkeypatch):
     iteration) with injected noise and every legal 3x3 layer on the F(4x4,3x3) kernel, against the CPU oracle's trajectory
     (oracle/sampler_oracle.pc_sample = /root/reference/sampling.py:390-409).  The 10-step golden above pins the start; this
     one shows that the coarser Winograd rounding does not accumulate: the per-step pixel MSE must stay under the
-    north-star bound 1e-8 * max|x|^2 at EVERY step, and the error may not grow by more than 4x from the first decade of
+    bounds of _util.TRAJ_* (1e-12 max|x|^2, 5e-6 max|x|) at EVERY step, and the error may not grow by more than 4x from the first decade of
     steps to the last.  The per-step table goes to gpurun_out/ (copied to profiles/ by the builder)."""
     from oracle import sampler_oracle
     monkeypatch.setenv("SSDE_WINOGRAD", "4")
@@ -323,10 +321,9 @@ def test_long_trajectory_error_growth_f4x4(monkeypatch):
         mse = float(((xs[i].double() - r.double()) ** 2).mean())
         rel.append(float((xs[i] - r).abs().max()) / mx)
         rows.append("step %2d  max|x| %9.4f  pixel-MSE/max^2 %.3e  max-abs-err/max %.3e" % (i, mx, mse / mx ** 2, rel[-1]))
-        assert mse <= 1e-8 * mx ** 2, rows[-1]
+        assert mse <= _util.TRAJ_MSE * mx ** 2 and rel[-1] <= _util.TRAJ_MAXABS, rows[-1]
     out = os.path.join(os.path.dirname(_util.GOLDEN), "..", "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "f4x4_trajectory_error_growth.txt"), "w") as f:
             f.write("\n".join(rows) + "\n")
-    assert max(rel) < 2e-4, max(rel)
     assert np.mean(rel[-10:]) < 4 * max(np.mean(rel[:10]), 1e-6), (np.mean(rel[:10]), np.mean(rel[-10:]))
