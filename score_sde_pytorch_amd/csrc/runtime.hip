@@ -13,6 +13,17 @@ void ssde_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* ssde_last_error(void) { return g_err; }
+
+int ssde_num_cus() {
+  static std::atomic<int> cus{0};
+  int c = cus.load(std::memory_order_relaxed);
+  if (c <= 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cus.store(c = v, std::memory_order_relaxed);
+  }
+  return c;
+}
 extern "C" int ssde_abi_version(void) { return SSDE_ABI_VERSION; }
 extern "C" int ssde_sizeof_op(void) { return (int)sizeof(ssde_op); }
 

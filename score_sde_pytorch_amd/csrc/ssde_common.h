@@ -46,6 +46,7 @@ int ssde_wgrad_wino4_launch(const ssde_wgrad_args* a, void* stream);
 
 #define SSDE_LAUNCH_CHECK()  SSDE_HIP_CHECK(hipGetLastError())
 
+int ssde_num_cus();                                                                   // runtime.hip: CUs of the current device (cached)
 static inline int ssde_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline int ssde_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline bool ssde_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -142,6 +143,15 @@ typedef __attribute__((address_space(3))) ssde_f32x2 ssde_lds_float2;
     __builtin_amdgcn_s_barrier();                \
     asm volatile("" ::: "memory");               \
   } while (0)
+
+// LDS hand-over between the lanes of ONE wave (no workgroup barrier): the hardware executes a wave's LDS operations in order,
+// so all that is needed is that the compiler keeps them in order and the data has landed; the test emulator runs lanes as
+// fibers and needs a real rendez-vous.
+#ifdef SSDE_EMULATED
+#define SSDE_WAVE_SYNC() ((void)emu::wave_exchange(0u))
+#else
+#define SSDE_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
 
 #ifdef __HIPCC__
 // x * sigmoid(x) = x * rcp(1 + exp2(-x log2 e)): v_mul + v_exp_f32 + v_add + v_rcp_f32 + v_mul, each ~1 ulp.

@@ -108,6 +108,25 @@ def check_backward_ops(dev):
     gg4 = torch.randn(2, 4, 4, 4, generator=g)
     ops.colsum(d(gg4), c=3, total=tot)
     assert rel_err(tot, gg4.sum((0, 1, 2))[:3]) < TOL_OP
+    # several pixel slices per sample, a ragged channel count, both destinations -- as one launch whose last-arriving block
+    # finishes the sums (the default) and as the three-kernel sequence; each form sums in its own fixed order
+    gb = torch.randn(5, 16, 16, 72, generator=g)
+    res = {}
+    for fused in ("1", "0"):
+        os.environ["SSDE_COLSUM_FUSED"] = fused
+        per, tot = torch.zeros(5, 80, device=dev), torch.zeros(68, device=dev)
+        ops.colsum(d(gb), c=68, g_off=4, scale=1.3, per_sample=per, ps_off=8, total=tot)
+        assert rel_err(per[:, 8:76], 1.3 * gb[..., 4:].sum((1, 2))) < TOL_OP and rel_err(tot, 1.3 * gb[..., 4:].sum((0, 1, 2))) < TOL_OP
+        tot1 = torch.zeros(72, device=dev)
+        ops.colsum(d(gb), scale=0.5, total=tot1)                 # total only: the slices cut the rows of the whole batch
+        assert rel_err(tot1, 0.5 * gb.sum((0, 1, 2))) < TOL_OP
+        res[fused] = (per.cpu().clone(), tot.cpu().clone())
+        for _ in range(2):                                       # tickets return to zero: the same launch again
+            tot2 = torch.zeros(72, device=dev)
+            ops.colsum(d(gb), scale=0.5, total=tot2)
+            assert torch.equal(tot2, tot1)
+    os.environ.pop("SSDE_COLSUM_FUSED")
+    assert rel_err(res["1"][0], res["0"][0]) < 1e-6 and rel_err(res["1"][1], res["0"][1]) < 1e-6     # (different fixed orders)
     # ---- GroupNorm + SiLU backward over a concatenated source (group straddles nothing; 12 groups of 4)
     n, c0, c1, h = 3, 32, 16, 8
     x1 = torch.randn(n, c0, h, h, generator=g).requires_grad_()

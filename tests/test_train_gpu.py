@@ -22,7 +22,9 @@ def test_upfirdn_lds_tiles():
     T.check_upfirdn_tiles("cuda")
 
 
-def test_groupnorm_statistics_from_producer_epilogues(monkeypatch):
+@pytest.mark.parametrize("pipe", ["0", "2"])      # the plain GEMM kernels / the persistent pipelined one (its own partials code)
+def test_groupnorm_statistics_from_producer_epilogues(pipe, monkeypatch):
+    monkeypatch.setenv("SSDE_GEMM_PIPE", pipe)
     T.check_fused_gn_statistics("cuda", monkeypatch)
 
 

@@ -46,9 +46,10 @@ if __name__ == "__main__":
         rows = min(n * h * h, 1 << 15)
         ref = x.reshape(-1, k)[:rows].double() @ w.double().t()
         line = "%2dx%-2d K=%4d N=%4d" % (h, h, k, cout)
-        for mode in ("f32", "bf16x6"):
+        for label, mode, bm, pf, pipe in (("f32", "f32", 0, 0, "0"), ("f32+pipe", "f32", 0, 0, "1"), ("x6[128,1]", "bf16x6", 128, 1, "0"),
+                                          ("x6[64,1]", "bf16x6", 64, 1, "0"), ("x6+pipe", "bf16x6", 128, 1, "1")):
+            os.environ["SSDE_X6_BM"], os.environ["SSDE_X6_PF"], os.environ["SSDE_GEMM_PIPE"] = str(bm), str(pf), pipe
             ms, y = run(n, h, k, cout, mode, x, w)
             e = y.reshape(-1, cout)[:rows].double() - ref
-            line += "   %s %.4f ms %6.1f TF/s err %.2e / %.2e" % (mode, ms, 2.0 * k * cout * n * h * h / ms / 1e9, (e.norm() / ref.norm()).item(),
-                                                                 (e.abs().max() / ref.abs().max()).item())
+            line += "   %s %.4f ms %5.1f TF/s err %.1e" % (label, ms, 2.0 * k * cout * n * h * h / ms / 1e9, (e.norm() / ref.norm()).item())
         print(line, flush=True)
