@@ -105,6 +105,13 @@ extern "C" int ssde_debug_w4_trace(void* buf) {
 #ifndef SSDE_W4_EPI_BATCH
 #define SSDE_W4_EPI_BATCH 8
 #endif
+// timing experiments (profiles/r4_wino4_upper_bounds.txt): variants that compute WRONG results on purpose, never the product
+#ifndef SSDE_W4_EXP_NOBARRIER
+#define SSDE_W4_EXP_NOBARRIER 0
+#endif
+#ifndef SSDE_W4_EXP_NOSTORE
+#define SSDE_W4_EXP_NOSTORE 0
+#endif
 #if SSDE_W4_PRIO
 #define SSDE_W4_HI() __builtin_amdgcn_s_setprio(2)
 #define SSDE_W4_LO() __builtin_amdgcn_s_setprio(0)
@@ -580,7 +587,14 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
       store_raw(rawb + cur * raw_stride, st + 2);
       SSDE_W4_LO();
     }
+#if SSDE_W4_EXP_NOBARRIER
+    // TIMING EXPERIMENT ONLY (wrong results): no stage barrier -- the waves run free, an upper bound on what any scheme that
+    // lets waves of a SIMD drift apart (third V buffer + LDS ready/free counters) could gain in the loop
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#else
     SSDE_LDS_BARRIER();
+#endif
     if (st < 8) SSDE_TR(8 + st * 10 + 8);
   };
   {
@@ -758,6 +772,11 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
       __syncthreads();
       if (rnd == 1 && tid == 0) { sy[0] = 0u; sy[1] = 0u; }              // ready for the next launch that is dealt these slots
     }
+#if SSDE_W4_EXP_NOSTORE
+    // TIMING EXPERIMENT ONLY (no output): the epilogue's coalesced store skipped -- an upper bound on what overlapping the
+    // store burst with the next tile's fill could gain
+    if (p.scale == 12345.f)
+#endif
     // round 1 has no accumulators left: all 8 rows of a thread (residual loads) in flight instead of 4
     if (rnd == 0) ssde_store_tile<256, 64, kEpiThreads, 4, 0>(park, kLdt, n0, e, pixfn, gn_entry, rpi_log2, gn_max);
     else ssde_store_tile<256, 64, kEpiThreads, SSDE_W4_EPI_BATCH, 0>(park, kLdt, n0, e, pixfn, gn_entry, rpi_log2, gn_max);
@@ -778,8 +797,9 @@ int pow2_floor(int v) { int q = 1; while (q * 2 <= v) q *= 2; return q; }
 int ssde_conv_wino4_splits(int wgs, int ctot, int c_out) {
   const char* se = getenv("SSDE_CONV_KSPLIT");
   if ((se && atoi(se) == 0) || c_out % 4 != 0) return 1;
-  if (wgs <= 64 && ctot >= 256) return 4;
-  if (wgs <= 128 && ctot >= 128) return 2;
+  const int cus = ssde_num_cus();                   // (256 on the MI355X: a quarter / half of the chip covered)
+  if (wgs <= cus / 4 && ctot >= 256) return 4;
+  if (wgs <= cus / 2 && ctot >= 128) return 2;
   return 1;
 }
 

@@ -15,6 +15,9 @@ void ssde_set_error(const char* fmt, ...) {
 extern "C" const char* ssde_last_error(void) { return g_err; }
 
 int ssde_num_cus() {
+  // SSDE_NUM_CUS overrides (read per call: the tests run persistent kernels on a pretend 3-CU device so that workgroups
+  // loop over several tiles; engine.Lowering reads the same variable)
+  if (const char* e = getenv("SSDE_NUM_CUS")) { const int v = atoi(e); if (v > 0) return v; }
   static std::atomic<int> cus{0};
   int c = cus.load(std::memory_order_relaxed);
   if (c <= 0) {

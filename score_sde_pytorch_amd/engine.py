@@ -528,6 +528,15 @@ class Lowering:
     def __init__(self, builder, weights, batch):
         self.b, self.w, self.n = builder, weights, batch
         self.parts = {}      # id(activation Buf) -> (partials Buf, slices per image, channels): written by its producer's epilogue
+        # compute units of the device the program will run on: the kernel choice below asks "does this launch fill the
+        # chip?" (256 on the MI355X; also the value used for CPU dry lowering).  SSDE_NUM_CUS overrides (tests)
+        import os
+        dev = getattr(builder, "device", None)
+        self.cus = 256
+        if os.environ.get("SSDE_NUM_CUS"):
+            self.cus = int(os.environ["SSDE_NUM_CUS"])
+        elif dev is not None and torch.device(dev).type == "cuda" and torch.cuda.is_available():
+            self.cus = int(torch.cuda.get_device_properties(torch.device(dev)).multi_processor_count)
 
     def _gn_slices(self, fields):
         """Slices per image of the GroupNorm partials the LAST launch of this conv spec would write (0: not available)."""
@@ -632,7 +641,8 @@ class Lowering:
         if mode == "2" or mode == "4":
             return 2 if legal2 else 0
         n_tiles = -(-c_out // 64)
-        if mode != "3" and legal4 and h >= 16 and w >= 16 and -(-(self.n * h * w) // 512) * n_tiles >= 256:
+        # (one workgroup per CU: F(4x4,3x3) workgroups own a whole CU's LDS and registers)
+        if mode != "3" and legal4 and h >= 16 and w >= 16 and -(-(self.n * h * w) // 512) * n_tiles >= self.cus:
             return 4
         # Fewer tiles than that (8x8 maps at batch 256: 128 tiles of 8 images x 64 couts): the kernel splits its reduction
         # over 2 or 4 workgroups per tile (conv_wino4.hip, ssde_conv_wino4_splits -- the same rule).  Measured
@@ -643,12 +653,13 @@ class Lowering:
             wgs4 = -(-(-(-(self.n * h * w) // 512)) // 8) * 8 * n_tiles
             splits = 1
             if c_out % 4 == 0 and os.environ.get("SSDE_CONV_KSPLIT", "1") != "0":
-                splits = 4 if wgs4 <= 64 and c_in >= 256 else 2 if wgs4 <= 128 and c_in >= 128 else 1
+                splits = 4 if wgs4 <= self.cus // 4 and c_in >= 256 else 2 if wgs4 <= self.cus // 2 and c_in >= 128 else 1
             if splits > 1 and wgs4 * splits >= int(os.environ["SSDE_W4_SPLIT_MIN_WGS"]):
                 return 4
-        # tools/heuristic_sweep.py (profiles/r2_heuristic_sweep.txt): F(4x4,3x3) wins from 256 of its workgroups, F(2x2,3x3)
-        # over the direct kernel from 128 of its own (by 2-6 %; at 64 the direct kernel is 1.5x faster)
-        return 2 if legal2 and -(-(self.n * h * w) // 256) * n_tiles >= 128 else 0
+        # tools/heuristic_sweep.py (profiles/r2_heuristic_sweep.txt): F(4x4,3x3) wins from one of its workgroups per CU (256),
+        # F(2x2,3x3) over the direct kernel from half a workgroup per CU (128; by 2-6 %; at 64 the direct kernel is 1.5x
+        # faster).  tools/batch_sweep.py: the sampler at batch 16 / 64 / 256 under this rule (profiles/r4_batch_sweep.txt)
+        return 2 if legal2 and -(-(self.n * h * w) // 256) * n_tiles >= self.cus // 2 else 0
 
     def upfirdn(self, src, n_ch, h_in, w_in, taps, up=1, down=1, pad=(0, 0), name="fir"):
         kh, kw = taps.shape

@@ -238,7 +238,7 @@ static inline const char* hipGetErrorString(hipError_t e) { return e == hipSucce
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 enum { hipDeviceAttributeMultiprocessorCount = 63 };
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
-static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 3; return hipSuccess; }   /* a small "device": persistent kernels loop */
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 256; return hipSuccess; }   /* (SSDE_NUM_CUS=3 in the tests of persistent kernels) */
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }

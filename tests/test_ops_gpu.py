@@ -298,6 +298,8 @@ GEMM1X1_CASES = [(2, 8, 64, 0, 128, 0, False), (3, 8, 40, 0, 96, 0, True), (1, 1
 def test_conv1x1_gemm_kernel(n, h, c1, c2, cout, pro, extras, matrix, pipe, monkeypatch):
     monkeypatch.setenv("SSDE_MATRIX", matrix)
     monkeypatch.setenv("SSDE_GEMM_PIPE", pipe)
+    if pipe == "2":
+        monkeypatch.setenv("SSDE_NUM_CUS", "3")      # a pretend 3-CU device: 8 persistent workgroups, several tiles each
     ops = _ops()
     g = torch.Generator().manual_seed(n * 1000 + cout)
     xa = torch.randn(n, c1, h, h, generator=g)

@@ -25,6 +25,8 @@ def test_upfirdn_lds_tiles():
 @pytest.mark.parametrize("pipe", ["0", "2"])      # the plain GEMM kernels / the persistent pipelined one (its own partials code)
 def test_groupnorm_statistics_from_producer_epilogues(pipe, monkeypatch):
     monkeypatch.setenv("SSDE_GEMM_PIPE", pipe)
+    if pipe == "2":
+        monkeypatch.setenv("SSDE_NUM_CUS", "3")      # persistent workgroups loop over several tiles
     T.check_fused_gn_statistics("cuda", monkeypatch)
 
 
