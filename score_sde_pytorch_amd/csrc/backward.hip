@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void colsum_total_kernel(const float* __restri
 
 // ---- column sums, one launch ------------------------------------------------------------------------------------------
 // The three kernels above are three launches of 5-8 us each for a few hundred KB of result (a training step has ~120 column
-// sums: ~1.3 ms of launch granularity, profiles/r3_train_step_kernel_stats_rocprofv3.csv).  Here the block that ARRIVES LAST
+// sums: ~1.3 ms of launch granularity, profiles/r3_train_step_kernel_stats_rocprofv3.csv).  VERDICT r3 item 4a asked for one
+// launch; measured SLOWER (see ssde_colsum), opt-in only.  Here the block that ARRIVES LAST
 // finishes the job: every block leaves its partial row in `part` (agent-scope stores), takes a ticket, and the holder of the
 // last ticket of a (channel chunk, sample) sums the pixel slices in FIXED order (the result does not depend on who arrived
 // when); with a per-sample destination a second ticket per chunk elects the block that sums the samples into `total`.
@@ -538,7 +539,10 @@ extern "C" int ssde_colsum(const ssde_colsum_args* a, void* stream) {
   const int ld = a->per_sample ? a->ps_ld : a->c, off = a->per_sample ? a->ps_off : 0;
   const int cl = ssde_cdiv(a->c, 4);
   {
-    // one launch (colsum_fused_kernel); SSDE_COLSUM_FUSED=0 keeps the three-kernel sequence (A/B, tests compare both)
+    // one launch (colsum_fused_kernel) on request: SSDE_COLSUM_FUSED=1.  Measured on the MI355X (profiles/r4_colsum_fused_ab.txt):
+    // the training step's element-wise class went from 7.8 to 11.1 ms with it -- the last-arriving block's fixed-order sums are
+    // chains of device-scope loads (~1 us each), longer than the two ~5 us launches they replace -- so the three-kernel
+    // sequence stays the default and this form is kept for the record (tests run both)
     const char* fe = getenv("SSDE_COLSUM_FUSED");
     const int chunks = ssde_cdiv(cl, 64);
     const bool want_per = a->per_sample != nullptr;
@@ -554,7 +558,7 @@ extern "C" int ssde_colsum(const ssde_colsum_args* a, void* stream) {
     }
     const int nz = want_per ? a->n : 1;
     const int need = chunks * nz + chunks;
-    unsigned* tickets = (fe && fe[0] == '0') || !a->scratch ? nullptr : ssde_conv_sync_slots(ssde_cdiv(need, 2));
+    unsigned* tickets = !(fe && fe[0] == '1') || !a->scratch ? nullptr : ssde_conv_sync_slots(ssde_cdiv(need, 2));
     if (tickets) {
       CsParams p{a->g, a->g_ld, a->g_off, a->hw, a->n, a->c, a->scale, a->scratch, per, ld, off, a->total, a->total2, tickets};
       const dim3 grid(chunks, fs, nz);

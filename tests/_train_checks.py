@@ -109,7 +109,7 @@ def check_backward_ops(dev):
     ops.colsum(d(gg4), c=3, total=tot)
     assert rel_err(tot, gg4.sum((0, 1, 2))[:3]) < TOL_OP
     # several pixel slices per sample, a ragged channel count, both destinations -- as one launch whose last-arriving block
-    # finishes the sums (the default) and as the three-kernel sequence; each form sums in its own fixed order
+    # finishes the sums (SSDE_COLSUM_FUSED=1, opt-in) and as the three-kernel sequence (default); each sums in its own fixed order
     gb = torch.randn(5, 16, 16, 72, generator=g)
     res = {}
     for fused in ("1", "0"):
