@@ -795,8 +795,31 @@ def main():
         # the likelihood of the same config at the config's own tolerance (rtol = atol = 1e-5, likelihood.py:40: ~1600
         # evaluations of forward + input gradient, ~110 s); --likelihood-tol loosens it for quick runs
         extra["subvp_likelihood"] = bench_likelihood(args, dev, dist, world, rank, tol=args.likelihood_tol)
-        out["extra"] = extra
         _phase("subvp_likelihood done")
+        # SSDE_MATRIX=bf16x6 (opt-in): the GEMM-shaped kernels on the BF16 matrix pipe through a 3-way split of both
+        # operands (exact products, fp32 accumulation; error table in profiles/r4_bf16_split_error_budget.txt).  The headline
+        # `value` above stays on the fp32-MFMA kernels; this is the same sampler / training step measured in the same run.
+        os.environ["SSDE_MATRIX"] = "bf16x6"
+        try:
+            rb, eb, mb, _, _ = bench_pc(args, "ve/cifar10_ncsnpp_continuous", args.batch, args.sde_steps, dev, dist, world, rank,
+                                        args.steps, args.warmup, False)
+            del eb, mb
+            torch.cuda.empty_cache()
+            mx = {"dtype": "f32 via 3-way bf16 split on the BF16 matrix pipe (1x1 / NIN / Linear GEMMs), fp32 accumulate; 3x3 convolutions "
+                           "and attention on the fp32-MFMA kernels",
+                  "sampler": {k: rb[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "state_finite")}}
+            if not args.no_train:
+                a2 = argparse.Namespace(**vars(args))
+                a2.no_roofline = True
+                a2.train_steps, a2.train_warmup = min(args.train_steps, 30), min(args.train_warmup, 5)
+                tb = bench_train(a2, _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous"), dev, dist, world, rank, sync_all)
+                mx["train"] = {k: tb[k] for k in ("value", "unit", "steps", "warmup", "loss")}
+                torch.cuda.empty_cache()
+            extra["matrix_bf16x6"] = mx
+        finally:
+            os.environ.pop("SSDE_MATRIX", None)
+        _phase("matrix_bf16x6 done")
+        out["extra"] = extra
 
     if rank == 0:
         print(json.dumps(out))

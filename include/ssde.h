@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSDE_ABI_VERSION 5   /* 5: SSDE_PACK_WINO4 image re-ordered per wave (plan blobs of version 4 carry the old image), ODE ops in programs */
+#define SSDE_ABI_VERSION 6   /* 6: ssde_conv_args.wino_v / ssde_wgrad_args.v_pre (forward by-product feeds the weight gradient); 5: SSDE_PACK_WINO4 image re-ordered per wave (plan blobs of version 4 carry the old image), ODE ops in programs */
 
 /* ---- prologue applied to a source tensor while it is staged into LDS ---- */
 enum {
@@ -91,6 +91,11 @@ typedef struct ssde_conv_args {
   float* gn_part;        /* optional: GroupNorm partial statistics of dst, [N][S][c_out/4][3] = (mean, M2, count) per
                           * (image, slice, channel quad), written by the epilogue; S = ssde_conv_gn_slices(args) > 0
                           * (every workgroup tile lies inside one image).  Merged by ssde_gn_finalize. */
+  float* wino_v;         /* optional, SSDE_TILE_WINOGRAD4 only (ABI 6): the kernel also leaves the transformed input
+                          * V[pos][(c0+c1)/4][t][4] = B^T pro(main) B (36 positions, channel quads, t = ((image * H/4) + tile
+                          * row) * W/4 + tile column, fp32; 36 * N*H*W/16 * (c0+c1) floats, < 4 GB) -- what the F(4x4,3x3)
+                          * weight gradient of the same layer multiplies with
+                          * (ssde_wgrad_args.v_pre); a by-product of the first 64-cout tile's staging.  NULL: not written. */
 } ssde_conv_args;
 
 enum { SSDE_TILE_AUTO = 0, SSDE_TILE_256x64 = 1, SSDE_TILE_128x64 = 2, SSDE_TILE_64x64 = 3, SSDE_TILE_256x32 = 4,
@@ -264,6 +269,9 @@ typedef struct ssde_wgrad_args {
    * returns the floats needed for the split the library would choose with unlimited scratch. */
   float* scratch;
   int64_t scratch_floats;
+  const float* v_pre;      /* optional (ABI 6): the transformed input the FORWARD launch of this layer left behind
+                            * (ssde_conv_args.wino_v, same src and prologue); taken only when ssde_wgrad_wants_winograd4()
+                            * is true for these arguments -- the input-transform pass of the weight gradient is then skipped */
 } ssde_wgrad_args;
 
 /* ---- column sums of a gradient: bias and Dense_0(temb) addend gradients ------------------- */
@@ -428,6 +436,9 @@ int ssde_rk_error_norm(const ssde_rk_error_args* a, void* stream);
 int ssde_pf_drift(const ssde_pf_drift_args* a, void* stream);
 int ssde_hutch_div(const ssde_hutch_div_args* a, void* stream);
 int ssde_conv_wgrad(const ssde_wgrad_args* a, void* stream);
+/* 1 when ssde_conv_wgrad would run these arguments on the F(4x4,3x3) path (wgrad_wino4.hip), i.e. when a forward launch
+ * may usefully fill ssde_conv_args.wino_v for it; shape-only query (pointers are not dereferenced) */
+int ssde_wgrad_wants_winograd4(const ssde_wgrad_args* a);
 int ssde_colsum(const ssde_colsum_args* a, void* stream);
 int ssde_gn_bwd_reduce(const ssde_gn_bwd_reduce_args* a, void* stream);
 int ssde_prologue_bwd(const ssde_prologue_bwd_args* a, void* stream);

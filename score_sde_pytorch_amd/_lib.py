@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SSDE_LIB_PATH: developer switch for A/B timing of kernel variants built by _build.build_variant (tools/ab_bench.sh)
 LIB_PATH = os.environ.get("SSDE_LIB_PATH") or os.path.join(_HERE, "libssde_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_SILU = 0, 1, 2, 3
 TILE_AUTO, TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32, TILE_WINOGRAD, TILE_WINOGRAD4 = 0, 1, 2, 3, 4, 5, 6
@@ -37,7 +37,7 @@ class ConvArgs(C.Structure):
                 ("h_out", C.c_int32), ("w_out", C.c_int32), ("c_out", C.c_int32),
                 ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("tile", C.c_int32),
                 ("bias", _fp), ("chan_add", _fp), ("chan_add_ld", C.c_int32), ("resid_post", C.c_int32),
-                ("resid", _fp), ("out_scale", C.c_float), ("_pad1", C.c_int32), ("dst", _fp), ("gn_part", _fp)]
+                ("resid", _fp), ("out_scale", C.c_float), ("_pad1", C.c_int32), ("dst", _fp), ("gn_part", _fp), ("wino_v", _fp)]
 
 
 class GnStatsArgs(C.Structure):
@@ -152,7 +152,7 @@ class WgradArgs(C.Structure):
                 ("n", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32), ("h_out", C.c_int32), ("w_out", C.c_int32),
                 ("c_out", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("cin_store", C.c_int32), ("transpose_out", C.c_int32), ("splits", C.c_int32), ("scale", C.c_float),
-                ("dw", _fp), ("scratch", _fp), ("scratch_floats", C.c_int64)]
+                ("dw", _fp), ("scratch", _fp), ("scratch_floats", C.c_int64), ("v_pre", _fp)]
 
 
 class ColsumArgs(C.Structure):
@@ -244,7 +244,7 @@ EXPORTS = ["ssde_conv2d", "ssde_groupnorm_stats", "ssde_upfirdn2d", "ssde_attent
            "ssde_abi_version", "ssde_sizeof_op", "ssde_last_error", "ssde_conv_lds_bytes",
            "ssde_conv_wgrad", "ssde_colsum", "ssde_gn_bwd_reduce", "ssde_prologue_bwd", "ssde_attention_bwd",
            "ssde_perturb", "ssde_dsm_loss", "ssde_sumsq_flat", "ssde_adam_clip_ema", "ssde_memset", "ssde_axpy",
-           "ssde_wgrad_scratch_floats", "ssde_pack_weights", "ssde_project_update", "ssde_gn_finalize", "ssde_conv_gn_slices", "ssde_rk_combine", "ssde_rk_error_norm", "ssde_pf_drift", "ssde_hutch_div", "ssde_sample_update", "ssde_mfma_probe",
+           "ssde_wgrad_scratch_floats", "ssde_wgrad_wants_winograd4", "ssde_pack_weights", "ssde_project_update", "ssde_gn_finalize", "ssde_conv_gn_slices", "ssde_rk_combine", "ssde_rk_error_norm", "ssde_pf_drift", "ssde_hutch_div", "ssde_sample_update", "ssde_mfma_probe",
            # plan-level entry points (csrc/plan.hip; argument types: plan_export.bind)
            "ssde_plan_load", "ssde_plan_load_file", "ssde_plan_destroy", "ssde_plan_info", "ssde_plan_param",
            "ssde_plan_refresh_weights", "ssde_unet_forward", "ssde_pc_reset", "ssde_pc_run", "ssde_pc_state",
@@ -285,6 +285,7 @@ def bind(lib):
     lib.ssde_conv_gn_slices.argtypes = [C.POINTER(ConvArgs)]
     lib.ssde_wgrad_scratch_floats.argtypes = [C.POINTER(WgradArgs)]
     lib.ssde_wgrad_scratch_floats.restype = C.c_int64
+    lib.ssde_wgrad_wants_winograd4.argtypes = [C.POINTER(WgradArgs)]
     if lib.ssde_abi_version() != ABI_VERSION:
         raise SsdeError("ABI mismatch: library %d, binding %d" % (lib.ssde_abi_version(), ABI_VERSION))
     if lib.ssde_sizeof_op() != C.sizeof(Op):

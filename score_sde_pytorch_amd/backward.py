@@ -324,7 +324,9 @@ class TrainEngine(E.UNetEngine):
                           c_out=part["rows"], ksize=ksize, stride=stride, pad=pad, cin_store=meta["cin_store"],
                           transpose_out=int(part["transpose"]), splits=0, scale=float(scale),
                           dw=part["view"] if part.get("view") is not None else self.flat.grad_view(part["param"]),
-                          scratch=None, scratch_floats=0)
+                          scratch=None, scratch_floats=0,
+                          # the forward launch's by-product (engine.Lowering.conv: only allocated when THIS launch takes it)
+                          v_pre=f.get("wino_v") if (ksize == 3 and len(parts) == 1) else None)
             need = self._wgrad_scratch(fields)
             if need > 0:
                 fields.update(scratch=b.buf(need, name="wgrad_slabs"), scratch_floats=need)

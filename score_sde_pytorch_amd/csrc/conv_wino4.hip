@@ -166,6 +166,8 @@ struct Wino4Params {
   unsigned* sync;          // ksplit > 1: this launch's (shares started, shares handed over) pairs, one per tile, from
                            // conv_mfma.hip's g_conv_sync (zero before and after)
   int ticket_off;          // float index of the hand-over ticket in LDS (behind everything else)
+  float* wino_v;           // kEmitV: V[pos][t][Ctot] = B^T pro(x) B for the F(4x4,3x3) weight gradient (ssde_conv_args.wino_v)
+  int T, tiles_h, tiles_w; // 4x4 tiles of the whole batch / per image column / per image row
 };
 
 // 1-D input transform (one column / row of B^T d, B^T rows: [4,0,-5,0,1,0] [0,-4,-4,1,1,0] [0,4,-4,-1,1,0]
@@ -219,7 +221,15 @@ __device__ __forceinline__ void bt6(const ssde_f32x2 (&d)[6], ssde_f32x2 (&o)[6]
 // the order the workgroups START (an atomic counter per tile, as a decoupled look-back scan numbers its blocks): share k
 // only ever waits for shares < k, which are resident or done -- no assumption about the dispatch order -- and the sums are
 // formed in the fixed order ((s0 + s1) + s2) + s3, so the result does not depend on who arrived when.
-template <bool kGn, int kKs>
+// kEmitV (training forward, ssde_conv_args.wino_v): the workgroups of the FIRST cout tile also leave the transformed input of
+// every stage in HBM, in the layout the F(4x4,3x3) weight-gradient GEMM reads (wgrad_wino4.hip: V[pos][t][ci]) -- the
+// weight gradient of the layer then skips its own input-transform pass (wino4_xform_v_kernel: one read of x, the prologue and
+// the 6x6 transform per element, 2.25x the tensor written: 2.4-2.7 ms of a training step).  Layout [pos][Ctot / 4][t][4].  Per stage 1152 float4 (36 positions
+// x 32 tiles x 4 channels) leave LDS V[cur], 2.25 per thread, in the last three position slots, which carry no other
+// vector-memory instruction.  Stores count in vmcnt like the loads: the counted waits of the stage stay correct (a wait for
+// "at most n outstanding" can only become stricter when younger stores are still in flight), and the stores sit as far
+// from the next counted wait -- the head of the next stage -- as the stage allows.
+template <bool kGn, int kKs, bool kEmitV = false>
 __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const Wino4Params p) {
   constexpr bool kSplit = kKs > 1;
   SSDE_LDS(smem);
@@ -313,6 +323,32 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
   const int t_vcol = t_real ? t_tile * 4 + t_pair * 2 : kTiles * kKc + (lane & 7) * 2;
   const int t_rawoff = t_pair * raw_plane + (t_base + t_line) * 2;
 
+  // V by-product plan: thread = (tile tid & 31, positions (tid >> 5) + 16 i).  One 32-bit byte offset per thread (the launcher
+  // checks that V is smaller than 4 GB), the position block i and the stage's channels ride in the scalar base; 0xFFFFFFFF =
+  // this thread stores nothing (another cout tile, a tile outside the batch)
+  uint32_t ev_off = 0xFFFFFFFFu;
+  const uint32_t ev_lds = (uint32_t)(((tid >> 5) * kVP + (tid & 31) * 4) * 4);
+  if constexpr (kEmitV) {
+    const int etile = tid & 31;
+    const int eil = etile >> (p.lTWt + p.lTHt);
+    const int etr = (etile >> p.lTWt) & (THt - 1), etc = etile & (TWt - 1);
+    const int eimg = img0 + eil, eyy = ty * THt + etr, exx = tx * TWt + etc;
+    // layout [pos][Ctot / 4][t][4]: the 32 tiles of a workgroup are consecutive t for every map the networks have (a patch is
+    // whole tile rows of one image, or whole images) -> one 512-byte run per position and stage.  (As [pos][t][Ctot], the
+    // layout wino4_xform_v_kernel writes, every lane's 16 bytes were a separate memory transaction: the forward + input-gradient
+    // class went from 25.0 to 31.6 ms, profiles/r4_wino_v_from_forward_ab.txt)
+    if (p.wino_v != nullptr && nt == 0 && eimg < p.N && eyy < p.tiles_h && exx < p.tiles_w)
+      ev_off = (uint32_t)((((tid >> 5) * (Ctot >> 2)) * p.T + (eimg * p.tiles_h + eyy) * p.tiles_w + exx) * 16);
+  }
+  auto emit_v = [&](const float* Vc, int st, int it) __attribute__((always_inline)) {
+    if constexpr (kEmitV) {
+      if (ev_off != 0xFFFFFFFFu && (it < 2 || tid < 128)) {          // positions 32..35: the first four 32-thread rows
+        const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(Vc) + it * (16 * kVP * 4) + ev_lds);
+        char* base = reinterpret_cast<char*>(p.wino_v) + ((size_t)it * 16 * (Ctot >> 2) + (size_t)(st + st_off)) * p.T * 16;
+        *reinterpret_cast<float4*>(base + ev_off) = v;
+      }
+    }
+  };
   // GroupNorm tables in LDS: (mean, rstd) of every (tile image, group), gamma and beta of every channel
   float* gn_tab = rawb + 2 * raw_stride;       // [IMGS][groups][2]
   float* gb_tab = gn_tab + 2 * IMGS * (kGn ? s.gn_groups : 0);   // [2][Ctot]
@@ -576,9 +612,13 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
     __builtin_amdgcn_sched_barrier(0);
     SSDE_W4_POS(6);
     if (has1) SSDE_GLDS16_S_SAME_BASE_LO32(w_voff, wb, wl, 2048);
+    emit_v(Vc, st, 0);
     __builtin_amdgcn_sched_barrier(0);
     SSDE_W4_POS(7);
+    emit_v(Vc, st, 1);
+    __builtin_amdgcn_sched_barrier(0);
     SSDE_W4_POS(8);
+    emit_v(Vc, st, 2);
 #undef SSDE_W4_POS
     if (st < 8) SSDE_TR(8 + st * 10 + 6);
     if (has2 && gy) {
@@ -837,6 +877,9 @@ int ssde_conv_wino4_launch(const ssde_conv_args* a, void* stream, int* lds_out) 
   p.bias = a->bias; p.chan_add = a->chan_add; p.chan_add_ld = a->chan_add_ld;
   p.resid = a->resid; p.resid_post = a->resid_post; p.scale = a->out_scale; p.dst = a->dst;
   p.gn_part = a->gn_part;
+  p.wino_v = a->wino_v; p.tiles_h = a->h_out / 4; p.tiles_w = a->w_out / 4; p.T = a->n * p.tiles_h * p.tiles_w;
+  SSDE_REQUIRE(!a->wino_v || 36ull * (unsigned long long)p.T * (unsigned)(s.c0 + s.c1) * 4ull < (1ull << 32),
+               "conv(winograd 4x4): a transformed-input by-product of 4 GB or more is not addressable by this kernel");
   // GroupNorm partials: a workgroup tile is part of one image (two epilogue rounds: 2 x tiles_per_img slices of 8 wave
   // entries) or holds `imgs` >= 2 whole images (imgs / 2 per round; 512 / imgs rows per image >= the 32 rows of one
   // epilogue trip)
@@ -873,12 +916,17 @@ int ssde_conv_wino4_launch(const ssde_conv_args* a, void* stream, int* lds_out) 
     hipLaunchKernelGGL(kfn, grid, dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
     return true;
   };
-  static std::atomic<bool> set[2][3];
+  static std::atomic<bool> set[2][3], setv[2][3];
   const int si = p.ksplit == 4 ? 2 : p.ksplit == 2 ? 1 : 0;
-  const bool ok = gn ? (si == 2 ? go(conv_wino4_kernel<true, 4>, set[1][2]) : si == 1 ? go(conv_wino4_kernel<true, 2>, set[1][1])
-                                                                                     : go(conv_wino4_kernel<true, 1>, set[1][0]))
-                     : (si == 2 ? go(conv_wino4_kernel<false, 4>, set[0][2]) : si == 1 ? go(conv_wino4_kernel<false, 2>, set[0][1])
-                                                                                      : go(conv_wino4_kernel<false, 1>, set[0][0]));
+  const bool ok = a->wino_v
+      ? (gn ? (si == 2 ? go(conv_wino4_kernel<true, 4, true>, setv[1][2]) : si == 1 ? go(conv_wino4_kernel<true, 2, true>, setv[1][1])
+                                                                                    : go(conv_wino4_kernel<true, 1, true>, setv[1][0]))
+            : (si == 2 ? go(conv_wino4_kernel<false, 4, true>, setv[0][2]) : si == 1 ? go(conv_wino4_kernel<false, 2, true>, setv[0][1])
+                                                                                     : go(conv_wino4_kernel<false, 1, true>, setv[0][0])))
+      : (gn ? (si == 2 ? go(conv_wino4_kernel<true, 4>, set[1][2]) : si == 1 ? go(conv_wino4_kernel<true, 2>, set[1][1])
+                                                                            : go(conv_wino4_kernel<true, 1>, set[1][0]))
+            : (si == 2 ? go(conv_wino4_kernel<false, 4>, set[0][2]) : si == 1 ? go(conv_wino4_kernel<false, 2>, set[0][1])
+                                                                             : go(conv_wino4_kernel<false, 1>, set[0][0])));
   SSDE_REQUIRE(ok, "conv(winograd 4x4): hipFuncSetAttribute failed");
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;

@@ -507,6 +507,8 @@ int make_plan(const ssde_wgrad_args* a, WgPlan* pl) {
 
 }  // namespace
 
+extern "C" int ssde_wgrad_wants_winograd4(const ssde_wgrad_args* a) { return a && ssde_wgrad_wino4_wants(a) ? 1 : 0; }
+
 extern "C" int64_t ssde_wgrad_scratch_floats(const ssde_wgrad_args* a) {
   if (a && ssde_wgrad_wino4_wants(a)) return ssde_wgrad_wino4_scratch_floats(a);    // Winograd F(4x4,3x3): wgrad_wino4.hip
   if (a && ssde_wgrad_wino_wants(a)) return ssde_wgrad_wino_scratch_floats(a);      // Winograd F(2x2,3x3): wgrad_wino.hip

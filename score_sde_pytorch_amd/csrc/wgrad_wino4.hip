@@ -57,6 +57,8 @@ struct W4Params {
   float scale;
   float* dw;
   float* V; float* Z; float* slabs;
+  int v_quads;             // 1: V is the forward launch's by-product, [pos][Ctot / 4][t][4] (conv_wino4.hip kEmitV: a workgroup's 32
+                           // tiles are one 512-byte run per position and stage); 0: wino4_xform_v_kernel's [pos][t][Ctot]
 };
 
 // ---- transforms: thread = (tile t, VEC channels), consecutive threads = consecutive channels: 36 (16) coalesced loads and 36
@@ -217,6 +219,7 @@ __global__ __launch_bounds__(256) void wino4_xform_z_kernel(const W4Params p) {
 // a stage = 16 tiles: rows [t][128 channels] of both operands, K-major exactly as they lie in memory, double buffered, one
 // barrier per stage.  MFMA operands: lane (li, lh) reads row (k + lh), column (block + li) -- 32 consecutive floats per
 // half wave, conflict-free; the rows of a stage sit LDP = 132 floats apart.
+template <bool kVQuads>
 __global__ __launch_bounds__(kGemmThreads, 4) void wgrad4_gemm_kernel(const W4Params p) {
   SSDE_LDS(smem);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -243,6 +246,10 @@ __global__ __launch_bounds__(kGemmThreads, 4) void wgrad4_gemm_kernel(const W4Pa
   // staging: thread = (row r0 = tid >> 5 (+8), channel quad q = tid & 31) of both operands: 2 float4 per operand and stage
   const int q4 = (tid & 31) * 4, r0 = tid >> 5;
   const bool zc_ok = co0 + q4 < p.Cout, vc_ok = ci0 + q4 < p.Ctot;
+  // V in the by-product layout [pos][Ctot / 4][t][4]: thread = (tile row t = tid & 15, channel quads (tid >> 4) + 16 i) -- 16 lanes
+  // read 256 contiguous bytes, and the float4 of a 16-lane group land in LDS rows 132 floats apart (all 64 banks once)
+  const int vt = tid & 15, vq = tid >> 4;
+  const float* Vq = p.V + (size_t)pos * (p.Ctot >> 2) * p.T * 4;
   float4 zv[2], vv[2];
   auto load_stage = [&](int st) {
 #pragma unroll
@@ -251,16 +258,24 @@ __global__ __launch_bounds__(kGemmThreads, 4) void wgrad4_gemm_kernel(const W4Pa
       const bool ok = t < k1;
       const size_t row = (size_t)(ok ? t : k0);
       zv[i] = *reinterpret_cast<const float4*>(Zp + row * p.Cout + (zc_ok ? co0 + q4 : 0));
-      vv[i] = *reinterpret_cast<const float4*>(Vp + row * p.Ctot + (vc_ok ? ci0 + q4 : 0));
       if (!ok || !zc_ok) zv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!ok || !vc_ok) vv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kVQuads) {
+        const int tq = k0 + st * BK + vt, cq = (ci0 >> 2) + vq + 16 * i;
+        const bool okq = tq < k1 && cq * 4 < p.Ctot;
+        vv[i] = *reinterpret_cast<const float4*>(Vq + ((size_t)(okq ? cq : 0) * p.T + (okq ? tq : k0)) * 4);
+        if (!okq) vv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        vv[i] = *reinterpret_cast<const float4*>(Vp + row * p.Ctot + (vc_ok ? ci0 + q4 : 0));
+        if (!ok || !vc_ok) vv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   };
   auto store_stage = [&](float* buf) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       *reinterpret_cast<float4*>(buf + (r0 + i * 8) * LDP + q4) = zv[i];
-      *reinterpret_cast<float4*>(buf + (BK + r0 + i * 8) * LDP + q4) = vv[i];
+      if (kVQuads) *reinterpret_cast<float4*>(buf + (BK + vt) * LDP + (vq + 16 * i) * 4) = vv[i];
+      else *reinterpret_cast<float4*>(buf + (BK + r0 + i * 8) * LDP + q4) = vv[i];
     }
   };
 
@@ -459,28 +474,42 @@ int ssde_wgrad_wino4_launch(const ssde_wgrad_args* a, void* stream) {
     p.splits = ssde_cdiv(p.T, p.k_per_split);
   }
   SSDE_REQUIRE(a->scratch, "wgrad(winograd 4x4): scratch missing");
-  p.V = a->scratch;
+  // v_pre: the forward launch of this layer left V behind (conv_wino4.hip, kEmitV): no input-transform pass here
+  const bool have_v = a->v_pre != nullptr;
+  p.V = have_v ? const_cast<float*>(a->v_pre) : a->scratch;
+  p.v_quads = have_v ? 1 : 0;
+  if (have_v) {
+    p.Z = a->scratch;
+    p.slabs = p.Z + (size_t)kPos * p.T * p.Cout;
+  } else {
   p.Z = p.V + (size_t)kPos * p.T * p.Ctot;
   p.slabs = p.Z + (size_t)kPos * p.T * p.Cout;
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
   auto grid_for = [](long long total) { long long b = (total + 255) / 256; return (unsigned)(b > 256 * 32 ? 256 * 32 : (b < 1 ? 1 : b)); };
   static const int xvec = getenv("SSDE_WGRAD4_XVEC") ? atoi(getenv("SSDE_WGRAD4_XVEC")) : 2;      // channels per transform thread
   const bool v2 = xvec == 2 && p.Ctot % 2 == 0 && p.Cout % 2 == 0 && s.c0 % 2 == 0 && p.g_ld % 2 == 0 && p.g_off % 2 == 0;
   const dim3 gv(grid_for((long long)p.T * p.Ctot / (v2 ? 2 : 1))), gz(grid_for((long long)p.T * p.Cout / (v2 ? 2 : 1)));
   if (v2) {
-    if (gn) hipLaunchKernelGGL((wino4_xform_v_kernel<true, 2>), gv, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((wino4_xform_v_kernel<false, 2>), gv, dim3(256), 0, st, p);
-    SSDE_LAUNCH_CHECK();
+    if (!have_v) {
+      if (gn) hipLaunchKernelGGL((wino4_xform_v_kernel<true, 2>), gv, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((wino4_xform_v_kernel<false, 2>), gv, dim3(256), 0, st, p);
+      SSDE_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(wino4_xform_z_kernel<2>, gz, dim3(256), 0, st, p);
   } else {
-    if (gn) hipLaunchKernelGGL((wino4_xform_v_kernel<true, 1>), gv, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((wino4_xform_v_kernel<false, 1>), gv, dim3(256), 0, st, p);
-    SSDE_LAUNCH_CHECK();
+    if (!have_v) {
+      if (gn) hipLaunchKernelGGL((wino4_xform_v_kernel<true, 1>), gv, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((wino4_xform_v_kernel<false, 1>), gv, dim3(256), 0, st, p);
+      SSDE_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(wino4_xform_z_kernel<1>, gz, dim3(256), 0, st, p);
   }
   SSDE_LAUNCH_CHECK();
   const int lds = 2 * kStage * 4;
-  hipLaunchKernelGGL(wgrad4_gemm_kernel, dim3(ssde_cdiv(kPos * p.splits, 8) * 8 * p.co_tiles * p.ci_tiles), dim3(kGemmThreads), lds, st, p);
+  const dim3 gg(ssde_cdiv(kPos * p.splits, 8) * 8 * p.co_tiles * p.ci_tiles);
+  if (have_v) hipLaunchKernelGGL(wgrad4_gemm_kernel<true>, gg, dim3(kGemmThreads), lds, st, p);
+  else hipLaunchKernelGGL(wgrad4_gemm_kernel<false>, gg, dim3(kGemmThreads), lds, st, p);
   SSDE_LAUNCH_CHECK();
   if (p.splits > 1) {
     hipLaunchKernelGGL(wgrad4_sum_splits_kernel, dim3(grid_for((long long)kPos * p.Cout * p.Ctot / 4)), dim3(256), 0, st, p);

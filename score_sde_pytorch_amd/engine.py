@@ -210,7 +210,7 @@ def _expand(kind, fields, fclass, fl):
     a.update(aux=_NOSRC, w_aux=None, resid=None, resid_post=0, out_scale=1.0, dst=fields["_split_tmp"], gn_part=None)
     b = dict(fields)
     b.update(main=_NOSRC, w_main=None, ksize=0, bias=None, chan_add=None, chan_add_ld=0, resid=fields["_split_tmp"],
-             resid_post=0, tile=L.TILE_AUTO)
+             resid_post=0, tile=L.TILE_AUTO, wino_v=None)
     return [(a, fclass, fl - fl1), (b, FC_CONV1, fl1)]
 
 
@@ -610,7 +610,14 @@ class Lowering:
             w_main=w_main, w_aux=w_aux, n=self.n, h_in=h_in, w_in=w_in, h_out=h_out, w_out=w_out, c_out=c_out,
             ksize=3 if main is not None else 0, stride=stride, pad=pad, tile=tile, bias=bias, chan_add=chan_add,
             chan_add_ld=chan_add_ld, resid_post=resid_post, resid=resid, out_scale=float(scale), dst=dst, gn_part=None,
-            _split_tmp=split_tmp)
+            wino_v=None, _split_tmp=split_tmp)
+        if wino == 4 and getattr(self, "emit_wino_v", False) and self._wgrad_takes_wino4(fields) and \
+                36 * self.n * (h_out // 4) * (w_out // 4) * (main["c0"] + main["c1"]) * 4 < 2 ** 32:
+            # training forward: the kernel leaves B^T pro(x) B behind for the layer's F(4x4,3x3) weight gradient
+            # (ssde_conv_args.wino_v -> ssde_wgrad_args.v_pre, backward.TrainEngine._bwd_branch); 2.25x the input, alive
+            # until that weight gradient has been enqueued
+            ctot = main["c0"] + main["c1"]
+            fields["wino_v"] = self.b.buf(36 * self.n * (h_out // 4) * (w_out // 4) * ctot, name="wino_v")
         if stats and isinstance(dst, Buf):
             slices = self._gn_slices(fields)
             if slices > 0:
@@ -618,6 +625,24 @@ class Lowering:
                 fields["gn_part"] = part
                 self.parts[id(dst)] = (part, slices, c_out)
         self.b.add(L.OP_CONV, fields, FC_CONV3 if main is not None else FC_CONV1, flops)
+
+    def _wgrad_takes_wino4(self, f):
+        """Would ssde_conv_wgrad run the weight gradient of this forward conv on the F(4x4,3x3) path?  (shape-only query with
+        the arguments backward.TrainEngine._bwd_branch will pass: g = d dst, one part covering the whole weight)"""
+        import os
+        if os.environ.get("SSDE_WINO_V_FROM_FORWARD", "1") == "0":
+            return False
+        meta = self.w.meta.get(id(f["w_main"]))
+        if meta is None or len(meta["parts"]) != 1 or meta["parts"][0]["transpose"]:
+            return False
+        a = L.WgradArgs()
+        s = f["main"]
+        a.src.c0, a.src.c1, a.src.pro_mode, a.src.gn_groups = s["c0"], s["c1"], s["pro_mode"], s["gn_groups"]
+        a.g_ld, a.g_off = f["c_out"], meta["parts"][0]["row0"]
+        a.n, a.h_in, a.w_in, a.h_out, a.w_out = f["n"], f["h_in"], f["w_in"], f["h_out"], f["w_out"]
+        a.c_out, a.ksize, a.stride, a.pad = meta["parts"][0]["rows"], 3, f["stride"], f["pad"]
+        a.cin_store, a.transpose_out = meta["cin_store"], 0
+        return bool(L.load().ssde_wgrad_wants_winograd4(C.byref(a)))
 
     def wino_ok(self, h, w, c_out, c_in):
         """Which 3x3 / stride 1 kernel a layer gets: 0 = direct, 2 = Winograd F(2x2,3x3), 4 = F(4x4,3x3).
@@ -692,6 +717,9 @@ class UNetEngine:
         self.b = ProgramBuilder(device)
         self.weights = WeightStore(device)
         self.low = Lowering(self.b, self.weights, batch)
+        # a training program with parameter gradients (backward.TrainEngine sets param_grads before lowering): the forward
+        # F(4x4,3x3) launches leave their transformed input behind for the weight gradients
+        self.low.emit_wino_v = bool(getattr(self, "param_grads", False))
         self.channels = model.channels
         # static I/O (addresses are baked into the program / graph)
         self.x_in = self.b.buf(batch, self.channels, height, width, name="x_in", persistent=True)

@@ -440,6 +440,44 @@ def check_unet_grads(kind, dev, cfg=None, batch=2):
     return compare_param_grads(model, eng.flat, ref)
 
 
+def check_wino_v_from_forward(dev, monkeypatch, dropout=False):
+    """The F(4x4,3x3) weight gradient fed by the forward launch's by-product (ssde_conv_args.wino_v -> ssde_wgrad_args.v_pre,
+    conv_wino4.hip kEmitV): with every legal 3x3 layer on the F(4x4,3x3) kernels, forward and weight gradient, the training
+    program must carry such pairs, every gradient must match autograd through the oracle, and the gradients must equal -- to
+    rounding of the two transform implementations -- those of the same program with the by-product switched off."""
+    from score_sde_pytorch_amd.models import utils as mutils
+    from score_sde_pytorch_amd import backward as B, _lib as L
+    monkeypatch.setenv("SSDE_WINOGRAD", "4")
+    monkeypatch.setenv("SSDE_WGRAD_WINOGRAD", "44")
+    cfg = small_cfg("ncsnpp")
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    sd = {k: v.clone() for k, v in _util.load_seeded(model, seed=1).items()}
+    sd["sigmas"] = model.sigmas.clone()
+    model = model.to(dev)
+    R, batch = cfg.data.image_size, 3
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(batch, 3, R, R, generator=g) * 2
+    cond = torch.exp(torch.rand(batch, generator=g) * 4 - 2)
+    gout = torch.randn(batch, 3, R, R, generator=g)
+    y_ref, gx_ref, ref = oracle_grads(cfg, sd, x, cond, gout)
+    grads = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SSDE_WINO_V_FROM_FORWARD", mode)
+        eng = B.TrainEngine(model, batch, R, R, torch.device(dev), input_grad=True, dropout=False)
+        prog = eng.program
+        n_v = sum(1 for i in range(prog.n) if prog.ops[i].kind == L.OP_CONV and prog.ops[i].u.conv.wino_v)
+        n_pre = sum(1 for i in range(prog.n) if prog.ops[i].kind == L.OP_WGRAD and prog.ops[i].u.wgrad.v_pre)
+        assert (n_v >= 4 and n_pre == n_v) if mode == "1" else (n_v == 0 and n_pre == 0), (mode, n_v, n_pre)
+        y = eng.forward_train(x.to(dev), cond.to(dev)).clone()
+        assert rel_err(y, y_ref) < 1e-4
+        eng.backward(gout.to(dev))
+        assert rel_err(eng.gx_view(), gx_ref) < TOL_GRAD
+        compare_param_grads(model, eng.flat, ref)
+        grads[mode] = eng.flat.grad.detach().cpu().clone()
+    assert rel_err(grads["1"], grads["0"]) < 1e-5
+
+
 def check_autograd_bridge(dev):
     """model(x, labels) under torch autograd: loss.backward() fills p.grad and x.grad via the HIP backward program."""
     from score_sde_pytorch_amd.models import utils as mutils

@@ -62,7 +62,9 @@ def test_winograd_kernels_own_m0_and_keep_scratch_out_of_the_loop(src, kernel, t
         scratch = [l.strip() for l in loop if re.match(r"\s+scratch_", l)]
         assert not scratch, (sym, scratch[:4])
     spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", isa)]
-    assert max(spills) <= 16, spills
+    # (outside the loop: set-up and the two-round epilogue; the training-forward instantiations that also store the transformed
+    #  input -- kEmitV -- carry two more live values through the epilogue)
+    assert max(spills) <= 24, spills
 
 
 def _regs(text):

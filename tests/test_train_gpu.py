@@ -138,3 +138,7 @@ def test_generic_loss_closures_run_the_hip_loss_head():
 
 def test_1x1_weight_gradients_pipelined_and_chunked():
     T.check_wgrad_1x1("cuda")
+
+
+def test_weight_gradient_fed_by_the_forward_launch(monkeypatch):
+    T.check_wino_v_from_forward("cuda", monkeypatch)
