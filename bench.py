@@ -799,6 +799,11 @@ def main():
         # SSDE_MATRIX=bf16x6 (opt-in): the GEMM-shaped kernels on the BF16 matrix pipe through a 3-way split of both
         # operands (exact products, fp32 accumulation; error table in profiles/r4_bf16_split_error_budget.txt).  The headline
         # `value` above stays on the fp32-MFMA kernels; this is the same sampler / training step measured in the same run.
+        # (the fp32 sampler is measured again right before it: minutes into the run the device is warmer than for the headline)
+        ra, ea, ma, _, _ = bench_pc(args, "ve/cifar10_ncsnpp_continuous", args.batch, args.sde_steps, dev, dist, world, rank,
+                                    args.steps, args.warmup, False)
+        del ea, ma
+        torch.cuda.empty_cache()
         os.environ["SSDE_MATRIX"] = "bf16x6"
         try:
             rb, eb, mb, _, _ = bench_pc(args, "ve/cifar10_ncsnpp_continuous", args.batch, args.sde_steps, dev, dist, world, rank,
@@ -807,7 +812,9 @@ def main():
             torch.cuda.empty_cache()
             mx = {"dtype": "f32 via 3-way bf16 split on the BF16 matrix pipe (1x1 / NIN / Linear GEMMs), fp32 accumulate; 3x3 convolutions "
                            "and attention on the fp32-MFMA kernels",
-                  "sampler": {k: rb[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "state_finite")}}
+                  "sampler": {k: rb[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "state_finite")},
+                  "sampler_f32_measured_just_before": {k: ra[k] for k in ("value", "unit", "ms_per_step")},
+                  "sampler_speedup_over_f32": rb["value"] / ra["value"]}
             if not args.no_train:
                 a2 = argparse.Namespace(**vars(args))
                 a2.no_roofline = True
