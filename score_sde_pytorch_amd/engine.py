@@ -320,6 +320,35 @@ def pack_wino4_weight(w):
     return full.reshape(nt, 2, 32, c4, 4, 9, 4).permute(3, 0, 6, 1, 5, 2, 4).contiguous()
 
 
+def split3_bf16(t):
+    """fp32 tensor -> three int16 tensors of bf16 bit patterns whose values sum to t exactly: the top 16 bits of t, of the
+    remainder, and of what is left (at most 8 significant bits) -- ssde_split3 of csrc/ssde_common.h in torch."""
+    t = t.contiguous().to(torch.float32)
+    mask = torch.tensor(-65536, dtype=torch.int32, device=t.device)           # 0xFFFF0000
+    out, r = [], t
+    for _ in range(3):
+        hi = (r.view(torch.int32) & mask)
+        out.append((hi >> 16).to(torch.int16))
+        r = r - hi.view(torch.float32)
+    return out
+
+
+def pack_wino4x_weight(w):
+    """[Cout, Cin, 3, 3] -> the F(4x4,3x3) weights of pack_wino4_weight as three bf16 pieces per element, the LDS image
+    conv_wino4x.hip reads (SSDE_TILE_WINOGRAD4X): [ceil(Cin/4)][ceil(Cout/64)][8 waves][9][32 couts][3 pieces][4 channels] bf16,
+    returned as a float32 tensor of the same bytes (6 floats per (position, cout))."""
+    cout, cin = w.shape[0], w.shape[1]
+    G = _WINO4_G.to(w.device)
+    u = torch.einsum("ak,ockl,bl->ocab", G, w.detach().to(torch.float64), G).to(torch.float32)     # [Cout, Cin, 6, 6]
+    c4, nt = (cin + 3) // 4, (cout + 63) // 64
+    full = torch.zeros(nt * 64, c4 * 4, 36, dtype=torch.float32, device=w.device)
+    full[:cout, :cin] = u.reshape(cout, cin, 36)
+    pieces = torch.stack(split3_bf16(full))                                   # [3, nt*64, c4*4, 36] int16
+    # [piece, nt, h, cl, c4, e, j, q] -> [c4, nt, q, h, j, cl, piece, e]
+    img = pieces.reshape(3, nt, 2, 32, c4, 4, 9, 4).permute(4, 1, 7, 2, 6, 3, 0, 5).contiguous()
+    return img.view(torch.float32)
+
+
 def pack_matrix(w):
     """[Cout, Cin] (nn.Linear / 1x1 conv orientation) -> [ceil(Cin/8)][roundup(Cout,64)][8]."""
     return pack_conv_weight(w.reshape(w.shape[0], w.shape[1], 1, 1))

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/train_pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras --train-steps 2"
+BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras --train-steps 2 --train-warmup 1"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o bench --output-format csv -- $BENCH > $OUT/pmc_$C.log 2>&1
   echo "pmc $C rc=$?"
