@@ -104,7 +104,10 @@ enum { SSDE_TILE_AUTO = 0, SSDE_TILE_256x64 = 1, SSDE_TILE_128x64 = 2, SSDE_TILE
        SSDE_TILE_WINOGRAD = 5,
        /* Winograd F(4x4,3x3) kernel (3x3, stride 1, pad 1, output a multiple of 4, no aux): w_main packed as
         * [ceil(Cin/4)][ceil(Cout/64)][36 positions][64 couts][4 channels], G g G^T with the 6x3 G of F(4,3) */
-       SSDE_TILE_WINOGRAD4 = 6 };
+       SSDE_TILE_WINOGRAD4 = 6,
+       /* the same on the BF16 matrix pipe (exact-fp32 products of a 3-way bf16 split, conv_wino4x.hip): w_main packed as
+        * [ceil(Cin/4)][ceil(Cout/64)][8 waves][9][32 couts][3 pieces][4 channels] bf16; inference launches only */
+       SSDE_TILE_WINOGRAD4X = 7 };
 
 /* ---- GroupNorm statistics: mean / rstd per (sample, group) -----------------
  * replaces the reduction half of nn.GroupNorm(min(C/4,32), C, eps=1e-6)

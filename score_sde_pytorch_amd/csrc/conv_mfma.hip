@@ -563,6 +563,7 @@ unsigned* ssde_conv_sync_slots(int need) {
 extern "C" int ssde_conv2d(const ssde_conv_args* a, void* stream) {
   if (a && a->tile == SSDE_TILE_WINOGRAD) return ssde_conv_wino_launch(a, stream, nullptr);
   if (a && a->tile == SSDE_TILE_WINOGRAD4) return ssde_conv_wino4_launch(a, stream, nullptr);
+  if (a && a->tile == SSDE_TILE_WINOGRAD4X) return ssde_conv_wino4x_launch(a, stream, nullptr);
   if (a && a->dst && ssde_conv1x1_wants(a)) return ssde_conv1x1_launch(a, stream, nullptr);   // 1x1-only: GEMM kernel (conv1x1.hip)
   ConvPlan pl;
   if (int rc = make_plan(a, &pl)) return rc;
@@ -581,9 +582,10 @@ extern "C" int ssde_conv_gn_slices(const ssde_conv_args* a) {
   if (!a || a->c_out % 4 != 0) return 0;
   ssde_conv_args q = *a;
   q.gn_part = nullptr;
-  if (q.tile == SSDE_TILE_WINOGRAD || q.tile == SSDE_TILE_WINOGRAD4) {
+  if (q.tile == SSDE_TILE_WINOGRAD || q.tile == SSDE_TILE_WINOGRAD4 || q.tile == SSDE_TILE_WINOGRAD4X) {
     int s = 0;
-    if ((q.tile == SSDE_TILE_WINOGRAD ? ssde_conv_wino_launch : ssde_conv_wino4_launch)(&q, reinterpret_cast<void*>(1), &s)) return 0;     // plan-only query form
+    auto fn = q.tile == SSDE_TILE_WINOGRAD ? ssde_conv_wino_launch : q.tile == SSDE_TILE_WINOGRAD4 ? ssde_conv_wino4_launch : ssde_conv_wino4x_launch;
+    if (fn(&q, reinterpret_cast<void*>(1), &s)) return 0;     // plan-only query form
     return s;
   }
   if (q.dst && ssde_conv1x1_wants(&q)) {
@@ -599,9 +601,10 @@ extern "C" int ssde_conv_gn_slices(const ssde_conv_args* a) {
 }
 
 extern "C" int ssde_conv_lds_bytes(const ssde_conv_args* a) {
-  if (a && (a->tile == SSDE_TILE_WINOGRAD || a->tile == SSDE_TILE_WINOGRAD4)) {
+  if (a && (a->tile == SSDE_TILE_WINOGRAD || a->tile == SSDE_TILE_WINOGRAD4 || a->tile == SSDE_TILE_WINOGRAD4X)) {
     int lds = 0;
-    if (int rc = (a->tile == SSDE_TILE_WINOGRAD ? ssde_conv_wino_launch : ssde_conv_wino4_launch)(a, nullptr, &lds)) return rc;
+    auto fn = a->tile == SSDE_TILE_WINOGRAD ? ssde_conv_wino_launch : a->tile == SSDE_TILE_WINOGRAD4 ? ssde_conv_wino4_launch : ssde_conv_wino4x_launch;
+    if (int rc = fn(a, nullptr, &lds)) return rc;
     return lds;
   }
   if (a && a->dst && ssde_conv1x1_wants(a)) {

@@ -395,9 +395,12 @@ class WeightStore:
         cout_l, cin_l = max(param.shape[0], cout_pad or 0), max(param.shape[1], cin_pad or 0)
         meta = dict(kind="conv3", sources=[param], logical=logical, dims=(cout_l, cin_l),
                     parts=[dict(param=param, row0=0, rows=param.shape[0], transpose=False)], cin_store=param.shape[1])
-        pack = pack_wino4_weight if wino == 4 else pack_wino_weight if wino else pack_conv_weight
-        recipe = [dict(kind=L.PACK_WINO4 if wino == 4 else L.PACK_WINO3 if wino else L.PACK_CONV3, src=param, cout=param.shape[0], cin=param.shape[1],
-                       cout_l=cout_l, cin_l=cin_l, flags=0, n="dst")]
+        # wino 5 = F(4x4,3x3) on the BF16 matrix pipe (conv_wino4x.hip): three bf16 pieces per element, packed in torch (no
+        # device re-pack recipe: inference programs, the weights change on checkpoint loads only)
+        pack = pack_wino4x_weight if wino == 5 else pack_wino4_weight if wino == 4 else pack_wino_weight if wino else pack_conv_weight
+        recipe = None if wino == 5 else \
+            [dict(kind=L.PACK_WINO4 if wino == 4 else L.PACK_WINO3 if wino else L.PACK_CONV3, src=param, cout=param.shape[0], cin=param.shape[1],
+                  cout_l=cout_l, cin_l=cin_l, flags=0, n="dst")]
         return self.add([param], lambda w: pack(logical(w)), meta, recipe)
 
     def matrix(self, parts, cin_pad=None):
@@ -625,7 +628,7 @@ class Lowering:
         split_tmp = None
         if wino:
             assert main is not None and stride == 1 and pad == 1 and (h_in, w_in) == (h_out, w_out)
-            tile = L.TILE_WINOGRAD4 if wino == 4 else L.TILE_WINOGRAD
+            tile = L.TILE_WINOGRAD4X if wino == 5 else L.TILE_WINOGRAD4 if wino == 4 else L.TILE_WINOGRAD
             if aux is not None:
                 split_tmp = self.b.buf(self.n, h_out, w_out, c_out, name="wino_tmp")
         px = self.n * h_out * w_out
@@ -673,6 +676,15 @@ class Lowering:
         a.cin_store, a.transpose_out = meta["cin_store"], 0
         return bool(L.load().ssde_wgrad_wants_winograd4(C.byref(a)))
 
+    def _wino4x_on(self):
+        """F(4x4,3x3) on the BF16 matrix pipe (conv_wino4x.hip) instead of conv_wino4.hip: inference programs, and only on
+        request -- SSDE_MATRIX=bf16x6 together with SSDE_WINO4X=1.  Its first version is parity-green but 6-13 % SLOWER than the
+        fp32 kernel (profiles/r4_wino4x_v1.txt: the matrix time halves, the per-position issue work -- five fragment reads, the
+        operand copies, the masked LDS-DMA piece -- and the transform phases do not), so the bf16x6 mode keeps the fp32 kernel."""
+        import os
+        return bool(getattr(self, "allow_wino4x", False)) and os.environ.get("SSDE_MATRIX", "").startswith("b") and \
+            os.environ.get("SSDE_WINO4X", "0") == "1"
+
     def wino_ok(self, h, w, c_out, c_in):
         """Which 3x3 / stride 1 kernel a layer gets: 0 = direct, 2 = Winograd F(2x2,3x3), 4 = F(4x4,3x3).
         Winograd pays when the matrix pipe is the bound: enough channels to fill the 64-cout tile, and enough workgroups
@@ -691,13 +703,13 @@ class Lowering:
         legal2 = h % 2 == 0 and w % 2 == 0 and h >= 8 and w >= 8 and c_out >= 32 and c_in >= 8 and c_in % 8 == 0
         legal4 = h % 4 == 0 and w % 4 == 0 and h >= 8 and w >= 8 and c_out >= 32 and c_in >= 8 and c_in % 4 == 0
         if mode == "4" and legal4:
-            return 4
+            return 5 if self._wino4x_on() else 4
         if mode == "2" or mode == "4":
             return 2 if legal2 else 0
         n_tiles = -(-c_out // 64)
         # (one workgroup per CU: F(4x4,3x3) workgroups own a whole CU's LDS and registers)
         if mode != "3" and legal4 and h >= 16 and w >= 16 and -(-(self.n * h * w) // 512) * n_tiles >= self.cus:
-            return 4
+            return 5 if self._wino4x_on() else 4
         # Fewer tiles than that (8x8 maps at batch 256: 128 tiles of 8 images x 64 couts): the kernel splits its reduction
         # over 2 or 4 workgroups per tile (conv_wino4.hip, ssde_conv_wino4_splits -- the same rule).  Measured
         # (profiles/r3_wino4_split_reduction_ab.txt): 17-40 % over the unsplit kernel, but only level with F(2x2,3x3) on
@@ -749,6 +761,7 @@ class UNetEngine:
         # a training program with parameter gradients (backward.TrainEngine sets param_grads before lowering): the forward
         # F(4x4,3x3) launches leave their transformed input behind for the weight gradients
         self.low.emit_wino_v = bool(getattr(self, "param_grads", False))
+        self.low.allow_wino4x = type(self) is UNetEngine and not train and not input_grad
         self.channels = model.channels
         # static I/O (addresses are baked into the program / graph)
         self.x_in = self.b.buf(batch, self.channels, height, width, name="x_in", persistent=True)

@@ -1211,7 +1211,7 @@ def check_conv_split_reduction(dev, monkeypatch, n, repeats=3):
             assert (m2 - mr).abs().max().item() < 1e-5 and ((r2 - rr).abs() / rr).max().item() < 1e-4
 
 
-def check_conv_winograd4(dev, big=False):
+def check_conv_winograd4(dev, big=False, split=False):
     """conv_wino4.hip (F(4x4,3x3)): plain convolutions over the tilings it knows (part of one image, several whole
     images, ragged batch tails, cout tiles that are not full), then the fully fused form (concat source, GroupNorm + SiLU
     prologue, bias, per-image addend, residual, scale, GroupNorm partials of the result) against torch.  Tolerance 2e-5:
@@ -1220,7 +1220,11 @@ def check_conv_winograd4(dev, big=False):
     import numpy as np
     import torch.nn.functional as F
     from score_sde_pytorch_amd import hipops as ops, _lib as L
-    from score_sde_pytorch_amd.engine import pack_wino4_weight
+    from score_sde_pytorch_amd.engine import pack_wino4_weight, pack_wino4x_weight
+    # split=True: the same cases on conv_wino4x.hip (BF16 matrix pipe, 3-way bf16 split of both operands), tolerances unchanged
+    TILE = L.TILE_WINOGRAD4X if split else L.TILE_WINOGRAD4
+    if split:
+        pack_wino4_weight = pack_wino4x_weight
     lib = L.load()
     g = torch.Generator().manual_seed(2)
     # (>= 128 / 256 input channels and few workgroups: the reduction is split over two / four workgroups per tile, checked
@@ -1236,7 +1240,7 @@ def check_conv_winograd4(dev, big=False):
         for ksplit in (("1", "0") if cin >= 128 else ("1",)):
             os.environ["SSDE_CONV_KSPLIT"] = ksplit
             try:
-                y = ops.conv2d(x.permute(0, 2, 3, 1).contiguous().to(dev), w.to(dev), b.to(dev), tile=L.TILE_WINOGRAD4)
+                y = ops.conv2d(x.permute(0, 2, 3, 1).contiguous().to(dev), w.to(dev), b.to(dev), tile=TILE)
             finally:
                 del os.environ["SSDE_CONV_KSPLIT"]
             assert _util.rel_err(y.cpu().permute(0, 3, 1, 2), ref) < 2e-5, (n, cin, cout, h, ksplit)
@@ -1260,7 +1264,7 @@ def check_conv_winograd4(dev, big=False):
         wp, bd, cad, rd = pack_wino4_weight(w.to(dev)), b.to(dev), ca.to(dev), resid.to(dev)
         dst = torch.full((n, h, h, cout), float("nan"), device=dev)
         a.w_main, a.ksize, a.stride, a.pad, a.h_in, a.w_in = wp.data_ptr(), 3, 1, 1, h, h
-        a.n, a.h_out, a.w_out, a.c_out, a.out_scale, a.dst, a.tile = n, h, h, cout, 0.7, dst.data_ptr(), L.TILE_WINOGRAD4
+        a.n, a.h_out, a.w_out, a.c_out, a.out_scale, a.dst, a.tile = n, h, h, cout, 0.7, dst.data_ptr(), TILE
         a.bias, a.chan_add, a.chan_add_ld, a.resid = bd.data_ptr(), cad.data_ptr(), cout, rd.data_ptr()
         sl = lib.ssde_conv_gn_slices(C.byref(a))
         assert sl > 0

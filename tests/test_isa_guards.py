@@ -51,7 +51,8 @@ def _main_loop(body):
     return lines[best[0]:best[1] + 1]
 
 
-@pytest.mark.parametrize("src,kernel", [("conv_wino4.hip", "conv_wino4_kernel"), ("conv_wino.hip", "conv_wino_kernel")])
+@pytest.mark.parametrize("src,kernel", [("conv_wino4.hip", "conv_wino4_kernel"), ("conv_wino.hip", "conv_wino_kernel"),
+                                        ("conv_wino4x.hip", "conv_wino4x_kernel")])
 def test_winograd_kernels_own_m0_and_keep_scratch_out_of_the_loop(src, kernel, tmp_path):
     isa = _isa(src, tmp_path)
     for sym, body in _kernels(isa, kernel):

@@ -142,3 +142,7 @@ def test_1x1_weight_gradients_pipelined_and_chunked():
 
 def test_weight_gradient_fed_by_the_forward_launch(monkeypatch):
     T.check_wino_v_from_forward("cuda", monkeypatch)
+
+
+def test_conv3x3_winograd_f4x4_on_the_bf16_matrix_pipe():
+    T.check_conv_winograd4("cuda", big=True, split=True)

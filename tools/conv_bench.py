@@ -11,7 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from score_sde_pytorch_amd import hipops as ops, _lib as L  # noqa: E402
-from score_sde_pytorch_amd.engine import pack_conv_weight, pack_wino_weight, pack_wino4_weight  # noqa: E402
+from score_sde_pytorch_amd.engine import pack_conv_weight, pack_wino_weight, pack_wino4_weight, pack_wino4x_weight  # noqa: E402
 
 
 def time_conv(n, cin, cout, h, tile, gn=False, reps=5, resid=False):
@@ -25,7 +25,7 @@ def time_conv(n, cin, cout, h, tile, gn=False, reps=5, resid=False):
         mean, rstd = ops.groupnorm_stats(x, G, 1e-6)
         gnt = (mean, rstd, torch.ones(cin, device=dev), torch.zeros(cin, device=dev), G)
     ops._fill_src(a.main, x, None, {0: L.PRO_NONE, 1: L.PRO_GN_SILU, 2: L.PRO_GN, 3: L.PRO_SILU}[int(gn)], gnt)
-    wp = {L.TILE_WINOGRAD: pack_wino_weight, L.TILE_WINOGRAD4: pack_wino4_weight}.get(tile, pack_conv_weight)(w)
+    wp = {L.TILE_WINOGRAD: pack_wino_weight, L.TILE_WINOGRAD4: pack_wino4_weight, L.TILE_WINOGRAD4X: pack_wino4x_weight}.get(tile, pack_conv_weight)(w)
     dst = torch.empty(n, h, h, cout, device=dev)
     if resid:
         rs = torch.randn(n, h, h, cout, device=dev)

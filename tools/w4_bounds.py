@@ -14,4 +14,7 @@ if __name__ == "__main__":
     for cin, cout, h in [(128, 128, 32), (256, 128, 32), (256, 256, 16), (512, 256, 16), (384, 128, 32)]:
         tf, ms = cb.time_conv(n, cin, cout, h, L.TILE_WINOGRAD4, 1, reps=10)
         out.append("%d->%d@%d %.4f ms (%.0f TF/s)" % (cin, cout, h, ms, tf))
+        if os.environ.get("W4_BOUNDS_SPLIT"):                      # + the bf16-split kernel (conv_wino4x.hip)
+            tf, ms = cb.time_conv(n, cin, cout, h, L.TILE_WINOGRAD4X, 1, reps=10)
+            out[-1] += " ; bf16 split %.4f ms (%.0f TF/s)" % (ms, tf)
     print(os.path.basename(os.environ.get("SSDE_LIB_PATH", "product")), " | ".join(out), flush=True)
