@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSDE_ABI_VERSION 6   /* 6: ssde_conv_args.wino_v / ssde_wgrad_args.v_pre (forward by-product feeds the weight gradient); 5: SSDE_PACK_WINO4 image re-ordered per wave (plan blobs of version 4 carry the old image), ODE ops in programs */
+#define SSDE_ABI_VERSION 7   /* 7: ssde_gn_bwd_reduce_args.g0 / g1 (GroupNorm backward in one pass over dp and x); 6: ssde_conv_args.wino_v / ssde_wgrad_args.v_pre (forward by-product feeds the weight gradient); 5: SSDE_PACK_WINO4 image re-ordered per wave (plan blobs of version 4 carry the old image), ODE ops in programs */
 
 /* ---- prologue applied to a source tensor while it is staged into LDS ---- */
 enum {
@@ -304,6 +304,14 @@ typedef struct ssde_gn_bwd_reduce_args {
   float* dgamma; float* dbeta;   /* [c0+c1] written (not accumulated) */
   float* scratch;          /* >= N*slices*(G*2 + C*2) floats */
   int32_t slices; int32_t _pad0;
+  /* ABI 7, optional: with g0 or g1 set the call also applies the formula (what ssde_prologue_bwd would do with dp_ld = c0+c1,
+   * dp_off = 0): where one sample's run of whole groups fits the registers of a workgroup (hw <= 8192 at 4 channels per
+   * group) dp and x are read ONCE by a single kernel that reduces and applies; elsewhere the call runs the reduction, the
+   * finalize and the apply kernel one after the other.  `sums` may then be NULL unless the three-kernel path is taken
+   * (callers that cannot know pass it). */
+  float* g0; float* g1;    /* gradients of p0 [N*hw, c0] and p1 [N*hw, c1] (NULL: that source needs no gradient) */
+  int32_t acc0, acc1;      /* 1: g += ..., 0: g = ... */
+  float scale; int32_t _pad1;
 } ssde_gn_bwd_reduce_args;
 
 typedef struct ssde_prologue_bwd_args {

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SSDE_LIB_PATH: developer switch for A/B timing of kernel variants built by _build.build_variant (tools/ab_bench.sh)
 LIB_PATH = os.environ.get("SSDE_LIB_PATH") or os.path.join(_HERE, "libssde_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_SILU = 0, 1, 2, 3
 TILE_AUTO, TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32, TILE_WINOGRAD, TILE_WINOGRAD4, TILE_WINOGRAD4X = 0, 1, 2, 3, 4, 5, 6, 7
@@ -163,7 +163,8 @@ class ColsumArgs(C.Structure):
 
 class GnBwdReduceArgs(C.Structure):
     _fields_ = [("src", Src), ("dp", _fp), ("n", C.c_int32), ("hw", C.c_int32), ("sums", _fp),
-                ("dgamma", _fp), ("dbeta", _fp), ("scratch", _fp), ("slices", C.c_int32), ("_pad0", C.c_int32)]
+                ("dgamma", _fp), ("dbeta", _fp), ("scratch", _fp), ("slices", C.c_int32), ("_pad0", C.c_int32),
+                ("g0", _fp), ("g1", _fp), ("acc0", C.c_int32), ("acc1", C.c_int32), ("scale", C.c_float), ("_pad1", C.c_int32)]
 
 
 class PrologueBwdArgs(C.Structure):

@@ -233,8 +233,11 @@ class TrainEngine(E.UNetEngine):
         ctot = src["c0"] + src["c1"]
         e0 = self._gentry(src["p0"]) if self._needs(src["p0"]) else None
         e1 = self._gentry(src["p1"]) if self._needs(src["p1"]) else None
-        sums = None
-        if src["pro_mode"] in (L.PRO_GN, L.PRO_GN_SILU) and (e0 is not None or e1 is not None or self.param_grads):
+        if src["pro_mode"] in (L.PRO_GN, L.PRO_GN_SILU):
+            if e0 is None and e1 is None and not self.param_grads:
+                return
+            # ONE op: reduction, dgamma / dbeta and (with g0 / g1) the gradient of the sources; the library reads dp and x
+            # once where a sample's run of groups fits a workgroup's registers (backward.hip, gn_bwd_fused_kernel)
             groups = src["gn_groups"]
             sums = b.buf(n, groups, 2, name="gn_bwd_sums")
             slices = max(1, min(int(math.ceil(256 / n)), hw // 64)) if hw >= 128 else 1
@@ -244,12 +247,15 @@ class TrainEngine(E.UNetEngine):
                                            else b.buf(ctot, name="dgamma_unused"),
                                            dbeta=self.flat.grad_view(self._param_of(src["gn_beta"])) if self.param_grads
                                            else b.buf(ctot, name="dbeta_unused"),
-                                           scratch=scratch, slices=slices), FC_BWD)
-        if e0 is None and e1 is None:
-            return
-        b.add(L.OP_PROLOGUE_BWD, dict(src=src, dp=dP, dp_ld=ctot, dp_off=0, n=n, hw=hw, sums=sums, scale=1.0,
-                                      acc0=int(e0[1]) if e0 else 0, acc1=int(e1[1]) if e1 else 0,
-                                      g0=e0[0] if e0 else None, g1=e1[0] if e1 else None), FC_BWD)
+                                           scratch=scratch, slices=slices,
+                                           g0=e0[0] if e0 else None, g1=e1[0] if e1 else None,
+                                           acc0=int(e0[1]) if e0 else 0, acc1=int(e1[1]) if e1 else 0, scale=1.0), FC_BWD)
+        else:
+            if e0 is None and e1 is None:
+                return
+            b.add(L.OP_PROLOGUE_BWD, dict(src=src, dp=dP, dp_ld=ctot, dp_off=0, n=n, hw=hw, sums=None, scale=1.0,
+                                          acc0=int(e0[1]) if e0 else 0, acc1=int(e1[1]) if e1 else 0,
+                                          g0=e0[0] if e0 else None, g1=e1[0] if e1 else None), FC_BWD)
         if e0:
             e0[1] = True
         if e1:

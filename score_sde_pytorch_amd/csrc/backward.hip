@@ -270,11 +270,11 @@ __global__ __launch_bounds__(kGbThreads) void gn_bwd_reduce_kernel(const GbParam
 // role A (blockIdx.y == 0): sums[n][g] = (mean_g dxh, mean_g dxh*xhat), dxh = du*gamma; one thread per (n, g)
 // role B (blockIdx.y == 1): dgamma[c], dbeta[c] = sum over samples and slices; block = 32 channels x 8 (sample,slice)
 //                            lanes + an LDS tree (a serial loop over 128 samples x slices was 45 us of latency)
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const GbParams p) {
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const GbParams p, const int role0) {
   SSDE_LDS(smem);                                        // [2][8][32]
   const ssde_src& s = p.src;
   const int C = s.c0 + s.c1, G = s.gn_groups, cpg = C / G;
-  if (blockIdx.y == 0) {
+  if ((int)blockIdx.y + role0 == 0) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.n * G) return;
     const int n = idx / G, g = idx % G;
@@ -306,6 +306,150 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const GbParams p) 
       for (int k = 0; k < 8; ++k) { tg += smem[k * 32 + cl]; tb += smem[256 + k * 32 + cl]; }
       p.dgamma[c] = tg;
       p.dbeta[c] = tb;
+    }
+  }
+}
+
+// ---- GroupNorm backward in ONE pass over dp and x (ABI 7: ssde_gn_bwd_reduce_args.g0 / g1) -------------------------------
+// The reduction above and prologue_bwd_kernel below each read dp and x once: five tensor passes and three launches per
+// GroupNorm.  A (sample, group) is small -- 32x32 pixels x 4 channels is 16 KB per tensor -- so a 1024-thread workgroup
+// that owns one sample and a run of whole groups keeps its share of BOTH tensors in registers (<= 8 pixels x one channel
+// quad of dp and x per thread = 64 registers, 256 KB per workgroup), reduces the two per-channel sums through LDS in a
+// fixed order, and applies  dx = rstd (du gamma - A - xhat B)  to the values it still holds: dp and x are read once, three
+// tensor passes (four where the gradient accumulates) and one launch; the per-channel sums go to scratch[n][C][2] for the
+// dgamma / dbeta role of gn_bwd_finalize_kernel.  Maps whose (sample, group) does not fit (hw > 8192 at 4 channels per
+// group: the 128x128 and 256x256 levels of FFHQ) stay on the three-kernel path.
+constexpr int kGfMaxThreads = 1024, kGfR = 8;
+constexpr int kGfMaxClc = 256;                      // channel quads per workgroup (>= 4 pixel lanes)
+constexpr int kGfNxt = kGfMaxThreads + 8 * kGfMaxClc;  // floats of the second reduction area: ceil(PL / 8) rows of 8 clc values
+
+struct GfParams {
+  GbParams b; int acc0, acc1; float* g0; float* g1; float scale;
+  int gpc, clc, pl;      // groups per workgroup, channel quads per workgroup (= gpc * cpg / 4), pixel lanes (= 1024 / clc)
+};
+
+template <int kGfThreads>
+__global__ __launch_bounds__(kGfThreads, 4) void gn_bwd_fused_kernel(const GfParams p) {
+  SSDE_LDS(smem);                                     // [1024][8] partial sums | [<= 1024 + 64][8 clc / clc] | group sums
+  const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const ssde_src& s = p.b.src;
+  const int C = s.c0 + s.c1, G = s.gn_groups, cpg = C / G, hw = p.b.hw;
+  const int CLc = p.clc, PL = p.pl, T = CLc * 8;
+  const SsdePro pro = ssde_pro_decode(s);
+  const int cl = tid % CLc, pl = tid / CLc;
+  const int ch0 = chunk * p.gpc * cpg, ch = ch0 + cl * 4;
+  const bool live = pl < PL && ch < C;
+  const bool first = ch < s.c0;
+  const int Cs = first ? s.c0 : s.c1, cc = first ? ch : ch - s.c0;
+  const float* xsrc = (first ? s.p0 : s.p1) + cc;
+  float* gdst = first ? p.g0 : p.g1;
+  const bool acc = first ? p.acc0 : p.acc1;
+  float gm[4] = {0.f, 0.f, 0.f, 0.f}, bt[4] = {0.f, 0.f, 0.f, 0.f};
+  float mu = 0.f, rs = 0.f;
+  if (live) {
+    const float4 gam = *reinterpret_cast<const float4*>(s.gn_gamma + ch);
+    const float4 bet = *reinterpret_cast<const float4*>(s.gn_beta + ch);
+    gm[0] = gam.x; gm[1] = gam.y; gm[2] = gam.z; gm[3] = gam.w;
+    bt[0] = bet.x; bt[1] = bet.y; bt[2] = bet.z; bt[3] = bet.w;
+    mu = s.gn_mean[n * G + ch / cpg]; rs = s.gn_rstd[n * G + ch / cpg];
+  }
+  // every load of the thread in flight before the first use
+  float4 dv[kGfR], xv[kGfR];
+#pragma unroll
+  for (int r = 0; r < kGfR; ++r) {
+    const int px = pl + r * PL;
+    dv[r] = make_float4(0.f, 0.f, 0.f, 0.f); xv[r] = dv[r];
+    if (live && px < hw) {
+      const size_t pix = (size_t)n * hw + px;
+      dv[r] = *reinterpret_cast<const float4*>(p.b.dp + pix * C + ch);
+      xv[r] = *reinterpret_cast<const float4*>(xsrc + pix * Cs);
+    }
+  }
+  // du = dp * keep * silu'(u) and xhat replace dp and x in the registers
+  float a1[4] = {0.f, 0.f, 0.f, 0.f}, a0[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < kGfR; ++r) {
+    const int px = pl + r * PL;
+    if (!(live && px < hw)) continue;
+    const uint32_t pix = (uint32_t)n * (uint32_t)hw + (uint32_t)px;
+    float d[4] = {dv[r].x, dv[r].y, dv[r].z, dv[r].w}, x[4] = {xv[r].x, xv[r].y, xv[r].z, xv[r].w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xh = (x[k] - mu) * rs;
+      float du = d[k];
+      if (pro.silu) du *= ssde_silu_grad(xh * gm[k] + bt[k]);
+      if (pro.drop) du *= ssde_keep(pix * (uint32_t)C + (uint32_t)(ch + k), pro);
+      a1[k] += du * xh;
+      a0[k] += du;
+      d[k] = du; x[k] = xh;
+    }
+    dv[r] = make_float4(d[0], d[1], d[2], d[3]); xv[r] = make_float4(x[0], x[1], x[2], x[3]);
+  }
+  // rows = pixel lanes, T = 8 clc values per row (S1[4], S0[4] of every channel quad); eight rows per thread and round,
+  // the grouping depends on (PL, T) only
+  float* cur = smem;
+  float* nxt = smem + kGfThreads * 8;
+  if (pl < PL) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { cur[pl * T + cl * 8 + k] = a1[k]; cur[pl * T + cl * 8 + 4 + k] = a0[k]; }
+  }
+  __syncthreads();
+  int rows = PL;
+  while (rows > 1) {
+    const int J = (rows + 7) >> 3;
+    for (int t = tid; t < J * T; t += kGfThreads) {
+      const int j = t / T, v = t - j * T;
+      float a = 0.f;
+      for (int r = j; r < rows; r += J) a += cur[r * T + v];
+      nxt[t] = a;
+    }
+    __syncthreads();
+    float* sw = cur; cur = nxt; nxt = sw;
+    rows = J;
+  }
+  // cur[q * 8 + k] = S1 = sum du xhat, cur[q * 8 + 4 + k] = S0 = sum du of channel ch0 + 4 q + k
+  float* gsum = smem + kGfThreads * 8 + kGfNxt;                    // behind both ping-pong areas
+  if (tid < CLc * 4 && ch0 + tid < C) {
+    const int q = tid >> 2, k = tid & 3;
+    *reinterpret_cast<float2*>(p.b.scratch + ((size_t)n * C + ch0 + tid) * 2) = make_float2(cur[q * 8 + k], cur[q * 8 + 4 + k]);
+  }
+  if (tid < p.gpc && chunk * p.gpc + tid < G) {
+    float A = 0.f, B = 0.f;
+    for (int c = 0; c < cpg; ++c) {
+      const int lc = tid * cpg + c;
+      const float g = s.gn_gamma[ch0 + lc];
+      B += g * cur[(lc >> 2) * 8 + (lc & 3)];
+      A += g * cur[(lc >> 2) * 8 + 4 + (lc & 3)];
+    }
+    const float inv = 1.0f / ((float)cpg * (float)hw);
+    gsum[tid * 2] = A * inv;
+    gsum[tid * 2 + 1] = B * inv;
+    if (p.b.sums) { p.b.sums[(n * G + chunk * p.gpc + tid) * 2] = A * inv; p.b.sums[(n * G + chunk * p.gpc + tid) * 2 + 1] = B * inv; }
+  }
+  __syncthreads();
+  if (!live || !gdst) return;
+  const float A = gsum[(cl * 4 / cpg) * 2], B = gsum[(cl * 4 / cpg) * 2 + 1];
+  constexpr int kB = 4;                                // rows whose old gradient is in flight together
+#pragma unroll
+  for (int r0 = 0; r0 < kGfR; r0 += kB) {
+    float4 old[kB];
+#pragma unroll
+    for (int b = 0; b < kB; ++b) {
+      const int px = pl + (r0 + b) * PL;
+      old[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (acc && px < hw) old[b] = *reinterpret_cast<const float4*>(gdst + ((size_t)n * hw + px) * Cs + cc);
+    }
+#pragma unroll
+    for (int b = 0; b < kB; ++b) {
+      const int r = r0 + b, px = pl + r * PL;
+      if (px >= hw) continue;
+      const float du[4] = {dv[r].x, dv[r].y, dv[r].z, dv[r].w}, xh[4] = {xv[r].x, xv[r].y, xv[r].z, xv[r].w};
+      float o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = rs * (du[k] * gm[k] - A - xh[k] * B) * p.scale;
+      float4 w = make_float4(o[0], o[1], o[2], o[3]);
+      if (acc) { w.x += old[b].x; w.y += old[b].y; w.z += old[b].z; w.w += old[b].w; }
+      *reinterpret_cast<float4*>(gdst + ((size_t)n * hw + px) * Cs + cc) = w;
     }
   }
 }
@@ -586,20 +730,72 @@ extern "C" int ssde_colsum(const ssde_colsum_args* a, void* stream) {
   return SSDE_OK;
 }
 
+// Shape of the one-pass kernel for (n, hw, C, G), or false: the largest run of whole groups whose pixels fit kGfR per
+// thread, narrowed while the launch has fewer than two workgroups per CU (the per-thread row count only falls).
+static bool gn_bwd_fused_shape(int kGfThreads, int n, int hw, int C, int G, int* gpc_out, int* clc_out, int* pl_out) {
+  const int cpg = C / G;
+  if (cpg % 4 != 0) return false;
+  int best = 0;
+  for (int gpc = G; gpc >= 1; --gpc) {
+    const int clc = gpc * cpg / 4;
+    if (clc > kGfMaxClc) continue;
+    const int pl = kGfThreads / clc;
+    if (ssde_cdiv(hw, pl) > kGfR) continue;
+    if (!best) best = gpc;
+    if ((long)n * ssde_cdiv(G, gpc) >= 2L * ssde_num_cus()) { best = gpc; break; }
+    best = gpc;
+  }
+  if (!best) return false;
+  *gpc_out = best; *clc_out = best * cpg / 4; *pl_out = kGfThreads / *clc_out;
+  return true;
+}
+
 extern "C" int ssde_gn_bwd_reduce(const ssde_gn_bwd_reduce_args* a, void* stream) {
-  SSDE_REQUIRE(a && a->dp && a->sums && a->dgamma && a->dbeta && a->scratch, "gn_bwd_reduce: null args");
+  SSDE_REQUIRE(a && a->dp && a->dgamma && a->dbeta && a->scratch, "gn_bwd_reduce: null args");
+  const bool apply = a->g0 || a->g1;
+  SSDE_REQUIRE(apply || a->sums, "gn_bwd_reduce: neither sums nor gradient destinations");
   if (int rc = src_ok(a->src, "gn_bwd_reduce", true)) return rc;
   SSDE_REQUIRE(a->src.pro_mode == SSDE_PRO_GN || a->src.pro_mode == SSDE_PRO_GN_SILU, "gn_bwd_reduce: source has no GroupNorm prologue");
   const int C = a->src.c0 + a->src.c1;
   SSDE_REQUIRE(C <= 4 * kGbThreads && a->n > 0 && a->hw > 0, "gn_bwd_reduce: bad shape");
+  SSDE_REQUIRE(!(a->g1 && a->src.c1 == 0), "gn_bwd_reduce: g1 without a second source");
   const int slices = a->slices > 0 ? a->slices : 1;
   GbParams p{a->src, a->dp, a->n, a->hw, slices, a->sums, a->dgamma, a->dbeta, a->scratch};
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const int bx_a = ssde_cdiv(a->n * a->src.gn_groups, 256), bx_b = ssde_cdiv(C, 32);
+  if (apply) {
+    // ABI 7: the gradient of the sources in the same call -- one pass where a (sample, run of groups) fits the registers
+    // of a workgroup (SSDE_GN_BWD_FUSED=0: always the three kernels, for A/B timing and the tests of both forms)
+    const char* env = getenv("SSDE_GN_BWD_FUSED");
+    // (512-thread workgroups, two per CU, measured slower: the step 0.0587 -> 0.0591 s, profiles/r4_gn_bwd_one_pass_ab.txt --
+    // a workgroup's rows shrink to 64-byte runs of 4 channel quads)
+    constexpr int nt = 1024;
+    int gpc = 0, clc = 0, pl = 0;
+    if (!(env && env[0] == '0') && (size_t)a->n * a->hw < (1ull << 31) &&
+        gn_bwd_fused_shape(nt, a->n, a->hw, C, a->src.gn_groups, &gpc, &clc, &pl)) {
+      GfParams f{p, a->acc0, a->acc1, a->g0, a->g1, a->scale, gpc, clc, pl};
+      f.b.slices = 1;                                   // scratch[n][C][2]
+      const dim3 grid(ssde_cdiv(a->src.gn_groups, gpc), a->n);
+      const size_t lds = (size_t)(nt * 8 + kGfNxt + 2 * kGfMaxClc) * sizeof(float);
+      hipLaunchKernelGGL(gn_bwd_fused_kernel<nt>, grid, dim3(nt), lds, st, f);
+      SSDE_LAUNCH_CHECK();
+      // dgamma / dbeta: role B of the finalize kernel only (grid.y == 1 with the role offset)
+      hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(bx_b, 1), dim3(256), 2 * 8 * 32 * 4, st, f.b, 1);
+      SSDE_LAUNCH_CHECK();
+      return SSDE_OK;
+    }
+    SSDE_REQUIRE(a->sums, "gn_bwd_reduce: the three-kernel path needs the sums buffer");
+  }
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(slices, a->n), dim3(kGbThreads), kGbThreads * 8 * 4, st, p);
   SSDE_LAUNCH_CHECK();
-  const int bx_a = ssde_cdiv(a->n * a->src.gn_groups, 256), bx_b = ssde_cdiv(C, 32);
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(bx_a > bx_b ? bx_a : bx_b, 2), dim3(256), 2 * 8 * 32 * 4, st, p);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(bx_a > bx_b ? bx_a : bx_b, 2), dim3(256), 2 * 8 * 32 * 4, st, p, 0);
   SSDE_LAUNCH_CHECK();
+  if (apply) {
+    ssde_prologue_bwd_args q{};
+    q.src = a->src; q.dp = a->dp; q.dp_ld = C; q.dp_off = 0; q.n = a->n; q.hw = a->hw; q.sums = a->sums; q.scale = a->scale;
+    q.acc0 = a->acc0; q.acc1 = a->acc1; q.g0 = a->g0; q.g1 = a->g1;
+    return ssde_prologue_bwd(&q, stream);
+  }
   return SSDE_OK;
 }
 

@@ -241,8 +241,11 @@ def colsum_slices(hw):
     return max(1, min(32, hw // 64))
 
 
-def gn_backward(x, dp, gn, pro, x2=None, dropout=None, slices=1, scale=1.0, acc=(False, False), want=(True, True)):
-    """GroupNorm(+SiLU)(+dropout) backward: returns (dx, dx2, dgamma, dbeta) for dp = d loss / d pro(x)."""
+def gn_backward(x, dp, gn, pro, x2=None, dropout=None, slices=1, scale=1.0, acc=(False, False), want=(True, True), one_call=True,
+                dx=None, dx2=None):
+    """GroupNorm(+SiLU)(+dropout) backward: returns (dx, dx2, dgamma, dbeta) for dp = d loss / d pro(x).
+    one_call: ssde_gn_bwd_reduce with its gradient destinations set (ABI 7: one pass over dp and x where the shape allows);
+    otherwise the reduction and ssde_prologue_bwd as two calls."""
     _need_cuda(x, dp)
     n = x.shape[0]
     hw = int(np.prod(x.shape[1:-1]))
@@ -256,9 +259,15 @@ def gn_backward(x, dp, gn, pro, x2=None, dropout=None, slices=1, scale=1.0, acc=
     dgamma, dbeta = torch.empty(ctot, device=x.device), torch.empty(ctot, device=x.device)
     scratch = torch.empty(n * slices * ctot * 2, device=x.device)
     r.dp, r.n, r.hw, r.sums, r.dgamma, r.dbeta, r.scratch, r.slices = _p(dp), n, hw, _p(sums), _p(dgamma), _p(dbeta), _p(scratch), slices
+    if dx is None:
+        dx = torch.zeros_like(x) if want[0] else None
+    if dx2 is None:
+        dx2 = torch.zeros_like(x2) if (x2 is not None and want[1]) else None
+    if one_call and (dx is not None or dx2 is not None):
+        r.g0, r.g1, r.acc0, r.acc1, r.scale = _p(dx), _p(dx2), int(acc[0]), int(acc[1]), scale
+        L.check(L.load().ssde_gn_bwd_reduce(C.byref(r), _stream()), "ssde_gn_bwd_reduce")
+        return dx, dx2, dgamma, dbeta
     L.check(L.load().ssde_gn_bwd_reduce(C.byref(r), _stream()), "ssde_gn_bwd_reduce")
-    dx = torch.zeros_like(x) if want[0] else None
-    dx2 = torch.zeros_like(x2) if (x2 is not None and want[1]) else None
     prologue_bwd(x, dp, pro, dx, dx2, x2=x2, gn=gn, sums=sums, dropout=dropout, scale=scale, acc=acc)
     return dx, dx2, dgamma, dbeta
 

@@ -138,11 +138,42 @@ def check_backward_ops(dev):
     F.silu(F.group_norm(torch.cat([x1, x2], 1), G, gamma, beta, 1e-6)).backward(dp)
     a1, a2 = d(nhwc(x1.detach())), d(nhwc(x2.detach()))
     mean, rstd = ops.groupnorm_stats(a1, G, 1e-6, x2=a2)
+    gn_t = (mean, rstd, d(gamma.detach()), d(beta.detach()), G)
     for slices in (1, 4):
-        dx, dx2, dga, dbe = ops.gn_backward(a1, d(nhwc(dp)), (mean, rstd, d(gamma.detach()), d(beta.detach()), G),
-                                            L.PRO_GN_SILU, x2=a2, slices=slices)
+        dx, dx2, dga, dbe = ops.gn_backward(a1, d(nhwc(dp)), gn_t, L.PRO_GN_SILU, x2=a2, slices=slices, one_call=False)
         assert rel_err(nchw(dx.cpu()), x1.grad) < TOL_OP and rel_err(nchw(dx2.cpu()), x2.grad) < TOL_OP
         assert rel_err(dga, gamma.grad) < TOL_OP and rel_err(dbe, beta.grad) < TOL_OP
+    # the same through ONE call (ABI 7): the one-pass kernel with every group in one workgroup / ragged runs of 5, 5, 2 groups /
+    # one group per workgroup, and the library's own three-kernel sequence; then accumulation, a scale, one source without gradient
+    for env in ({"SSDE_NUM_CUS": "1"}, {"SSDE_NUM_CUS": "4"}, {}, {"SSDE_GN_BWD_FUSED": "0"}):
+        os.environ.update(env)
+        try:
+            dx, dx2, dga, dbe = ops.gn_backward(a1, d(nhwc(dp)), gn_t, L.PRO_GN_SILU, x2=a2, slices=4)
+            assert rel_err(nchw(dx.cpu()), x1.grad) < TOL_OP and rel_err(nchw(dx2.cpu()), x2.grad) < TOL_OP, env
+            assert rel_err(dga, gamma.grad) < TOL_OP and rel_err(dbe, beta.grad) < TOL_OP, env
+            base = torch.randn(n, h, h, c1, generator=g)
+            acc2 = d(base.clone())
+            dx, dx2, dga, dbe = ops.gn_backward(a1, d(nhwc(dp)), gn_t, L.PRO_GN_SILU, x2=a2, scale=0.25, acc=(False, True), want=(False, True),
+                                                dx2=acc2)
+            assert dx is None and rel_err(nchw(dx2.cpu()), nchw(base) + 0.25 * x2.grad) < TOL_OP, env
+            assert rel_err(dga, gamma.grad) < TOL_OP and rel_err(dbe, beta.grad) < TOL_OP, env
+        finally:
+            for k in env:
+                os.environ.pop(k)
+    # a 32x32 map (8 pixels of a channel quad per thread), plain GroupNorm, one source; and a map too large for the one-pass
+    # kernel (96x96 at 4 channels per group: 9 pixels per thread) that the same call runs as three kernels
+    for (n_, c_, g_, h_, mode) in [(2, 32, 8, 32, L.PRO_GN), (1, 8, 2, 96, L.PRO_GN_SILU)]:
+        xb = torch.randn(n_, c_, h_, h_, generator=g).requires_grad_()
+        gb_ = (1 + 0.1 * torch.randn(c_, generator=g)).requires_grad_()
+        bb_ = (0.1 * torch.randn(c_, generator=g)).requires_grad_()
+        dpb = torch.randn(n_, c_, h_, h_, generator=g)
+        yb = F.group_norm(xb, g_, gb_, bb_, 1e-6)
+        (F.silu(yb) if mode == L.PRO_GN_SILU else yb).backward(dpb)
+        ab = d(nhwc(xb.detach()))
+        mb, rb = ops.groupnorm_stats(ab, g_, 1e-6)
+        dx, _, dga, dbe = ops.gn_backward(ab, d(nhwc(dpb)), (mb, rb, d(gb_.detach()), d(bb_.detach()), g_), mode, slices=2)
+        assert rel_err(nchw(dx.cpu()), xb.grad) < TOL_OP, (h_, rel_err(nchw(dx.cpu()), xb.grad))
+        assert rel_err(dga, gb_.grad) < 2 * TOL_OP and rel_err(dbe, bb_.grad) < 2 * TOL_OP, h_
     # ---- attention backward
     for (n, Lt, Cc) in [(2, 64, 32), (1, 16, 64), (2, 256, 32)]:
         qkv = torch.randn(n, Lt, 3 * Cc, generator=g).requires_grad_()

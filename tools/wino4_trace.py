@@ -22,7 +22,7 @@ def main():
     assert lib.ssde_debug_w4_trace(C.c_void_p(buf.data_ptr())) == 0
     for (cin, cout, h, gn) in [(128, 128, 32, 1), (128, 128, 32, 0), (256, 256, 16, 1), (512, 256, 16, 1)]:
         buf.zero_()
-        tf, ms = cb.time_conv(256, cin, cout, h, L.TILE_WINOGRAD4, gn, reps=1)
+        tf, ms = cb.time_conv(int(os.environ.get('W4_TRACE_BATCH', '256')), cin, cout, h, L.TILE_WINOGRAD4, gn, reps=1)
         torch.cuda.synchronize()
         t = buf.cpu().numpy().reshape(2, 128)
         print("== %d->%d @%dx%d gn=%d: %.1f TF/s %.3f ms (traced)" % (cin, cout, h, h, gn, tf, ms))
