@@ -107,7 +107,11 @@ enum { SSDE_TILE_AUTO = 0, SSDE_TILE_256x64 = 1, SSDE_TILE_128x64 = 2, SSDE_TILE
        SSDE_TILE_WINOGRAD4 = 6,
        /* the same on the BF16 matrix pipe (exact-fp32 products of a 3-way bf16 split, conv_wino4x.hip): w_main packed as
         * [ceil(Cin/4)][ceil(Cout/64)][8 waves][9][32 couts][3 pieces][4 channels] bf16; inference launches only */
-       SSDE_TILE_WINOGRAD4X = 7 };
+       SSDE_TILE_WINOGRAD4X = 7,
+       /* F(4x4,3x3) in two kernels (conv_wino4g.hip): the input transform V = B^T pro(x) B as its own HBM-bound pass into
+        * ssde_conv_args.wino_v (REQUIRED here: 36 * N*H*W/16 * Cin floats), then a matrix kernel without prologue or transform;
+        * w_main packed as for SSDE_TILE_WINOGRAD4.  Pays where a V tile feeds four or more 64-cout tiles */
+       SSDE_TILE_WINOGRAD4G = 8 };
 
 /* ---- GroupNorm statistics: mean / rstd per (sample, group) -----------------
  * replaces the reduction half of nn.GroupNorm(min(C/4,32), C, eps=1e-6)

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("SSDE_LIB_PATH") or os.path.join(_HERE, "libssde_hip.s
 ABI_VERSION = 7
 
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_SILU = 0, 1, 2, 3
-TILE_AUTO, TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32, TILE_WINOGRAD, TILE_WINOGRAD4, TILE_WINOGRAD4X = 0, 1, 2, 3, 4, 5, 6, 7
+TILE_AUTO, TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32, TILE_WINOGRAD, TILE_WINOGRAD4, TILE_WINOGRAD4X, TILE_WINOGRAD4G = 0, 1, 2, 3, 4, 5, 6, 7, 8
 (OP_CONV, OP_GN_STATS, OP_UPFIRDN, OP_ATTN, OP_EMBED, OP_TO_NHWC, OP_TO_NCHW, OP_BIAS_ACT, OP_SUMSQ,
  OP_RANDN, OP_LANGEVIN, OP_PREDICTOR, OP_FILL, OP_STEP_INC, OP_WGRAD, OP_COLSUM, OP_GN_BWD_REDUCE, OP_PROLOGUE_BWD,
  OP_ATTN_BWD, OP_PERTURB, OP_DSM_LOSS, OP_SUMSQ_FLAT, OP_ADAM, OP_MEMSET, OP_AXPY, OP_PACK, OP_PROJECT,

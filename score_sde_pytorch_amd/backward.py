@@ -332,7 +332,7 @@ class TrainEngine(E.UNetEngine):
                           dw=part["view"] if part.get("view") is not None else self.flat.grad_view(part["param"]),
                           scratch=None, scratch_floats=0,
                           # the forward launch's by-product (engine.Lowering.conv: only allocated when THIS launch takes it)
-                          v_pre=f.get("wino_v") if (ksize == 3 and len(parts) == 1) else None)
+                          v_pre=f.get("wino_v") if (ksize == 3 and len(parts) == 1 and f.get("_v_for_wgrad", True)) else None)
             need = self._wgrad_scratch(fields)
             if need > 0:
                 fields.update(scratch=b.buf(need, name="wgrad_slabs"), scratch_floats=need)

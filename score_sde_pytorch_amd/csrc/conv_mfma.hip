@@ -564,6 +564,13 @@ extern "C" int ssde_conv2d(const ssde_conv_args* a, void* stream) {
   if (a && a->tile == SSDE_TILE_WINOGRAD) return ssde_conv_wino_launch(a, stream, nullptr);
   if (a && a->tile == SSDE_TILE_WINOGRAD4) return ssde_conv_wino4_launch(a, stream, nullptr);
   if (a && a->tile == SSDE_TILE_WINOGRAD4X) return ssde_conv_wino4x_launch(a, stream, nullptr);
+  if (a && a->tile == SSDE_TILE_WINOGRAD4G) {
+    // the input-transform pass into wino_v, then the matrix kernel (SSDE_W4G_V_GIVEN=1, tests: the caller filled wino_v)
+    const char* given = getenv("SSDE_W4G_V_GIVEN");
+    if (!(given && given[0] == '1'))
+      if (int rc = ssde_wino4_xform_vq_launch(a, stream)) return rc;
+    return ssde_conv_wino4g_launch(a, stream, nullptr);
+  }
   if (a && a->dst && ssde_conv1x1_wants(a)) return ssde_conv1x1_launch(a, stream, nullptr);   // 1x1-only: GEMM kernel (conv1x1.hip)
   ConvPlan pl;
   if (int rc = make_plan(a, &pl)) return rc;
@@ -582,9 +589,10 @@ extern "C" int ssde_conv_gn_slices(const ssde_conv_args* a) {
   if (!a || a->c_out % 4 != 0) return 0;
   ssde_conv_args q = *a;
   q.gn_part = nullptr;
-  if (q.tile == SSDE_TILE_WINOGRAD || q.tile == SSDE_TILE_WINOGRAD4 || q.tile == SSDE_TILE_WINOGRAD4X) {
+  if (q.tile == SSDE_TILE_WINOGRAD || q.tile == SSDE_TILE_WINOGRAD4 || q.tile == SSDE_TILE_WINOGRAD4X || q.tile == SSDE_TILE_WINOGRAD4G) {
     int s = 0;
-    auto fn = q.tile == SSDE_TILE_WINOGRAD ? ssde_conv_wino_launch : q.tile == SSDE_TILE_WINOGRAD4 ? ssde_conv_wino4_launch : ssde_conv_wino4x_launch;
+    auto fn = q.tile == SSDE_TILE_WINOGRAD ? ssde_conv_wino_launch : q.tile == SSDE_TILE_WINOGRAD4 ? ssde_conv_wino4_launch
+            : q.tile == SSDE_TILE_WINOGRAD4G ? ssde_conv_wino4g_launch : ssde_conv_wino4x_launch;
     if (fn(&q, reinterpret_cast<void*>(1), &s)) return 0;     // plan-only query form
     return s;
   }
@@ -601,9 +609,10 @@ extern "C" int ssde_conv_gn_slices(const ssde_conv_args* a) {
 }
 
 extern "C" int ssde_conv_lds_bytes(const ssde_conv_args* a) {
-  if (a && (a->tile == SSDE_TILE_WINOGRAD || a->tile == SSDE_TILE_WINOGRAD4 || a->tile == SSDE_TILE_WINOGRAD4X)) {
+  if (a && (a->tile == SSDE_TILE_WINOGRAD || a->tile == SSDE_TILE_WINOGRAD4 || a->tile == SSDE_TILE_WINOGRAD4X || a->tile == SSDE_TILE_WINOGRAD4G)) {
     int lds = 0;
-    auto fn = a->tile == SSDE_TILE_WINOGRAD ? ssde_conv_wino_launch : a->tile == SSDE_TILE_WINOGRAD4 ? ssde_conv_wino4_launch : ssde_conv_wino4x_launch;
+    auto fn = a->tile == SSDE_TILE_WINOGRAD ? ssde_conv_wino_launch : a->tile == SSDE_TILE_WINOGRAD4 ? ssde_conv_wino4_launch
+            : a->tile == SSDE_TILE_WINOGRAD4G ? ssde_conv_wino4g_launch : ssde_conv_wino4x_launch;
     if (int rc = fn(a, nullptr, &lds)) return rc;
     return lds;
   }

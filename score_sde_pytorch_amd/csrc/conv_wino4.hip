@@ -112,6 +112,11 @@ extern "C" int ssde_debug_w4_trace(void* buf) {
 #ifndef SSDE_W4_EXP_NOSTORE
 #define SSDE_W4_EXP_NOSTORE 0
 #endif
+// 1: the stage body without the GroupNorm / SiLU prologue and without both passes of the input transform (V is garbage): what the
+// main loop would cost if V arrived already transformed, from a separate HBM-bound pass (the classical two-kernel Winograd)
+#ifndef SSDE_W4_EXP_NOXFORM
+#define SSDE_W4_EXP_NOXFORM 0
+#endif
 #if SSDE_W4_PRIO
 #define SSDE_W4_HI() __builtin_amdgcn_s_setprio(2)
 #define SSDE_W4_LO() __builtin_amdgcn_s_setprio(0)
@@ -531,19 +536,19 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
     SSDE_OPAQUE_VGPR(ua);
     // ---- head ----
     GnRegs gnr;
-    if (has2 && !gy && SSDE_W4_GNFIRST) gnr = gn_fetch(st + 2);        // (tables: no dependence on the weight pieces)
+    if (has2 && !gy && SSDE_W4_GNFIRST && !SSDE_W4_EXP_NOXFORM) gnr = gn_fetch(st + 2);        // (tables: no dependence on the weight pieces)
     if (has2 && !gy) SSDE_WAIT_VMCNT_FOR(3, rv[0], rv[1]); else SSDE_WAIT_VMCNT_FENCE(3);
 #pragma unroll
     for (int j = 0; j < SSDE_W4_PF; ++j) {
       af[j] = *(ssde_lds_cfloat2*)(va + kPS * j * kVP);
       bf[j] = *(ssde_lds_cfloat2*)(ua + j * 128);
     }
-    if (has1) {
+    if (has1 && !SSDE_W4_EXP_NOXFORM) {
       const float* rp = rawb + nxt * raw_stride + t_rawoff;
 #pragma unroll
       for (int a = 0; a < 6; ++a) { const float2 q = *reinterpret_cast<const float2*>(rp + a * HWd * 2); td[a].x = q.x; td[a].y = q.y; }
     }
-    if (has2 && !gy) {
+    if (has2 && !gy && !SSDE_W4_EXP_NOXFORM) {
       SSDE_W4_HI();
       if (SSDE_W4_GNFIRST) store_raw_with(rawb + cur * raw_stride, st + 2, gnr);
       else store_raw(rawb + cur * raw_stride, st + 2);
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
     if (hasl) load_piece(st_l, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (st < 8) SSDE_TR(8 + st * 10 + 2);
-    if (has1) {
+    if (has1 && !SSDE_W4_EXP_NOXFORM) {
       SSDE_W4_HI();
       bt6(td, to);
 #pragma unroll
@@ -589,7 +594,7 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
     if (hasl) load_piece(st_l, 1);
     __builtin_amdgcn_sched_barrier(0);
     if (st < 8) SSDE_TR(8 + st * 10 + 4);
-    if (has1) {
+    if (has1 && !SSDE_W4_EXP_NOXFORM) {
 #pragma unroll
       for (int b = 0; b < 6; ++b) td[b] = *(ssde_lds_float2*)(vp + b * kVP);
     }
@@ -601,7 +606,7 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
     SSDE_W4_POS(5);
     if (has1) SSDE_GLDS16_S_SAME_BASE(w_voff, wb, wl, 1024);
     __builtin_amdgcn_sched_barrier(0);
-    if (has1) {
+    if (has1 && !SSDE_W4_EXP_NOXFORM) {
       SSDE_W4_HI();
       bt6(td, to);
 #pragma unroll
@@ -621,7 +626,7 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4_kernel(const 
     emit_v(Vc, st, 2);
 #undef SSDE_W4_POS
     if (st < 8) SSDE_TR(8 + st * 10 + 6);
-    if (has2 && gy) {
+    if (has2 && gy && !SSDE_W4_EXP_NOXFORM) {
       SSDE_WAIT_VMCNT_FOR(3 * n1, rv[0], rv[1]);
       SSDE_W4_HI();
       store_raw(rawb + cur * raw_stride, st + 2);

@@ -629,6 +629,8 @@ class Lowering:
         if wino:
             assert main is not None and stride == 1 and pad == 1 and (h_in, w_in) == (h_out, w_out)
             tile = L.TILE_WINOGRAD4X if wino == 5 else L.TILE_WINOGRAD4 if wino == 4 else L.TILE_WINOGRAD
+            if wino == 4 and self._wino4_two_kernels(h_out, w_out, c_out, main["c0"] + main["c1"]):
+                tile = L.TILE_WINOGRAD4G
             if aux is not None:
                 split_tmp = self.b.buf(self.n, h_out, w_out, c_out, name="wino_tmp")
         px = self.n * h_out * w_out
@@ -643,13 +645,17 @@ class Lowering:
             ksize=3 if main is not None else 0, stride=stride, pad=pad, tile=tile, bias=bias, chan_add=chan_add,
             chan_add_ld=chan_add_ld, resid_post=resid_post, resid=resid, out_scale=float(scale), dst=dst, gn_part=None,
             wino_v=None, _split_tmp=split_tmp)
-        if wino == 4 and getattr(self, "emit_wino_v", False) and self._wgrad_takes_wino4(fields) and \
-                36 * self.n * (h_out // 4) * (w_out // 4) * (main["c0"] + main["c1"]) * 4 < 2 ** 32:
-            # training forward: the kernel leaves B^T pro(x) B behind for the layer's F(4x4,3x3) weight gradient
-            # (ssde_conv_args.wino_v -> ssde_wgrad_args.v_pre, backward.TrainEngine._bwd_branch); 2.25x the input, alive
-            # until that weight gradient has been enqueued
+        if wino == 4:
+            # the transformed input B^T pro(x) B in HBM (2.25x the input): the two-kernel form (conv_wino4g.hip) cannot do without
+            # it; in a training forward the one-kernel form leaves it behind as a by-product when the layer's weight gradient
+            # takes the F(4x4,3x3) route (ssde_conv_args.wino_v -> ssde_wgrad_args.v_pre, backward.TrainEngine._bwd_branch:
+            # alive until that weight gradient has been enqueued)
             ctot = main["c0"] + main["c1"]
-            fields["wino_v"] = self.b.buf(36 * self.n * (h_out // 4) * (w_out // 4) * ctot, name="wino_v")
+            v_floats = 36 * self.n * (h_out // 4) * (w_out // 4) * ctot
+            takes = getattr(self, "emit_wino_v", False) and v_floats * 4 < 2 ** 32 and self._wgrad_takes_wino4(fields)
+            if tile == L.TILE_WINOGRAD4G or takes:
+                fields["wino_v"] = self.b.buf(v_floats, name="wino_v")
+                fields["_v_for_wgrad"] = bool(takes)
         if stats and isinstance(dst, Buf):
             slices = self._gn_slices(fields)
             if slices > 0:
@@ -657,6 +663,19 @@ class Lowering:
                 fields["gn_part"] = part
                 self.parts[id(dst)] = (part, slices, c_out)
         self.b.add(L.OP_CONV, fields, FC_CONV3 if main is not None else FC_CONV1, flops)
+
+    def _wino4_two_kernels(self, h, w, c_out, c_in):
+        """F(4x4,3x3) as a transform pass + a matrix kernel (conv_wino4g.hip) instead of the one fused kernel?  The pass costs
+        one more read of x and 2.25x of it written and read; the matrix kernel saves the prologue and transform VALU work that
+        serialises with fp32 MFMAs in EVERY 64-cout workgroup of a pixel tile.  Measured at batch 256 (profiles/
+        r4_wino4_two_kernels.txt): 256->256 @16x16 0.281 -> 0.245 ms, 512->256 @16x16 0.496 -> 0.457, level at 128 couts
+        (128->128 @32x32 0.357 -> 0.346, 256->128 0.599 -> 0.594), a loss at 384->128 @32x32 (0.78 -> 0.95: three times the
+        input for two cout tiles) -- so: from four cout tiles up.  SSDE_WINO4_TWO: 0 = never, 2 = wherever F(4x4,3x3) runs."""
+        import os
+        mode = os.environ.get("SSDE_WINO4_TWO", "1")
+        if mode == "0" or 36 * self.n * (h // 4) * (w // 4) * c_in * 4 >= 2 ** 32:
+            return False
+        return mode == "2" or c_out >= 256
 
     def _wgrad_takes_wino4(self, f):
         """Would ssde_conv_wgrad run the weight gradient of this forward conv on the F(4x4,3x3) path?  (shape-only query with

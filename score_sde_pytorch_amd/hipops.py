@@ -69,7 +69,8 @@ def conv2d(x=None, weight=None, bias=None, stride=1, pad=1, x2=None, pro=L.PRO_N
         if out_hw is not None:      # top-left crop of the full result (transposed strided convolutions)
             h_out, w_out = out_hw
         _fill_src(a.main, x, x2, pro, gn)
-        packer = {L.TILE_WINOGRAD: pack_wino_weight, L.TILE_WINOGRAD4: pack_wino4_weight, L.TILE_WINOGRAD4X: pack_wino4x_weight}.get(tile, pack_conv_weight)
+        packer = {L.TILE_WINOGRAD: pack_wino_weight, L.TILE_WINOGRAD4: pack_wino4_weight, L.TILE_WINOGRAD4X: pack_wino4x_weight,
+                  L.TILE_WINOGRAD4G: pack_wino4_weight}.get(tile, pack_conv_weight)
         wp = packer(weight.to(x.device)); keep.append(wp)
         a.w_main, a.ksize, a.stride, a.pad, a.h_in, a.w_in = _p(wp), 3, stride, pad, h_in, w_in
     else:

@@ -1313,3 +1313,67 @@ def check_conv_winograd4(dev, big=False, split=False):
         L.check(lib.ssde_gn_finalize(C.byref(f), ops._stream()))
         mr, rr = ops.groupnorm_stats(dst, Go, 1e-6)
         assert (m2 - mr).abs().max().item() < 1e-5 and ((r2 - rr).abs() / rr).max().item() < 1e-4
+
+
+def check_conv_winograd4_two_kernels(dev, big=False):
+    """conv_wino4g.hip (F(4x4,3x3) as an input-transform pass + a matrix kernel, SSDE_TILE_WINOGRAD4G) against torch and against
+    conv_wino4.hip: with the transformed input taken from conv_wino4's own by-product (SSDE_W4G_V_GIVEN=1: the caller filled
+    wino_v) the matrix kernel must reproduce conv_wino4's output BIT FOR BIT (same products, same order); with its own transform
+    pass the result is within rounding of it and within the F(4x4,3x3) tolerance of torch.  Tilings: part of one image, whole
+    images, ragged batch tails, cout tiles that are not full; the fused epilogue and the GroupNorm partials."""
+    import ctypes as C
+    import numpy as np
+    import torch.nn.functional as F
+    from score_sde_pytorch_amd import hipops as ops, _lib as L
+    from score_sde_pytorch_amd.engine import pack_wino4_weight
+    lib = L.load()
+    g = torch.Generator().manual_seed(5)
+    cases = [(5, 32, 16, 64, 16), (9, 64, 0, 96, 8), (3, 24, 32, 128, 32), (1, 8, 0, 64, 16), (2, 128, 0, 256, 16), (1, 16, 0, 40, 64)]
+    if big:
+        cases += [(12, 128, 128, 128, 32), (10, 256, 256, 256, 16), (33, 256, 0, 256, 16)]
+    for (n, c0, c1, cout, h) in cases:
+        cin = c0 + c1
+        x0 = torch.randn(n, h, h, c0, generator=g) * 1.5 + 0.3
+        x1 = torch.randn(n, h, h, c1, generator=g) if c1 else None
+        xcat = torch.cat([x0, x1], -1) if c1 else x0
+        w = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
+        b, gamma, beta = torch.randn(cout, generator=g), torch.randn(cin, generator=g), torch.randn(cin, generator=g)
+        resid, ca = torch.randn(n, h, h, cout, generator=g), torch.randn(n, cout, generator=g)
+        G = 32 if cin % 32 == 0 and (cin // 32) % 4 == 0 else cin // 4
+        x0d, x1d = x0.to(dev), (x1.to(dev) if c1 else None)
+        mean, rstd = ops.groupnorm_stats(x0d, G, 1e-6, x2=x1d)
+        a = L.ConvArgs()
+        gn = (mean, rstd, gamma.to(dev), beta.to(dev), G)
+        ops._fill_src(a.main, x0d, x1d, L.PRO_GN_SILU, gn)
+        wp, bd, cad, rd = pack_wino4_weight(w.to(dev)), b.to(dev), ca.to(dev), resid.to(dev)
+        a.w_main, a.ksize, a.stride, a.pad, a.h_in, a.w_in = wp.data_ptr(), 3, 1, 1, h, h
+        a.n, a.h_out, a.w_out, a.c_out, a.out_scale = n, h, h, cout, 0.7
+        a.bias, a.chan_add, a.chan_add_ld, a.resid = bd.data_ptr(), cad.data_ptr(), cout, rd.data_ptr()
+        xn = F.silu(F.group_norm(xcat.permute(0, 3, 1, 2), G, gamma, beta, 1e-6))
+        ref = ((F.conv2d(xn, w, b, padding=1) + ca[:, :, None, None]).permute(0, 2, 3, 1) + resid) * 0.7
+        out, parts = {}, {}
+        v = torch.full((36 * n * (h // 4) * (h // 4) * cin,), float("nan"), device=dev)
+        a.wino_v = v.data_ptr()
+        for name, tile, env in (("one kernel", L.TILE_WINOGRAD4, {}), ("matrix kernel on the by-product", L.TILE_WINOGRAD4G, {"SSDE_W4G_V_GIVEN": "1"}),
+                                ("two kernels", L.TILE_WINOGRAD4G, {})):
+            a.tile = tile
+            dst = torch.full((n, h, h, cout), float("nan"), device=dev)
+            a.dst, a.gn_part = dst.data_ptr(), None
+            sl = lib.ssde_conv_gn_slices(C.byref(a))
+            assert sl > 0, (name, lib.ssde_last_error())
+            part = torch.full((n, sl, cout // 4, 3), float("nan"), device=dev)
+            a.gn_part = part.data_ptr()
+            if name == "two kernels":
+                v.fill_(float("nan"))
+            env = dict(env, SSDE_CONV_KSPLIT="0")        # (a split reduction of conv_wino4.hip sums in another order)
+            os.environ.update(env)
+            try:
+                L.check(lib.ssde_conv2d(C.byref(a), ops._stream()))
+            finally:
+                for k in env:
+                    os.environ.pop(k)
+            assert _util.rel_err(dst.cpu(), ref) < 2e-5, (name, n, c0, c1, cout, h, _util.rel_err(dst.cpu(), ref))
+            out[name], parts[name] = dst.cpu(), part.cpu()
+        assert torch.equal(out["matrix kernel on the by-product"], out["one kernel"]), (n, c0, c1, cout, h)
+        assert torch.equal(parts["matrix kernel on the by-product"], parts["one kernel"])
+        assert _util.rel_err(out["two kernels"], out["one kernel"]) < 5e-6

@@ -185,6 +185,8 @@ static inline void emu_global_load_lds(const void* g, __attribute__((address_spa
 #define SSDE_GLDS16_S_LO48(voff, sbase, lds_wave_base, imm) \
   do { if (emu::cur->lane < 48) SSDE_GLDS16_S(voff, sbase, lds_wave_base, imm); } while (0)
 #define SSDE_GLDS16_S_SAME_BASE_LO48(voff, sbase, lds_wave_base, imm) SSDE_GLDS16_S_LO48(voff, sbase, lds_wave_base, imm)
+#define SSDE_GLDS16_S_LO16(voff, sbase, lds_wave_base, imm) \
+  do { if (emu::cur->lane < 16) SSDE_GLDS16_S(voff, sbase, lds_wave_base, imm); } while (0)
 #define SSDE_GLOAD16(dst, voff, sbase) memcpy(&(dst), (const char*)(sbase) + (voff), 16)
 #define SSDE_WAIT_VMCNT_FOR(n, a, b) ((void)0)
 #define SSDE_WAIT_VMCNT_FENCE(n) ((void)0)

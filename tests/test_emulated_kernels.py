@@ -96,6 +96,23 @@ def test_unet_forward_on_the_bf16_matrix_pipe(monkeypatch):
     test_unet_forward_matches_reference_golden("unet_small_ffhq")
 
 
+def test_unet_forward_winograd_f4x4_in_two_kernels(monkeypatch):
+    """every legal 3x3 layer as a transform pass + the matrix kernel of conv_wino4g.hip (SSDE_WINO4_TWO=2 forces what the
+    lowering takes from four cout tiles up), emulated"""
+    from score_sde_pytorch_amd import engine as E, _lib as L
+    monkeypatch.setenv("SSDE_WINOGRAD", "4")
+    monkeypatch.setenv("SSDE_WINO4_TWO", "2")
+    seen = []
+    real = E.Lowering.conv
+
+    def spy(self, *a, **k):
+        real(self, *a, **k)
+        seen.append(self.b.specs[-1][1]["tile"])
+    monkeypatch.setattr(E.Lowering, "conv", spy)
+    test_unet_forward_matches_reference_golden("unet_small_ffhq")
+    assert seen.count(L.TILE_WINOGRAD4G) >= 8 and L.TILE_WINOGRAD4 not in seen
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_unet_forward_matches_reference_golden(name):
     from score_sde_pytorch_amd.models import utils as mutils

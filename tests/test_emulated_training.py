@@ -68,6 +68,15 @@ def test_whole_network_gradients_winograd_f4x4(monkeypatch):
     T.check_unet_grads("ncsnpp", "cpu")
 
 
+def test_whole_network_gradients_winograd_f4x4_in_two_kernels(monkeypatch):
+    """forward and input-gradient convolutions as transform pass + matrix kernel (conv_wino4g.hip); the weight gradients read
+    the transform pass's output (ssde_wgrad_args.v_pre)"""
+    monkeypatch.setenv("SSDE_WINOGRAD", "4")
+    monkeypatch.setenv("SSDE_WINO4_TWO", "2")
+    monkeypatch.setenv("SSDE_WGRAD_WINOGRAD", "44")
+    T.check_unet_grads("ncsnpp", "cpu")
+
+
 def test_autograd_bridge(monkeypatch):
     from score_sde_pytorch_amd.models import ncsnpp
     # the product refuses CPU tensors; under the emulator "device" memory IS host memory
@@ -128,3 +137,7 @@ def test_weight_gradient_fed_by_the_forward_launch(monkeypatch):
 
 def test_conv3x3_winograd_f4x4_on_the_bf16_matrix_pipe():
     T.check_conv_winograd4("cpu", big=False, split=True)
+
+
+def test_conv3x3_winograd_f4x4_in_two_kernels():
+    T.check_conv_winograd4_two_kernels("cpu")

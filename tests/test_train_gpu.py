@@ -146,3 +146,15 @@ def test_weight_gradient_fed_by_the_forward_launch(monkeypatch):
 
 def test_conv3x3_winograd_f4x4_on_the_bf16_matrix_pipe():
     T.check_conv_winograd4("cuda", big=True, split=True)
+
+
+def test_conv3x3_winograd_f4x4_in_two_kernels():
+    T.check_conv_winograd4_two_kernels("cuda", big=True)
+
+
+def test_whole_network_gradients_winograd_f4x4_in_two_kernels(monkeypatch):
+    """forward and input-gradient convolutions as transform pass + matrix kernel; weight gradients fed by the transform pass"""
+    monkeypatch.setenv("SSDE_WINOGRAD", "4")
+    monkeypatch.setenv("SSDE_WINO4_TWO", "2")
+    monkeypatch.setenv("SSDE_WGRAD_WINOGRAD", "44")
+    T.check_unet_grads("ncsnpp", "cuda", batch=3)
