@@ -67,6 +67,14 @@ constexpr int kUFloats = kPos * 64 * kKc;           // one U stage, 36 KB
 constexpr int kURegion = kNP * 32 * kKc;            // the floats of a stage only wave (q, h) reads
 constexpr int kLdm = 66, kLdt = 68;                 // pitches of the product exchange and of the parked output tile (conv_wino4.hip)
 constexpr int kPF = 3;                              // fragment reads run this many positions ahead of their MFMAs
+// timing experiments (wrong results on purpose, variant libraries only): the stage body without its LDS-DMA pieces / without its
+// fragment reads -- where the ~700 cycles per stage beside the 2304 matrix cycles go (profiles/r4_wino4_two_kernels.txt)
+#ifndef SSDE_W4G_EXP_NODMA
+#define SSDE_W4G_EXP_NODMA 0
+#endif
+#ifndef SSDE_W4G_EXP_NOREAD
+#define SSDE_W4G_EXP_NOREAD 0
+#endif
 // 1: the stage barrier in the middle of the stage (see the stage body); 0: at its end.  Measured level (0.246-0.259 vs 0.2515 ms
 // at 128 -> 128 @32x32, 0.191 vs 0.1905 at 256 -> 256 @16x16, profiles/r4_wino4_two_kernels.txt): the simpler form is the default
 #ifndef SSDE_W4G_MID_BARRIER
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4g_kernel(const
   //   slots 5, 6, 7 issue V''0, V''1, V''2
   int vcur = 0;                                  // ring slot of V(st)
   auto stage = [&](auto H1, auto H2, const int st) __attribute__((always_inline)) {
-    constexpr bool has1 = decltype(H1)::value, has2 = decltype(H2)::value;
+    constexpr bool has1 = decltype(H1)::value && !SSDE_W4G_EXP_NODMA, has2 = decltype(H2)::value && !SSDE_W4G_EXP_NODMA;
     constexpr int n1 = has1 ? 1 : 0, n2 = has2 ? 1 : 0;
     const int cur = st & 1, nxt = cur ^ 1;
     const float* Vc = Vb + vcur * kVFloats;
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4g_kernel(const
     __builtin_amdgcn_sched_barrier(0);
 #define SSDE_W4G_POS(J)                                                                                          \
     do {                                                                                                         \
-      if ((J) + kPF < kNP) {                                                                                     \
+      if ((J) + kPF < kNP && !SSDE_W4G_EXP_NOREAD) {                                                             \
         af[((J) + kPF) % (kPF + 1)] = *(ssde_lds_cfloat2*)(va + kPS * ((J) + kPF) * kVP);                        \
         bf[((J) + kPF) % (kPF + 1)] = *(ssde_lds_cfloat2*)(ua + ((J) + kPF) * 128);                              \
       }                                                                                                          \
