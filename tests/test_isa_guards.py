@@ -52,7 +52,7 @@ def _main_loop(body):
 
 
 @pytest.mark.parametrize("src,kernel", [("conv_wino4.hip", "conv_wino4_kernel"), ("conv_wino.hip", "conv_wino_kernel"),
-                                        ("conv_wino4x.hip", "conv_wino4x_kernel")])
+                                        ("conv_wino4x.hip", "conv_wino4x_kernel"), ("conv_wino4g.hip", "conv_wino4g_kernel")])
 def test_winograd_kernels_own_m0_and_keep_scratch_out_of_the_loop(src, kernel, tmp_path):
     isa = _isa(src, tmp_path)
     for sym, body in _kernels(isa, kernel):
@@ -112,3 +112,18 @@ def test_asm_halo_loads_are_not_read_before_their_counted_wait(tmp_path):
                                 break
                         assert not l.startswith("s_endpgm"), (sym, lines[i].strip(), "reached the end without a wait")
                     j += 1
+
+
+def test_two_kernel_winograd_matrix_loop_counts_its_own_dma_pieces(tmp_path):
+    """conv_wino4g.hip: the steady-state stage of the matrix kernel is 18 MFMAs, 18 fragment reads and 8 LDS-DMA pieces per wave
+    with the hand-counted waits 6 / 6 / 7 / 8 / 8 (the comment above the stage body derives them) and ONE barrier; hipcc must not
+    add a vmcnt wait of its own inside the loop (it would be a vmcnt(0): a full memory latency per stage)."""
+    isa = _isa("conv_wino4g.hip", tmp_path)
+    (sym, body), = _kernels(isa, "conv_wino4g_kernel")
+    loop = _main_loop(body)
+    assert sum("v_mfma_f32_32x32x2" in l for l in loop) == 18
+    assert sum("global_load_lds_dwordx4" in l for l in loop) == 8
+    assert 9 <= sum(l.strip().startswith("ds_read") for l in loop) <= 18      # (18 fragments of 8 bytes; hipcc pairs some as ds_read2)
+    assert sum(l.strip().startswith("s_barrier") for l in loop) == 1
+    waits = [int(m.group(1)) for l in loop for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", l)] if m]
+    assert waits == [6, 6, 7, 8, 8], waits
