@@ -304,7 +304,10 @@ def op_bytes(op):
         return 4.0 * a.n * a.hw * c * (3 + (1 if (a.acc0 or a.acc1) else 0))
     if k == L.OP_GN_BWD_REDUCE:
         a = op.u.gn_bwd
-        return 8.0 * a.n * a.hw * (a.src.c0 + a.src.c1)
+        c = a.src.c0 + a.src.c1
+        if a.g0 or a.g1:                              # reduction AND apply in one call: read dp, read x, write (or accumulate) dx
+            return 4.0 * a.n * a.hw * c * (3 + (1 if (a.acc0 or a.acc1) else 0))
+        return 8.0 * a.n * a.hw * c
     if k == L.OP_COLSUM:
         return 4.0 * op.u.colsum.n * op.u.colsum.hw * op.u.colsum.c
     if k == L.OP_TO_NHWC:
@@ -342,7 +345,8 @@ def roofline_of(prog, E, L, reps=3):
     cls = np.array(prog.classes)
     fl = np.array(prog.flops)
     tiles = np.array([int(prog.ops[i].u.conv.tile) if int(prog.ops[i].kind) == L.OP_CONV else -1 for i in range(prog.n)])
-    wino4 = tiles == L.TILE_WINOGRAD4
+    wino4 = np.isin(tiles, (L.TILE_WINOGRAD4, L.TILE_WINOGRAD4G, L.TILE_WINOGRAD4X))     # F(4x4,3x3): fused, two kernels, bf16 split
+    wino4g = tiles == L.TILE_WINOGRAD4G
     wino = (tiles == L.TILE_WINOGRAD) | wino4
     executed = np.where(wino4, fl / WINOGRAD4_FLOP_RATIO, np.where(wino, fl / WINOGRAD_FLOP_RATIO, fl))
     nbytes = np.array([op_bytes(prog.ops[i]) for i in range(prog.n)])
@@ -378,7 +382,7 @@ def roofline_of(prog, E, L, reps=3):
     dom4 = float(ms[wino4].sum()) >= float(ms[wino & ~wino4].sum())
     wl = [i for i in range(prog.n) if (wino4[i] if dom4 else (wino[i] and not wino4[i]))]
     alg_bytes_wino = float(np.mean([conv_bytes(prog.ops[i].u.conv) for i in wl])) if wl else None
-    return dict(ms=ms, cls=cls, fl=fl, wino=wino, wino4=wino4, dominant="conv_wino4_kernel" if dom4 else "conv_wino_kernel",
+    return dict(ms=ms, cls=cls, fl=fl, wino=wino, wino4=wino4, wino4g=wino4g, dominant="conv_wino4_kernel" if dom4 else "conv_wino_kernel",
                 executed=executed, conv3=conv3, by_class=by_class,
                 achieved_exec=achieved_exec, achieved_alg=achieved_alg, alg_bytes_wino=alg_bytes_wino)
 
@@ -727,13 +731,16 @@ def main():
         n3 = int(roof["conv3"].sum())
         n3w = int((roof["conv3"] & roof["wino"]).sum())
         n3w4 = int((roof["conv3"] & roof["wino4"]).sum())
+        n3w4g = int((roof["conv3"] & roof["wino4g"]).sum())
         out["roofline"] = {
             "bound": "mfma", "achieved": roof["achieved_exec"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": roof["achieved_exec"] / PEAK_FP32_MFMA_TFLOPS,
             "achieved_algorithmic": roof["achieved_alg"], "frac_algorithmic": roof["achieved_alg"] / PEAK_FP32_MFMA_TFLOPS,
             "traffic": traffic, "traffic_algorithmic": roof["alg_bytes_wino"], "mfma_busy_pmc": mfma_busy,
             "kernel": "the %d 3x3 convolution launches of one U-Net evaluation: %d on conv_wino4_kernel (Winograd F(4x4,3x3), fp32 MFMA), "
-                      "%d on conv_wino_kernel (F(2x2,3x3)), %d on conv_mfma_kernel (direct)" % (n3, n3w4, n3w - n3w4, n3 - n3w),
+                      "%d as wino4_xform_vq_kernel + conv_wino4g_kernel (F(4x4,3x3) in two kernels: layers of 256 couts and more), "
+                      "%d on conv_wino_kernel (F(2x2,3x3)), %d on conv_mfma_kernel (direct)"
+                      % (n3, n3w4 - n3w4g, n3w4g, n3w - n3w4, n3 - n3w),
             "note": "achieved = EXECUTED matrix FLOPs (F(4x4,3x3) launches at 1/4, F(2x2,3x3) launches at 1/2.25 of their direct-form "
                     "FLOPs) / HIP-event time of those launches; achieved_algorithmic = direct-form FLOPs / the same time; "
                     "traffic(_algorithmic) = bytes per %s launch (PMC / op list)" % roof["dominant"],

@@ -22,7 +22,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             for key in ("wgrad_wino_kernel", "wgrad_wino_reduce_kernel", "wgrad_kernel", "wgrad_reduce_kernel", "conv_wino_kernel", "gemm1x1_kernel",
                         "prologue_bwd_kernel", "gn_bwd_reduce_kernel", "attn_bwd_kv_kernel", "attn_bwd_q_kernel", "adam_kernel", "colsum_kernel",
                         "conv_wino4_kernel", "wino4_xform_v_kernel", "wino4_xform_z_kernel", "wgrad4_gemm_kernel", "wgrad4_sum_splits_kernel",
-                        "wgrad1x1_gemm_kernel", "gn_bwd_finalize_kernel", "conv_mfma_kernel"):
+                        "wgrad1x1_gemm_kernel", "gn_bwd_finalize_kernel", "conv_mfma_kernel", "conv_wino4g_kernel", "wino4_xform_vq_kernel", "gn_bwd_fused_kernel"):
                 if key + "<" in k or key + "(" in k:
                     a = acc[key][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 out = {}
