@@ -95,7 +95,9 @@ typedef struct ssde_conv_args {
                           * V[pos][(c0+c1)/4][t][4] = B^T pro(main) B (36 positions, channel quads, t = ((image * H/4) + tile
                           * row) * W/4 + tile column, fp32; 36 * N*H*W/16 * (c0+c1) floats, < 4 GB) -- what the F(4x4,3x3)
                           * weight gradient of the same layer multiplies with
-                          * (ssde_wgrad_args.v_pre); a by-product of the first 64-cout tile's staging.  NULL: not written. */
+                          * (ssde_wgrad_args.v_pre); a by-product of the first 64-cout tile's staging.  NULL: not written.
+                          * SSDE_TILE_WINOGRAD4G: REQUIRED -- the same tensor in the same layout, written by the launch's
+                          * transform pass and read by its matrix kernel (and still good for v_pre afterwards). */
 } ssde_conv_args;
 
 enum { SSDE_TILE_AUTO = 0, SSDE_TILE_256x64 = 1, SSDE_TILE_128x64 = 2, SSDE_TILE_64x64 = 3, SSDE_TILE_256x32 = 4,
