@@ -39,6 +39,20 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// -DSSDE_WG4_TRACE (tools/wgrad4_trace.py, a variant library only): s_memtime stamps of wave 0 of the first GEMM workgroup
+#ifdef SSDE_WG4_TRACE
+__device__ unsigned long long* g_wg4_trace;
+extern "C" int ssde_debug_wg4_trace(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_wg4_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -5;
+}
+#define SSDE_WT(slot)                                                                                     \
+  do {                                                                                                    \
+    if (tr_on) g_wg4_trace[slot] = __builtin_amdgcn_s_memtime();                                          \
+  } while (0)
+#else
+#define SSDE_WT(slot) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int kPos = 36;
@@ -228,6 +242,10 @@ __global__ __launch_bounds__(kGemmThreads, 4) void wgrad4_gemm_kernel(const W4Pa
   // on ONE XCD (blocks are dealt round-robin over the 8 XCDs, each with its own L2) -- as consecutive blocks they landed on
   // different XCDs and every operand row was fetched from HBM once per block that uses it (PMC: 469 MB per launch
   // against 263 MB of operands, profiles/r3_train_pmc.json)
+#ifdef SSDE_WG4_TRACE
+  const bool tr_on = blockIdx.x == 0 && tid == 0 && g_wg4_trace != nullptr;
+#endif
+  SSDE_WT(0);
   const int ntiles = p.co_tiles * p.ci_tiles;
   const int xcd = blockIdx.x & 7, lin = blockIdx.x >> 3;
   const int tile = p.xcd_order ? lin % ntiles : (int)blockIdx.x % ntiles;
@@ -292,9 +310,14 @@ __global__ __launch_bounds__(kGemmThreads, 4) void wgrad4_gemm_kernel(const W4Pa
   load_stage(0);
   store_stage(smem);
   __syncthreads();
+  SSDE_WT(1);
+#ifdef SSDE_WG4_TRACE
+  if (tr_on) g_wg4_trace[100] = (unsigned long long)nst;
+#endif
   for (int st = 0; st < nst; ++st) {
     const float* cur = smem + (st & 1) * kStage;
     const bool has_next = st + 1 < nst;
+    if (st < 8) SSDE_WT(4 + 4 * st);
     if (has_next) load_stage(st + 1);
     float af[2][2], bf[2][2];
 #pragma unroll
@@ -318,9 +341,13 @@ __global__ __launch_bounds__(kGemmThreads, 4) void wgrad4_gemm_kernel(const W4Pa
       if (kk + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     }
+    if (st < 8) SSDE_WT(4 + 4 * st + 1);
     if (has_next) store_stage(smem + ((st + 1) & 1) * kStage);
+    if (st < 8) SSDE_WT(4 + 4 * st + 2);
     __syncthreads();
+    if (st < 8) SSDE_WT(4 + 4 * st + 3);
   }
+  SSDE_WT(2);
 
   // slab[split][pos][co][ci]: a lane's 32 consecutive ci are a 128-byte run
   float* slab = p.slabs + ((size_t)split * kPos + pos) * (size_t)p.Cout * p.Ctot;
@@ -335,6 +362,7 @@ __global__ __launch_bounds__(kGemmThreads, 4) void wgrad4_gemm_kernel(const W4Pa
         if (co < p.Cout && ci < p.Ctot) slab[(size_t)co * p.Ctot + ci] = acc[a][c][r];
       }
     }
+  SSDE_WT(3);
 }
 
 // Reduction in two launches.  (a) slab[0] += slab[1] + .. + slab[splits-1], element-wise in float4s over all 36 x Cout x Cin
@@ -404,8 +432,14 @@ void plan(const ssde_wgrad_args* a, W4Params* p) {
   p->T = a->n * p->tx * p->ty;
   p->co_tiles = ssde_cdiv(a->c_out, BM); p->ci_tiles = ssde_cdiv(p->Ctot, BN);
   // four workgroups share a CU: aim at SSDE_WGRAD4_WGS (default 768) of them, at least 32 stages (512 tiles) each; every
-  // split costs a slab of 36 x Cout x Cin floats that the reduction reads back
-  static const int target = getenv("SSDE_WGRAD4_WGS") ? atoi(getenv("SSDE_WGRAD4_WGS")) : 768;
+  // split costs a slab of 36 x Cout x Cin floats that the reduction reads back.  (The K loop itself runs near the MFMA bound --
+  // 6.4 k cycles per 16-tile stage with three workgroups on the CU, tools/wgrad4_trace.py -- and what a launch loses is
+  // quantisation: 576 workgroups are 3 on a quarter of the CUs and 2 on the rest.  A rule that minimises
+  // ceil(workgroups / CUs) x (stages + 3) + 1.2 per split was built and measured: 256 -> 128 @32x32 0.455 -> 0.42 ms and 8x8
+  // 512 -> 256 0.113 -> 0.104, but 384 -> 256 @16x16 0.248 -> 0.284 and 128 -> 128 @32x32 0.265 -> 0.278; the weight-gradient
+  // class of the training step 16.59 -> 16.54 ms -- not adopted, profiles/r4_wgrad4_kernel_times.txt.)
+  const char* te = getenv("SSDE_WGRAD4_WGS");
+  const int target = te ? atoi(te) : 768;
   const int blocks = kPos * p->co_tiles * p->ci_tiles;
   int splits = (target + blocks / 2) / blocks;
   const int max_splits = p->T / 512;
