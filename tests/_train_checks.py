@@ -407,6 +407,16 @@ def check_dropout_mask(dev):
     import ctypes as C_
     L.check(L.load().ssde_conv2d(C_.byref(a), ops._stream()), "ssde_conv2d")
     assert rel_err(nchw(dst.cpu()), y.detach()) < TOL_OP
+    # the same mask in the F(4x4,3x3) kernels: the fused one applies it in its halo prologue, the two-kernel form in its
+    # transform pass (conv_wino4g.hip) -- whose output is also what the weight gradient below may be handed (v_pre)
+    from score_sde_pytorch_amd.engine import pack_wino4_weight
+    wp4 = pack_wino4_weight(w.detach().to(dev))
+    vbuf = torch.full((36 * n * (h // 4) ** 2 * C,), float("nan"), device=dev)
+    for tile in (L.TILE_WINOGRAD4, L.TILE_WINOGRAD4G):
+        dst4 = torch.full((n, h, h, cout), float("nan"), device=dev)
+        a.w_main, a.tile, a.dst, a.wino_v = wp4.data_ptr(), tile, dst4.data_ptr(), vbuf.data_ptr()
+        L.check(L.load().ssde_conv2d(C_.byref(a), ops._stream()), "ssde_conv2d")
+        assert rel_err(nchw(dst4.cpu()), y.detach()) < 2e-5, tile
     dw = torch.zeros(cout, C, 3, 3, device=dev)
     ops.conv_wgrad(xa, d(nhwc(gout)), 3, dw, pro=L.PRO_GN_SILU, gn=gn, dropout=(p, seed_t, salt))
     assert rel_err(dw, w.grad) < TOL_OP
