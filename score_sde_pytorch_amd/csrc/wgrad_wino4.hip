@@ -71,6 +71,8 @@ struct W4Params {
   float scale;
   float* dw;
   float* V; float* Z; float* slabs;
+  int sk_on, sk_per, sk_S, sk_groups;   // stream-K (default): workgroup group g owns stages [g sk_per, (g+1) sk_per) of the flattened
+                           // (position, K stage) space, sk_S stages per position (see wgrad4_gemm_kernel); splits = the most segments a position has
   int v_quads;             // 1: V is the forward launch's by-product, [pos][Ctot / 4][t][4] (conv_wino4.hip kEmitV: a workgroup's 32
                            // tiles are one 512-byte run per position and stage); 0: wino4_xform_v_kernel's [pos][t][Ctot]
 };
@@ -249,14 +251,35 @@ __global__ __launch_bounds__(kGemmThreads, 4) void wgrad4_gemm_kernel(const W4Pa
   const int ntiles = p.co_tiles * p.ci_tiles;
   const int xcd = blockIdx.x & 7, lin = blockIdx.x >> 3;
   const int tile = p.xcd_order ? lin % ntiles : (int)blockIdx.x % ntiles;
-  const int grp = p.xcd_order ? (lin / ntiles) * 8 + xcd : (int)blockIdx.x / ntiles;       // (position, split) pair
-  if (grp >= kPos * p.splits) return;
+  const int grp = p.xcd_order ? (lin / ntiles) * 8 + xcd : (int)blockIdx.x / ntiles;       // (position, split) pair / stream-K group
+  if (grp >= (p.sk_on ? p.sk_groups : kPos * p.splits)) return;
   const int ci_t = tile % p.ci_tiles, co_t = tile / p.ci_tiles;
-  const int split = grp % p.splits;
-  const int pos = grp / p.splits;
   const int co0 = co_t * BM, ci0 = ci_t * BN;
-  const int k0 = split * p.k_per_split;
-  const int k1 = min(p.T, k0 + p.k_per_split);
+  // Stream-K (default; SSDE_WGRAD4_STREAMK=0 switches it off): the 36 positions x sk_S stages are ONE line of work that the groups cut into equal runs of
+  // sk_per stages, so every CU gets the same number of stages whatever 36 x blocks x splits comes to (the plain split leaves
+  // 576 workgroups on 256 CUs for the 256 -> 256 @16x16 and 128 -> 128 @32x32 layers: 0.75 of the chip).  A group is the
+  // ntiles workgroups that share operand rows (same XCD, same K range at the same time).  A run that crosses a position
+  // boundary is two segments: each accumulates from zero and leaves its own partial slab, slot = group - first group of
+  // that position; the reduction adds a position's slots in order (deterministic).
+  int sk_cur = p.sk_on ? grp * p.sk_per : 0;
+  const int sk_end = p.sk_on ? min(kPos * p.sk_S, sk_cur + p.sk_per) : 1;
+  for (; sk_cur < sk_end;) {
+  int pos, k0, k1, slot;
+  if (p.sk_on) {
+    pos = sk_cur / p.sk_S;
+    const int s0 = sk_cur - pos * p.sk_S;
+    const int s1 = min(p.sk_S, s0 + (sk_end - sk_cur));
+    k0 = s0 * BK; k1 = min(p.T, s1 * BK);
+    slot = grp - (pos * p.sk_S) / p.sk_per;
+    sk_cur += s1 - s0;
+  } else {
+    const int split = grp % p.splits;
+    pos = grp / p.splits;
+    k0 = split * p.k_per_split;
+    k1 = min(p.T, k0 + p.k_per_split);
+    slot = split;
+    sk_cur = sk_end;
+  }
   const int nst = (k1 - k0 + BK - 1) / BK;
   const float* Zp = p.Z + (size_t)pos * p.T * p.Cout;
   const float* Vp = p.V + (size_t)pos * p.T * p.Ctot;
@@ -350,7 +373,7 @@ __global__ __launch_bounds__(kGemmThreads, 4) void wgrad4_gemm_kernel(const W4Pa
   SSDE_WT(2);
 
   // slab[split][pos][co][ci]: a lane's 32 consecutive ci are a 128-byte run
-  float* slab = p.slabs + ((size_t)split * kPos + pos) * (size_t)p.Cout * p.Ctot;
+  float* slab = p.slabs + ((size_t)slot * kPos + pos) * (size_t)p.Cout * p.Ctot;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -362,6 +385,7 @@ __global__ __launch_bounds__(kGemmThreads, 4) void wgrad4_gemm_kernel(const W4Pa
         if (co < p.Cout && ci < p.Ctot) slab[(size_t)co * p.Ctot + ci] = acc[a][c][r];
       }
     }
+  }                                              // next segment of a stream-K run
   SSDE_WT(3);
 }
 
@@ -373,7 +397,12 @@ __global__ __launch_bounds__(256) void wgrad4_sum_splits_kernel(const W4Params p
   const size_t stride = (size_t)kPos * p.Cout * p.Ctot;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x) {
     float4 a = *reinterpret_cast<const float4*>(p.slabs + i * 4);
-    for (int sp = 1; sp < p.splits; ++sp) {
+    int ns = p.splits;
+    if (p.sk_on) {                                 // stream-K: the slots this position's segments filled
+      const int pos = (int)(i * 4 / ((size_t)p.Cout * p.Ctot));
+      ns = ((pos + 1) * p.sk_S - 1) / p.sk_per - (pos * p.sk_S) / p.sk_per + 1;
+    }
+    for (int sp = 1; sp < ns; ++sp) {
       const float4 v = *reinterpret_cast<const float4*>(p.slabs + (size_t)sp * stride + i * 4);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
@@ -448,6 +477,23 @@ void plan(const ssde_wgrad_args* a, W4Params* p) {
   if (splits < 1) splits = 1;
   p->k_per_split = ssde_cdiv(ssde_cdiv(p->T, splits), BK) * BK;
   p->splits = ssde_cdiv(p->T, p->k_per_split);
+  p->sk_on = 0; p->sk_per = p->sk_S = p->sk_groups = 0;
+  {
+    const char* sk = getenv("SSDE_WGRAD4_STREAMK");
+    if (!(sk && sk[0] == '0') && a->splits <= 0) {      // (default on; SSDE_WGRAD4_STREAMK=0: the plain split, for A/B runs and tests)
+      // three workgroups per CU are what the kernel's registers and LDS keep resident beside each other at full rate
+      const int ntiles = p->co_tiles * p->ci_tiles;
+      const int S = ssde_cdiv(p->T, BK), total = kPos * S;
+      int groups = 3 * ssde_num_cus() / ntiles;
+      if (groups < 1) groups = 1;
+      int per = ssde_cdiv(total, groups);
+      if (per < 8) per = 8;                        // (at least 8 stages per run)
+      if (per < S || groups >= kPos) {             // otherwise whole positions per group: the plain form with one split
+        p->sk_on = 1; p->sk_per = per; p->sk_S = S; p->sk_groups = ssde_cdiv(total, per);
+        p->splits = ssde_cdiv(S, per) + 1;         // the most slots a position can have
+      }
+    }
+  }
   p->scale = a->scale; p->dw = a->dw;
   { const char* e = getenv("SSDE_WGRAD4_XCD"); p->xcd_order = !(e && e[0] == '0'); }
 }
@@ -506,6 +552,7 @@ int ssde_wgrad_wino4_launch(const ssde_wgrad_args* a, void* stream) {
                  (long long)kPos * p.T * (p.Ctot + p.Cout) + (long long)kPos * p.Cout * p.Ctot);
     p.k_per_split = ssde_cdiv(ssde_cdiv(p.T, fit), BK) * BK;
     p.splits = ssde_cdiv(p.T, p.k_per_split);
+    p.sk_on = 0;
   }
   SSDE_REQUIRE(a->scratch, "wgrad(winograd 4x4): scratch missing");
   // v_pre: the forward launch of this layer left V behind (conv_wino4.hip, kEmitV): no input-transform pass here
@@ -541,7 +588,7 @@ int ssde_wgrad_wino4_launch(const ssde_wgrad_args* a, void* stream) {
   }
   SSDE_LAUNCH_CHECK();
   const int lds = 2 * kStage * 4;
-  const dim3 gg(ssde_cdiv(kPos * p.splits, 8) * 8 * p.co_tiles * p.ci_tiles);
+  const dim3 gg(ssde_cdiv(p.sk_on ? p.sk_groups : kPos * p.splits, 8) * 8 * p.co_tiles * p.ci_tiles);
   if (have_v) hipLaunchKernelGGL(wgrad4_gemm_kernel<true>, gg, dim3(kGemmThreads), lds, st, p);
   else hipLaunchKernelGGL(wgrad4_gemm_kernel<false>, gg, dim3(kGemmThreads), lds, st, p);
   SSDE_LAUNCH_CHECK();

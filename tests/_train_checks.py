@@ -1387,3 +1387,45 @@ def check_conv_winograd4_two_kernels(dev, big=False):
         assert torch.equal(out["matrix kernel on the by-product"], out["one kernel"]), (n, c0, c1, cout, h)
         assert torch.equal(parts["matrix kernel on the by-product"], parts["one kernel"])
         assert _util.rel_err(out["two kernels"], out["one kernel"]) < 5e-6
+
+
+def check_wgrad_wino4_streamk(dev, big=False):
+    """F(4x4,3x3) weight gradient with the stream-K work split of its GEMM (the default; SSDE_WGRAD4_STREAMK=0 = the plain split: equal runs of K stages cut
+    across the 36 positions, a run that crosses a position boundary leaves two partial slabs) against torch autograd and
+    against the plain split: GroupNorm + SiLU prologue, a concatenated source, (co, ci) tile grids of 1 and 4, ragged last
+    stages, runs of different lengths (SSDE_NUM_CUS)."""
+    import torch.nn.functional as F
+    from score_sde_pytorch_amd import hipops as ops, _lib as L
+    g = torch.Generator().manual_seed(21)
+    cases = [(5, 32, 64, 0, 64, "256"), (3, 32, 96, 32, 160, "256"), (9, 16, 128, 0, 128, "64"), (2, 32, 32, 0, 32, "40")]
+    if big:
+        cases += [(32, 16, 256, 0, 256, "256"), (16, 32, 128, 128, 128, "256")]
+    for (n, h, c1, c2, cout, cus) in cases:
+        k = c1 + c2
+        x = torch.randn(n, k, h, h, generator=g).requires_grad_(False)
+        G = min(32, k // 4)
+        gamma, beta = 1 + 0.1 * torch.randn(k, generator=g), 0.1 * torch.randn(k, generator=g)
+        w = (torch.randn(cout, k, 3, 3, generator=g) / np.sqrt(9 * k)).requires_grad_()
+        gy = torch.randn(n, cout, h, h, generator=g)
+        F.conv2d(F.silu(F.group_norm(x, G, gamma, beta, 1e-6)), w, padding=1).backward(gy)
+        xa = x[:, :c1].permute(0, 2, 3, 1).contiguous().to(dev)
+        xb = x[:, c1:].permute(0, 2, 3, 1).contiguous().to(dev) if c2 else None
+        mean, rstd = ops.groupnorm_stats(xa, G, 1e-6, x2=xb)
+        gn = (mean, rstd, gamma.to(dev), beta.to(dev), G)
+        gyd = gy.permute(0, 2, 3, 1).contiguous().to(dev)
+        out = {}
+        for sk in ("0", "1"):
+            env = {"SSDE_WGRAD_WINOGRAD": "44", "SSDE_WGRAD4_STREAMK": sk, "SSDE_NUM_CUS": cus}
+            os.environ.update(env)
+            try:
+                dw = torch.zeros(cout, k, 3, 3, device=dev)
+                ops.conv_wgrad(xa, gyd, 3, dw, pad=1, x2=xb, pro=L.PRO_GN_SILU, gn=gn)
+                dw2 = torch.zeros(cout, k, 3, 3, device=dev)
+                ops.conv_wgrad(xa, gyd, 3, dw2, pad=1, x2=xb, pro=L.PRO_GN_SILU, gn=gn)
+            finally:
+                for key in env:
+                    os.environ.pop(key)
+            assert torch.equal(dw, dw2), (sk, n, h, k, cout)                     # fixed order of the partial sums
+            assert rel_err(dw, w.grad) < 2e-4, (sk, n, h, k, cout, rel_err(dw, w.grad))
+            out[sk] = dw.cpu()
+        assert rel_err(out["1"], out["0"]) < 2e-5, (n, h, k, cout)

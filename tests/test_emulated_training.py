@@ -141,3 +141,7 @@ def test_conv3x3_winograd_f4x4_on_the_bf16_matrix_pipe():
 
 def test_conv3x3_winograd_f4x4_in_two_kernels():
     T.check_conv_winograd4_two_kernels("cpu")
+
+
+def test_winograd_f4x4_weight_gradient_with_the_stream_k_split():
+    T.check_wgrad_wino4_streamk("cpu")

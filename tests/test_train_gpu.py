@@ -158,3 +158,7 @@ def test_whole_network_gradients_winograd_f4x4_in_two_kernels(monkeypatch):
     monkeypatch.setenv("SSDE_WINO4_TWO", "2")
     monkeypatch.setenv("SSDE_WGRAD_WINOGRAD", "44")
     T.check_unet_grads("ncsnpp", "cuda", batch=3)
+
+
+def test_winograd_f4x4_weight_gradient_with_the_stream_k_split():
+    T.check_wgrad_wino4_streamk("cuda", big=True)
