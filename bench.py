@@ -345,7 +345,7 @@ def roofline_of(prog, E, L, reps=3):
     cls = np.array(prog.classes)
     fl = np.array(prog.flops)
     tiles = np.array([int(prog.ops[i].u.conv.tile) if int(prog.ops[i].kind) == L.OP_CONV else -1 for i in range(prog.n)])
-    wino4 = np.isin(tiles, (L.TILE_WINOGRAD4, L.TILE_WINOGRAD4G, L.TILE_WINOGRAD4X))     # F(4x4,3x3): fused, two kernels, bf16 split
+    wino4 = np.isin(tiles, L.TILES_WINOGRAD4)     # F(4x4,3x3): fused, two kernels (LDS- or register-fed matrix kernel)
     wino4g = tiles == L.TILE_WINOGRAD4G
     wino = (tiles == L.TILE_WINOGRAD) | wino4
     executed = np.where(wino4, fl / WINOGRAD4_FLOP_RATIO, np.where(wino, fl / WINOGRAD_FLOP_RATIO, fl))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSDE_ABI_VERSION 7   /* 7: ssde_gn_bwd_reduce_args.g0 / g1 (GroupNorm backward in one pass over dp and x); 6: ssde_conv_args.wino_v / ssde_wgrad_args.v_pre (forward by-product feeds the weight gradient); 5: SSDE_PACK_WINO4 image re-ordered per wave (plan blobs of version 4 carry the old image), ODE ops in programs */
+#define SSDE_ABI_VERSION 8   /* 8: routing switches moved from environment variables into ssde_conv_args.flags / ssde_wgrad_args.flags / ssde_gn_bwd_reduce_args.flags, SSDE_TILE_WINOGRAD4R + SSDE_PACK_WINO4R (register-fed F(4x4,3x3) matrix kernel), SSDE_TILE_WINOGRAD4X removed; 7: ssde_gn_bwd_reduce_args.g0 / g1 (GroupNorm backward in one pass over dp and x); 6: ssde_conv_args.wino_v / ssde_wgrad_args.v_pre (forward by-product feeds the weight gradient); 5: SSDE_PACK_WINO4 image re-ordered per wave (plan blobs of version 4 carry the old image), ODE ops in programs */
 
 /* ---- prologue applied to a source tensor while it is staged into LDS ---- */
 enum {
@@ -86,7 +86,9 @@ typedef struct ssde_conv_args {
   int32_t resid_post;    /* 0: out = scale*(... + resid) (residual tail); 1: out = scale*(...) + resid (gradient accumulation) */
   const float* resid;    /* [N, h_out, w_out, c_out] or NULL (may alias dst) */
   float out_scale;       /* 1 or 1/sqrt(2)                                 */
-  int32_t _pad1;
+  uint32_t flags;        /* SSDE_CONVF_* routing switches (ABI 8; 0 = the library's own choice everywhere).  They replace the
+                          * environment variables rounds 2-4 read inside the launchers: the route of a launch is part of its
+                          * arguments (and of a plan blob), not of the process */
   float* dst;            /* [N, h_out, w_out, c_out]                       */
   float* gn_part;        /* optional: GroupNorm partial statistics of dst, [N][S][c_out/4][3] = (mean, M2, count) per
                           * (image, slice, channel quad), written by the epilogue; S = ssde_conv_gn_slices(args) > 0
@@ -100,6 +102,15 @@ typedef struct ssde_conv_args {
                           * transform pass and read by its matrix kernel (and still good for v_pre afterwards). */
 } ssde_conv_args;
 
+enum { SSDE_CONVF_V_GIVEN = 1u,      /* SSDE_TILE_WINOGRAD4G / 4R: wino_v already holds B^T pro(main) B -- skip the transform pass */
+       SSDE_CONVF_BF16X6 = 2u,       /* contractions that have a split kernel (1x1 / NIN / Linear GEMMs) run on the BF16 matrix pipe as
+                                      * exact-fp32 products of a 3-way bf16 split, fp32 accumulation (conv1x1.hip) */
+       SSDE_CONVF_NO_KSPLIT = 4u,    /* never split the reduction of a launch over several workgroups */
+       SSDE_CONVF_BKC8 = 8u,         /* direct kernel: 8-channel stages everywhere (default: 64-channel stages where they fit) */
+       SSDE_CONVF_GEMM_PIPE = 16u,   /* 1x1 GEMM: force the persistent pipelined kernel (default: where it pays, bf16x6 only) */
+       SSDE_CONVF_NO_GEMM_PIPE = 32u,/* 1x1 GEMM: never take it */
+       SSDE_CONVF_X6_BM64 = 64u,     /* bf16x6 GEMM: 64 rows per workgroup instead of 128 */
+       SSDE_CONVF_X6_PF2 = 128u };   /* bf16x6 GEMM: rows loaded two stages ahead instead of one */
 enum { SSDE_TILE_AUTO = 0, SSDE_TILE_256x64 = 1, SSDE_TILE_128x64 = 2, SSDE_TILE_64x64 = 3, SSDE_TILE_256x32 = 4,
        /* Winograd F(2x2,3x3) kernel (3x3, stride 1, pad 1, even output, no aux): w_main must then be packed as
         * [ceil(Cin/8)][ceil(Cout/64)][16 positions][4 channel pairs][64 couts, bit 4 ^= pair parity][2], G g G^T */
@@ -107,13 +118,19 @@ enum { SSDE_TILE_AUTO = 0, SSDE_TILE_256x64 = 1, SSDE_TILE_128x64 = 2, SSDE_TILE
        /* Winograd F(4x4,3x3) kernel (3x3, stride 1, pad 1, output a multiple of 4, no aux): w_main packed as
         * [ceil(Cin/4)][ceil(Cout/64)][36 positions][64 couts][4 channels], G g G^T with the 6x3 G of F(4,3) */
        SSDE_TILE_WINOGRAD4 = 6,
-       /* the same on the BF16 matrix pipe (exact-fp32 products of a 3-way bf16 split, conv_wino4x.hip): w_main packed as
-        * [ceil(Cin/4)][ceil(Cout/64)][8 waves][9][32 couts][3 pieces][4 channels] bf16; inference launches only */
-       SSDE_TILE_WINOGRAD4X = 7,
+       /* 7 was SSDE_TILE_WINOGRAD4X (F(4x4,3x3) on the BF16 matrix pipe through a 3-way bf16 split): parity-green but 6-24 % slower
+        * than the fp32 kernel in both structures built; removed from the library in ABI 8, sources + logs under
+        * tools/experiments/conv_wino4x/ */
        /* F(4x4,3x3) in two kernels (conv_wino4g.hip): the input transform V = B^T pro(x) B as its own HBM-bound pass into
         * ssde_conv_args.wino_v (REQUIRED here: 36 * N*H*W/16 * Cin floats), then a matrix kernel without prologue or transform;
         * w_main packed as for SSDE_TILE_WINOGRAD4.  Pays where a V tile feeds four or more 64-cout tiles */
-       SSDE_TILE_WINOGRAD4G = 8 };
+       SSDE_TILE_WINOGRAD4G = 8,
+       /* the same two-kernel form with the matrix kernel fed from REGISTERS (conv_wino4r.hip, ABI 8): no LDS and no barrier in its
+        * main loop, every wave loads the V runs and its private weights straight into the MFMA operands.  wino_v REQUIRED as for
+        * SSDE_TILE_WINOGRAD4G; w_main packed per lane (SSDE_PACK_WINO4R):
+        * [ceil(Cin/4)][ceil(Cout/64)][8 waves (q, h)][4 pieces x [64 lanes][4] | [64 lanes][2]] where lane (lh, li) of wave (q, h)
+        * holds, of cout 32 h + li and channels 2 lh, 2 lh + 1, the positions q + 4 (2 i), q + 4 (2 i + 1) in piece i and q + 32 last */
+       SSDE_TILE_WINOGRAD4R = 9 };
 
 /* ---- GroupNorm statistics: mean / rstd per (sample, group) -----------------
  * replaces the reduction half of nn.GroupNorm(min(C/4,32), C, eps=1e-6)
@@ -272,6 +289,7 @@ typedef struct ssde_wgrad_args {
   int32_t transpose_out;   /* ksize 1 only: dw is [cin_store][c_out] (NIN.W, models/layers.py:550) */
   int32_t splits;          /* pixel-dimension split (0 = library chooses, bounded by scratch_floats) */
   float scale;
+  uint32_t flags;          /* SSDE_WGRADF_* routing switches (ABI 8; 0 = the library's own choice) */
   float* dw;               /* [c_out][cin_store][k][k] (OIHW); dw += result */
   /* split > 1: every workgroup writes its partial tile to `scratch` with coalesced stores and a second
    * kernel sums the splits in a fixed order (deterministic, no atomics).  ssde_wgrad_scratch_floats()
@@ -282,6 +300,14 @@ typedef struct ssde_wgrad_args {
                             * (ssde_conv_args.wino_v, same src and prologue); taken only when ssde_wgrad_wants_winograd4()
                             * is true for these arguments -- the input-transform pass of the weight gradient is then skipped */
 } ssde_wgrad_args;
+
+enum { SSDE_WGRADF_DIRECT = 1u,        /* never a Winograd weight-gradient kernel */
+       SSDE_WGRADF_F2 = 2u,            /* F(2x2,3x3) wherever it is legal, never F(4x4,3x3) */
+       SSDE_WGRADF_F4_FORCE = 4u,      /* F(4x4,3x3) wherever it is legal (default: where it is legal and pays) */
+       SSDE_WGRADF_NO_STREAMK = 8u,    /* F(4x4,3x3) GEMM: the plain split over K instead of the stream-K runs */
+       SSDE_WGRADF_NO_XCD_ORDER = 16u, /* F(4x4,3x3) GEMM: workgroups in launch order */
+       SSDE_WGRADF_1X1_CHUNKED = 32u,  /* 1x1 / NIN / Linear: the chunked kernel instead of the pipelined GEMM */
+       SSDE_WGRADF_XVEC1 = 64u };      /* F(4x4,3x3) transforms: one channel per thread instead of two */
 
 /* ---- column sums of a gradient: bias and Dense_0(temb) addend gradients ------------------- */
 typedef struct ssde_colsum_args {
@@ -309,7 +335,8 @@ typedef struct ssde_gn_bwd_reduce_args {
   float* sums;             /* [N, G, 2]: mean_g(dxh), mean_g(dxh*xhat) */
   float* dgamma; float* dbeta;   /* [c0+c1] written (not accumulated) */
   float* scratch;          /* >= N*slices*(G*2 + C*2) floats */
-  int32_t slices; int32_t _pad0;
+  int32_t slices;
+  uint32_t flags;          /* SSDE_GNBWDF_* (ABI 8) */
   /* ABI 7, optional: with g0 or g1 set the call also applies the formula (what ssde_prologue_bwd would do with dp_ld = c0+c1,
    * dp_off = 0): where one sample's run of whole groups fits the registers of a workgroup (hw <= 8192 at 4 channels per
    * group) dp and x are read ONCE by a single kernel that reduces and applies; elsewhere the call runs the reduction, the
@@ -319,6 +346,8 @@ typedef struct ssde_gn_bwd_reduce_args {
   int32_t acc0, acc1;      /* 1: g += ..., 0: g = ... */
   float scale; int32_t _pad1;
 } ssde_gn_bwd_reduce_args;
+
+enum { SSDE_GNBWDF_THREE_KERNELS = 1u };   /* ssde_gn_bwd_reduce with g0 / g1: always reduce + finalize + apply, never the one-pass kernel */
 
 typedef struct ssde_prologue_bwd_args {
   ssde_src src;            /* forward source (p0/p1 may be NULL for SSDE_PRO_NONE) */
@@ -378,7 +407,8 @@ typedef struct ssde_memset_args { void* dst; int64_t bytes; int32_t value; int32
  * parameters stay in the reference layouts (state_dict compatibility).  One launch per kind re-packs
  * every weight of the model from a device-resident descriptor table. */
 enum { SSDE_PACK_CONV3 = 1, SSDE_PACK_WINO3 = 2, SSDE_PACK_MATRIX = 3, SSDE_PACK_VECTOR = 4,
-       SSDE_PACK_WINO4 = 5 /* conv -> the F(4x4,3x3) image of SSDE_TILE_WINOGRAD4 */ };
+       SSDE_PACK_WINO4 = 5 /* conv -> the F(4x4,3x3) image of SSDE_TILE_WINOGRAD4 */,
+       SSDE_PACK_WINO4R = 6 /* conv -> the per-lane F(4x4,3x3) image of SSDE_TILE_WINOGRAD4R */ };
 typedef struct ssde_pack_desc {
   const float* src;        /* parameter: conv [cout][cin][3][3]; matrix [cout][cin]; vector [n] */
   const float* src2;       /* vector: optional second addend (Conv_1.bias + Conv_2.bias) */

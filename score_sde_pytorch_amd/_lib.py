@@ -10,15 +10,22 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SSDE_LIB_PATH: developer switch for A/B timing of kernel variants built by _build.build_variant (tools/ab_bench.sh)
 LIB_PATH = os.environ.get("SSDE_LIB_PATH") or os.path.join(_HERE, "libssde_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_SILU = 0, 1, 2, 3
-TILE_AUTO, TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32, TILE_WINOGRAD, TILE_WINOGRAD4, TILE_WINOGRAD4X, TILE_WINOGRAD4G = 0, 1, 2, 3, 4, 5, 6, 7, 8
+TILE_AUTO, TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32, TILE_WINOGRAD, TILE_WINOGRAD4 = 0, 1, 2, 3, 4, 5, 6
+TILE_WINOGRAD4G, TILE_WINOGRAD4R = 8, 9            # (7 was the bf16-split F(4x4,3x3) kernel: tools/experiments/conv_wino4x/)
+TILES_WINOGRAD4 = (TILE_WINOGRAD4, TILE_WINOGRAD4G, TILE_WINOGRAD4R)
+# routing switches of a launch (include/ssde.h: SSDE_CONVF_*, SSDE_WGRADF_*, SSDE_GNBWDF_*)
+CONVF_V_GIVEN, CONVF_BF16X6, CONVF_NO_KSPLIT, CONVF_BKC8, CONVF_GEMM_PIPE, CONVF_NO_GEMM_PIPE, CONVF_X6_BM64, CONVF_X6_PF2 = \
+    1, 2, 4, 8, 16, 32, 64, 128
+WGRADF_DIRECT, WGRADF_F2, WGRADF_F4_FORCE, WGRADF_NO_STREAMK, WGRADF_NO_XCD_ORDER, WGRADF_1X1_CHUNKED, WGRADF_XVEC1 = 1, 2, 4, 8, 16, 32, 64
+GNBWDF_THREE_KERNELS = 1
 (OP_CONV, OP_GN_STATS, OP_UPFIRDN, OP_ATTN, OP_EMBED, OP_TO_NHWC, OP_TO_NCHW, OP_BIAS_ACT, OP_SUMSQ,
  OP_RANDN, OP_LANGEVIN, OP_PREDICTOR, OP_FILL, OP_STEP_INC, OP_WGRAD, OP_COLSUM, OP_GN_BWD_REDUCE, OP_PROLOGUE_BWD,
  OP_ATTN_BWD, OP_PERTURB, OP_DSM_LOSS, OP_SUMSQ_FLAT, OP_ADAM, OP_MEMSET, OP_AXPY, OP_PACK, OP_PROJECT,
  OP_GN_FINALIZE, OP_PF_DRIFT, OP_HUTCH_DIV) = range(1, 31)
-PACK_CONV3, PACK_WINO3, PACK_MATRIX, PACK_VECTOR, PACK_WINO4 = 1, 2, 3, 4, 5
+PACK_CONV3, PACK_WINO3, PACK_MATRIX, PACK_VECTOR, PACK_WINO4, PACK_WINO4R = 1, 2, 3, 4, 5, 6
 
 _fp = C.c_void_p  # device pointers are passed as integers
 
@@ -37,7 +44,7 @@ class ConvArgs(C.Structure):
                 ("h_out", C.c_int32), ("w_out", C.c_int32), ("c_out", C.c_int32),
                 ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("tile", C.c_int32),
                 ("bias", _fp), ("chan_add", _fp), ("chan_add_ld", C.c_int32), ("resid_post", C.c_int32),
-                ("resid", _fp), ("out_scale", C.c_float), ("_pad1", C.c_int32), ("dst", _fp), ("gn_part", _fp), ("wino_v", _fp)]
+                ("resid", _fp), ("out_scale", C.c_float), ("flags", C.c_uint32), ("dst", _fp), ("gn_part", _fp), ("wino_v", _fp)]
 
 
 class GnStatsArgs(C.Structure):
@@ -152,7 +159,7 @@ class WgradArgs(C.Structure):
                 ("n", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32), ("h_out", C.c_int32), ("w_out", C.c_int32),
                 ("c_out", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
                 ("cin_store", C.c_int32), ("transpose_out", C.c_int32), ("splits", C.c_int32), ("scale", C.c_float),
-                ("dw", _fp), ("scratch", _fp), ("scratch_floats", C.c_int64), ("v_pre", _fp)]
+                ("flags", C.c_uint32), ("dw", _fp), ("scratch", _fp), ("scratch_floats", C.c_int64), ("v_pre", _fp)]
 
 
 class ColsumArgs(C.Structure):
@@ -163,7 +170,7 @@ class ColsumArgs(C.Structure):
 
 class GnBwdReduceArgs(C.Structure):
     _fields_ = [("src", Src), ("dp", _fp), ("n", C.c_int32), ("hw", C.c_int32), ("sums", _fp),
-                ("dgamma", _fp), ("dbeta", _fp), ("scratch", _fp), ("slices", C.c_int32), ("_pad0", C.c_int32),
+                ("dgamma", _fp), ("dbeta", _fp), ("scratch", _fp), ("slices", C.c_int32), ("flags", C.c_uint32),
                 ("g0", _fp), ("g1", _fp), ("acc0", C.c_int32), ("acc1", C.c_int32), ("scale", C.c_float), ("_pad1", C.c_int32)]
 
 
@@ -252,6 +259,50 @@ EXPORTS = ["ssde_conv2d", "ssde_groupnorm_stats", "ssde_upfirdn2d", "ssde_attent
            "ssde_train_step", "ssde_train_forward", "ssde_unet_backward", "ssde_plan_copy_io"]
 
 _lib = None
+
+
+# ---- environment -> routing flags -----------------------------------------------------------------------------------------
+# The library itself reads no routing switch from the environment (ABI 8): a launch's route is part of its arguments.  For
+# A/B runs and the tests of alternative kernels the HOST side maps the round-2..4 variables to flags at the moment it builds
+# arguments (engine.ProgramBuilder.finalize, the hipops wrappers), so a lowered program -- and a plan blob exported from it --
+# carries its routes with it and two programs in one process may differ.
+def conv_route_flags(env=None):
+    e = os.environ if env is None else env
+    f = 0
+    if e.get("SSDE_MATRIX", "").startswith("b"):
+        f |= CONVF_BF16X6
+    if e.get("SSDE_CONV_KSPLIT", "1") == "0":
+        f |= CONVF_NO_KSPLIT
+    if e.get("SSDE_CONV_BKC64", "") == "8":
+        f |= CONVF_BKC8
+    if e.get("SSDE_GEMM_PIPE", "") == "0":
+        f |= CONVF_NO_GEMM_PIPE
+    if e.get("SSDE_GEMM_PIPE", "") == "2":
+        f |= CONVF_GEMM_PIPE
+    if e.get("SSDE_X6_BM", "") == "64":
+        f |= CONVF_X6_BM64
+    if e.get("SSDE_X6_PF", "") == "2":
+        f |= CONVF_X6_PF2
+    return f
+
+
+def wgrad_route_flags(env=None):
+    e = os.environ if env is None else env
+    f = {"0": WGRADF_DIRECT, "2": WGRADF_F2, "44": WGRADF_F4_FORCE}.get(e.get("SSDE_WGRAD_WINOGRAD", ""), 0)
+    if e.get("SSDE_WGRAD4_STREAMK", "1") == "0":
+        f |= WGRADF_NO_STREAMK
+    if e.get("SSDE_WGRAD4_XCD", "1") == "0":
+        f |= WGRADF_NO_XCD_ORDER
+    if e.get("SSDE_WGRAD_1X1_PIPELINED", "1") == "0":
+        f |= WGRADF_1X1_CHUNKED
+    if e.get("SSDE_WGRAD4_XVEC", "2") == "1":
+        f |= WGRADF_XVEC1
+    return f
+
+
+def gn_bwd_route_flags(env=None):
+    e = os.environ if env is None else env
+    return GNBWDF_THREE_KERNELS if e.get("SSDE_GN_BWD_FUSED", "1") == "0" else 0
 
 
 class SsdeError(RuntimeError):

@@ -349,9 +349,9 @@ class TrainEngine(E.UNetEngine):
         gsrc = _src(g, g_ld)
         if ksize == 3:
             wino = low.wino_ok(h_in, w_in, ctot, g_ld) if stride == 1 else 0
-            pack = {4: E.pack_wino4_weight, 2: E.pack_wino_weight}.get(wino, E.pack_conv_weight)
+            pack = {6: E.pack_wino4r_weight, 4: E.pack_wino4_weight, 2: E.pack_wino_weight}.get(wino, E.pack_conv_weight)
             wd = self.weights.derived(wpacked, lambda w: pack(w.permute(1, 0, 2, 3).flip(2, 3)),
-                                      {4: "dgrad_wino4", 2: "dgrad_wino"}.get(wino, "dgrad"))
+                                      {6: "dgrad_wino4r", 4: "dgrad_wino4", 2: "dgrad_wino"}.get(wino, "dgrad"))
             if stride == 1:
                 low.conv(dst, h_in, w_in, ctot, main=gsrc, w_main=wd, h_in=ho, w_in=wo, stride=1, pad=1, resid=resid,
                          resid_post=1, scale=scale, wino=wino)
@@ -376,6 +376,7 @@ class TrainEngine(E.UNetEngine):
             setattr(a, k, fields[k])
         s = fields["src"]
         a.src.c0, a.src.c1, a.src.pro_mode, a.src.gn_groups = s["c0"], s["c1"], s["pro_mode"], s["gn_groups"]
+        a.flags = fields.get("flags", L.wgrad_route_flags())
         r = int(L.load().ssde_wgrad_scratch_floats(C.byref(a)))
         if r < 0:
             L.check(r, "ssde_wgrad_scratch_floats")

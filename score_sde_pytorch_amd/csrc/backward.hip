@@ -83,131 +83,6 @@ __global__ __launch_bounds__(256) void colsum_total_kernel(const float* __restri
   }
 }
 
-// ---- column sums, one launch ------------------------------------------------------------------------------------------
-// The three kernels above are three launches of 5-8 us each for a few hundred KB of result (a training step has ~120 column
-// sums: ~1.3 ms of launch granularity, profiles/r3_train_step_kernel_stats_rocprofv3.csv).  VERDICT r3 item 4a asked for one
-// launch; measured SLOWER (see ssde_colsum), opt-in only.  Here the block that ARRIVES LAST
-// finishes the job: every block leaves its partial row in `part` (agent-scope stores), takes a ticket, and the holder of the
-// last ticket of a (channel chunk, sample) sums the pixel slices in FIXED order (the result does not depend on who arrived
-// when); with a per-sample destination a second ticket per chunk elects the block that sums the samples into `total`.
-//   kPer = true : grid (chunks, slices, N), partials [n][slice][c], per-sample sums written, total optional
-//   kPer = false: grid (chunks, slices, 1), the slices cut the N * hw pixel rows of the whole batch, total only
-// Tickets come from conv_mfma.hip's zero-initialised table and are returned to zero by their last user.
-struct CsParams {
-  const float* g; int g_ld, g_off, hw, n, c;
-  float scale;
-  float* part; float* per; int ld, off;
-  float* total; float* total2;
-  unsigned* tickets;
-};
-
-template <bool kPer>
-__global__ __launch_bounds__(256) void colsum_fused_kernel(const CsParams p) {
-  SSDE_LDS(smem);                                      // [4][64] float4, then one flag word
-  float4* red = reinterpret_cast<float4*>(smem);
-  int* flag = reinterpret_cast<int*>(smem + 4 * 64 * 4);
-  const int chunk = blockIdx.x, slice = blockIdx.y, z = blockIdx.z, slices = gridDim.y, nz = gridDim.z;
-  const int cl = chunk * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
-  const int col = p.g_off + cl * 4;
-  const bool lane_ok = cl * 4 < p.c && col + 4 <= p.g_ld;
-  const long long rows = kPer ? p.hw : (long long)p.n * p.hw;
-  const long long per_slice = (rows + slices - 1) / slices;
-  const long long q0 = slice * per_slice, q1 = q0 + per_slice < rows ? q0 + per_slice : rows;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (lane_ok) {
-    const float* base = p.g + (size_t)(kPer ? z : 0) * p.hw * p.g_ld + col;
-    long long px = q0 + pl;
-    for (; px + 12 < q1; px += 16) {
-      const float4 a = *reinterpret_cast<const float4*>(base + (size_t)px * p.g_ld);
-      const float4 b = *reinterpret_cast<const float4*>(base + (size_t)(px + 4) * p.g_ld);
-      const float4 d = *reinterpret_cast<const float4*>(base + (size_t)(px + 8) * p.g_ld);
-      const float4 e = *reinterpret_cast<const float4*>(base + (size_t)(px + 12) * p.g_ld);
-      s.x += (a.x + b.x) + (d.x + e.x); s.y += (a.y + b.y) + (d.y + e.y);
-      s.z += (a.z + b.z) + (d.z + e.z); s.w += (a.w + b.w) + (d.w + e.w);
-    }
-    for (; px < q1; px += 4) {
-      const float4 a = *reinterpret_cast<const float4*>(base + (size_t)px * p.g_ld);
-      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
-    }
-  }
-  // fixed-order sum of the four float4 rows of `red` (one per pixel lane)
-  auto fold = [&](float (&v)[4]) {
-    const float4 a = red[threadIdx.x], b = red[threadIdx.x + 64], d = red[threadIdx.x + 128], e = red[threadIdx.x + 192];
-    v[0] = (a.x + b.x) + (d.x + e.x); v[1] = (a.y + b.y) + (d.y + e.y); v[2] = (a.z + b.z) + (d.z + e.z); v[3] = (a.w + b.w) + (d.w + e.w);
-  };
-  // the block that takes the last of `count` tickets continues (tickets[idx] is back at zero when it does)
-  auto last_of = [&](int idx, int count) {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0);                     // this thread's agent-scope stores are acknowledged ...
-    __syncthreads();                                   // ... and every thread's
-    if (threadIdx.x == 0) {
-      const unsigned t = atomicAdd(p.tickets + idx, 1u);
-      const bool last = t == (unsigned)(count - 1);
-      if (last) __hip_atomic_store(p.tickets + idx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *flag = last ? 1 : 0;
-    }
-    __syncthreads();
-    const bool r = *flag != 0;
-    __syncthreads();
-    return r;
-  };
-  red[threadIdx.x] = s;
-  __syncthreads();
-  float v[4];
-  if (pl == 0 && lane_ok) {
-    fold(v);
-    float* o = p.part + ((size_t)z * slices + slice) * p.c + cl * 4;
-    for (int k = 0; k < 4; ++k)
-      if (cl * 4 + k < p.c) __hip_atomic_store(o + k, v[k] * p.scale, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (slices > 1) {
-    if (!last_of(chunk * nz + z, slices)) return;
-    // the slices of (chunk, z), pixel lane pl taking slices pl, pl + 4, ...: the grouping depends on `slices` only
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane_ok)
-      for (int i = pl; i < slices; i += 4) {
-        const float* o = p.part + ((size_t)z * slices + i) * p.c + cl * 4;
-        float w[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < 4; ++k)
-          if (cl * 4 + k < p.c) w[k] = __hip_atomic_load(o + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t.x += w[0]; t.y += w[1]; t.z += w[2]; t.w += w[3];
-      }
-    red[threadIdx.x] = t;
-    __syncthreads();
-    if (pl == 0 && lane_ok) fold(v);
-  } else if (pl == 0 && lane_ok) {
-    for (int k = 0; k < 4; ++k) v[k] *= p.scale;
-  }
-  if (!kPer) {
-    if (pl == 0 && lane_ok)
-      for (int k = 0; k < 4; ++k)
-        if (cl * 4 + k < p.c) { p.total[cl * 4 + k] = v[k]; if (p.total2) p.total2[cl * 4 + k] = v[k]; }
-    return;
-  }
-  // per-sample sums of sample z
-  if (pl == 0 && lane_ok)
-    for (int k = 0; k < 4; ++k)
-      if (cl * 4 + k < p.c) __hip_atomic_store(p.per + (size_t)z * p.ld + p.off + cl * 4 + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (!p.total) return;
-  if (!last_of(gridDim.x * nz + chunk, nz)) return;
-  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (lane_ok)
-    for (int i = pl; i < p.n; i += 4) {
-      const float* o = p.per + (size_t)i * p.ld + p.off + cl * 4;
-      float w[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int k = 0; k < 4; ++k)
-        if (cl * 4 + k < p.c) w[k] = __hip_atomic_load(o + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      t.x += w[0]; t.y += w[1]; t.z += w[2]; t.w += w[3];
-    }
-  red[threadIdx.x] = t;
-  __syncthreads();
-  if (pl == 0 && lane_ok) {
-    fold(v);
-    for (int k = 0; k < 4; ++k)
-      if (cl * 4 + k < p.c) { p.total[cl * 4 + k] = v[k]; if (p.total2) p.total2[cl * 4 + k] = v[k]; }
-  }
-}
-
 // ---- GroupNorm backward: reduction -----------------------------------------------------------------
 constexpr int kGbThreads = 1024;
 
@@ -682,36 +557,6 @@ extern "C" int ssde_colsum(const ssde_colsum_args* a, void* stream) {
   float* per = a->per_sample ? a->per_sample : a->scratch + (size_t)a->n * slices * a->c;
   const int ld = a->per_sample ? a->ps_ld : a->c, off = a->per_sample ? a->ps_off : 0;
   const int cl = ssde_cdiv(a->c, 4);
-  {
-    // one launch (colsum_fused_kernel) on request: SSDE_COLSUM_FUSED=1.  Measured on the MI355X (profiles/r4_colsum_fused_ab.txt):
-    // the training step's element-wise class went from 7.8 to 11.1 ms with it -- the last-arriving block's fixed-order sums are
-    // chains of device-scope loads (~1 us each), longer than the two ~5 us launches they replace -- so the three-kernel
-    // sequence stays the default and this form is kept for the record (tests run both)
-    const char* fe = getenv("SSDE_COLSUM_FUSED");
-    const int chunks = ssde_cdiv(cl, 64);
-    const bool want_per = a->per_sample != nullptr;
-    // total only: the slices cut the rows of the whole batch; as many as fill the chip twice and fit the scratch rows
-    int fs = slices;
-    if (!want_per) {
-      const long long rows = (long long)a->n * a->hw;
-      long long s2 = rows / 64;
-      const long long cap = (long long)a->n * (slices + 1), fill = ssde_cdiv(2 * ssde_num_cus(), chunks);
-      if (s2 > cap) s2 = cap;
-      if (s2 > fill) s2 = fill;
-      fs = s2 < 1 ? 1 : (int)s2;
-    }
-    const int nz = want_per ? a->n : 1;
-    const int need = chunks * nz + chunks;
-    unsigned* tickets = !(fe && fe[0] == '1') || !a->scratch ? nullptr : ssde_conv_sync_slots(ssde_cdiv(need, 2));
-    if (tickets) {
-      CsParams p{a->g, a->g_ld, a->g_off, a->hw, a->n, a->c, a->scale, a->scratch, per, ld, off, a->total, a->total2, tickets};
-      const dim3 grid(chunks, fs, nz);
-      if (want_per) hipLaunchKernelGGL(colsum_fused_kernel<true>, grid, dim3(256), 4 * 64 * 16 + 16, st, p);
-      else hipLaunchKernelGGL(colsum_fused_kernel<false>, grid, dim3(256), 4 * 64 * 16 + 16, st, p);
-      SSDE_LAUNCH_CHECK();
-      return SSDE_OK;
-    }
-  }
   if (slices == 1) {
     hipLaunchKernelGGL(colsum_kernel, dim3(ssde_cdiv(cl, 64), 1, a->n), dim3(256), 4 * 64 * 16, st,
                        a->g, a->g_ld, a->g_off, a->hw, a->c, a->scale, per, ld, off);
@@ -765,13 +610,12 @@ extern "C" int ssde_gn_bwd_reduce(const ssde_gn_bwd_reduce_args* a, void* stream
   const int bx_a = ssde_cdiv(a->n * a->src.gn_groups, 256), bx_b = ssde_cdiv(C, 32);
   if (apply) {
     // ABI 7: the gradient of the sources in the same call -- one pass where a (sample, run of groups) fits the registers
-    // of a workgroup (SSDE_GN_BWD_FUSED=0: always the three kernels, for A/B timing and the tests of both forms)
-    const char* env = getenv("SSDE_GN_BWD_FUSED");
+    // of a workgroup (SSDE_GNBWDF_THREE_KERNELS: always the three kernels, for A/B timing and the tests of both forms)
     // (512-thread workgroups, two per CU, measured slower: the step 0.0587 -> 0.0591 s, profiles/r4_gn_bwd_one_pass_ab.txt --
     // a workgroup's rows shrink to 64-byte runs of 4 channel quads)
     constexpr int nt = 1024;
     int gpc = 0, clc = 0, pl = 0;
-    if (!(env && env[0] == '0') && (size_t)a->n * a->hw < (1ull << 31) &&
+    if (!(a->flags & SSDE_GNBWDF_THREE_KERNELS) && (size_t)a->n * a->hw < (1ull << 31) &&
         gn_bwd_fused_shape(nt, a->n, a->hw, C, a->src.gn_groups, &gpc, &clc, &pl)) {
       GfParams f{p, a->acc0, a->acc1, a->g0, a->g1, a->scale, gpc, clc, pl};
       f.b.slices = 1;                                   // scratch[n][C][2]
@@ -954,6 +798,7 @@ __global__ __launch_bounds__(256) void pack_wino3_kernel(const ssde_pack_desc* _
 // it reads the 3x3 filter once and writes its 36 positions (consecutive lanes = the 4 channels of consecutive couts: 512 B
 // runs per position).  The products are formed in
 // fp64 and rounded once, like the host packing (engine.pack_wino4_weight).
+template <bool kPerLane>
 __global__ __launch_bounds__(256) void pack_wino4_kernel(const ssde_pack_desc* __restrict__ table) {
   const ssde_pack_desc d = table[blockIdx.y];
   const int ntl = (d.cout_l + 63) / 64;
@@ -979,9 +824,17 @@ __global__ __launch_bounds__(256) void pack_wino4_kernel(const ssde_pack_desc* _
 #pragma unroll
       for (int b = 0; b < 6; ++b)
       {
-        const int pos = a * 6 + b, wv = (pos & 3) * 2 + (cs >> 5);
-        d.dst[(((r * 8 + wv) * 9 + (pos >> 2)) * 32 + (cs & 31)) * 4 + e] =
-            (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
+        const int pos = a * 6 + b, wv = (pos & 3) * 2 + (cs >> 5), j = pos >> 2;
+        const float u = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
+        if (!kPerLane) {
+          d.dst[(((r * 8 + wv) * 9 + j) * 32 + (cs & 31)) * 4 + e] = u;
+        } else {
+          // SSDE_PACK_WINO4R (conv_wino4r.hip): lane (lh = e >> 1, li = cout & 31) of wave wv holds channels 2 lh, 2 lh + 1 of
+          // positions 2 i, 2 i + 1 in piece i (four floats per lane), position 8 in a last piece of two floats per lane
+          const int lane = (e >> 1) * 32 + (cs & 31);
+          const size_t base = (r * 8 + wv) * (size_t)(9 * 32 * 4);
+          d.dst[base + (j < 8 ? ((j >> 1) * 64 + lane) * 4 + (j & 1) * 2 + (e & 1) : 1024 + lane * 2 + (e & 1))] = u;
+        }
       }
   }
 }
@@ -1014,7 +867,8 @@ extern "C" int ssde_pack_weights(const ssde_pack_args* a, void* stream) {
   switch (a->kind) {
     case SSDE_PACK_CONV3: hipLaunchKernelGGL(pack_conv3_kernel, grid, dim3(256), 0, st, a->table); break;
     case SSDE_PACK_WINO3: hipLaunchKernelGGL(pack_wino3_kernel, grid, dim3(256), 0, st, a->table); break;
-    case SSDE_PACK_WINO4: hipLaunchKernelGGL(pack_wino4_kernel, grid, dim3(256), 0, st, a->table); break;
+    case SSDE_PACK_WINO4: hipLaunchKernelGGL(pack_wino4_kernel<false>, grid, dim3(256), 0, st, a->table); break;
+    case SSDE_PACK_WINO4R: hipLaunchKernelGGL(pack_wino4_kernel<true>, grid, dim3(256), 0, st, a->table); break;
     case SSDE_PACK_MATRIX: hipLaunchKernelGGL(pack_matrix_kernel, grid, dim3(256), 0, st, a->table); break;
     case SSDE_PACK_VECTOR: hipLaunchKernelGGL(pack_vector_kernel, grid, dim3(256), 0, st, a->table); break;
     default: ssde_set_error("pack_weights: unknown kind %d", a->kind); return SSDE_EINVAL;

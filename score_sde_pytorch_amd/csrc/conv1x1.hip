@@ -832,20 +832,20 @@ int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
   SSDE_REQUIRE(!a->gn_part || gn_ok, "conv1x1: GroupNorm partials need H*W %% 64 == 0 or a power of two in 8..32");
   p.lHW = ssde_ilog2(p.HW);
   p.gn_entries = p.HW >= 64 ? a->n * (p.HW / 64) : a->n;
-  const bool x6 = ssde_matrix_bf16x6();
+  const bool x6 = (a->flags & SSDE_CONVF_BF16X6) != 0;
   // the persistent, software-pipelined form: when workgroups get more than one tile each (otherwise there is nothing to overlap
   // and the plain kernels' 3-4 workgroups per CU cover each other better than its 2)
   {
-    const char* pe = getenv("SSDE_GEMM_PIPE");
     const int total = ssde_cdiv(p.m_tiles, 8) * 8 * p.n_tiles;
     const int wgs = (2 * ssde_num_cus() + 7) / 8 * 8;
-    const bool pipe_ok = !(pe && pe[0] == '0') && a->c_out % 4 == 0 && (!a->gn_part || p.HW % 64 == 0) && (!a->chan_add || p.HW % 8 == 0);
+    const bool pipe_ok = !(a->flags & SSDE_CONVF_NO_GEMM_PIPE) && a->c_out % 4 == 0 && (!a->gn_part || p.HW % 64 == 0) && (!a->chan_add || p.HW % 8 == 0);
     // Measured (profiles/r4_gemm_pipe_ab.txt, batch 256): with exact-fp32 MFMAs the pipelined form LOSES 0-8 % -- the drain's
     // VALU and the fp32 MFMAs share a datapath, and two workgroups per CU hide less than four -- so it is not taken there; with
     // the bf16 split it wins 9-10 % from 512 input or output channels up and loses up to 10 % below (the loop is too short for
-    // the drain).  SSDE_GEMM_PIPE: 0 = never, 2 = always (tests), unset = this rule
+    // the drain).  SSDE_CONVF_NO_GEMM_PIPE = never, SSDE_CONVF_GEMM_PIPE = always (tests), neither = this rule
     const bool pays = x6 && (p.K >= 512 || a->c_out >= 512) && total > wgs;
-    if (pipe_ok && (pays || (pe && pe[0] == '2'))) {
+    // (round 5: the fp32 instantiation of the pipelined kernel is no longer built -- it lost everywhere)
+    if (pipe_ok && x6 && (pays || (a->flags & SSDE_CONVF_GEMM_PIPE))) {
       const int lds = 2 * (x6 ? X6<128>::kStageBytes : kStage * 4) + 4 * kSlabFloats * 4;
       if (lds_out) { *lds_out = lds; return SSDE_OK; }
       const dim3 grid(total < wgs ? total : wgs);
@@ -857,9 +857,8 @@ int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
         hipLaunchKernelGGL(kfn, grid, dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
         return true;
       };
-      static std::atomic<bool> pset[4];
-      const bool ok = x6 ? (gn ? go(gemm1x1_pipe_kernel<true, true>, pset[0]) : go(gemm1x1_pipe_kernel<false, true>, pset[1]))
-                         : (gn ? go(gemm1x1_pipe_kernel<true, false>, pset[2]) : go(gemm1x1_pipe_kernel<false, false>, pset[3]));
+      static std::atomic<bool> pset[2];
+      const bool ok = gn ? go(gemm1x1_pipe_kernel<true, true>, pset[0]) : go(gemm1x1_pipe_kernel<false, true>, pset[1]);
       SSDE_REQUIRE(ok, "conv1x1: hipFuncSetAttribute failed");
       SSDE_LAUNCH_CHECK();
       return SSDE_OK;
@@ -868,9 +867,8 @@ int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
   // shape of the split kernel (see there): rows per workgroup and load-ahead depth; A/B-selectable per call
   int xbm = 128, xpf = 1;
   if (x6) {
-    const char* eb = getenv("SSDE_X6_BM"); const char* ep = getenv("SSDE_X6_PF");
-    if (eb && atoi(eb) == 64) xbm = 64;
-    if (ep && atoi(ep) == 2) xpf = 2;
+    if (a->flags & SSDE_CONVF_X6_BM64) xbm = 64;
+    if (a->flags & SSDE_CONVF_X6_PF2) xpf = 2;
     p.m_tiles = ssde_cdiv(p.M, xbm);
   }
   const int lds_ops = x6 ? 2 * (xbm == 64 ? X6<64>::kStageBytes : X6<128>::kStageBytes) : 2 * kStage * 4, lds_epi = 64 * (BN + 4) * 4;

@@ -452,8 +452,7 @@ int make_plan(const ssde_conv_args* a, ConvPlan* pl) {
   (void)SSDE_TILE_WINOGRAD;
   int lTW = 0, lTH = 0;
   pl->bkc = 8;
-  const char* be = getenv("SSDE_CONV_BKC64");            // "8": the 8-channel stages everywhere (A/B, tests)
-  const bool deep_ok = !be || atoi(be) != 8;
+  const bool deep_ok = !(a->flags & SSDE_CONVF_BKC8);     // (the flag: 8-channel stages everywhere -- A/B runs, tests)
   if (pl->has3) {
     // the halo of the chosen tile must fit the per-thread staging plan (5 x 256 float4 items)
     while (true) {
@@ -502,8 +501,7 @@ int make_plan(const ssde_conv_args* a, ConvPlan* pl) {
   pl->lds_bytes = lds > epi_bytes ? lds : epi_bytes;
   pl->tile = tile;
   // split the reduction when the launch would leave every CU with at most one workgroup (see g_conv_sync)
-  const char* se = getenv("SSDE_CONV_KSPLIT");           // read per call: the tests compare both forms in one process
-  const bool split_ok = !se || atoi(se) != 0;
+  const bool split_ok = !(a->flags & SSDE_CONVF_NO_KSPLIT);
   const int wgs = ssde_cdiv(g.m_tiles, 8) * 8 * g.n_tiles;
   const int ctot = pl->has3 ? a->main.c0 + a->main.c1 : 0;
   kp.ksplit = (split_ok && pl->has3 && tile == SSDE_TILE_64x64 && wgs <= 320 && ctot >= 128 && a->c_out % 4 == 0 &&
@@ -560,16 +558,26 @@ unsigned* ssde_conv_sync_slots(int need) {
   return base + 2 * (size_t)at;
 }
 
+// the Winograd kernels have their own launchers: launch (lds_out == NULL), LDS query, or GroupNorm-slice query (stream == 1)
+typedef int (*ssde_wino_launcher)(const ssde_conv_args*, void*, int*);
+static ssde_wino_launcher wino_launcher(int tile) {
+  switch (tile) {
+    case SSDE_TILE_WINOGRAD: return ssde_conv_wino_launch;
+    case SSDE_TILE_WINOGRAD4: return ssde_conv_wino4_launch;
+    case SSDE_TILE_WINOGRAD4G: return ssde_conv_wino4g_launch;
+    case SSDE_TILE_WINOGRAD4R: return ssde_conv_wino4r_launch;
+    default: return nullptr;
+  }
+}
+
 extern "C" int ssde_conv2d(const ssde_conv_args* a, void* stream) {
-  if (a && a->tile == SSDE_TILE_WINOGRAD) return ssde_conv_wino_launch(a, stream, nullptr);
-  if (a && a->tile == SSDE_TILE_WINOGRAD4) return ssde_conv_wino4_launch(a, stream, nullptr);
-  if (a && a->tile == SSDE_TILE_WINOGRAD4X) return ssde_conv_wino4x_launch(a, stream, nullptr);
-  if (a && a->tile == SSDE_TILE_WINOGRAD4G) {
-    // the input-transform pass into wino_v, then the matrix kernel (SSDE_W4G_V_GIVEN=1, tests: the caller filled wino_v)
-    const char* given = getenv("SSDE_W4G_V_GIVEN");
-    if (!(given && given[0] == '1'))
-      if (int rc = ssde_wino4_xform_vq_launch(a, stream)) return rc;
-    return ssde_conv_wino4g_launch(a, stream, nullptr);
+  if (a) {
+    if (ssde_wino_launcher fn = wino_launcher(a->tile)) {
+      // the two-kernel forms: the input-transform pass into wino_v first, unless the caller says wino_v already holds it
+      if ((a->tile == SSDE_TILE_WINOGRAD4G || a->tile == SSDE_TILE_WINOGRAD4R) && !(a->flags & SSDE_CONVF_V_GIVEN))
+        if (int rc = ssde_wino4_xform_vq_launch(a, stream)) return rc;
+      return fn(a, stream, nullptr);
+    }
   }
   if (a && a->dst && ssde_conv1x1_wants(a)) return ssde_conv1x1_launch(a, stream, nullptr);   // 1x1-only: GEMM kernel (conv1x1.hip)
   ConvPlan pl;
@@ -589,10 +597,8 @@ extern "C" int ssde_conv_gn_slices(const ssde_conv_args* a) {
   if (!a || a->c_out % 4 != 0) return 0;
   ssde_conv_args q = *a;
   q.gn_part = nullptr;
-  if (q.tile == SSDE_TILE_WINOGRAD || q.tile == SSDE_TILE_WINOGRAD4 || q.tile == SSDE_TILE_WINOGRAD4X || q.tile == SSDE_TILE_WINOGRAD4G) {
+  if (ssde_wino_launcher fn = wino_launcher(q.tile)) {
     int s = 0;
-    auto fn = q.tile == SSDE_TILE_WINOGRAD ? ssde_conv_wino_launch : q.tile == SSDE_TILE_WINOGRAD4 ? ssde_conv_wino4_launch
-            : q.tile == SSDE_TILE_WINOGRAD4G ? ssde_conv_wino4g_launch : ssde_conv_wino4x_launch;
     if (fn(&q, reinterpret_cast<void*>(1), &s)) return 0;     // plan-only query form
     return s;
   }
@@ -609,10 +615,8 @@ extern "C" int ssde_conv_gn_slices(const ssde_conv_args* a) {
 }
 
 extern "C" int ssde_conv_lds_bytes(const ssde_conv_args* a) {
-  if (a && (a->tile == SSDE_TILE_WINOGRAD || a->tile == SSDE_TILE_WINOGRAD4 || a->tile == SSDE_TILE_WINOGRAD4X || a->tile == SSDE_TILE_WINOGRAD4G)) {
+  if (ssde_wino_launcher fn = a ? wino_launcher(a->tile) : nullptr) {
     int lds = 0;
-    auto fn = a->tile == SSDE_TILE_WINOGRAD ? ssde_conv_wino_launch : a->tile == SSDE_TILE_WINOGRAD4 ? ssde_conv_wino4_launch
-            : a->tile == SSDE_TILE_WINOGRAD4G ? ssde_conv_wino4g_launch : ssde_conv_wino4x_launch;
     if (int rc = fn(a, nullptr, &lds)) return rc;
     return lds;
   }

@@ -838,10 +838,9 @@ int pow2_floor(int v) { int q = 1; while (q * 2 <= v) q *= 2; return q; }
 
 // over how many workgroups per tile (1, 2 or 4) a launch of `wgs` tiles over `ctot` input channels splits its reduction: up
 // to 256 workgroups, at least 16 channel stages each (engine.py picks this kernel for 8x8 maps only where the split fills
-// the chip -- same rule there).  SSDE_CONV_KSPLIT=0 switches it off (read per call: the tests compare both forms).
-int ssde_conv_wino4_splits(int wgs, int ctot, int c_out) {
-  const char* se = getenv("SSDE_CONV_KSPLIT");
-  if ((se && atoi(se) == 0) || c_out % 4 != 0) return 1;
+// the chip -- same rule there).  SSDE_CONVF_NO_KSPLIT in the launch's flags switches it off.
+int ssde_conv_wino4_splits(int wgs, int ctot, int c_out, unsigned flags) {
+  if ((flags & SSDE_CONVF_NO_KSPLIT) || c_out % 4 != 0) return 1;
   const int cus = ssde_num_cus();                   // (256 on the MI355X: a quarter / half of the chip covered)
   if (wgs <= cus / 4 && ctot >= 256) return 4;
   if (wgs <= cus / 2 && ctot >= 128) return 2;
@@ -908,7 +907,7 @@ int ssde_conv_wino4_launch(const ssde_conv_args* a, void* stream, int* lds_out) 
   // Split the reduction when the launch would leave half of the CUs or more without a workgroup (8x8 maps at batch 256:
   // 128 tiles of 8 images x 64 couts)
   const int wgs = ssde_cdiv(p.m_tiles, 8) * 8 * p.n_tiles;
-  p.ksplit = a->resid != a->dst ? ssde_conv_wino4_splits(wgs, s.c0 + s.c1, a->c_out) : 1;
+  p.ksplit = a->resid != a->dst ? ssde_conv_wino4_splits(wgs, s.c0 + s.c1, a->c_out, a->flags) : 1;
   p.sync = p.ksplit > 1 ? ssde_conv_sync_slots(p.m_tiles * p.n_tiles) : nullptr;
   if (!p.sync) p.ksplit = 1;
   const dim3 grid(wgs * p.ksplit);

@@ -1,0 +1,312 @@
+// 3x3 / stride 1 / pad 1 convolution by Winograd F(4x4, 3x3), two-kernel form, matrix kernel fed from REGISTERS.
+//
+//   wino4_xform_vq_kernel (conv_wino4g.hip)   V[pos][Cin/4][t][4] = B^T pro(x) B      HBM-bound pass
+//   conv_wino4r_kernel (this file)            Y = A^T [ sum_ci U .* V ] A             no LDS, no barrier in the main loop
+//
+// Round 4's matrix kernel (conv_wino4g.hip) moves both operands through LDS by LDS-DMA and sits at ~3050 cycles per 4-channel
+// stage for 2304 matrix cycles.  tools/microbench/fill_path.hip (profiles/r5_fill_path_microbench.txt) separates the causes:
+// beside a running fp32 MFMA chain the CU takes 64 KB per stage from L2 at NO cost by either route (LDS-DMA 2376 cycles per
+// stage, global_load_dwordx4 into VGPRs 2304 = the matrix bound), so neither the TA, nor the TCP -> LDS write, nor the L2 is the
+// 18 B/clk/CU "fill bound" of round 4.  What the product pays for is its lock step: one barrier per stage makes every wave wait
+// for the slowest LDS-DMA piece of the stage (V streams from HBM), with the weights fetched only half a stage ahead.  And the
+// 36 KB of weights per stage are wave-PRIVATE: the LDS round trip shares them with nobody.
+//
+// This kernel therefore keeps NOTHING in LDS during the main loop.  A wave (q, h) owns transform positions q + 4 j (j = 0..8)
+// and cout half h of a 32-tile x 64-cout workgroup tile, as in conv_wino4.hip; per 4-channel stage it needs
+//   A: V[q + 4 j][stage][tile = lane & 31][2 (lane >> 5) .. + 1]        one global_load_dwordx2 per position (512-byte runs)
+//   B: U[q + 4 j][cout = 32 h + (lane & 31)][2 (lane >> 5) .. + 1]      packed per LANE (SSDE_PACK_WINO4R): four dwordx4
+//                                                                       (two positions each) + one dwordx2 per stage
+// straight into the registers its 18 v_mfma_f32_32x32x2_f32 read.  A register is re-loaded for the NEXT stage right after the
+// MFMAs that consumed it, so every load has a whole stage (~1.1 us) to land, 11-13 loads are in flight per wave at any time, and
+// the only synchronisation is the wave's own counted s_waitcnt vmcnt (five per stage).  Waves drift freely: a late V piece
+// stalls one wave while its SIMD sibling keeps the matrix pipe busy.  The two cout halves of a position load the same V run
+// (L1 / L2 serve the second).  LDS is used by the epilogue only (conv_wino4.hip's: products -> LDS, A^T M A, parked tile,
+// shared coalesced store with GroupNorm partials).
+#include "ssde_common.h"
+#include <atomic>
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// -DSSDE_W4R_TRACE (a variant library only): s_memtime stamps of waves 0 and 7 of the first workgroup
+#ifdef SSDE_W4R_TRACE
+__device__ unsigned long long* g_w4r_trace;
+extern "C" int ssde_debug_w4r_trace(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_w4r_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -5;
+}
+#define SSDE_RT(slot)                                                                                     \
+  do {                                                                                                    \
+    if (tr_on) g_w4r_trace[tr_base + (slot)] = __builtin_amdgcn_s_memtime();                              \
+  } while (0)
+#else
+#define SSDE_RT(slot) do { } while (0)
+#endif
+
+namespace {
+
+constexpr int kWaves = 8, kThreads = kWaves * 64;
+constexpr int kNP = 9, kPS = 4;                     // positions per wave; wave (q, h) owns positions q + kPS * j
+constexpr int kEpiThreads = 512;
+constexpr int kPos = 36, kTiles = 32;
+constexpr int kURegion = kNP * 32 * 4;              // floats of a stage's weight image only wave (q, h) reads (4.5 KB)
+constexpr int kUFloats = kWaves * kURegion;         // one (stage, cout tile) of the image
+constexpr int kLdm = 66, kLdt = 68;                 // pitches of the product exchange and of the parked output tile (conv_wino4.hip)
+
+struct Wino4rParams {
+  const float* v;          // [36][Ctot / 4][T][4]
+  const float* wpk;        // SSDE_PACK_WINO4R: [Ctot / 4][n_tiles][8 waves][4 x [64 lanes][4] | [64 lanes][2]]
+  int N, H, W, Cout, Ctot;
+  int lTWt, lTHt;
+  int tiles_x, tiles_per_img, m_tiles, n_tiles;
+  const float* bias; const float* chan_add; int chan_add_ld;
+  const float* resid; int resid_post;
+  float scale;
+  float* dst;
+  float* gn_part;
+  int T, tiles_h, tiles_w;
+};
+
+__global__ __launch_bounds__(kThreads, kWaves / 4) void conv_wino4r_kernel(const Wino4rParams p) {
+  SSDE_LDS(smem);                               // the epilogue's only
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+
+  // XCD-aware order (conv_wino4.hip): the cout tiles of one pixel tile run on one XCD at the same time -- they read the same V
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, l = bid >> 3;
+  const int nt = l % p.n_tiles;
+  const int mt = (l / p.n_tiles) * 8 + xcd;
+#ifdef SSDE_W4R_TRACE
+  const bool tr_on = lane == 0 && (wave == 0 || wave == 7) && bid == 0 && g_w4r_trace != nullptr;
+  const int tr_base = (wave == 0 ? 0 : 1) * 128;
+#endif
+  SSDE_RT(0);
+  if (mt >= p.m_tiles) return;
+
+  const int TWt = 1 << p.lTWt, THt = 1 << p.lTHt;
+  const int IMGS = kTiles >> (p.lTWt + p.lTHt);
+  const int img0 = (mt / p.tiles_per_img) * IMGS;
+  const int trem = mt % p.tiles_per_img;
+  const int ty = trem / p.tiles_x, tx = trem % p.tiles_x;
+  const int n0 = nt * 64;
+  const int nst = p.Ctot >> 2;
+  const int wq = wave >> 1;
+
+  // ---- A operand: the lane's byte offset of position slot j inside one stage's [36][Q][T][4] view of V (32-bit: the launcher
+  // checks V < 4 GB); the stage rides in the scalar base.  Tiles outside the batch / the image read tile 0's run (a valid
+  // address; their outputs are never stored).
+  uint32_t v_off[kNP];
+  {
+    const int il = li >> (p.lTWt + p.lTHt);
+    const int tr = (li >> p.lTWt) & (THt - 1), tc = li & (TWt - 1);
+    const int img = img0 + il, yy = ty * THt + tr, xx = tx * TWt + tc;
+    const uint32_t t = (img < p.N && yy < p.tiles_h && xx < p.tiles_w) ? (uint32_t)((img * p.tiles_h + yy) * p.tiles_w + xx) : 0u;
+    const uint32_t QT = (uint32_t)(p.Ctot >> 2) * (uint32_t)p.T;
+#pragma unroll
+    for (int j = 0; j < kNP; ++j) v_off[j] = ((uint32_t)(wq + kPS * j) * QT + t) * 16u + 8u * (uint32_t)lh;
+  }
+  const char* vs = reinterpret_cast<const char*>(p.v);                 // stage st: + st * T * 16 bytes
+  const size_t v_stage = (size_t)p.T * 16;
+  // ---- B operand: the wave's 4.5 KB of a stage, lane-major; four 1 KB pieces at immediates -2048 .. 1024 around the base and
+  // one 512-byte piece behind them
+  const uint32_t u_off = (uint32_t)lane * 16u, u_off8 = 2048u + (uint32_t)lane * 8u;
+  const char* us = reinterpret_cast<const char*>(p.wpk + ((size_t)nt * kWaves + wave) * kURegion) + 2048;
+  const size_t u_stage = (size_t)p.n_tiles * kUFloats * 4;
+
+  f32x16 acc[kNP];
+#pragma unroll
+  for (int j = 0; j < kNP; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  ssde_f32x2 va[kNP], u2;
+  ssde_f32x4 u4[4];
+
+  // The VMEM queue of a wave is a ring of 14 loads per stage, always in this order (loads return in order):
+  //   V0 V1 U0 | V2 V3 U1 | V4 V5 U2 | V6 V7 U3 | V8 U4            (Ui = positions 2 i and 2 i + 1 of the weights, U4 = position 8)
+  // each re-issued for stage st + 1 in the slot that consumed it in stage st.  Slot 2 i needs Ui of this stage: the loads issued
+  // since are indices 3 i + 3 .. 13 of the previous round and 0 .. 3 i - 1 of this one = 11, so s_waitcnt vmcnt(11) (which
+  // covers V(2 i) and V(2 i + 1), both older); slot 8 needs U4: vmcnt(12).  In the LAST stage nothing is re-issued:
+  // vmcnt(11 - 3 i) and vmcnt(0).
+#define SSDE_W4R_LOADV(J) SSDE_GLOAD8_I(va[J], v_off[J], vn, 0)
+#define SSDE_W4R_MFMA(J, B0, B1)                                                                   \
+  do {                                                                                             \
+    acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[J].x, (B0), acc[J], 0, 0, 0);                 \
+    acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[J].y, (B1), acc[J], 0, 0, 0);                 \
+  } while (0)
+#define SSDE_W4R_PAIR(I, IMM)                                                                      \
+  do {                                                                                             \
+    SSDE_WAIT_VMCNT_FOR3(has_next ? 11 : 11 - 3 * (I), va[2 * (I)], va[2 * (I) + 1], u4[I]);       \
+    SSDE_W4R_MFMA(2 * (I), u4[I].x, u4[I].y);                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    if (has_next) SSDE_W4R_LOADV(2 * (I));                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    SSDE_W4R_MFMA(2 * (I) + 1, u4[I].z, u4[I].w);                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    if (has_next) { SSDE_W4R_LOADV(2 * (I) + 1); SSDE_GLOAD16_I(u4[I], u_off, un, IMM); }          \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  } while (0)
+
+  SSDE_RT(1);
+  {
+    const char* vn = vs; const char* un = us;
+    SSDE_W4R_LOADV(0); SSDE_W4R_LOADV(1); SSDE_GLOAD16_I(u4[0], u_off, un, -2048);
+    SSDE_W4R_LOADV(2); SSDE_W4R_LOADV(3); SSDE_GLOAD16_I(u4[1], u_off, un, -1024);
+    SSDE_W4R_LOADV(4); SSDE_W4R_LOADV(5); SSDE_GLOAD16_I(u4[2], u_off, un, 0);
+    SSDE_W4R_LOADV(6); SSDE_W4R_LOADV(7); SSDE_GLOAD16_I(u4[3], u_off, un, 1024);
+    SSDE_W4R_LOADV(8); SSDE_GLOAD8_I(u2, u_off8, un, 0);
+  }
+  SSDE_RT(2);
+  auto stage = [&](auto H1, const int st) __attribute__((always_inline)) {
+    constexpr bool has_next = decltype(H1)::value;
+    const char* vn = vs + (size_t)(st + 1) * v_stage;
+    const char* un = us + (size_t)(st + 1) * u_stage;
+    if (st < 8) SSDE_RT(8 + st * 2);
+    SSDE_W4R_PAIR(0, -2048);
+    SSDE_W4R_PAIR(1, -1024);
+    SSDE_W4R_PAIR(2, 0);
+    if (st < 8) SSDE_RT(8 + st * 2 + 1);
+    SSDE_W4R_PAIR(3, 1024);
+    SSDE_WAIT_VMCNT_FOR(has_next ? 12 : 0, va[8], u2);
+    SSDE_W4R_MFMA(8, u2.x, u2.y);
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) { SSDE_W4R_LOADV(8); SSDE_GLOAD8_I(u2, u_off8, un, 0); }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  {
+    int st = 0;
+    for (; st + 1 < nst; ++st) stage(std::true_type{}, st);
+    stage(std::false_type{}, st);
+  }
+#undef SSDE_W4R_PAIR
+#undef SSDE_W4R_MFMA
+#undef SSDE_W4R_LOADV
+  SSDE_RT(3);
+
+  // ---- epilogue (conv_wino4.hip): 16 tiles (accumulator rows r < 8, then r >= 8 of every wave) at a time: products -> LDS
+  // M[pos][16 tiles][64 couts], A^T M A per (tile, cout pair), parked 4x4 outputs, shared coalesced store ----
+  SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, p.Cout, p.gn_part};
+  const int gn_base = !p.gn_part ? -1 : (IMGS == 1 ? (img0 * p.tiles_per_img + trem) * 2 : img0);
+  const int rpi_log2 = IMGS > 2 ? 8 - (4 - p.lTWt - p.lTHt) : 30;
+  const int wh = wave & 1;
+  const int e_tl = tid >> 5, e_cp = tid & 31;
+  float* park = smem;
+#pragma unroll
+  for (int rnd = 0; rnd < 2; ++rnd) {
+#pragma unroll
+    for (int j = 0; j < kNP; ++j)
+#pragma unroll
+      for (int r8 = 0; r8 < 8; ++r8) {
+        const int r = rnd * 8 + r8;
+        const int tl = (r & 3) + 4 * lh + 8 * ((r >> 2) & 1);
+        smem[((wq + kPS * j) * 16 + tl) * kLdm + wh * 32 + li] = acc[j][r];
+      }
+    __syncthreads();
+    float2 y[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) y[a][b] = make_float2(0.f, 0.f);
+    const float* mp = smem + e_tl * kLdm + 2 * e_cp;
+#pragma unroll
+    for (int px = 0; px < 6; ++px) {
+      float2 m[6];
+#pragma unroll
+      for (int py = 0; py < 6; ++py) m[py] = *reinterpret_cast<const float2*>(mp + (py * 6 + px) * (16 * kLdm));
+      float2 t[4];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float m0 = c ? m[0].y : m[0].x, m1 = c ? m[1].y : m[1].x, m2 = c ? m[2].y : m[2].x;
+        const float m3 = c ? m[3].y : m[3].x, m4 = c ? m[4].y : m[4].x, m5 = c ? m[5].y : m[5].x;
+        const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+        const float t0 = m0 + s1 + s2, t1 = d1 + 2.f * d2, t2 = s1 + 4.f * s2, t3 = d1 + 8.f * d2 + m5;
+        if (c) { t[0].y = t0; t[1].y = t1; t[2].y = t2; t[3].y = t3; }
+        else   { t[0].x = t0; t[1].x = t1; t[2].x = t2; t[3].x = t3; }
+      }
+      constexpr float kA[6][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f},
+                                  {1.f, 2.f, 4.f, 8.f}, {1.f, -2.f, 4.f, -8.f}, {0.f, 0.f, 0.f, 1.f}};
+#pragma unroll
+      for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx)
+          if (kA[px][dx] != 0.f) { y[dy][dx].x += kA[px][dx] * t[dy].x; y[dy][dx].y += kA[px][dx] * t[dy].y; }
+    }
+    __syncthreads();                           // every thread has read its products: the parked tile may overwrite them
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 4; ++dx)
+        *reinterpret_cast<float2*>(park + (e_tl * 16 + dy * 4 + dx) * kLdt + 2 * e_cp) = y[dy][dx];
+    __syncthreads();
+    const int gn_entry = gn_base < 0 ? -1 : (IMGS == 1 ? gn_base + rnd : gn_base + rnd * (IMGS >> 1));
+    auto pixfn = [&](int row, size_t& pix, int& img) {
+      const int tile = rnd * 16 + (row >> 4), dy = (row >> 2) & 3, dx = row & 3;
+      const int il = tile >> (p.lTWt + p.lTHt);
+      const int tr = (tile >> p.lTWt) & (THt - 1), tc = tile & (TWt - 1);
+      img = img0 + il;
+      const int oy = (ty * THt + tr) * 4 + dy, ox = (tx * TWt + tc) * 4 + dx;
+      if (img >= p.N || oy >= p.H || ox >= p.W) return false;
+      pix = ((size_t)img * p.H + oy) * p.W + ox;
+      return true;
+    };
+    const int gn_max = IMGS == 1 ? p.N * p.tiles_per_img * 2 : p.N;
+    if (rnd == 0) ssde_store_tile<256, 64, kEpiThreads, 4, 0>(park, kLdt, n0, e, pixfn, gn_entry, rpi_log2, gn_max);
+    else ssde_store_tile<256, 64, kEpiThreads, 8, 0>(park, kLdt, n0, e, pixfn, gn_entry, rpi_log2, gn_max);
+    if (rnd == 0) { __syncthreads(); SSDE_RT(4); }
+  }
+  SSDE_RT(5);
+}
+
+int pow2_floor(int v) { int q = 1; while (q * 2 <= v) q *= 2; return q; }
+
+}  // namespace
+
+// stream == (void*)1 with lds_out: plan-only query of the GroupNorm slices per image (conv_mfma.hip, ssde_conv_gn_slices)
+int ssde_conv_wino4r_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
+  SSDE_REQUIRE(a && a->dst && a->main.p0 && a->w_main, "conv(winograd 4x4, register-fed): null args");
+  SSDE_REQUIRE(a->ksize == 3 && a->stride == 1 && a->pad == 1, "conv(winograd 4x4, register-fed): needs 3x3, stride 1, pad 1");
+  SSDE_REQUIRE(a->aux.p0 == nullptr, "conv(winograd 4x4, register-fed): fused 1x1 source not supported (issue it as a second conv)");
+  SSDE_REQUIRE(a->h_in == a->h_out && a->w_in == a->w_out && a->h_out % 4 == 0 && a->w_out % 4 == 0 && a->h_out >= 8 && a->w_out >= 8,
+               "conv(winograd 4x4, register-fed): same-size output, multiples of 4, at least 8x8 (got %dx%d)", a->h_out, a->w_out);
+  const ssde_src& s = a->main;
+  SSDE_REQUIRE(s.c0 > 0 && s.c0 % 4 == 0 && s.c1 % 4 == 0 && (s.c1 == 0 || s.p1), "conv(winograd 4x4, register-fed): channels must be multiples of 4");
+  Wino4rParams p;
+  p.v = a->wino_v; p.wpk = a->w_main;
+  p.N = a->n; p.H = a->h_out; p.W = a->w_out; p.Cout = a->c_out; p.Ctot = s.c0 + s.c1;
+  const int twt = pow2_floor((a->w_out / 4) < 8 ? (a->w_out / 4) : 8);
+  int tht = kTiles / twt; if (tht > a->h_out / 4) tht = a->h_out / 4;
+  tht = pow2_floor(tht);
+  const int imgs = kTiles / (twt * tht);
+  p.lTWt = ssde_ilog2(twt); p.lTHt = ssde_ilog2(tht);
+  p.tiles_x = ssde_cdiv(a->w_out, 4 * twt);
+  p.tiles_per_img = p.tiles_x * ssde_cdiv(a->h_out, 4 * tht);
+  p.m_tiles = ssde_cdiv(a->n, imgs) * p.tiles_per_img;
+  p.n_tiles = ssde_cdiv(a->c_out, 64);
+  p.bias = a->bias; p.chan_add = a->chan_add; p.chan_add_ld = a->chan_add_ld;
+  p.resid = a->resid; p.resid_post = a->resid_post; p.scale = a->out_scale; p.dst = a->dst;
+  p.gn_part = a->gn_part;
+  p.tiles_h = a->h_out / 4; p.tiles_w = a->w_out / 4; p.T = a->n * p.tiles_h * p.tiles_w;
+  const bool gn_ok = a->c_out % 4 == 0 && (imgs == 1 || (p.tiles_per_img == 1 && imgs <= 8));
+  SSDE_REQUIRE(!a->gn_part || gn_ok, "conv(winograd 4x4, register-fed): GroupNorm partials not available for this tiling");
+  if (lds_out && stream == reinterpret_cast<void*>(1)) {
+    *lds_out = gn_ok ? (imgs == 1 ? 2 * p.tiles_per_img : 1) * (kEpiThreads / 64) : 0;
+    return SSDE_OK;
+  }
+  const int lds = kPos * 16 * kLdm * 4;            // the epilogue's product exchange (the parked tile fits inside)
+  static_assert(256 * kLdt <= kPos * 16 * kLdm, "parked tile");
+  SSDE_REQUIRE(lds <= 160 * 1024, "conv(winograd 4x4, register-fed): %d bytes of LDS", lds);
+  if (lds_out) { *lds_out = lds; return SSDE_OK; }
+  SSDE_REQUIRE(a->wino_v, "conv(winograd 4x4, register-fed): the transformed-input buffer (ssde_conv_args.wino_v) is missing");
+  SSDE_REQUIRE(36ull * (unsigned long long)p.T * (unsigned)p.Ctot * 4ull < (1ull << 32),
+               "conv(winograd 4x4, register-fed): a transformed input of 4 GB or more is not addressable by this kernel");
+  const int wgs = ssde_cdiv(p.m_tiles, 8) * 8 * p.n_tiles;
+  static std::atomic<bool> attr_set;
+  if (!attr_set) {                              // once, before any stream capture
+    SSDE_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024) == hipSuccess, "conv(winograd 4x4, register-fed): hipFuncSetAttribute failed");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_wino4r_kernel, dim3(wgs), dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}

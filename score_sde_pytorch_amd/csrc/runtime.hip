@@ -18,12 +18,17 @@ int ssde_num_cus() {
   // SSDE_NUM_CUS overrides (read per call: the tests run persistent kernels on a pretend 3-CU device so that workgroups
   // loop over several tiles; engine.Lowering reads the same variable)
   if (const char* e = getenv("SSDE_NUM_CUS")) { const int v = atoi(e); if (v > 0) return v; }
-  static std::atomic<int> cus{0};
-  int c = cus.load(std::memory_order_relaxed);
+  // cached per device id: a process may drive devices of different size (partition modes, mixed nodes), and the planners
+  // (conv_wino4 splits, stream-K groups, gn_bwd_fused_shape) must agree with the device the launch goes to
+  constexpr int kMaxDev = 64;
+  static std::atomic<int> cus[kMaxDev];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
+  int c = cus[dev].load(std::memory_order_relaxed);
   if (c <= 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    cus.store(c = v, std::memory_order_relaxed);
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cus[dev].store(c = v, std::memory_order_relaxed);
   }
   return c;
 }

@@ -18,11 +18,11 @@ int ssde_conv_wino_launch(const ssde_conv_args* a, void* stream, int* lds_out);
 int ssde_conv_wino4_launch(const ssde_conv_args* a, void* stream, int* lds_out);   // conv_wino4.hip, same forms
 int ssde_conv_wino4g_launch(const ssde_conv_args* a, void* stream, int* lds_out);  // conv_wino4g.hip (two-kernel form), same forms
 int ssde_wino4_xform_vq_launch(const ssde_conv_args* a, void* stream);              // conv_wino4g.hip: V = B^T pro(x) B into a->wino_v
-int ssde_conv_wino4x_launch(const ssde_conv_args* a, void* stream, int* lds_out);  // conv_wino4x.hip (bf16 split), same forms
+int ssde_conv_wino4r_launch(const ssde_conv_args* a, void* stream, int* lds_out);  // conv_wino4r.hip (two-kernel form, operands from registers)
 bool ssde_conv1x1_wants(const ssde_conv_args* a);                                    // conv1x1.hip
 int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out);
 unsigned* ssde_conv_sync_slots(int need);                                            // conv_mfma.hip
-int ssde_conv_wino4_splits(int wgs, int ctot, int c_out);                           // conv_wino4.hip
+int ssde_conv_wino4_splits(int wgs, int ctot, int c_out, unsigned flags);                         // conv_wino4.hip
 bool ssde_wgrad_wino_wants(const ssde_wgrad_args* a);                                // wgrad_wino.hip
 int64_t ssde_wgrad_wino_scratch_floats(const ssde_wgrad_args* a);
 int ssde_wgrad_wino_launch(const ssde_wgrad_args* a, void* stream);
@@ -119,6 +119,14 @@ typedef float ssde_f32x4 __attribute__((ext_vector_type(4)));
 #define SSDE_GLOAD16(dst, voff, sbase) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) :)
 #define SSDE_WAIT_VMCNT_FOR(n, a, b) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(n) : "memory")
 #define SSDE_WAIT_VMCNT_FENCE(n) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(n) : "memory")
+#endif
+// The same with a 13-bit signed immediate offset, and the 8-byte form (conv_wino4r.hip: operands straight into MFMA registers)
+#ifndef SSDE_GLOAD16_I
+#define SSDE_GLOAD16_I(dst, voff, sbase, imm) \
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(imm) :)
+#define SSDE_GLOAD8_I(dst, voff, sbase, imm) \
+  asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(imm) :)
+#define SSDE_WAIT_VMCNT_FOR3(n, a, b, c) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(n) : "memory")
 #endif
 
 // An LDS address the compiler must treat as one opaque 32-bit register (so that constant distances from it become the
@@ -389,12 +397,8 @@ __device__ __forceinline__ void ssde_split3(const float4& v, uint2& p0, uint2& p
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ssde_bf16x8, (A)[0]), __builtin_bit_cast(ssde_bf16x8, (B)[0]), acc, 0, 0, 0); \
   } while (0)
 
-// SSDE_MATRIX (read per call on the host: the tests compare both forms in one process): "bf16x6" routes the contractions
-// that have a split kernel through the BF16 matrix pipe; anything else = the exact-fp32 MFMA kernels
-static inline bool ssde_matrix_bf16x6() {
-  const char* e = getenv("SSDE_MATRIX");
-  return e && e[0] == 'b';
-}
+// SSDE_CONVF_BF16X6 in a launch's flags routes the contractions that have a split kernel through the BF16 matrix pipe;
+// without it = the exact-fp32 MFMA kernels (the host side maps SSDE_MATRIX=bf16x6 to the flag when it builds the arguments)
 
 __device__ __forceinline__ float ssde_wave_sum(float v) {
 #pragma unroll

@@ -422,10 +422,9 @@ int pow2_floor(int v) { int q = 1; while (q * 2 <= v) q *= 2; return q; }
 
 struct WgPlan { WgParams p; int lds; int64_t slab_floats; int pref_splits; };
 
-// 1x1 / NIN / Linear gradients go to wgrad1x1_gemm_kernel (SSDE_WGRAD_1X1_PIPELINED=0: the chunked kernel, read per call)
+// 1x1 / NIN / Linear gradients go to wgrad1x1_gemm_kernel (SSDE_WGRADF_1X1_CHUNKED: the chunked kernel)
 bool pipelined_1x1(const ssde_wgrad_args* a) {
-  const char* e = getenv("SSDE_WGRAD_1X1_PIPELINED");
-  return a->ksize == 1 && (!e || atoi(e) != 0);
+  return a->ksize == 1 && !(a->flags & SSDE_WGRADF_1X1_CHUNKED);
 }
 
 int make_plan(const ssde_wgrad_args* a, WgPlan* pl) {

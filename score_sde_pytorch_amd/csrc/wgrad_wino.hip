@@ -347,16 +347,13 @@ __global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const WwParams p
   }
 }
 
-bool winograd_enabled() {                          // SSDE_WGRAD_WINOGRAD=0: the direct kernel everywhere (read per call)
-  const char* e = getenv("SSDE_WGRAD_WINOGRAD");
-  return !(e && e[0] == '0');
-}
+bool winograd_enabled(const ssde_wgrad_args* a) { return !(a->flags & SSDE_WGRADF_DIRECT); }
 
 }  // namespace
 
 // ssde_conv_wgrad / ssde_wgrad_scratch_floats (wgrad.hip) route eligible launches here.
 bool ssde_wgrad_wino_wants(const ssde_wgrad_args* a) {
-  if (!winograd_enabled() || a->ksize != 3 || a->stride != 1 || a->pad != 1 || a->transpose_out) return false;
+  if (!winograd_enabled(a) || a->ksize != 3 || a->stride != 1 || a->pad != 1 || a->transpose_out) return false;
   if (a->h_in != a->h_out || a->w_in != a->w_out || a->h_out % 4 != 0 || a->w_out % 8 != 0) return false;
   const ssde_src& s = a->src;
   const int Ctot = s.c0 + s.c1;

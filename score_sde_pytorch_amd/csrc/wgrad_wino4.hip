@@ -444,13 +444,11 @@ __global__ __launch_bounds__(256) void wgrad4_reduce_kernel(const W4Params p) {
   }
 }
 
-// SSDE_WGRAD_WINOGRAD: 0 = direct kernel everywhere, 2 = F(2x2,3x3) wherever legal, 44 = F(4x4,3x3) wherever legal (tests),
-// anything else = F(4x4,3x3) where it is legal and pays, F(2x2,3x3) for the rest (read per call: a host-side getenv, tests
-// switch kernels in one process)
-int mode() {
-  const char* e = getenv("SSDE_WGRAD_WINOGRAD");
-  const int v = e ? atoi(e) : 4;
-  return (v == 0 || v == 2 || v == 44) ? v : 4;
+// ssde_wgrad_args.flags: SSDE_WGRADF_DIRECT = direct kernel everywhere (0), SSDE_WGRADF_F2 = F(2x2,3x3) wherever legal (2),
+// SSDE_WGRADF_F4_FORCE = F(4x4,3x3) wherever legal (44, tests), none = F(4x4,3x3) where it is legal and pays, F(2x2,3x3) for
+// the rest (4)
+int mode(const ssde_wgrad_args* a) {
+  return (a->flags & SSDE_WGRADF_DIRECT) ? 0 : (a->flags & SSDE_WGRADF_F2) ? 2 : (a->flags & SSDE_WGRADF_F4_FORCE) ? 44 : 4;
 }
 
 void plan(const ssde_wgrad_args* a, W4Params* p) {
@@ -460,15 +458,14 @@ void plan(const ssde_wgrad_args* a, W4Params* p) {
   p->tx = a->w_out / 4; p->ty = a->h_out / 4;
   p->T = a->n * p->tx * p->ty;
   p->co_tiles = ssde_cdiv(a->c_out, BM); p->ci_tiles = ssde_cdiv(p->Ctot, BN);
-  // four workgroups share a CU: aim at SSDE_WGRAD4_WGS (default 768) of them, at least 32 stages (512 tiles) each; every
+  // four workgroups share a CU: aim at 768 of them, at least 32 stages (512 tiles) each; every
   // split costs a slab of 36 x Cout x Cin floats that the reduction reads back.  (The K loop itself runs near the MFMA bound --
   // 6.4 k cycles per 16-tile stage with three workgroups on the CU, tools/wgrad4_trace.py -- and what a launch loses is
   // quantisation: 576 workgroups are 3 on a quarter of the CUs and 2 on the rest.  A rule that minimises
   // ceil(workgroups / CUs) x (stages + 3) + 1.2 per split was built and measured: 256 -> 128 @32x32 0.455 -> 0.42 ms and 8x8
   // 512 -> 256 0.113 -> 0.104, but 384 -> 256 @16x16 0.248 -> 0.284 and 128 -> 128 @32x32 0.265 -> 0.278; the weight-gradient
   // class of the training step 16.59 -> 16.54 ms -- not adopted, profiles/r4_wgrad4_kernel_times.txt.)
-  const char* te = getenv("SSDE_WGRAD4_WGS");
-  const int target = te ? atoi(te) : 768;
+  const int target = 768;
   const int blocks = kPos * p->co_tiles * p->ci_tiles;
   int splits = (target + blocks / 2) / blocks;
   const int max_splits = p->T / 512;
@@ -479,8 +476,7 @@ void plan(const ssde_wgrad_args* a, W4Params* p) {
   p->splits = ssde_cdiv(p->T, p->k_per_split);
   p->sk_on = 0; p->sk_per = p->sk_S = p->sk_groups = 0;
   {
-    const char* sk = getenv("SSDE_WGRAD4_STREAMK");
-    if (!(sk && sk[0] == '0') && a->splits <= 0) {      // (default on; SSDE_WGRAD4_STREAMK=0: the plain split, for A/B runs and tests)
+    if (!(a->flags & SSDE_WGRADF_NO_STREAMK) && a->splits <= 0) {      // (default on; the flag: the plain split, for A/B runs and tests)
       // three workgroups per CU are what the kernel's registers and LDS keep resident beside each other at full rate
       const int ntiles = p->co_tiles * p->ci_tiles;
       const int S = ssde_cdiv(p->T, BK), total = kPos * S;
@@ -495,7 +491,7 @@ void plan(const ssde_wgrad_args* a, W4Params* p) {
     }
   }
   p->scale = a->scale; p->dw = a->dw;
-  { const char* e = getenv("SSDE_WGRAD4_XCD"); p->xcd_order = !(e && e[0] == '0'); }
+  p->xcd_order = !(a->flags & SSDE_WGRADF_NO_XCD_ORDER);
 }
 
 int64_t scratch_floats(const W4Params& p) {
@@ -506,7 +502,7 @@ int64_t scratch_floats(const W4Params& p) {
 
 // ssde_conv_wgrad / ssde_wgrad_scratch_floats (wgrad.hip) route eligible launches here, before wgrad_wino.hip
 bool ssde_wgrad_wino4_wants(const ssde_wgrad_args* a) {
-  const int m = mode();
+  const int m = mode(a);
   if ((m != 4 && m != 44) || a->ksize != 3 || a->stride != 1 || a->pad != 1 || a->transpose_out) return false;
   if (a->h_in != a->h_out || a->w_in != a->w_out || a->h_out % 4 != 0 || a->w_out % 4 != 0 || a->h_out < 8 || a->w_out < 8) return false;
   const ssde_src& s = a->src;
@@ -568,7 +564,7 @@ int ssde_wgrad_wino4_launch(const ssde_wgrad_args* a, void* stream) {
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   auto grid_for = [](long long total) { long long b = (total + 255) / 256; return (unsigned)(b > 256 * 32 ? 256 * 32 : (b < 1 ? 1 : b)); };
-  static const int xvec = getenv("SSDE_WGRAD4_XVEC") ? atoi(getenv("SSDE_WGRAD4_XVEC")) : 2;      // channels per transform thread
+  const int xvec = (a->flags & SSDE_WGRADF_XVEC1) ? 1 : 2;      // channels per transform thread
   const bool v2 = xvec == 2 && p.Ctot % 2 == 0 && p.Cout % 2 == 0 && s.c0 % 2 == 0 && p.g_ld % 2 == 0 && p.g_off % 2 == 0;
   const dim3 gv(grid_for((long long)p.T * p.Ctot / (v2 ? 2 : 1))), gz(grid_for((long long)p.T * p.Cout / (v2 ? 2 : 1)));
   if (v2) {

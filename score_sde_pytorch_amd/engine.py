@@ -18,6 +18,7 @@ Fusions encoded in the program (per ResnetBlockBigGANpp, models/layerspp.py:242-
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -90,6 +91,9 @@ _STRUCT = {L.OP_CONV: L.ConvArgs, L.OP_GN_STATS: L.GnStatsArgs, L.OP_UPFIRDN: L.
            L.OP_GN_BWD_REDUCE: L.GnBwdReduceArgs, L.OP_PROLOGUE_BWD: L.PrologueBwdArgs, L.OP_ATTN_BWD: L.AttnBwdArgs,
            L.OP_PERTURB: L.PerturbArgs, L.OP_DSM_LOSS: L.DsmLossArgs, L.OP_SUMSQ_FLAT: L.SumsqFlatArgs,
            L.OP_ADAM: L.AdamArgs, L.OP_MEMSET: L.MemsetArgs, L.OP_AXPY: L.AxpyArgs, L.OP_GN_FINALIZE: L.GnFinalizeArgs}
+
+
+_ROUTE = {L.OP_CONV: L.conv_route_flags, L.OP_WGRAD: L.wgrad_route_flags, L.OP_GN_BWD_REDUCE: L.gn_bwd_route_flags}
 
 
 class ProgramBuilder:
@@ -166,6 +170,8 @@ class ProgramBuilder:
             for sub_fields, sub_class, sub_fl in _expand(kind, fields, fclass, fl):
                 args = _STRUCT[kind]()
                 _fill(args, sub_fields)
+                if kind in _ROUTE and "flags" not in sub_fields:
+                    args.flags = _ROUTE[kind]()          # A/B switches of the environment, read ONCE here (see _lib.py)
                 ops.append(L.make_op(kind, args, sub_class))
                 classes.append(sub_class)
                 flops.append(sub_fl)
@@ -178,7 +184,6 @@ def _fir_pairs(specs):
     """A residual block resamples act(GroupNorm(x)) and x with the same FIR (layerspp.py:250-258): two adjacent
     OP_UPFIRDN specs on one source, the first with a prologue, the second without.  They run as ONE launch that reads x
     once (ssde_upfirdn_args.dst2); the specs stay separate for the backward lowering.  Returns {spec index: dst2 | None}."""
-    import os
     out = {}
     if os.environ.get("SSDE_FUSE_FIR", "1") == "0":
         return out
@@ -320,33 +325,18 @@ def pack_wino4_weight(w):
     return full.reshape(nt, 2, 32, c4, 4, 9, 4).permute(3, 0, 6, 1, 5, 2, 4).contiguous()
 
 
-def split3_bf16(t):
-    """fp32 tensor -> three int16 tensors of bf16 bit patterns whose values sum to t exactly: the top 16 bits of t, of the
-    remainder, and of what is left (at most 8 significant bits) -- ssde_split3 of csrc/ssde_common.h in torch."""
-    t = t.contiguous().to(torch.float32)
-    mask = torch.tensor(-65536, dtype=torch.int32, device=t.device)           # 0xFFFF0000
-    out, r = [], t
-    for _ in range(3):
-        hi = (r.view(torch.int32) & mask)
-        out.append((hi >> 16).to(torch.int16))
-        r = r - hi.view(torch.float32)
-    return out
-
-
-def pack_wino4x_weight(w):
-    """[Cout, Cin, 3, 3] -> the F(4x4,3x3) weights of pack_wino4_weight as three bf16 pieces per element, the LDS image
-    conv_wino4x.hip reads (SSDE_TILE_WINOGRAD4X): [ceil(Cin/4)][ceil(Cout/64)][8 waves][9][32 couts][3 pieces][4 channels] bf16,
-    returned as a float32 tensor of the same bytes (6 floats per (position, cout))."""
-    cout, cin = w.shape[0], w.shape[1]
-    G = _WINO4_G.to(w.device)
-    u = torch.einsum("ak,ockl,bl->ocab", G, w.detach().to(torch.float64), G).to(torch.float32)     # [Cout, Cin, 6, 6]
-    c4, nt = (cin + 3) // 4, (cout + 63) // 64
-    full = torch.zeros(nt * 64, c4 * 4, 36, dtype=torch.float32, device=w.device)
-    full[:cout, :cin] = u.reshape(cout, cin, 36)
-    pieces = torch.stack(split3_bf16(full))                                   # [3, nt*64, c4*4, 36] int16
-    # [piece, nt, h, cl, c4, e, j, q] -> [c4, nt, q, h, j, cl, piece, e]
-    img = pieces.reshape(3, nt, 2, 32, c4, 4, 9, 4).permute(4, 1, 7, 2, 6, 3, 0, 5).contiguous()
-    return img.view(torch.float32)
+def pack_wino4r_weight(w):
+    """[Cout, Cin, 3, 3] -> the F(4x4,3x3) weights of pack_wino4_weight arranged per LANE for conv_wino4r.hip, which loads them
+    straight into MFMA operand registers (SSDE_TILE_WINOGRAD4R / SSDE_PACK_WINO4R):
+    [ceil(Cin/4)][ceil(Cout/64)][8 waves (q, h)][4 pieces x [64 lanes][4] | [64 lanes][2]] -- lane (lh, li) of wave (q, h) holds, of
+    cout 64 nt + 32 h + li and channels 2 lh, 2 lh + 1, positions q + 4 (2 i) and q + 4 (2 i + 1) in piece i, position q + 32 last."""
+    img = pack_wino4_weight(w)                                   # [c4, nt, q, h, j, cl, e]
+    c4, nt = img.shape[0], img.shape[1]
+    v = img.reshape(c4, nt, 8, 9, 32, 2, 2)                      # [.., wave, j, cl, lh, e2]
+    pieces = v[:, :, :, :8].reshape(c4, nt, 8, 4, 2, 32, 2, 2)   # [.., wave, i, jj, cl, lh, e2]
+    pieces = pieces.permute(0, 1, 2, 3, 6, 5, 4, 7).reshape(c4, nt, 8, 4 * 64 * 4)      # [.., i, lh, cl, jj, e2]
+    last = v[:, :, :, 8].permute(0, 1, 2, 4, 3, 5).reshape(c4, nt, 8, 64 * 2)           # [.., lh, cl, e2]
+    return torch.cat([pieces, last], dim=3).contiguous()
 
 
 def pack_matrix(w):
@@ -383,8 +373,9 @@ class WeightStore:
     # -- typed registrations -------------------------------------------------------------------
     def conv3(self, param, cin_pad=None, cout_pad=None, wino=False):
         """[Cout, Cin, 3, 3] conv weight, optionally zero-padded to cin_pad / cout_pad channels; wino (see
-        Lowering.wino_ok): 2 / True = packed for the Winograd F(2x2,3x3) kernel (G g G^T, conv_wino.hip), 4 = for the
-        F(4x4,3x3) kernel (conv_wino4.hip), 0 = for the direct one."""
+        Lowering.wino_ok): 2 / True = packed for the Winograd F(2x2,3x3) kernel (G g G^T, conv_wino.hip), 4 = for the fused
+        F(4x4,3x3) kernel (conv_wino4.hip; also read by the LDS-fed matrix kernel of conv_wino4g.hip), 6 = per lane for the
+        register-fed matrix kernel (conv_wino4r.hip), 0 = for the direct one."""
         def logical(w):
             w = w.to(torch.float32)
             if cin_pad and w.shape[1] < cin_pad:
@@ -395,12 +386,9 @@ class WeightStore:
         cout_l, cin_l = max(param.shape[0], cout_pad or 0), max(param.shape[1], cin_pad or 0)
         meta = dict(kind="conv3", sources=[param], logical=logical, dims=(cout_l, cin_l),
                     parts=[dict(param=param, row0=0, rows=param.shape[0], transpose=False)], cin_store=param.shape[1])
-        # wino 5 = F(4x4,3x3) on the BF16 matrix pipe (conv_wino4x.hip): three bf16 pieces per element, packed in torch (no
-        # device re-pack recipe: inference programs, the weights change on checkpoint loads only)
-        pack = pack_wino4x_weight if wino == 5 else pack_wino4_weight if wino == 4 else pack_wino_weight if wino else pack_conv_weight
-        recipe = None if wino == 5 else \
-            [dict(kind=L.PACK_WINO4 if wino == 4 else L.PACK_WINO3 if wino else L.PACK_CONV3, src=param, cout=param.shape[0], cin=param.shape[1],
-                  cout_l=cout_l, cin_l=cin_l, flags=0, n="dst")]
+        pack = pack_wino4r_weight if wino == 6 else pack_wino4_weight if wino == 4 else pack_wino_weight if wino else pack_conv_weight
+        kind = L.PACK_WINO4R if wino == 6 else L.PACK_WINO4 if wino == 4 else L.PACK_WINO3 if wino else L.PACK_CONV3
+        recipe = [dict(kind=kind, src=param, cout=param.shape[0], cin=param.shape[1], cout_l=cout_l, cin_l=cin_l, flags=0, n="dst")]
         return self.add([param], lambda w: pack(logical(w)), meta, recipe)
 
     def matrix(self, parts, cin_pad=None):
@@ -450,14 +438,14 @@ class WeightStore:
 
     def derived(self, packed, fn, tag):
         """The input-gradient packing of an existing entry's logical weight: fn(logical) -> packed, with tag
-        'dgrad' (direct conv / matrix), 'dgrad_wino' or 'dgrad_wino4'."""
+        'dgrad' (direct conv / matrix), 'dgrad_wino', 'dgrad_wino4' or 'dgrad_wino4r'."""
         meta = self.meta[id(packed)]
         key = (id(packed), tag)
         if key not in self.meta:
             cout_l, cin_l = meta["dims"]
             if meta["kind"] == "conv3":
                 p_ = meta["sources"][0]
-                kind = {"dgrad_wino": L.PACK_WINO3, "dgrad_wino4": L.PACK_WINO4}.get(tag, L.PACK_CONV3)
+                kind = {"dgrad_wino": L.PACK_WINO3, "dgrad_wino4": L.PACK_WINO4, "dgrad_wino4r": L.PACK_WINO4R}.get(tag, L.PACK_CONV3)
                 recipe = [dict(kind=kind, src=p_, cout=p_.shape[0], cin=p_.shape[1],
                                cout_l=cin_l, cin_l=cout_l, flags=1, n="dst")]
             else:
@@ -562,7 +550,6 @@ class Lowering:
         self.parts = {}      # id(activation Buf) -> (partials Buf, slices per image, channels): written by its producer's epilogue
         # compute units of the device the program will run on: the kernel choice below asks "does this launch fill the
         # chip?" (256 on the MI355X; also the value used for CPU dry lowering).  SSDE_NUM_CUS overrides (tests)
-        import os
         dev = getattr(builder, "device", None)
         self.cus = 256
         if os.environ.get("SSDE_NUM_CUS"):
@@ -572,7 +559,6 @@ class Lowering:
 
     def _gn_slices(self, fields):
         """Slices per image of the GroupNorm partials the LAST launch of this conv spec would write (0: not available)."""
-        import os
         if os.environ.get("SSDE_GN_FUSE", "1") == "0":
             return 0
         sub = _expand(L.OP_CONV, fields, 0, 0.0)[-1][0]
@@ -592,6 +578,7 @@ class Lowering:
         for k in ("n", "h_in", "w_in", "h_out", "w_out", "c_out", "ksize", "stride", "pad", "tile"):
             setattr(a, k, sub[k])
         a.dst = dummy
+        a.flags = sub.get("flags", L.conv_route_flags())
         return int(L.load().ssde_conv_gn_slices(C.byref(a)))
 
     # -- GroupNorm statistics of a (possibly concatenated) NHWC source
@@ -622,15 +609,16 @@ class Lowering:
     def conv(self, dst, h_out, w_out, c_out, main=None, w_main=None, h_in=0, w_in=0, stride=1, pad=1,
              aux=None, w_aux=None, bias=None, chan_add=None, chan_add_ld=0, resid=None, scale=1.0, tile=L.TILE_AUTO,
              resid_post=0, wino=False, stats=False):
-        """wino (2 / True or 4): w_main is Winograd-packed (see wino_ok); a fused 1x1 source then runs as a second launch.
+        """wino (2 / True, 4 or 6): w_main is Winograd-packed (see wino_ok); a fused 1x1 source then runs as a second launch.
         stats=True: dst feeds a GroupNorm later -- when the launch plan allows it (ssde_conv_gn_slices) the epilogue
         also writes the tensor's partial statistics and gn_stats() turns into a finalize of a few thousand floats."""
         split_tmp = None
         if wino:
             assert main is not None and stride == 1 and pad == 1 and (h_in, w_in) == (h_out, w_out)
-            tile = L.TILE_WINOGRAD4X if wino == 5 else L.TILE_WINOGRAD4 if wino == 4 else L.TILE_WINOGRAD
-            if wino == 4 and self._wino4_two_kernels(h_out, w_out, c_out, main["c0"] + main["c1"]):
-                tile = L.TILE_WINOGRAD4G
+            tile = L.TILE_WINOGRAD4R if wino == 6 else L.TILE_WINOGRAD4 if wino == 4 else L.TILE_WINOGRAD
+            if wino == 4 and os.environ.get("SSDE_WINO4_FEED", "regs") == "lds" and \
+                    self._wino4_two_kernels(h_out, w_out, c_out, main["c0"] + main["c1"]):
+                tile = L.TILE_WINOGRAD4G                 # round 4's LDS-fed matrix kernel on the fused kernel's weight image (A/B runs)
             if aux is not None:
                 split_tmp = self.b.buf(self.n, h_out, w_out, c_out, name="wino_tmp")
         px = self.n * h_out * w_out
@@ -645,7 +633,7 @@ class Lowering:
             ksize=3 if main is not None else 0, stride=stride, pad=pad, tile=tile, bias=bias, chan_add=chan_add,
             chan_add_ld=chan_add_ld, resid_post=resid_post, resid=resid, out_scale=float(scale), dst=dst, gn_part=None,
             wino_v=None, _split_tmp=split_tmp)
-        if wino == 4:
+        if wino in (4, 6):
             # the transformed input B^T pro(x) B in HBM (2.25x the input): the two-kernel form (conv_wino4g.hip) cannot do without
             # it; in a training forward the one-kernel form leaves it behind as a by-product when the layer's weight gradient
             # takes the F(4x4,3x3) route (ssde_conv_args.wino_v -> ssde_wgrad_args.v_pre, backward.TrainEngine._bwd_branch:
@@ -653,7 +641,7 @@ class Lowering:
             ctot = main["c0"] + main["c1"]
             v_floats = 36 * self.n * (h_out // 4) * (w_out // 4) * ctot
             takes = getattr(self, "emit_wino_v", False) and v_floats * 4 < 2 ** 32 and self._wgrad_takes_wino4(fields)
-            if tile == L.TILE_WINOGRAD4G or takes:
+            if tile in (L.TILE_WINOGRAD4G, L.TILE_WINOGRAD4R) or takes:
                 fields["wino_v"] = self.b.buf(v_floats, name="wino_v")
                 fields["_v_for_wgrad"] = bool(takes)
         if stats and isinstance(dst, Buf):
@@ -671,7 +659,6 @@ class Lowering:
         r4_wino4_two_kernels.txt): 256->256 @16x16 0.281 -> 0.245 ms, 512->256 @16x16 0.496 -> 0.457, level at 128 couts
         (128->128 @32x32 0.357 -> 0.346, 256->128 0.599 -> 0.594), a loss at 384->128 @32x32 (0.78 -> 0.95: three times the
         input for two cout tiles) -- so: from four cout tiles up.  SSDE_WINO4_TWO: 0 = never, 2 = wherever F(4x4,3x3) runs."""
-        import os
         mode = os.environ.get("SSDE_WINO4_TWO", "1")
         if mode == "0" or 36 * self.n * (h // 4) * (w // 4) * c_in * 4 >= 2 ** 32:
             return False
@@ -680,7 +667,6 @@ class Lowering:
     def _wgrad_takes_wino4(self, f):
         """Would ssde_conv_wgrad run the weight gradient of this forward conv on the F(4x4,3x3) path?  (shape-only query with
         the arguments backward.TrainEngine._bwd_branch will pass: g = d dst, one part covering the whole weight)"""
-        import os
         if os.environ.get("SSDE_WINO_V_FROM_FORWARD", "1") == "0":
             return False
         meta = self.w.meta.get(id(f["w_main"]))
@@ -693,19 +679,13 @@ class Lowering:
         a.n, a.h_in, a.w_in, a.h_out, a.w_out = f["n"], f["h_in"], f["w_in"], f["h_out"], f["w_out"]
         a.c_out, a.ksize, a.stride, a.pad = meta["parts"][0]["rows"], 3, f["stride"], f["pad"]
         a.cin_store, a.transpose_out = meta["cin_store"], 0
+        a.flags = L.wgrad_route_flags()
         return bool(L.load().ssde_wgrad_wants_winograd4(C.byref(a)))
 
-    def _wino4x_on(self):
-        """F(4x4,3x3) on the BF16 matrix pipe (conv_wino4x.hip) instead of conv_wino4.hip: inference programs, and only on
-        request -- SSDE_MATRIX=bf16x6 together with SSDE_WINO4X=1.  Its first version is parity-green but 6-13 % SLOWER than the
-        fp32 kernel (profiles/r4_wino4x_v1.txt: the matrix time halves, the per-position issue work -- five fragment reads, the
-        operand copies, the masked LDS-DMA piece -- and the transform phases do not), so the bf16x6 mode keeps the fp32 kernel."""
-        import os
-        return bool(getattr(self, "allow_wino4x", False)) and os.environ.get("SSDE_MATRIX", "").startswith("b") and \
-            os.environ.get("SSDE_WINO4X", "0") == "1"
-
     def wino_ok(self, h, w, c_out, c_in):
-        """Which 3x3 / stride 1 kernel a layer gets: 0 = direct, 2 = Winograd F(2x2,3x3), 4 = F(4x4,3x3).
+        """Which 3x3 / stride 1 kernel a layer gets: 0 = direct, 2 = Winograd F(2x2,3x3), 4 = F(4x4,3x3) in one fused kernel
+        (conv_wino4.hip), 6 = F(4x4,3x3) as a transform pass + the register-fed matrix kernel (conv_wino4r.hip; _wino4_two_kernels
+        decides between 4 and 6).
         Winograd pays when the matrix pipe is the bound: enough channels to fill the 64-cout tile, and enough workgroups
         to cover the 256 CUs (F(2x2,3x3): 64 tiles x 64 couts per workgroup -- measured x1.2-1.5 over the direct kernel
         from 8x8 up at batch 256, x0.5 at 4x4 where only 64 workgroups exist).  F(4x4,3x3) does 1.78x less matrix work
@@ -715,20 +695,20 @@ class Lowering:
         tests allow (tools/experiments/wino43_error_budget.py).
         SSDE_WINOGRAD: 0 = direct (bitwise fmaf-chain) kernel everywhere, 1 = this heuristic (default), 2 = F(2x2,3x3)
         wherever it is legal, 3 = the heuristic without F(4x4,3x3), 4 = F(4x4,3x3) wherever it is legal."""
-        import os
         mode = os.environ.get("SSDE_WINOGRAD", "1")
         if mode == "0":
             return 0
         legal2 = h % 2 == 0 and w % 2 == 0 and h >= 8 and w >= 8 and c_out >= 32 and c_in >= 8 and c_in % 8 == 0
         legal4 = h % 4 == 0 and w % 4 == 0 and h >= 8 and w >= 8 and c_out >= 32 and c_in >= 8 and c_in % 4 == 0
+        four = lambda: 6 if (os.environ.get("SSDE_WINO4_FEED", "regs") != "lds" and self._wino4_two_kernels(h, w, c_out, c_in)) else 4  # noqa: E731
         if mode == "4" and legal4:
-            return 5 if self._wino4x_on() else 4
+            return four()
         if mode == "2" or mode == "4":
             return 2 if legal2 else 0
         n_tiles = -(-c_out // 64)
         # (one workgroup per CU: F(4x4,3x3) workgroups own a whole CU's LDS and registers)
         if mode != "3" and legal4 and h >= 16 and w >= 16 and -(-(self.n * h * w) // 512) * n_tiles >= self.cus:
-            return 5 if self._wino4x_on() else 4
+            return four()
         # Fewer tiles than that (8x8 maps at batch 256: 128 tiles of 8 images x 64 couts): the kernel splits its reduction
         # over 2 or 4 workgroups per tile (conv_wino4.hip, ssde_conv_wino4_splits -- the same rule).  Measured
         # (profiles/r3_wino4_split_reduction_ab.txt): 17-40 % over the unsplit kernel, but only level with F(2x2,3x3) on
@@ -780,7 +760,6 @@ class UNetEngine:
         # a training program with parameter gradients (backward.TrainEngine sets param_grads before lowering): the forward
         # F(4x4,3x3) launches leave their transformed input behind for the weight gradients
         self.low.emit_wino_v = bool(getattr(self, "param_grads", False))
-        self.low.allow_wino4x = type(self) is UNetEngine and not train and not input_grad
         self.channels = model.channels
         # static I/O (addresses are baked into the program / graph)
         self.x_in = self.b.buf(batch, self.channels, height, width, name="x_in", persistent=True)

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .engine import pack_conv_weight, pack_matrix, pack_wino_weight, pack_wino4_weight, pack_wino4x_weight
+from .engine import pack_conv_weight, pack_matrix, pack_wino_weight, pack_wino4_weight, pack_wino4r_weight
 
 
 def _stream():
@@ -56,8 +56,9 @@ def groupnorm_stats(x, groups, eps=1e-6, x2=None, slices=1):
 
 def conv2d(x=None, weight=None, bias=None, stride=1, pad=1, x2=None, pro=L.PRO_NONE, gn=None,
            aux=None, aux2=None, aux_weight=None, aux_pro=L.PRO_NONE, aux_gn=None,
-           chan_add=None, resid=None, scale=1.0, tile=L.TILE_AUTO, out_hw=None):
-    """k x k (k=3) conv of NHWC `x` (weight OIHW) plus optional 1x1 conv of `aux` (weight [Cout, Cin])."""
+           chan_add=None, resid=None, scale=1.0, tile=L.TILE_AUTO, out_hw=None, flags=None):
+    """k x k (k=3) conv of NHWC `x` (weight OIHW) plus optional 1x1 conv of `aux` (weight [Cout, Cin]).
+    flags: SSDE_CONVF_* routing switches (None: the A/B variables of the environment, _lib.conv_route_flags)."""
     _need_cuda(x, aux, resid)
     a = L.ConvArgs()
     keep = []
@@ -69,9 +70,13 @@ def conv2d(x=None, weight=None, bias=None, stride=1, pad=1, x2=None, pro=L.PRO_N
         if out_hw is not None:      # top-left crop of the full result (transposed strided convolutions)
             h_out, w_out = out_hw
         _fill_src(a.main, x, x2, pro, gn)
-        packer = {L.TILE_WINOGRAD: pack_wino_weight, L.TILE_WINOGRAD4: pack_wino4_weight, L.TILE_WINOGRAD4X: pack_wino4x_weight,
-                  L.TILE_WINOGRAD4G: pack_wino4_weight}.get(tile, pack_conv_weight)
+        packer = {L.TILE_WINOGRAD: pack_wino_weight, L.TILE_WINOGRAD4: pack_wino4_weight, L.TILE_WINOGRAD4G: pack_wino4_weight,
+                  L.TILE_WINOGRAD4R: pack_wino4r_weight}.get(tile, pack_conv_weight)
         wp = packer(weight.to(x.device)); keep.append(wp)
+        if tile in (L.TILE_WINOGRAD4G, L.TILE_WINOGRAD4R):      # the two-kernel forms need the transformed-input buffer
+            wv = torch.empty(36 * n * (h_in // 4) * (w_in // 4) * (x.shape[-1] + (x2.shape[-1] if x2 is not None else 0)), device=x.device)
+            keep.append(wv)
+            a.wino_v = _p(wv)
         a.w_main, a.ksize, a.stride, a.pad, a.h_in, a.w_in = _p(wp), 3, stride, pad, h_in, w_in
     else:
         n, h_out, w_out = aux.shape[0], aux.shape[1], aux.shape[2]
@@ -88,6 +93,7 @@ def conv2d(x=None, weight=None, bias=None, stride=1, pad=1, x2=None, pro=L.PRO_N
     if chan_add is not None:
         a.chan_add, a.chan_add_ld = _p(chan_add), chan_add.shape[-1]
     a.resid, a.out_scale, a.dst = _p(resid), scale, _p(dst)
+    a.flags = L.conv_route_flags() if flags is None else flags
     L.check(L.load().ssde_conv2d(C.byref(a), _stream()), "ssde_conv2d")
     return dst
 
@@ -187,10 +193,12 @@ def set_dropout(s, p, seed_t, salt):
 
 
 def conv_wgrad(x, g, ksize, dw, stride=1, pad=1, x2=None, pro=L.PRO_NONE, gn=None, g_off=0, c_out=None, cin_store=None,
-               transpose_out=False, scale=1.0, splits=0, dropout=None):
-    """dw += scale * sum_pixels g[:, g_off:g_off+c_out]^T pro(x)[shifted]; x, g NHWC; dw in the reference layout."""
+               transpose_out=False, scale=1.0, splits=0, dropout=None, flags=None):
+    """dw += scale * sum_pixels g[:, g_off:g_off+c_out]^T pro(x)[shifted]; x, g NHWC; dw in the reference layout.
+    flags: SSDE_WGRADF_* (None: the A/B variables of the environment, _lib.wgrad_route_flags)."""
     _need_cuda(x, g, dw)
     a = L.WgradArgs()
+    a.flags = L.wgrad_route_flags() if flags is None else flags
     _fill_src(a.src, x, x2, pro, gn)
     if dropout is not None:
         set_dropout(a.src, *dropout)
@@ -253,6 +261,7 @@ def gn_backward(x, dp, gn, pro, x2=None, dropout=None, slices=1, scale=1.0, acc=
     ctot = x.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
     groups = gn[4]
     r = L.GnBwdReduceArgs()
+    r.flags = L.gn_bwd_route_flags()
     _fill_src(r.src, x, x2, pro, gn)
     if dropout is not None:
         set_dropout(r.src, *dropout)

@@ -108,25 +108,20 @@ def check_backward_ops(dev):
     gg4 = torch.randn(2, 4, 4, 4, generator=g)
     ops.colsum(d(gg4), c=3, total=tot)
     assert rel_err(tot, gg4.sum((0, 1, 2))[:3]) < TOL_OP
-    # several pixel slices per sample, a ragged channel count, both destinations -- as one launch whose last-arriving block
-    # finishes the sums (SSDE_COLSUM_FUSED=1, opt-in) and as the three-kernel sequence (default); each sums in its own fixed order
+    # several pixel slices per sample, a ragged channel count, both destinations (the one-launch form of round 4 lives on as
+    # tools/experiments/colsum_fused.patch)
     gb = torch.randn(5, 16, 16, 72, generator=g)
-    res = {}
-    for fused in ("1", "0"):
-        os.environ["SSDE_COLSUM_FUSED"] = fused
+    for _once in (0,):
         per, tot = torch.zeros(5, 80, device=dev), torch.zeros(68, device=dev)
         ops.colsum(d(gb), c=68, g_off=4, scale=1.3, per_sample=per, ps_off=8, total=tot)
         assert rel_err(per[:, 8:76], 1.3 * gb[..., 4:].sum((1, 2))) < TOL_OP and rel_err(tot, 1.3 * gb[..., 4:].sum((0, 1, 2))) < TOL_OP
         tot1 = torch.zeros(72, device=dev)
         ops.colsum(d(gb), scale=0.5, total=tot1)                 # total only: the slices cut the rows of the whole batch
         assert rel_err(tot1, 0.5 * gb.sum((0, 1, 2))) < TOL_OP
-        res[fused] = (per.cpu().clone(), tot.cpu().clone())
-        for _ in range(2):                                       # tickets return to zero: the same launch again
+        for _ in range(2):                                       # fixed summation order: the same launch again, bit for bit
             tot2 = torch.zeros(72, device=dev)
             ops.colsum(d(gb), scale=0.5, total=tot2)
             assert torch.equal(tot2, tot1)
-    os.environ.pop("SSDE_COLSUM_FUSED")
-    assert rel_err(res["1"][0], res["0"][0]) < 1e-6 and rel_err(res["1"][1], res["0"][1]) < 1e-6     # (different fixed orders)
     # ---- GroupNorm + SiLU backward over a concatenated source (group straddles nothing; 12 groups of 4)
     n, c0, c1, h = 3, 32, 16, 8
     x1 = torch.randn(n, c0, h, h, generator=g).requires_grad_()
@@ -409,12 +404,12 @@ def check_dropout_mask(dev):
     assert rel_err(nchw(dst.cpu()), y.detach()) < TOL_OP
     # the same mask in the F(4x4,3x3) kernels: the fused one applies it in its halo prologue, the two-kernel form in its
     # transform pass (conv_wino4g.hip) -- whose output is also what the weight gradient below may be handed (v_pre)
-    from score_sde_pytorch_amd.engine import pack_wino4_weight
-    wp4 = pack_wino4_weight(w.detach().to(dev))
+    from score_sde_pytorch_amd.engine import pack_wino4_weight, pack_wino4r_weight
+    wp4, wp4r = pack_wino4_weight(w.detach().to(dev)), pack_wino4r_weight(w.detach().to(dev))
     vbuf = torch.full((36 * n * (h // 4) ** 2 * C,), float("nan"), device=dev)
-    for tile in (L.TILE_WINOGRAD4, L.TILE_WINOGRAD4G):
+    for tile in (L.TILE_WINOGRAD4, L.TILE_WINOGRAD4G, L.TILE_WINOGRAD4R):
         dst4 = torch.full((n, h, h, cout), float("nan"), device=dev)
-        a.w_main, a.tile, a.dst, a.wino_v = wp4.data_ptr(), tile, dst4.data_ptr(), vbuf.data_ptr()
+        a.w_main, a.tile, a.dst, a.wino_v = (wp4r if tile == L.TILE_WINOGRAD4R else wp4).data_ptr(), tile, dst4.data_ptr(), vbuf.data_ptr()
         L.check(L.load().ssde_conv2d(C_.byref(a), ops._stream()), "ssde_conv2d")
         assert rel_err(nchw(dst4.cpu()), y.detach()) < 2e-5, tile
     dw = torch.zeros(cout, C, 3, 3, device=dev)
@@ -636,7 +631,7 @@ def check_fused_step(dev, steps=3, sde_kind="vesde"):
     return float(loss)
 
 
-def check_device_repack(dev, kind="ncsnpp"):
+def check_device_repack(dev, kind="ncsnpp", need_kind=None):
     """ssde_pack_weights (four launches for the whole model, driven by a device-resident descriptor table) against the
     torch packers in engine.py, for every packed operand incl. Winograd and input-gradient variants."""
     from score_sde_pytorch_amd.models import utils as mutils
@@ -662,6 +657,9 @@ def check_device_repack(dev, kind="ncsnpp"):
             assert float((e[0] - r).abs().max()) < 1e-6, (e[4][0]["kind"], e[4][0].get("flags"), tuple(e[0].shape))
             n += 1
     assert n >= len(ws.entries) - 2
+    if need_kind is not None:                     # the pack kind under test is really in this store, forward and input-gradient
+        flags = {d.get("flags", 0) for e in ws.entries if e[4] is not None for d in e[4] if d["kind"] == need_kind}
+        assert flags == {0, 1}, flags
 
 
 def check_op_package(dev):
@@ -1227,6 +1225,7 @@ def check_conv_split_reduction(dev, monkeypatch, n, repeats=3):
                 a.w_main, a.ksize, a.stride, a.pad, a.h_in, a.w_in = wp.data_ptr(), 3, 1, 1, h, h
                 a.n, a.h_out, a.w_out, a.c_out, a.out_scale, a.dst, a.tile = n, h, h, cout, 0.7, dst.data_ptr(), L.TILE_AUTO
                 a.bias, a.chan_add, a.chan_add_ld, a.resid = bd.data_ptr(), ca.data_ptr(), cout, resid.data_ptr()
+                a.flags = L.conv_route_flags()                 # (SSDE_CONV_KSPLIT=0 -> SSDE_CONVF_NO_KSPLIT)
                 sl = lib.ssde_conv_gn_slices(C.byref(a))
                 part = torch.full((n, max(sl, 1), cout // 4, 3), float("nan"), device=dev)
                 if sl > 0:
@@ -1252,7 +1251,7 @@ def check_conv_split_reduction(dev, monkeypatch, n, repeats=3):
             assert (m2 - mr).abs().max().item() < 1e-5 and ((r2 - rr).abs() / rr).max().item() < 1e-4
 
 
-def check_conv_winograd4(dev, big=False, split=False):
+def check_conv_winograd4(dev, big=False, regs=False):
     """conv_wino4.hip (F(4x4,3x3)): plain convolutions over the tilings it knows (part of one image, several whole
     images, ragged batch tails, cout tiles that are not full), then the fully fused form (concat source, GroupNorm + SiLU
     prologue, bias, per-image addend, residual, scale, GroupNorm partials of the result) against torch.  Tolerance 2e-5:
@@ -1261,11 +1260,12 @@ def check_conv_winograd4(dev, big=False, split=False):
     import numpy as np
     import torch.nn.functional as F
     from score_sde_pytorch_amd import hipops as ops, _lib as L
-    from score_sde_pytorch_amd.engine import pack_wino4_weight, pack_wino4x_weight
-    # split=True: the same cases on conv_wino4x.hip (BF16 matrix pipe, 3-way bf16 split of both operands), tolerances unchanged
-    TILE = L.TILE_WINOGRAD4X if split else L.TILE_WINOGRAD4
-    if split:
-        pack_wino4_weight = pack_wino4x_weight
+    from score_sde_pytorch_amd.engine import pack_wino4_weight, pack_wino4r_weight
+    # regs=True: the same cases as a transform pass + the register-fed matrix kernel (conv_wino4r.hip, SSDE_TILE_WINOGRAD4R, weights
+    # packed per lane), tolerances unchanged
+    TILE = L.TILE_WINOGRAD4R if regs else L.TILE_WINOGRAD4
+    if regs:
+        pack_wino4_weight = pack_wino4r_weight
     lib = L.load()
     g = torch.Generator().manual_seed(2)
     # (>= 128 / 256 input channels and few workgroups: the reduction is split over two / four workgroups per tile, checked
@@ -1307,6 +1307,8 @@ def check_conv_winograd4(dev, big=False, split=False):
         a.w_main, a.ksize, a.stride, a.pad, a.h_in, a.w_in = wp.data_ptr(), 3, 1, 1, h, h
         a.n, a.h_out, a.w_out, a.c_out, a.out_scale, a.dst, a.tile = n, h, h, cout, 0.7, dst.data_ptr(), TILE
         a.bias, a.chan_add, a.chan_add_ld, a.resid = bd.data_ptr(), cad.data_ptr(), cout, rd.data_ptr()
+        vbuf = torch.full((36 * n * (h // 4) * (h // 4) * cin,), float("nan"), device=dev) if regs else None
+        a.wino_v = vbuf.data_ptr() if regs else None
         sl = lib.ssde_conv_gn_slices(C.byref(a))
         assert sl > 0
         part = torch.full((n, sl, cout // 4, 3), float("nan"), device=dev)
@@ -1326,16 +1328,17 @@ def check_conv_winograd4(dev, big=False, split=False):
 
 
 def check_conv_winograd4_two_kernels(dev, big=False):
-    """conv_wino4g.hip (F(4x4,3x3) as an input-transform pass + a matrix kernel, SSDE_TILE_WINOGRAD4G) against torch and against
-    conv_wino4.hip: with the transformed input taken from conv_wino4's own by-product (SSDE_W4G_V_GIVEN=1: the caller filled
-    wino_v) the matrix kernel must reproduce conv_wino4's output BIT FOR BIT (same products, same order); with its own transform
+    """F(4x4,3x3) as an input-transform pass + a matrix kernel -- conv_wino4r.hip (operands from registers, SSDE_TILE_WINOGRAD4R,
+    the product's form) and conv_wino4g.hip (operands through LDS, SSDE_TILE_WINOGRAD4G) -- against torch and against
+    conv_wino4.hip: with the transformed input taken from conv_wino4's own by-product (SSDE_CONVF_V_GIVEN: the caller filled
+    wino_v) either matrix kernel must reproduce conv_wino4's output BIT FOR BIT (same products, same order); with its own transform
     pass the result is within rounding of it and within the F(4x4,3x3) tolerance of torch.  Tilings: part of one image, whole
     images, ragged batch tails, cout tiles that are not full; the fused epilogue and the GroupNorm partials."""
     import ctypes as C
     import numpy as np
     import torch.nn.functional as F
     from score_sde_pytorch_amd import hipops as ops, _lib as L
-    from score_sde_pytorch_amd.engine import pack_wino4_weight
+    from score_sde_pytorch_amd.engine import pack_wino4_weight, pack_wino4r_weight
     lib = L.load()
     g = torch.Generator().manual_seed(5)
     cases = [(5, 32, 16, 64, 16), (9, 64, 0, 96, 8), (3, 24, 32, 128, 32), (1, 8, 0, 64, 16), (2, 128, 0, 256, 16), (1, 16, 0, 40, 64)]
@@ -1356,7 +1359,9 @@ def check_conv_winograd4_two_kernels(dev, big=False):
         gn = (mean, rstd, gamma.to(dev), beta.to(dev), G)
         ops._fill_src(a.main, x0d, x1d, L.PRO_GN_SILU, gn)
         wp, bd, cad, rd = pack_wino4_weight(w.to(dev)), b.to(dev), ca.to(dev), resid.to(dev)
-        a.w_main, a.ksize, a.stride, a.pad, a.h_in, a.w_in = wp.data_ptr(), 3, 1, 1, h, h
+        wpr = pack_wino4r_weight(w.to(dev))
+        assert wpr.numel() == wp.numel()
+        a.ksize, a.stride, a.pad, a.h_in, a.w_in = 3, 1, 1, h, h
         a.n, a.h_out, a.w_out, a.c_out, a.out_scale = n, h, h, cout, 0.7
         a.bias, a.chan_add, a.chan_add_ld, a.resid = bd.data_ptr(), cad.data_ptr(), cout, rd.data_ptr()
         xn = F.silu(F.group_norm(xcat.permute(0, 3, 1, 2), G, gamma, beta, 1e-6))
@@ -1364,29 +1369,29 @@ def check_conv_winograd4_two_kernels(dev, big=False):
         out, parts = {}, {}
         v = torch.full((36 * n * (h // 4) * (h // 4) * cin,), float("nan"), device=dev)
         a.wino_v = v.data_ptr()
-        for name, tile, env in (("one kernel", L.TILE_WINOGRAD4, {}), ("matrix kernel on the by-product", L.TILE_WINOGRAD4G, {"SSDE_W4G_V_GIVEN": "1"}),
-                                ("two kernels", L.TILE_WINOGRAD4G, {})):
-            a.tile = tile
+        # (SSDE_CONVF_NO_KSPLIT: a split reduction of conv_wino4.hip sums in another order)
+        for name, tile, flags in (("one kernel", L.TILE_WINOGRAD4, 0),
+                                  ("register-fed matrix kernel on the by-product", L.TILE_WINOGRAD4R, L.CONVF_V_GIVEN),
+                                  ("LDS-fed matrix kernel on the by-product", L.TILE_WINOGRAD4G, L.CONVF_V_GIVEN),
+                                  ("two kernels", L.TILE_WINOGRAD4R, 0), ("two kernels, LDS-fed", L.TILE_WINOGRAD4G, 0)):
+            a.tile, a.flags = tile, flags | L.CONVF_NO_KSPLIT
+            a.w_main = (wpr if tile == L.TILE_WINOGRAD4R else wp).data_ptr()
             dst = torch.full((n, h, h, cout), float("nan"), device=dev)
             a.dst, a.gn_part = dst.data_ptr(), None
             sl = lib.ssde_conv_gn_slices(C.byref(a))
             assert sl > 0, (name, lib.ssde_last_error())
             part = torch.full((n, sl, cout // 4, 3), float("nan"), device=dev)
             a.gn_part = part.data_ptr()
-            if name == "two kernels":
+            if name.startswith("two kernels"):
                 v.fill_(float("nan"))
-            env = dict(env, SSDE_CONV_KSPLIT="0")        # (a split reduction of conv_wino4.hip sums in another order)
-            os.environ.update(env)
-            try:
-                L.check(lib.ssde_conv2d(C.byref(a), ops._stream()))
-            finally:
-                for k in env:
-                    os.environ.pop(k)
+            L.check(lib.ssde_conv2d(C.byref(a), ops._stream()))
             assert _util.rel_err(dst.cpu(), ref) < 2e-5, (name, n, c0, c1, cout, h, _util.rel_err(dst.cpu(), ref))
             out[name], parts[name] = dst.cpu(), part.cpu()
-        assert torch.equal(out["matrix kernel on the by-product"], out["one kernel"]), (n, c0, c1, cout, h)
-        assert torch.equal(parts["matrix kernel on the by-product"], parts["one kernel"])
+        for name in ("register-fed matrix kernel on the by-product", "LDS-fed matrix kernel on the by-product"):
+            assert torch.equal(out[name], out["one kernel"]), (name, n, c0, c1, cout, h)
+            assert torch.equal(parts[name], parts["one kernel"]), name
         assert _util.rel_err(out["two kernels"], out["one kernel"]) < 5e-6
+        assert torch.equal(out["two kernels"], out["two kernels, LDS-fed"])
 
 
 def check_wgrad_wino4_streamk(dev, big=False):

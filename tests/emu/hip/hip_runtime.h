@@ -189,6 +189,9 @@ static inline void emu_global_load_lds(const void* g, __attribute__((address_spa
   do { if (emu::cur->lane < 16) SSDE_GLDS16_S(voff, sbase, lds_wave_base, imm); } while (0)
 #define SSDE_GLOAD16(dst, voff, sbase) memcpy(&(dst), (const char*)(sbase) + (voff), 16)
 #define SSDE_WAIT_VMCNT_FOR(n, a, b) ((void)0)
+#define SSDE_GLOAD16_I(dst, voff, sbase, imm) memcpy(&(dst), (const char*)(sbase) + (voff) + (imm), 16)
+#define SSDE_GLOAD8_I(dst, voff, sbase, imm) memcpy(&(dst), (const char*)(sbase) + (voff) + (imm), 8)
+#define SSDE_WAIT_VMCNT_FOR3(n, a, b, c) ((void)0)
 #define SSDE_WAIT_VMCNT_FENCE(n) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)      /* only used on wave-uniform values */
 #define SSDE_GLDS16_OFF_SAME_BASE(gptr, lds_wave_base, imm) SSDE_GLDS16_OFF(gptr, lds_wave_base, imm)

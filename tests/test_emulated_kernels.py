@@ -89,16 +89,16 @@ def test_unet_forward_winograd_f4x4_kernel(name, monkeypatch):
 
 
 def test_unet_forward_on_the_bf16_matrix_pipe(monkeypatch):
-    """GEMMs and every legal 3x3 layer (conv_wino4x.hip) through the 3-way bf16 split, emulated"""
+    """the 1x1 / NIN / Linear GEMMs through the 3-way bf16 split (SSDE_MATRIX=bf16x6 -> SSDE_CONVF_BF16X6), emulated"""
     monkeypatch.setenv("SSDE_MATRIX", "bf16x6")
-    monkeypatch.setenv("SSDE_WINO4X", "1")
     monkeypatch.setenv("SSDE_WINOGRAD", "4")
     test_unet_forward_matches_reference_golden("unet_small_ffhq")
 
 
 def test_unet_forward_winograd_f4x4_in_two_kernels(monkeypatch):
-    """every legal 3x3 layer as a transform pass + the matrix kernel of conv_wino4g.hip (SSDE_WINO4_TWO=2 forces what the
-    lowering takes from four cout tiles up), emulated"""
+    """every legal 3x3 layer as a transform pass + a matrix kernel (SSDE_WINO4_TWO=2 forces what the lowering otherwise takes by
+    its cout-tile rule): the register-fed kernel of conv_wino4r.hip (the product's), then round 4's LDS-fed kernel of
+    conv_wino4g.hip (SSDE_WINO4_FEED=lds), emulated"""
     from score_sde_pytorch_amd import engine as E, _lib as L
     monkeypatch.setenv("SSDE_WINOGRAD", "4")
     monkeypatch.setenv("SSDE_WINO4_TWO", "2")
@@ -110,7 +110,11 @@ def test_unet_forward_winograd_f4x4_in_two_kernels(monkeypatch):
         seen.append(self.b.specs[-1][1]["tile"])
     monkeypatch.setattr(E.Lowering, "conv", spy)
     test_unet_forward_matches_reference_golden("unet_small_ffhq")
-    assert seen.count(L.TILE_WINOGRAD4G) >= 8 and L.TILE_WINOGRAD4 not in seen
+    assert seen.count(L.TILE_WINOGRAD4R) >= 8 and L.TILE_WINOGRAD4 not in seen and L.TILE_WINOGRAD4G not in seen
+    del seen[:]
+    monkeypatch.setenv("SSDE_WINO4_FEED", "lds")
+    test_unet_forward_matches_reference_golden("unet_small_ffhq")
+    assert seen.count(L.TILE_WINOGRAD4G) >= 8 and L.TILE_WINOGRAD4 not in seen and L.TILE_WINOGRAD4R not in seen
 
 
 @pytest.mark.parametrize("name", list(CASES))

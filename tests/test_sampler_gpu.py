@@ -302,7 +302,7 @@ def test_long_trajectory_error_growth_f4x4(monkeypatch):
     from score_sde_pytorch_amd import _lib as L
     tiles = [eng.unet.program.ops[i].u.conv.tile for i in range(eng.unet.program.n)
              if eng.unet.program.ops[i].kind == L.OP_CONV and eng.unet.program.ops[i].u.conv.ksize == 3]
-    assert sum(t in (L.TILE_WINOGRAD4, L.TILE_WINOGRAD4X, L.TILE_WINOGRAD4G) for t in tiles) >= 40, tiles
+    assert sum(t in L.TILES_WINOGRAD4 for t in tiles) >= 40, tiles
     eng.unet.weights.refresh()
     eng.reset(x_T.cuda())
     prog = eng.step_program(with_rng=False)

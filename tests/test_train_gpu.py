@@ -93,6 +93,14 @@ def test_device_weight_repack(kind):
     T.check_device_repack("cuda", kind)
 
 
+def test_device_weight_repack_of_the_per_lane_f4x4_image(monkeypatch):
+    """every legal 3x3 layer on the two-kernel F(4x4,3x3) form: SSDE_PACK_WINO4R (conv_wino4r.hip's per-lane image), forward and
+    input-gradient variants, against engine.pack_wino4r_weight"""
+    monkeypatch.setenv("SSDE_WINOGRAD", "4")
+    monkeypatch.setenv("SSDE_WINO4_TWO", "2")
+    T.check_device_repack("cuda", "ffhq", need_kind=6)
+
+
 def test_op_package():
     T.check_op_package("cuda")
 
@@ -144,8 +152,8 @@ def test_weight_gradient_fed_by_the_forward_launch(monkeypatch):
     T.check_wino_v_from_forward("cuda", monkeypatch)
 
 
-def test_conv3x3_winograd_f4x4_on_the_bf16_matrix_pipe():
-    T.check_conv_winograd4("cuda", big=True, split=True)
+def test_conv3x3_winograd_f4x4_register_fed_matrix_kernel():
+    T.check_conv_winograd4("cuda", big=True, regs=True)
 
 
 def test_conv3x3_winograd_f4x4_in_two_kernels():

@@ -44,10 +44,9 @@ def test_forward_direct_kernel_and_size_heuristic(name, mode, monkeypatch):
 
 @pytest.mark.parametrize("name", ["unet_small_ncsnpp", "unet_small_ffhq", "unet_cifar_ncsnpp"])
 def test_forward_on_the_bf16_matrix_pipe(name, monkeypatch):
-    """SSDE_MATRIX=bf16x6 with SSDE_WINO4X=1: the 1x1 / NIN GEMMs AND every legal 3x3 layer (conv_wino4x.hip) as exact-fp32
-    products of a 3-way bf16 split on the BF16 matrix pipe -- against the reference goldens at the unchanged tolerances"""
+    """SSDE_MATRIX=bf16x6: the 1x1 / NIN / Linear GEMMs as exact-fp32 products of a 3-way bf16 split on the BF16 matrix pipe --
+    against the reference goldens at the unchanged tolerances"""
     monkeypatch.setenv("SSDE_MATRIX", "bf16x6")
-    monkeypatch.setenv("SSDE_WINO4X", "1")
     monkeypatch.setenv("SSDE_WINOGRAD", "4")
     test_forward_matches_reference_golden(name)
 

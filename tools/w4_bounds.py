@@ -14,13 +14,10 @@ if __name__ == "__main__":
     for cin, cout, h in [(128, 128, 32), (256, 128, 32), (256, 256, 16), (512, 256, 16), (384, 128, 32)]:
         tf, ms = cb.time_conv(n, cin, cout, h, L.TILE_WINOGRAD4, 1, reps=10)
         out.append("%d->%d@%d %.4f ms (%.0f TF/s)" % (cin, cout, h, ms, tf))
-        if os.environ.get("W4_BOUNDS_TWO"):                        # + the two-kernel form (conv_wino4g.hip): both kernels, the matrix kernel alone
-            tf, ms = cb.time_conv(n, cin, cout, h, L.TILE_WINOGRAD4G, 1, reps=10)
-            os.environ["SSDE_W4G_V_GIVEN"] = "1"
-            tf2, ms2 = cb.time_conv(n, cin, cout, h, L.TILE_WINOGRAD4G, 1, reps=10)
-            del os.environ["SSDE_W4G_V_GIVEN"]
-            out[-1] += " ; two kernels %.4f ms (%.0f TF/s) = transform pass %.4f + matrix kernel %.4f (%.0f TF/s)" % (ms, tf, ms - ms2, ms2, tf2)
-        if os.environ.get("W4_BOUNDS_SPLIT"):                      # + the bf16-split kernel (conv_wino4x.hip)
-            tf, ms = cb.time_conv(n, cin, cout, h, L.TILE_WINOGRAD4X, 1, reps=10)
-            out[-1] += " ; bf16 split %.4f ms (%.0f TF/s)" % (ms, tf)
+        if os.environ.get("W4_BOUNDS_TWO"):                        # + the two-kernel forms: both kernels, the matrix kernel alone
+            for label, tile in (("LDS-fed", L.TILE_WINOGRAD4G), ("register-fed", L.TILE_WINOGRAD4R)):
+                tf, ms = cb.time_conv(n, cin, cout, h, tile, 1, reps=10)
+                tf2, ms2 = cb.time_conv(n, cin, cout, h, tile, 1, reps=10, flags=L.CONVF_V_GIVEN)
+                out[-1] += " ; %s %.4f ms (%.0f TF/s) = transform pass %.4f + matrix kernel %.4f (%.0f TF/s)" % (label, ms, tf, ms - ms2, ms2, tf2)
+            out[-1] += "\n"
     print(os.path.basename(os.environ.get("SSDE_LIB_PATH", "product")), " | ".join(out), flush=True)
