@@ -346,7 +346,7 @@ def roofline_of(prog, E, L, reps=3):
     fl = np.array(prog.flops)
     tiles = np.array([int(prog.ops[i].u.conv.tile) if int(prog.ops[i].kind) == L.OP_CONV else -1 for i in range(prog.n)])
     wino4 = np.isin(tiles, L.TILES_WINOGRAD4)     # F(4x4,3x3): fused, two kernels (LDS- or register-fed matrix kernel)
-    wino4g = tiles == L.TILE_WINOGRAD4G
+    wino4g = tiles == L.TILE_WINOGRAD4R                 # two-kernel form: transform pass + register-fed matrix kernel
     wino = (tiles == L.TILE_WINOGRAD) | wino4
     executed = np.where(wino4, fl / WINOGRAD4_FLOP_RATIO, np.where(wino, fl / WINOGRAD_FLOP_RATIO, fl))
     nbytes = np.array([op_bytes(prog.ops[i]) for i in range(prog.n)])
@@ -738,7 +738,7 @@ def main():
             "achieved_algorithmic": roof["achieved_alg"], "frac_algorithmic": roof["achieved_alg"] / PEAK_FP32_MFMA_TFLOPS,
             "traffic": traffic, "traffic_algorithmic": roof["alg_bytes_wino"], "mfma_busy_pmc": mfma_busy,
             "kernel": "the %d 3x3 convolution launches of one U-Net evaluation: %d on conv_wino4_kernel (Winograd F(4x4,3x3), fp32 MFMA), "
-                      "%d as wino4_xform_vq_kernel + conv_wino4g_kernel (F(4x4,3x3) in two kernels: layers of 256 couts and more), "
+                      "%d as wino4_xform_vq_kernel + conv_wino4r_kernel (F(4x4,3x3) in two kernels, the matrix kernel fed from registers: layers of 256 couts and more), "
                       "%d on conv_wino_kernel (F(2x2,3x3)), %d on conv_mfma_kernel (direct)"
                       % (n3, n3w4 - n3w4g, n3w4g, n3w - n3w4, n3 - n3w),
             "note": "achieved = EXECUTED matrix FLOPs (F(4x4,3x3) launches at 1/4, F(2x2,3x3) launches at 1/2.25 of their direct-form "

@@ -98,11 +98,11 @@ typedef struct ssde_conv_args {
                           * row) * W/4 + tile column, fp32; 36 * N*H*W/16 * (c0+c1) floats, < 4 GB) -- what the F(4x4,3x3)
                           * weight gradient of the same layer multiplies with
                           * (ssde_wgrad_args.v_pre); a by-product of the first 64-cout tile's staging.  NULL: not written.
-                          * SSDE_TILE_WINOGRAD4G: REQUIRED -- the same tensor in the same layout, written by the launch's
+                          * SSDE_TILE_WINOGRAD4R: REQUIRED -- the same tensor in the same layout, written by the launch's
                           * transform pass and read by its matrix kernel (and still good for v_pre afterwards). */
 } ssde_conv_args;
 
-enum { SSDE_CONVF_V_GIVEN = 1u,      /* SSDE_TILE_WINOGRAD4G / 4R: wino_v already holds B^T pro(main) B -- skip the transform pass */
+enum { SSDE_CONVF_V_GIVEN = 1u,      /* SSDE_TILE_WINOGRAD4R: wino_v already holds B^T pro(main) B -- skip the transform pass */
        SSDE_CONVF_BF16X6 = 2u,       /* contractions that have a split kernel (1x1 / NIN / Linear GEMMs) run on the BF16 matrix pipe as
                                       * exact-fp32 products of a 3-way bf16 split, fp32 accumulation (conv1x1.hip) */
        SSDE_CONVF_NO_KSPLIT = 4u,    /* never split the reduction of a launch over several workgroups */
@@ -121,13 +121,15 @@ enum { SSDE_TILE_AUTO = 0, SSDE_TILE_256x64 = 1, SSDE_TILE_128x64 = 2, SSDE_TILE
        /* 7 was SSDE_TILE_WINOGRAD4X (F(4x4,3x3) on the BF16 matrix pipe through a 3-way bf16 split): parity-green but 6-24 % slower
         * than the fp32 kernel in both structures built; removed from the library in ABI 8, sources + logs under
         * tools/experiments/conv_wino4x/ */
-       /* F(4x4,3x3) in two kernels (conv_wino4g.hip): the input transform V = B^T pro(x) B as its own HBM-bound pass into
-        * ssde_conv_args.wino_v (REQUIRED here: 36 * N*H*W/16 * Cin floats), then a matrix kernel without prologue or transform;
-        * w_main packed as for SSDE_TILE_WINOGRAD4.  Pays where a V tile feeds four or more 64-cout tiles */
-       SSDE_TILE_WINOGRAD4G = 8,
-       /* the same two-kernel form with the matrix kernel fed from REGISTERS (conv_wino4r.hip, ABI 8): no LDS and no barrier in its
-        * main loop, every wave loads the V runs and its private weights straight into the MFMA operands.  wino_v REQUIRED as for
-        * SSDE_TILE_WINOGRAD4G; w_main packed per lane (SSDE_PACK_WINO4R):
+       /* 8 was SSDE_TILE_WINOGRAD4G (two-kernel F(4x4,3x3) whose matrix kernel took both operands through LDS by LDS-DMA,
+        * round 4): superseded by SSDE_TILE_WINOGRAD4R, which reproduces it bit for bit 7-14 % faster; removed in ABI 8,
+        * tools/experiments/conv_wino4g_lds_fed/ */
+       /* F(4x4,3x3) in two kernels: the input transform V = B^T pro(x) B as its own HBM-bound pass (wino4_xform.hip) into
+        * ssde_conv_args.wino_v (REQUIRED here: 36 * N*H*W/16 * Cin floats, Cin % 8 == 0), then a matrix kernel without prologue or
+        * transform that is fed from REGISTERS (conv_wino4r.hip, ABI 8): no LDS and no barrier in its main loop, every wave loads
+        * the V runs and its private weights straight into the MFMA operands, two stages ahead.  Pays where a V tile feeds four or
+        * more 64-cout tiles, and in training programs (V is what the weight gradient wants).  w_main packed per lane
+        * (SSDE_PACK_WINO4R):
         * [ceil(Cin/4)][ceil(Cout/64)][8 waves (q, h)][4 pieces x [64 lanes][4] | [64 lanes][2]] where lane (lh, li) of wave (q, h)
         * holds, of cout 32 h + li and channels 2 lh, 2 lh + 1, the positions q + 4 (2 i), q + 4 (2 i + 1) in piece i and q + 32 last */
        SSDE_TILE_WINOGRAD4R = 9 };
@@ -319,7 +321,32 @@ typedef struct ssde_colsum_args {
   float* total;            /* [c]: scale * sum_{n,hw} g  or NULL */
   float* total2;           /* optional second destination of the same sums (Conv_1.bias and Conv_2.bias share one) */
   float* scratch;          /* N * (min(32, max(1, hw/64)) + 1) * c floats (pixel-slice partials + per-sample sums) */
+  uint32_t flags;          /* SSDE_COLSUMF_DEFER (ABI 8): run only the pass over g -- pixel-slice partials [N][slices][c] into scratch,
+                            * slices = min(32, max(1, hw/64)); per_sample / total / total2 are written by a later ssde_colsum_finish
+                            * that lists this call among its jobs (one launch finishes up to SSDE_FINISH_JOBS column sums) */
+  int32_t _pad0;
 } ssde_colsum_args;
+enum { SSDE_COLSUMF_DEFER = 1u };
+
+/* ---- batched finishing launches (ABI 8) ------------------------------------------------------
+ * A training step has ~100 column sums and ~95 GroupNorm backward passes; each ended in one or two launches of 5-8 us that
+ * reduce a few thousand floats (690 launches under 13 us = 8 % of the round-4 step).  The producers now leave their partials
+ * behind (SSDE_COLSUMF_DEFER, SSDE_GNBWDF_DEFER_PARAMS) and ONE launch finishes up to SSDE_FINISH_JOBS of them, in the same
+ * fixed summation order as the per-call kernels (bit-identical results). */
+#define SSDE_FINISH_JOBS 16
+typedef struct ssde_colsum_job {
+  const float* part;       /* [n][slices][c] pixel-slice partials a deferred ssde_colsum left in its scratch */
+  float* per_sample;       /* [n, ps_ld] (+ ps_off) or NULL */
+  float* total; float* total2;   /* [c] or NULL */
+  int32_t n, slices, c, ps_ld, ps_off, _pad0;
+} ssde_colsum_job;
+typedef struct ssde_colsum_finish_args { int32_t count, _pad0; ssde_colsum_job job[SSDE_FINISH_JOBS]; } ssde_colsum_finish_args;
+typedef struct ssde_gn_bwd_job {
+  const float* scratch;    /* [rows][c][2]: per-(sample, slice) sums of du xhat and du a deferred ssde_gn_bwd_reduce left behind */
+  float* dgamma; float* dbeta;   /* [c] written */
+  int32_t rows, c;
+} ssde_gn_bwd_job;
+typedef struct ssde_gn_bwd_finish_args { int32_t count, _pad0; ssde_gn_bwd_job job[SSDE_FINISH_JOBS]; } ssde_gn_bwd_finish_args;
 
 /* ---- backward through a prologue: dx = d pro(x) / dx applied to dp ------------------------ *
  * GroupNorm backward (nn.GroupNorm autograd): with u = xhat*gamma+beta, y = silu(u) [* dropout mask],
@@ -347,7 +374,9 @@ typedef struct ssde_gn_bwd_reduce_args {
   float scale; int32_t _pad1;
 } ssde_gn_bwd_reduce_args;
 
-enum { SSDE_GNBWDF_THREE_KERNELS = 1u };   /* ssde_gn_bwd_reduce with g0 / g1: always reduce + finalize + apply, never the one-pass kernel */
+enum { SSDE_GNBWDF_THREE_KERNELS = 1u,     /* ssde_gn_bwd_reduce with g0 / g1: always reduce + finalize + apply, never the one-pass kernel */
+       SSDE_GNBWDF_DEFER_PARAMS = 2u };    /* dgamma / dbeta are NOT written: the per-(sample, slice) channel sums stay in scratch
+                                            * ([n * slices][c][2]; slices = 1 on the one-pass path) for a later ssde_gn_bwd_finish */
 
 typedef struct ssde_prologue_bwd_args {
   ssde_src src;            /* forward source (p0/p1 may be NULL for SSDE_PRO_NONE) */
@@ -487,6 +516,11 @@ int ssde_conv_wgrad(const ssde_wgrad_args* a, void* stream);
  * may usefully fill ssde_conv_args.wino_v for it; shape-only query (pointers are not dereferenced) */
 int ssde_wgrad_wants_winograd4(const ssde_wgrad_args* a);
 int ssde_colsum(const ssde_colsum_args* a, void* stream);
+int ssde_colsum_finish(const ssde_colsum_finish_args* a, void* stream);
+int ssde_gn_bwd_finish(const ssde_gn_bwd_finish_args* a, void* stream);
+/* rows of the scratch a deferred ssde_gn_bwd_reduce (SSDE_GNBWDF_DEFER_PARAMS) leaves behind: n on the one-pass path, n * slices
+ * on the three-kernel path -- what ssde_gn_bwd_job.rows must be (shape-only query) */
+int ssde_gn_bwd_scratch_rows(const ssde_gn_bwd_reduce_args* a);
 int ssde_gn_bwd_reduce(const ssde_gn_bwd_reduce_args* a, void* stream);
 int ssde_prologue_bwd(const ssde_prologue_bwd_args* a, void* stream);
 int ssde_attention_bwd(const ssde_attn_bwd_args* a, void* stream);
@@ -509,7 +543,7 @@ enum {
   SSDE_OP_WGRAD = 15, SSDE_OP_COLSUM = 16, SSDE_OP_GN_BWD_REDUCE = 17, SSDE_OP_PROLOGUE_BWD = 18,
   SSDE_OP_ATTN_BWD = 19, SSDE_OP_PERTURB = 20, SSDE_OP_DSM_LOSS = 21, SSDE_OP_SUMSQ_FLAT = 22,
   SSDE_OP_ADAM = 23, SSDE_OP_MEMSET = 24, SSDE_OP_AXPY = 25, SSDE_OP_PACK = 26, SSDE_OP_PROJECT = 27,
-  SSDE_OP_GN_FINALIZE = 28, SSDE_OP_PF_DRIFT = 29, SSDE_OP_HUTCH_DIV = 30
+  SSDE_OP_GN_FINALIZE = 28, SSDE_OP_PF_DRIFT = 29, SSDE_OP_HUTCH_DIV = 30, SSDE_OP_COLSUM_FINISH = 31, SSDE_OP_GN_BWD_FINISH = 32
 };
 typedef struct ssde_op {
   int32_t kind; int32_t flops_class;   /* flops_class: free tag echoed by timing */
@@ -524,6 +558,7 @@ typedef struct ssde_op {
     ssde_sumsq_flat_args sumsq_flat; ssde_adam_args adam; ssde_memset_args memset; ssde_axpy_args axpy;
     ssde_pack_args pack; ssde_project_args project; ssde_gn_finalize_args gn_fin;
     ssde_pf_drift_args pf_drift; ssde_hutch_div_args hutch_div;
+    ssde_colsum_finish_args colsum_fin; ssde_gn_bwd_finish_args gn_bwd_fin;
   } u;
 } ssde_op;
 

@@ -14,17 +14,19 @@ ABI_VERSION = 8
 
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_SILU = 0, 1, 2, 3
 TILE_AUTO, TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32, TILE_WINOGRAD, TILE_WINOGRAD4 = 0, 1, 2, 3, 4, 5, 6
-TILE_WINOGRAD4G, TILE_WINOGRAD4R = 8, 9            # (7 was the bf16-split F(4x4,3x3) kernel: tools/experiments/conv_wino4x/)
-TILES_WINOGRAD4 = (TILE_WINOGRAD4, TILE_WINOGRAD4G, TILE_WINOGRAD4R)
+TILE_WINOGRAD4R = 9       # (7, 8: the bf16-split and the LDS-fed F(4x4,3x3) kernels of round 4, tools/experiments/)
+TILES_WINOGRAD4 = (TILE_WINOGRAD4, TILE_WINOGRAD4R)
 # routing switches of a launch (include/ssde.h: SSDE_CONVF_*, SSDE_WGRADF_*, SSDE_GNBWDF_*)
 CONVF_V_GIVEN, CONVF_BF16X6, CONVF_NO_KSPLIT, CONVF_BKC8, CONVF_GEMM_PIPE, CONVF_NO_GEMM_PIPE, CONVF_X6_BM64, CONVF_X6_PF2 = \
     1, 2, 4, 8, 16, 32, 64, 128
 WGRADF_DIRECT, WGRADF_F2, WGRADF_F4_FORCE, WGRADF_NO_STREAMK, WGRADF_NO_XCD_ORDER, WGRADF_1X1_CHUNKED, WGRADF_XVEC1 = 1, 2, 4, 8, 16, 32, 64
-GNBWDF_THREE_KERNELS = 1
+GNBWDF_THREE_KERNELS, GNBWDF_DEFER_PARAMS = 1, 2
 (OP_CONV, OP_GN_STATS, OP_UPFIRDN, OP_ATTN, OP_EMBED, OP_TO_NHWC, OP_TO_NCHW, OP_BIAS_ACT, OP_SUMSQ,
  OP_RANDN, OP_LANGEVIN, OP_PREDICTOR, OP_FILL, OP_STEP_INC, OP_WGRAD, OP_COLSUM, OP_GN_BWD_REDUCE, OP_PROLOGUE_BWD,
  OP_ATTN_BWD, OP_PERTURB, OP_DSM_LOSS, OP_SUMSQ_FLAT, OP_ADAM, OP_MEMSET, OP_AXPY, OP_PACK, OP_PROJECT,
- OP_GN_FINALIZE, OP_PF_DRIFT, OP_HUTCH_DIV) = range(1, 31)
+ OP_GN_FINALIZE, OP_PF_DRIFT, OP_HUTCH_DIV, OP_COLSUM_FINISH, OP_GN_BWD_FINISH) = range(1, 33)
+FINISH_JOBS = 16
+COLSUMF_DEFER = 1
 PACK_CONV3, PACK_WINO3, PACK_MATRIX, PACK_VECTOR, PACK_WINO4, PACK_WINO4R = 1, 2, 3, 4, 5, 6
 
 _fp = C.c_void_p  # device pointers are passed as integers
@@ -165,7 +167,24 @@ class WgradArgs(C.Structure):
 class ColsumArgs(C.Structure):
     _fields_ = [("g", _fp), ("g_ld", C.c_int32), ("g_off", C.c_int32), ("n", C.c_int32), ("hw", C.c_int32),
                 ("c", C.c_int32), ("scale", C.c_float), ("per_sample", _fp), ("ps_ld", C.c_int32), ("ps_off", C.c_int32),
-                ("total", _fp), ("total2", _fp), ("scratch", _fp)]
+                ("total", _fp), ("total2", _fp), ("scratch", _fp), ("flags", C.c_uint32), ("_pad0", C.c_int32)]
+
+
+class ColsumJob(C.Structure):
+    _fields_ = [("part", _fp), ("per_sample", _fp), ("total", _fp), ("total2", _fp), ("n", C.c_int32), ("slices", C.c_int32),
+                ("c", C.c_int32), ("ps_ld", C.c_int32), ("ps_off", C.c_int32), ("_pad0", C.c_int32)]
+
+
+class ColsumFinishArgs(C.Structure):
+    _fields_ = [("count", C.c_int32), ("_pad0", C.c_int32), ("job", ColsumJob * FINISH_JOBS)]
+
+
+class GnBwdJob(C.Structure):
+    _fields_ = [("scratch", _fp), ("dgamma", _fp), ("dbeta", _fp), ("rows", C.c_int32), ("c", C.c_int32)]
+
+
+class GnBwdFinishArgs(C.Structure):
+    _fields_ = [("count", C.c_int32), ("_pad0", C.c_int32), ("job", GnBwdJob * FINISH_JOBS)]
 
 
 class GnBwdReduceArgs(C.Structure):
@@ -230,7 +249,7 @@ class _OpUnion(C.Union):
                 ("attn_bwd", AttnBwdArgs), ("perturb", PerturbArgs), ("dsm_loss", DsmLossArgs),
                 ("sumsq_flat", SumsqFlatArgs), ("adam", AdamArgs), ("memset", MemsetArgs), ("axpy", AxpyArgs),
                 ("pack", PackArgs), ("project", ProjectArgs), ("gn_fin", GnFinalizeArgs),
-                ("pf_drift", PfDriftArgs), ("hutch_div", HutchDivArgs)]
+                ("pf_drift", PfDriftArgs), ("hutch_div", HutchDivArgs), ("colsum_fin", ColsumFinishArgs), ("gn_bwd_fin", GnBwdFinishArgs)]
 
 
 class Op(C.Structure):
@@ -243,7 +262,8 @@ _UNION_FIELD = {OP_CONV: "conv", OP_GN_STATS: "gn", OP_UPFIRDN: "fir", OP_ATTN: 
                 OP_STEP_INC: "step_inc", OP_WGRAD: "wgrad", OP_COLSUM: "colsum", OP_GN_BWD_REDUCE: "gn_bwd",
                 OP_PROLOGUE_BWD: "pro_bwd", OP_ATTN_BWD: "attn_bwd", OP_PERTURB: "perturb", OP_DSM_LOSS: "dsm_loss",
                 OP_SUMSQ_FLAT: "sumsq_flat", OP_ADAM: "adam", OP_MEMSET: "memset", OP_AXPY: "axpy", OP_PACK: "pack", OP_PROJECT: "project",
-                OP_GN_FINALIZE: "gn_fin", OP_PF_DRIFT: "pf_drift", OP_HUTCH_DIV: "hutch_div"}
+                OP_GN_FINALIZE: "gn_fin", OP_PF_DRIFT: "pf_drift", OP_HUTCH_DIV: "hutch_div", OP_COLSUM_FINISH: "colsum_fin",
+                OP_GN_BWD_FINISH: "gn_bwd_fin"}
 
 EXPORTS = ["ssde_conv2d", "ssde_groupnorm_stats", "ssde_upfirdn2d", "ssde_attention", "ssde_embed", "ssde_to_nhwc",
            "ssde_to_nchw", "ssde_fused_bias_act", "ssde_sumsq", "ssde_randn", "ssde_langevin_update",
@@ -252,7 +272,7 @@ EXPORTS = ["ssde_conv2d", "ssde_groupnorm_stats", "ssde_upfirdn2d", "ssde_attent
            "ssde_abi_version", "ssde_sizeof_op", "ssde_last_error", "ssde_conv_lds_bytes",
            "ssde_conv_wgrad", "ssde_colsum", "ssde_gn_bwd_reduce", "ssde_prologue_bwd", "ssde_attention_bwd",
            "ssde_perturb", "ssde_dsm_loss", "ssde_sumsq_flat", "ssde_adam_clip_ema", "ssde_memset", "ssde_axpy",
-           "ssde_wgrad_scratch_floats", "ssde_wgrad_wants_winograd4", "ssde_pack_weights", "ssde_project_update", "ssde_gn_finalize", "ssde_conv_gn_slices", "ssde_rk_combine", "ssde_rk_error_norm", "ssde_pf_drift", "ssde_hutch_div", "ssde_sample_update", "ssde_mfma_probe",
+           "ssde_wgrad_scratch_floats", "ssde_wgrad_wants_winograd4", "ssde_pack_weights", "ssde_project_update", "ssde_gn_finalize", "ssde_conv_gn_slices", "ssde_rk_combine", "ssde_rk_error_norm", "ssde_pf_drift", "ssde_hutch_div", "ssde_sample_update", "ssde_mfma_probe", "ssde_colsum_finish", "ssde_gn_bwd_finish", "ssde_gn_bwd_scratch_rows",
            # plan-level entry points (csrc/plan.hip; argument types: plan_export.bind)
            "ssde_plan_load", "ssde_plan_load_file", "ssde_plan_destroy", "ssde_plan_info", "ssde_plan_param",
            "ssde_plan_refresh_weights", "ssde_unet_forward", "ssde_pc_reset", "ssde_pc_run", "ssde_pc_state",
@@ -331,13 +351,15 @@ def bind(lib):
                       ("ssde_sumsq_flat", SumsqFlatArgs), ("ssde_adam_clip_ema", AdamArgs), ("ssde_memset", MemsetArgs),
                       ("ssde_axpy", AxpyArgs), ("ssde_pack_weights", PackArgs), ("ssde_project_update", ProjectArgs),
                       ("ssde_gn_finalize", GnFinalizeArgs), ("ssde_rk_combine", RkCombineArgs), ("ssde_hutch_div", HutchDivArgs), ("ssde_sample_update", SampleUpdateArgs),
-                      ("ssde_rk_error_norm", RkErrorArgs), ("ssde_pf_drift", PfDriftArgs)]:
+                      ("ssde_rk_error_norm", RkErrorArgs), ("ssde_pf_drift", PfDriftArgs),
+                      ("ssde_colsum_finish", ColsumFinishArgs), ("ssde_gn_bwd_finish", GnBwdFinishArgs)]:
         getattr(lib, name).argtypes = [C.POINTER(typ), C.c_void_p]
     lib.ssde_conv_lds_bytes.argtypes = [C.POINTER(ConvArgs)]
     lib.ssde_conv_gn_slices.argtypes = [C.POINTER(ConvArgs)]
     lib.ssde_wgrad_scratch_floats.argtypes = [C.POINTER(WgradArgs)]
     lib.ssde_wgrad_scratch_floats.restype = C.c_int64
     lib.ssde_wgrad_wants_winograd4.argtypes = [C.POINTER(WgradArgs)]
+    lib.ssde_gn_bwd_scratch_rows.argtypes = [C.POINTER(GnBwdReduceArgs)]
     if lib.ssde_abi_version() != ABI_VERSION:
         raise SsdeError("ABI mismatch: library %d, binding %d" % (lib.ssde_abi_version(), ABI_VERSION))
     if lib.ssde_sizeof_op() != C.sizeof(Op):
@@ -363,6 +385,21 @@ def check(rc, what=""):
     if rc != 0:
         msg = load().ssde_last_error()
         raise SsdeError("%s failed (%d): %s" % (what or "libssde_hip call", rc, msg.decode() if msg else "?"))
+
+
+def pointer_offsets(struct_cls, base=0):
+    """Byte offsets of every pointer field of a ctypes structure: nested structures and arrays of structures included."""
+    out = []
+    for name, typ in struct_cls._fields_:
+        off = base + getattr(struct_cls, name).offset
+        if typ is C.c_void_p:
+            out.append(off)
+        elif isinstance(typ, type) and issubclass(typ, C.Structure):
+            out.extend(pointer_offsets(typ, off))
+        elif isinstance(typ, type) and issubclass(typ, C.Array) and issubclass(typ._type_, C.Structure):
+            for i in range(typ._length_):
+                out.extend(pointer_offsets(typ._type_, off + i * C.sizeof(typ._type_)))
+    return out
 
 
 def make_op(kind, args, flops_class=0):

@@ -161,6 +161,13 @@ class TrainEngine(E.UNetEngine):
         self.gout = self.b.buf(batch, self.channels, height, width, name="gout", persistent=True)
         self.gx = self.b.buf(batch, self.channels, height, width, name="gx", persistent=True) if input_grad else None
         self._G = {}
+        # the small second stages of column sums and GroupNorm backward passes (~200 launches of 5-8 us per step) are deferred
+        # and finished up to L.FINISH_JOBS at a time by one launch (ssde_colsum_finish / ssde_gn_bwd_finish); SSDE_DEFER_FINISH=0
+        # keeps the per-call launches (A/B runs, tests of both forms)
+        import os
+        self.defer_finish = os.environ.get("SSDE_DEFER_FINISH", "1") != "0"
+        self._jobs = {L.OP_COLSUM_FINISH: [], L.OP_GN_BWD_FINISH: []}
+        self._pending_per = set()
         self._lower_backward()
         self.program = self.b.finalize()
         self.n_fwd = self.program.spec_start[self.n_fwd]      # spec count -> op count
@@ -202,6 +209,34 @@ class TrainEngine(E.UNetEngine):
             h = handlers.get(kind)
             if h is not None:
                 h(f)
+        for kind in list(self._jobs):
+            self._flush_finish(kind)
+
+    # ------------------------------------------------------------------ deferred finishing launches
+    def _flush_finish(self, kind):
+        jobs = self._jobs[kind]
+        if jobs:
+            self.b.add(kind, dict(count=len(jobs), job=list(jobs)), FC_BWD)
+            del jobs[:]
+        if kind == L.OP_COLSUM_FINISH:
+            self._pending_per.clear()
+
+    def _defer(self, kind, job):
+        self._jobs[kind].append(job)
+        if len(self._jobs[kind]) == L.FINISH_JOBS:
+            self._flush_finish(kind)
+
+    def _colsum(self, fields):
+        """One column-sum call: its pass over g now, its reductions over slices and samples with the next finishing launch."""
+        if not self.defer_finish:
+            self.b.add(L.OP_COLSUM, fields, FC_BWD)
+            return
+        self.b.add(L.OP_COLSUM, dict(fields, per_sample=None, total=None, total2=None, flags=L.COLSUMF_DEFER), FC_BWD)
+        if fields["per_sample"] is not None:
+            self._pending_per.add(id(fields["per_sample"]))
+        self._defer(L.OP_COLSUM_FINISH, dict(part=fields["scratch"], per_sample=fields["per_sample"], total=fields["total"],
+                                             total2=fields["total2"], n=fields["n"], slices=max(1, min(32, fields["hw"] // 64)),
+                                             c=fields["c"], ps_ld=fields["ps_ld"], ps_off=fields["ps_off"]))
 
     def _bwd_to_nchw(self, f):
         e = self._gentry(f["src"])
@@ -242,14 +277,21 @@ class TrainEngine(E.UNetEngine):
             sums = b.buf(n, groups, 2, name="gn_bwd_sums")
             slices = max(1, min(int(math.ceil(256 / n)), hw // 64)) if hw >= 128 else 1
             scratch = b.buf(n * slices * ctot * 2, name="gn_bwd_scratch")
-            b.add(L.OP_GN_BWD_REDUCE, dict(src=src, dp=dP, n=n, hw=hw, sums=sums,
-                                           dgamma=self.flat.grad_view(self._param_of(src["gn_gamma"])) if self.param_grads
-                                           else b.buf(ctot, name="dgamma_unused"),
-                                           dbeta=self.flat.grad_view(self._param_of(src["gn_beta"])) if self.param_grads
-                                           else b.buf(ctot, name="dbeta_unused"),
-                                           scratch=scratch, slices=slices,
-                                           g0=e0[0] if e0 else None, g1=e1[0] if e1 else None,
-                                           acc0=int(e0[1]) if e0 else 0, acc1=int(e1[1]) if e1 else 0, scale=1.0), FC_BWD)
+            fields = dict(src=src, dp=dP, n=n, hw=hw, sums=sums,
+                          dgamma=self.flat.grad_view(self._param_of(src["gn_gamma"])) if self.param_grads else None,
+                          dbeta=self.flat.grad_view(self._param_of(src["gn_beta"])) if self.param_grads else None,
+                          scratch=scratch, slices=slices,
+                          g0=e0[0] if e0 else None, g1=e1[0] if e1 else None,
+                          acc0=int(e0[1]) if e0 else 0, acc1=int(e1[1]) if e1 else 0, scale=1.0, flags=L.gn_bwd_route_flags())
+            if self.defer_finish or not self.param_grads:
+                # dgamma / dbeta: with the next finishing launch -- or never, when no parameter gradient is wanted (likelihood.py)
+                dg, db = fields["dgamma"], fields["dbeta"]
+                fields.update(dgamma=None, dbeta=None, flags=fields["flags"] | L.GNBWDF_DEFER_PARAMS)
+                b.add(L.OP_GN_BWD_REDUCE, fields, FC_BWD)
+                if self.param_grads:
+                    self._defer(L.OP_GN_BWD_FINISH, dict(scratch=scratch, dgamma=dg, dbeta=db, rows=self._gn_bwd_rows(fields), c=ctot))
+            else:
+                b.add(L.OP_GN_BWD_REDUCE, fields, FC_BWD)
         else:
             if e0 is None and e1 is None:
                 return
@@ -261,6 +303,17 @@ class TrainEngine(E.UNetEngine):
         if e1:
             e1[1] = True
 
+    @staticmethod
+    def _gn_bwd_rows(fields):
+        """Rows of the channel sums a deferred GroupNorm backward call leaves in its scratch (shape-only query of the library)."""
+        a = L.GnBwdReduceArgs()
+        s = fields["src"]
+        a.src.c0, a.src.c1, a.src.pro_mode, a.src.gn_groups = s["c0"], s["c1"], s["pro_mode"], s["gn_groups"]
+        a.n, a.hw, a.slices, a.flags = fields["n"], fields["hw"], fields["slices"], fields["flags"]
+        a.g0 = 0x1000 if fields["g0"] is not None else None
+        a.g1 = 0x1000 if fields["g1"] is not None else None
+        return int(L.load().ssde_gn_bwd_scratch_rows(C.byref(a)))
+
     def _bwd_bias(self, f, g, g_ld, n, hw, scale):
         b = self.b
         if not self.param_grads:
@@ -268,9 +321,9 @@ class TrainEngine(E.UNetEngine):
                 tbuf, off = f["chan_add"]
                 e = self._gentry(tbuf)
                 e[1] = True
-                b.add(L.OP_COLSUM, dict(g=g, g_ld=g_ld, g_off=0, n=n, hw=hw, c=f["c_out"], scale=float(scale), per_sample=e[0],
+                self._colsum(dict(g=g, g_ld=g_ld, g_off=0, n=n, hw=hw, c=f["c_out"], scale=float(scale), per_sample=e[0],
                                         ps_ld=f["chan_add_ld"], ps_off=off, total=None, total2=None,
-                                        scratch=b.buf(n * (max(1, min(32, hw // 64)) + 1) * f["c_out"], name="colsum_scratch")), FC_BWD)
+                                        scratch=b.buf(n * (max(1, min(32, hw // 64)) + 1) * f["c_out"], name="colsum_scratch")))
             return
         per, ps_ld, ps_off = None, 0, 0
         if f["chan_add"] is not None:
@@ -286,29 +339,29 @@ class TrainEngine(E.UNetEngine):
             assert len(parts) == 2
             c = parts[0]["n"]
             scratch = b.buf(n * (max(1, min(32, hw // 64)) + 1) * c, name="colsum_scratch")
-            b.add(L.OP_COLSUM, dict(g=g, g_ld=g_ld, g_off=0, n=n, hw=hw, c=c, scale=float(scale), per_sample=per, ps_ld=ps_ld,
+            self._colsum(dict(g=g, g_ld=g_ld, g_off=0, n=n, hw=hw, c=c, scale=float(scale), per_sample=per, ps_ld=ps_ld,
                                     ps_off=ps_off, total=self.flat.grad_view(parts[0]["param"]),
-                                    total2=self.flat.grad_view(parts[1]["param"]), scratch=scratch), FC_BWD)
+                                    total2=self.flat.grad_view(parts[1]["param"]), scratch=scratch))
             return
         if not parts and per is not None:
-            b.add(L.OP_COLSUM, dict(g=g, g_ld=g_ld, g_off=0, n=n, hw=hw, c=f["c_out"], scale=float(scale), per_sample=per,
+            self._colsum(dict(g=g, g_ld=g_ld, g_off=0, n=n, hw=hw, c=f["c_out"], scale=float(scale), per_sample=per,
                                     ps_ld=ps_ld, ps_off=ps_off, total=None, total2=None,
-                                    scratch=b.buf(n * (max(1, min(32, hw // 64)) + 1) * f["c_out"], name="colsum_scratch")), FC_BWD)
+                                    scratch=b.buf(n * (max(1, min(32, hw // 64)) + 1) * f["c_out"], name="colsum_scratch")))
             return
         if len(parts) > 1 and per is None and self.flat.contiguous([pt["param"] for pt in parts]):
             # concatenated biases stored back to back (Dense_0 of every block): one launch for all of them
             c = sum(pt["n"] for pt in parts)
-            b.add(L.OP_COLSUM, dict(g=g, g_ld=g_ld, g_off=parts[0]["off"], n=n, hw=hw, c=c, scale=float(scale), per_sample=None,
+            self._colsum(dict(g=g, g_ld=g_ld, g_off=parts[0]["off"], n=n, hw=hw, c=c, scale=float(scale), per_sample=None,
                                     ps_ld=0, ps_off=0, total=self.flat.grad_run([pt["param"] for pt in parts]), total2=None,
-                                    scratch=b.buf(n * (max(1, min(32, hw // 64)) + 1) * c, name="colsum_scratch")), FC_BWD)
+                                    scratch=b.buf(n * (max(1, min(32, hw // 64)) + 1) * c, name="colsum_scratch")))
             return
         for i, part in enumerate(parts):
             use_per = per if (i == 0 and len(parts) == 1) else None
             assert per is None or len(parts) == 1
             scratch = b.buf(n * (max(1, min(32, hw // 64)) + 1) * part["n"], name="colsum_scratch")
-            b.add(L.OP_COLSUM, dict(g=g, g_ld=g_ld, g_off=part["off"], n=n, hw=hw, c=part["n"], scale=float(scale),
+            self._colsum(dict(g=g, g_ld=g_ld, g_off=part["off"], n=n, hw=hw, c=part["n"], scale=float(scale),
                                     per_sample=use_per, ps_ld=ps_ld, ps_off=ps_off,
-                                    total=self.flat.grad_view(part["param"]), total2=None, scratch=scratch), FC_BWD)
+                                    total=self.flat.grad_view(part["param"]), total2=None, scratch=scratch))
 
     def _bwd_branch(self, f, src, wpacked, g, g_ld, scale, ksize):
         b, low, n = self.b, self.low, f["n"]
@@ -387,6 +440,8 @@ class TrainEngine(E.UNetEngine):
         if e is None:
             return
         g, scale, n = e[0], f["out_scale"], f["n"]
+        if id(g) in self._pending_per:               # this gradient still waits for deferred per-sample column sums
+            self._flush_finish(L.OP_COLSUM_FINISH)
         hw, g_ld = f["h_out"] * f["w_out"], f["dst"].shape[-1]
         if f["resid"] is not None:
             self._accum(f["resid"], g, g_ld, 0, g_ld, n, hw, scale)
@@ -460,11 +515,10 @@ class TrainEngine(E.UNetEngine):
         base, end = self.flat.grad.data_ptr(), self.flat.grad.data_ptr() + self.flat.numel * 4
 
         def pointers(struct):
-            for name, typ in struct._fields_:
-                v = getattr(struct, name)
-                if isinstance(v, C.Structure):
-                    yield from pointers(v)
-                elif typ is C.c_void_p and v:
+            raw = bytes(struct)
+            for off in L.pointer_offsets(type(struct)):
+                v = int.from_bytes(raw[off:off + 8], "little")
+                if v:
                     yield v
         touch = []                                   # (float offset, op index) of every reference into flat.grad
         for i in range(self.n_fwd, self.program.n):

@@ -83,6 +83,61 @@ __global__ __launch_bounds__(256) void colsum_total_kernel(const float* __restri
   }
 }
 
+// ---- finishing launches for up to SSDE_FINISH_JOBS deferred calls at once (job = blockIdx.y) -----------------------------
+// colsum: what colsum_slices_kernel + colsum_total_kernel do for one call, in the same order -- per[n] = the slices of sample n
+// in order, total = the samples i = lane, lane + 8, ... per lane, the 8 lanes in order -- so the results are bit-identical.
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const ssde_colsum_finish_args a) {
+  SSDE_LDS(smem);                                        // [8][32]
+  const ssde_colsum_job& j = a.job[blockIdx.y];
+  if ((int)blockIdx.x * 32 >= j.c) return;               // (uniform per block: the grid is as wide as the widest job)
+  const int jl = threadIdx.x & 31, nl = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + jl;
+  float s = 0.f;
+  if (col < j.c)
+    for (int i = nl; i < j.n; i += 8) {
+      const float* p = j.part + (size_t)i * j.slices * j.c + col;
+      float t = 0.f;
+      for (int sl = 0; sl < j.slices; ++sl) t += p[(size_t)sl * j.c];
+      if (j.per_sample) j.per_sample[(size_t)i * j.ps_ld + j.ps_off + col] = t;
+      s += t;
+    }
+  if (!j.total) return;
+  smem[nl * 32 + jl] = s;
+  __syncthreads();
+  if (nl == 0 && col < j.c) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += smem[k * 32 + jl];
+    j.total[col] = t;
+    if (j.total2) j.total2[col] = t;
+  }
+}
+
+// GroupNorm backward: the dgamma / dbeta role of gn_bwd_finalize_kernel (same order)
+__global__ __launch_bounds__(256) void gn_bwd_finish_kernel(const ssde_gn_bwd_finish_args a) {
+  SSDE_LDS(smem);                                        // [2][8][32]
+  const ssde_gn_bwd_job& j = a.job[blockIdx.y];
+  if ((int)blockIdx.x * 32 >= j.c) return;
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float dg = 0.f, db = 0.f;
+  if (c < j.c)
+    for (int r = rl; r < j.rows; r += 8) {
+      const float2 o = *reinterpret_cast<const float2*>(j.scratch + ((size_t)r * j.c + c) * 2);
+      dg += o.x; db += o.y;
+    }
+  smem[rl * 32 + cl] = dg;
+  smem[256 + rl * 32 + cl] = db;
+  __syncthreads();
+  if (rl == 0 && c < j.c) {
+    float tg = 0.f, tb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { tg += smem[k * 32 + cl]; tb += smem[256 + k * 32 + cl]; }
+    j.dgamma[c] = tg;
+    j.dbeta[c] = tb;
+  }
+}
+
 // ---- GroupNorm backward: reduction -----------------------------------------------------------------
 constexpr int kGbThreads = 1024;
 
@@ -546,14 +601,21 @@ int src_ok(const ssde_src& s, const char* who, bool need_x) {
 extern "C" int ssde_colsum(const ssde_colsum_args* a, void* stream) {
   SSDE_REQUIRE(a && a->g && a->n > 0 && a->hw > 0 && a->c > 0, "colsum: bad args");
   SSDE_REQUIRE(a->g_ld % 4 == 0 && a->g_off % 4 == 0, "colsum: g columns must be 16-byte aligned");
-  SSDE_REQUIRE(a->per_sample || a->total, "colsum: nothing to compute");
+  const bool defer = (a->flags & SSDE_COLSUMF_DEFER) != 0;
+  SSDE_REQUIRE(defer || a->per_sample || a->total, "colsum: nothing to compute");
   hipStream_t st = static_cast<hipStream_t>(stream);
   // pixel slices: >= 64 pixels per block, at most 32 slices; scratch holds [N*slices][c] partials (+ [N][c] when
   // no per_sample destination exists)
   int slices = a->hw / 64;
   if (slices > 32) slices = 32;
   if (slices < 1) slices = 1;
-  SSDE_REQUIRE((slices == 1 && a->per_sample) || a->scratch, "colsum: scratch of N*(slices+1)*c floats needed (slices=%d)", slices);
+  SSDE_REQUIRE((slices == 1 && a->per_sample && !defer) || a->scratch, "colsum: scratch of N*(slices+1)*c floats needed (slices=%d)", slices);
+  if (defer) {                                 // only the pass over g: [N][slices][c] partials for a later ssde_colsum_finish
+    hipLaunchKernelGGL(colsum_kernel, dim3(ssde_cdiv(ssde_cdiv(a->c, 4), 64), slices, a->n), dim3(256), 4 * 64 * 16, st,
+                       a->g, a->g_ld, a->g_off, a->hw, a->c, a->scale, a->scratch, a->c, 0);
+    SSDE_LAUNCH_CHECK();
+    return SSDE_OK;
+  }
   float* per = a->per_sample ? a->per_sample : a->scratch + (size_t)a->n * slices * a->c;
   const int ld = a->per_sample ? a->ps_ld : a->c, off = a->per_sample ? a->ps_off : 0;
   const int cl = ssde_cdiv(a->c, 4);
@@ -572,6 +634,33 @@ extern "C" int ssde_colsum(const ssde_colsum_args* a, void* stream) {
     hipLaunchKernelGGL(colsum_total_kernel, dim3(ssde_cdiv(a->c, 32)), dim3(256), 8 * 32 * 4, st, per, ld, off, a->n, a->c, a->total, a->total2);
     SSDE_LAUNCH_CHECK();
   }
+  return SSDE_OK;
+}
+
+extern "C" int ssde_colsum_finish(const ssde_colsum_finish_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->count > 0 && a->count <= SSDE_FINISH_JOBS, "colsum_finish: bad job count");
+  int cmax = 0;
+  for (int i = 0; i < a->count; ++i) {
+    const ssde_colsum_job& j = a->job[i];
+    SSDE_REQUIRE(j.part && (j.per_sample || j.total) && j.n > 0 && j.slices > 0 && j.c > 0, "colsum_finish: job %d is incomplete", i);
+    SSDE_REQUIRE(!j.total2 || j.total, "colsum_finish: job %d has total2 without total", i);
+    if (j.c > cmax) cmax = j.c;
+  }
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(ssde_cdiv(cmax, 32), a->count), dim3(256), 8 * 32 * 4, static_cast<hipStream_t>(stream), *a);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}
+
+extern "C" int ssde_gn_bwd_finish(const ssde_gn_bwd_finish_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->count > 0 && a->count <= SSDE_FINISH_JOBS, "gn_bwd_finish: bad job count");
+  int cmax = 0;
+  for (int i = 0; i < a->count; ++i) {
+    const ssde_gn_bwd_job& j = a->job[i];
+    SSDE_REQUIRE(j.scratch && j.dgamma && j.dbeta && j.rows > 0 && j.c > 0, "gn_bwd_finish: job %d is incomplete", i);
+    if (j.c > cmax) cmax = j.c;
+  }
+  hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3(ssde_cdiv(cmax, 32), a->count), dim3(256), 2 * 8 * 32 * 4, static_cast<hipStream_t>(stream), *a);
+  SSDE_LAUNCH_CHECK();
   return SSDE_OK;
 }
 
@@ -595,8 +684,22 @@ static bool gn_bwd_fused_shape(int kGfThreads, int n, int hw, int C, int G, int*
   return true;
 }
 
+// does this call take the one-pass kernel?  (shape and flags only)
+static bool gn_bwd_one_pass(const ssde_gn_bwd_reduce_args* a, int* gpc, int* clc, int* pl) {
+  const int C = a->src.c0 + a->src.c1;
+  return (a->g0 || a->g1) && !(a->flags & SSDE_GNBWDF_THREE_KERNELS) && (size_t)a->n * a->hw < (1ull << 31) && a->src.gn_groups > 0 &&
+         gn_bwd_fused_shape(1024, a->n, a->hw, C, a->src.gn_groups, gpc, clc, pl);
+}
+
+extern "C" int ssde_gn_bwd_scratch_rows(const ssde_gn_bwd_reduce_args* a) {
+  if (!a) return 0;
+  int gpc, clc, pl;
+  return gn_bwd_one_pass(a, &gpc, &clc, &pl) ? a->n : a->n * (a->slices > 0 ? a->slices : 1);
+}
+
 extern "C" int ssde_gn_bwd_reduce(const ssde_gn_bwd_reduce_args* a, void* stream) {
-  SSDE_REQUIRE(a && a->dp && a->dgamma && a->dbeta && a->scratch, "gn_bwd_reduce: null args");
+  const bool defer = a && (a->flags & SSDE_GNBWDF_DEFER_PARAMS);
+  SSDE_REQUIRE(a && a->dp && (defer || (a->dgamma && a->dbeta)) && a->scratch, "gn_bwd_reduce: null args");
   const bool apply = a->g0 || a->g1;
   SSDE_REQUIRE(apply || a->sums, "gn_bwd_reduce: neither sums nor gradient destinations");
   if (int rc = src_ok(a->src, "gn_bwd_reduce", true)) return rc;
@@ -615,14 +718,14 @@ extern "C" int ssde_gn_bwd_reduce(const ssde_gn_bwd_reduce_args* a, void* stream
     // a workgroup's rows shrink to 64-byte runs of 4 channel quads)
     constexpr int nt = 1024;
     int gpc = 0, clc = 0, pl = 0;
-    if (!(a->flags & SSDE_GNBWDF_THREE_KERNELS) && (size_t)a->n * a->hw < (1ull << 31) &&
-        gn_bwd_fused_shape(nt, a->n, a->hw, C, a->src.gn_groups, &gpc, &clc, &pl)) {
+    if (gn_bwd_one_pass(a, &gpc, &clc, &pl)) {
       GfParams f{p, a->acc0, a->acc1, a->g0, a->g1, a->scale, gpc, clc, pl};
       f.b.slices = 1;                                   // scratch[n][C][2]
       const dim3 grid(ssde_cdiv(a->src.gn_groups, gpc), a->n);
       const size_t lds = (size_t)(nt * 8 + kGfNxt + 2 * kGfMaxClc) * sizeof(float);
       hipLaunchKernelGGL(gn_bwd_fused_kernel<nt>, grid, dim3(nt), lds, st, f);
       SSDE_LAUNCH_CHECK();
+      if (defer) return SSDE_OK;                        // dgamma / dbeta: a later ssde_gn_bwd_finish sums scratch[n][C][2]
       // dgamma / dbeta: role B of the finalize kernel only (grid.y == 1 with the role offset)
       hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(bx_b, 1), dim3(256), 2 * 8 * 32 * 4, st, f.b, 1);
       SSDE_LAUNCH_CHECK();
@@ -632,7 +735,8 @@ extern "C" int ssde_gn_bwd_reduce(const ssde_gn_bwd_reduce_args* a, void* stream
   }
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(slices, a->n), dim3(kGbThreads), kGbThreads * 8 * 4, st, p);
   SSDE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(bx_a > bx_b ? bx_a : bx_b, 2), dim3(256), 2 * 8 * 32 * 4, st, p, 0);
+  if (defer) hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(bx_a, 1), dim3(256), 2 * 8 * 32 * 4, st, p, 0);      // the group sums only
+  else hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(bx_a > bx_b ? bx_a : bx_b, 2), dim3(256), 2 * 8 * 32 * 4, st, p, 0);
   SSDE_LAUNCH_CHECK();
   if (apply) {
     ssde_prologue_bwd_args q{};

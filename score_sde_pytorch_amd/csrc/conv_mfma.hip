@@ -564,7 +564,6 @@ static ssde_wino_launcher wino_launcher(int tile) {
   switch (tile) {
     case SSDE_TILE_WINOGRAD: return ssde_conv_wino_launch;
     case SSDE_TILE_WINOGRAD4: return ssde_conv_wino4_launch;
-    case SSDE_TILE_WINOGRAD4G: return ssde_conv_wino4g_launch;
     case SSDE_TILE_WINOGRAD4R: return ssde_conv_wino4r_launch;
     default: return nullptr;
   }
@@ -574,7 +573,7 @@ extern "C" int ssde_conv2d(const ssde_conv_args* a, void* stream) {
   if (a) {
     if (ssde_wino_launcher fn = wino_launcher(a->tile)) {
       // the two-kernel forms: the input-transform pass into wino_v first, unless the caller says wino_v already holds it
-      if ((a->tile == SSDE_TILE_WINOGRAD4G || a->tile == SSDE_TILE_WINOGRAD4R) && !(a->flags & SSDE_CONVF_V_GIVEN))
+      if (a->tile == SSDE_TILE_WINOGRAD4R && !(a->flags & SSDE_CONVF_V_GIVEN))
         if (int rc = ssde_wino4_xform_vq_launch(a, stream)) return rc;
       return fn(a, stream, nullptr);
     }

@@ -94,6 +94,8 @@ static int run_one(const ssde_op& op, void* stream) {
     case SSDE_OP_GN_FINALIZE: return ssde_gn_finalize(&op.u.gn_fin, stream);
     case SSDE_OP_PF_DRIFT: return ssde_pf_drift(&op.u.pf_drift, stream);
     case SSDE_OP_HUTCH_DIV: return ssde_hutch_div(&op.u.hutch_div, stream);
+    case SSDE_OP_COLSUM_FINISH: return ssde_colsum_finish(&op.u.colsum_fin, stream);
+    case SSDE_OP_GN_BWD_FINISH: return ssde_gn_bwd_finish(&op.u.gn_bwd_fin, stream);
   }
   ssde_set_error("program: unknown op kind %d", op.kind);
   return SSDE_EINVAL;

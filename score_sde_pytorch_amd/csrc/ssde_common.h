@@ -16,8 +16,7 @@ void ssde_set_error(const char* fmt, ...);
 // conv_wino.hip: launch (lds_out == NULL) or plan-only (returns the LDS bytes through lds_out)
 int ssde_conv_wino_launch(const ssde_conv_args* a, void* stream, int* lds_out);
 int ssde_conv_wino4_launch(const ssde_conv_args* a, void* stream, int* lds_out);   // conv_wino4.hip, same forms
-int ssde_conv_wino4g_launch(const ssde_conv_args* a, void* stream, int* lds_out);  // conv_wino4g.hip (two-kernel form), same forms
-int ssde_wino4_xform_vq_launch(const ssde_conv_args* a, void* stream);              // conv_wino4g.hip: V = B^T pro(x) B into a->wino_v
+int ssde_wino4_xform_vq_launch(const ssde_conv_args* a, void* stream);              // wino4_xform.hip: V = B^T pro(x) B into a->wino_v
 int ssde_conv_wino4r_launch(const ssde_conv_args* a, void* stream, int* lds_out);  // conv_wino4r.hip (two-kernel form, operands from registers)
 bool ssde_conv1x1_wants(const ssde_conv_args* a);                                    // conv1x1.hip
 int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out);

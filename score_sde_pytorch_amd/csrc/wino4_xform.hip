@@ -1,0 +1,125 @@
+// The input-transform pass of the two-kernel F(4x4,3x3) convolution (SSDE_TILE_WINOGRAD4R):
+//   wino4_xform_vq_kernel (this file)        V[pos][Cin/4][t][4] = B^T pro(x) B      HBM-bound: reads x once, writes 2.25x of it
+//   conv_wino4r_kernel (conv_wino4r.hip)     Y = A^T [ sum_ci U .* V ] A             the matrix kernel: no prologue, no input transform
+// conv_wino4.hip does both in one kernel, and on gfx950 that costs matrix time twice over: the GroupNorm / SiLU prologue and the
+// two transform passes are VALU work that SERIALISES with fp32 MFMAs on a SIMD (~950 of a stage's ~4600 cycles, beside 2304
+// matrix cycles), and every 64-cout workgroup of a pixel tile repeats them.  The price of the split is the extra pass: x read
+// once more and V (2.25 x) written and read; it is paid back where a V tile feeds four or more cout tiles (the 256-cout layers)
+// and in training programs, where V is wanted anyway by the F(4x4,3x3) weight gradient (ssde_wgrad_args.v_pre).
+#include "ssde_common.h"
+
+namespace {
+
+// ---- the input-transform pass: V[pos][Q][t][4] = B^T pro(x) B, Q = Ctot / 4 channel quads, t = (img * tiles_h + ty) * tiles_w + tx.
+// One thread = one 6x6 input tile of one channel quad: 36 float4 loads (the prologue -- GroupNorm, SiLU, dropout -- applied once
+// per element and tile; out-of-image pixels are zeros of the ACTIVATED tensor), both 1-D passes in registers, 36 float4 stores.
+// A wave = 16 consecutive tiles x 4 consecutive quads, lane = quad * 16 + tile: a store instruction writes four 256-byte runs,
+// a load instruction reads 64 contiguous bytes (4 quads) of 16 pixels.  HBM-bound: x read ~2.25x through the tile overlap (L2),
+// V written once.
+struct XformVqParams {
+  ssde_src src; float* v;
+  int N, H, W, Ctot, T, tiles_h, tiles_w;
+};
+
+__device__ __forceinline__ void bt6q(const float4 (&d)[6], float4 (&o)[6]) {
+#define SSDE_BT6_LANE(c)                                                                                             \
+  {                                                                                                                  \
+    const float t1 = d[4].c - 4.f * d[2].c, t2 = d[3].c - 4.f * d[1].c, t3 = d[4].c - d[2].c, t4 = d[3].c - d[1].c;   \
+    o[0].c = 4.f * d[0].c - 5.f * d[2].c + d[4].c;                                                                    \
+    o[1].c = t1 + t2; o[2].c = t1 - t2; o[3].c = t3 + 2.f * t4; o[4].c = t3 - 2.f * t4;                               \
+    o[5].c = 4.f * d[1].c - 5.f * d[3].c + d[5].c;                                                                    \
+  }
+  SSDE_BT6_LANE(x) SSDE_BT6_LANE(y) SSDE_BT6_LANE(z) SSDE_BT6_LANE(w)
+#undef SSDE_BT6_LANE
+}
+
+template <bool kGn>
+__global__ __launch_bounds__(256, 2) void wino4_xform_vq_kernel(const XformVqParams p) {
+  const ssde_src& s = p.src;
+  SsdePro pro = ssde_pro_decode(s);
+  pro.gn = kGn;
+  const int Q = p.Ctot >> 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.x * 16 + (lane & 15);
+  const int q = (blockIdx.y * 4 + wave) * 4 + (lane >> 4);
+  if (t >= p.T || q >= Q) return;
+  const int c = q * 4;
+  const int per_img = p.tiles_h * p.tiles_w;
+  const int img = t / per_img, r = t - img * per_img;
+  const int ty = r / p.tiles_w, tx = r - ty * p.tiles_w;
+  const bool second = c >= s.c0;                      // (c0 % 4 == 0: a quad never straddles the sources)
+  const float* base = second ? s.p1 + (c - s.c0) : s.p0 + c;
+  const int C = second ? s.c1 : s.c0;
+  float mu = 0.f, rs = 1.f;
+  float4 ga = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (kGn) {
+    const int cpg = p.Ctot / s.gn_groups;             // (cpg % 4 == 0: a quad lies in one group)
+    mu = s.gn_mean[img * s.gn_groups + c / cpg];
+    rs = s.gn_rstd[img * s.gn_groups + c / cpg];
+    ga = *reinterpret_cast<const float4*>(s.gn_gamma + c);
+    be = *reinterpret_cast<const float4*>(s.gn_beta + c);
+  }
+  float4 v[6][6];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const int iy = ty * 4 - 1 + a, ix = tx * 4 - 1 + b;
+      const bool inb = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const int pix = (img * p.H + (inb ? iy : 0)) * p.W + (inb ? ix : 0);
+      v[a][b] = *reinterpret_cast<const float4*>(base + (size_t)pix * C);
+    }
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const int iy = ty * 4 - 1 + a, ix = tx * 4 - 1 + b;
+      const bool inb = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const int pix = (img * p.H + (inb ? iy : 0)) * p.W + (inb ? ix : 0);
+      const float4 x = ssde_pro_apply(v[a][b], mu, rs, ga, be, (uint32_t)pix * (uint32_t)p.Ctot + (uint32_t)c, pro);
+      v[a][b] = inb ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  // columns (over the rows a of every column b), then rows
+#pragma unroll
+  for (int b = 0; b < 6; ++b) {
+    float4 d[6], o[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) d[a] = v[a][b];
+    bt6q(d, o);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) v[a][b] = o[a];
+  }
+  float* dst = p.v + ((size_t)q * p.T + t) * 4;
+  const size_t plane = (size_t)Q * p.T * 4;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    float4 o[6];
+    bt6q(v[a], o);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) *reinterpret_cast<float4*>(dst + (size_t)(a * 6 + b) * plane) = o[b];
+  }
+}
+
+}  // namespace
+
+int ssde_wino4_xform_vq_launch(const ssde_conv_args* a, void* stream) {
+  SSDE_REQUIRE(a && a->main.p0 && a->wino_v, "conv(winograd 4x4, two kernels): the transformed-input buffer (ssde_conv_args.wino_v) is missing");
+  const ssde_src& s = a->main;
+  SSDE_REQUIRE(s.c0 > 0 && s.c0 % 4 == 0 && s.c1 % 4 == 0 && (s.c1 == 0 || s.p1), "conv(winograd 4x4, two kernels): channels must be multiples of 4");
+  SSDE_REQUIRE(a->h_in % 4 == 0 && a->w_in % 4 == 0 && a->n > 0, "conv(winograd 4x4, two kernels): bad shape");
+  const bool gn = s.pro_mode == SSDE_PRO_GN || s.pro_mode == SSDE_PRO_GN_SILU;
+  if (gn) {
+    SSDE_REQUIRE(s.gn_groups > 0 && (s.c0 + s.c1) % s.gn_groups == 0 && ((s.c0 + s.c1) / s.gn_groups) % 4 == 0,
+                 "conv(winograd 4x4, two kernels): GroupNorm needs channels-per-group %% 4 == 0");
+    SSDE_REQUIRE(s.gn_mean && s.gn_rstd && s.gn_gamma && s.gn_beta, "conv(winograd 4x4, two kernels): GroupNorm pointers missing");
+  }
+  SSDE_REQUIRE(s.drop_thresh == 0 || s.drop_seed, "conv(winograd 4x4, two kernels): dropout seed pointer missing");
+  XformVqParams p{s, a->wino_v, a->n, a->h_in, a->w_in, s.c0 + s.c1, a->n * (a->h_in / 4) * (a->w_in / 4), a->h_in / 4, a->w_in / 4};
+  SSDE_REQUIRE((unsigned long long)a->n * a->h_in * a->w_in * (unsigned)p.Ctot < (1ull << 32), "conv(winograd 4x4, two kernels): tensor too large");
+  const dim3 grid(ssde_cdiv(p.T, 16), ssde_cdiv(p.Ctot >> 2, 16));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (gn) hipLaunchKernelGGL(wino4_xform_vq_kernel<true>, grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(wino4_xform_vq_kernel<false>, grid, dim3(256), 0, st, p);
+  SSDE_LAUNCH_CHECK();
+  return SSDE_OK;
+}

@@ -54,6 +54,9 @@ def _walk_refs(value, fn):
     elif isinstance(value, dict):
         for v in value.values():
             _walk_refs(v, fn)
+    elif isinstance(value, list):                    # job lists of the batched finishing ops
+        for v in value:
+            _walk_refs(v, fn)
 
 
 def _ptr(value):
@@ -76,7 +79,10 @@ def _fill(struct, fields):
             _fill(cur, v)
         elif isinstance(v, (list, tuple)) and not (len(v) == 2 and isinstance(v[0], (Buf, torch.Tensor))):
             for i, x in enumerate(v):
-                cur[i] = x
+                if isinstance(x, dict):
+                    _fill(cur[i], x)             # an array of structures (the jobs of a batched finishing op)
+                else:
+                    cur[i] = x
         elif isinstance(v, (Buf, torch.Tensor, tuple)) or v is None:
             setattr(struct, k, _ptr(v))
         else:
@@ -90,7 +96,8 @@ _STRUCT = {L.OP_CONV: L.ConvArgs, L.OP_GN_STATS: L.GnStatsArgs, L.OP_UPFIRDN: L.
            L.OP_STEP_INC: L.StepIncArgs, L.OP_WGRAD: L.WgradArgs, L.OP_COLSUM: L.ColsumArgs,
            L.OP_GN_BWD_REDUCE: L.GnBwdReduceArgs, L.OP_PROLOGUE_BWD: L.PrologueBwdArgs, L.OP_ATTN_BWD: L.AttnBwdArgs,
            L.OP_PERTURB: L.PerturbArgs, L.OP_DSM_LOSS: L.DsmLossArgs, L.OP_SUMSQ_FLAT: L.SumsqFlatArgs,
-           L.OP_ADAM: L.AdamArgs, L.OP_MEMSET: L.MemsetArgs, L.OP_AXPY: L.AxpyArgs, L.OP_GN_FINALIZE: L.GnFinalizeArgs}
+           L.OP_ADAM: L.AdamArgs, L.OP_MEMSET: L.MemsetArgs, L.OP_AXPY: L.AxpyArgs, L.OP_GN_FINALIZE: L.GnFinalizeArgs,
+           L.OP_COLSUM_FINISH: L.ColsumFinishArgs, L.OP_GN_BWD_FINISH: L.GnBwdFinishArgs}
 
 
 _ROUTE = {L.OP_CONV: L.conv_route_flags, L.OP_WGRAD: L.wgrad_route_flags, L.OP_GN_BWD_REDUCE: L.gn_bwd_route_flags}
@@ -374,7 +381,7 @@ class WeightStore:
     def conv3(self, param, cin_pad=None, cout_pad=None, wino=False):
         """[Cout, Cin, 3, 3] conv weight, optionally zero-padded to cin_pad / cout_pad channels; wino (see
         Lowering.wino_ok): 2 / True = packed for the Winograd F(2x2,3x3) kernel (G g G^T, conv_wino.hip), 4 = for the fused
-        F(4x4,3x3) kernel (conv_wino4.hip; also read by the LDS-fed matrix kernel of conv_wino4g.hip), 6 = per lane for the
+        F(4x4,3x3) kernel (conv_wino4.hip), 6 = per lane for the
         register-fed matrix kernel (conv_wino4r.hip), 0 = for the direct one."""
         def logical(w):
             w = w.to(torch.float32)
@@ -500,6 +507,17 @@ class WeightStore:
         # (backward.FlatParams: fused optimizer step, EMA swap)
         return tuple((s.data_ptr(), s._version, getattr(getattr(s, "_ssde_flat", None), "generation", 0)) for s in sources)
 
+    def mark_fresh(self):
+        """The caller has just re-packed every entry that has a device recipe itself (the re-pack launches inside a captured
+        training step): record the sources' stamps so that the next refresh() does not do it again; entries without a recipe
+        are re-packed here."""
+        for e in self.entries:
+            st = self._stamp(e[1])
+            if e[4] is None and st != e[3]:
+                with torch.no_grad():
+                    e[0].copy_(e[2](*[s.detach() for s in e[1]]).to(self.device))
+            e[3] = st
+
     def refresh(self, force=False, on_device=None):
         """Bring packed copies up to date.  force=True (after the fused optimizer wrote the flat parameter buffer behind
         torch's back) re-packs everything: with the device kernels when the library can run here, else in torch."""
@@ -616,9 +634,6 @@ class Lowering:
         if wino:
             assert main is not None and stride == 1 and pad == 1 and (h_in, w_in) == (h_out, w_out)
             tile = L.TILE_WINOGRAD4R if wino == 6 else L.TILE_WINOGRAD4 if wino == 4 else L.TILE_WINOGRAD
-            if wino == 4 and os.environ.get("SSDE_WINO4_FEED", "regs") == "lds" and \
-                    self._wino4_two_kernels(h_out, w_out, c_out, main["c0"] + main["c1"]):
-                tile = L.TILE_WINOGRAD4G                 # round 4's LDS-fed matrix kernel on the fused kernel's weight image (A/B runs)
             if aux is not None:
                 split_tmp = self.b.buf(self.n, h_out, w_out, c_out, name="wino_tmp")
         px = self.n * h_out * w_out
@@ -634,14 +649,14 @@ class Lowering:
             chan_add_ld=chan_add_ld, resid_post=resid_post, resid=resid, out_scale=float(scale), dst=dst, gn_part=None,
             wino_v=None, _split_tmp=split_tmp)
         if wino in (4, 6):
-            # the transformed input B^T pro(x) B in HBM (2.25x the input): the two-kernel form (conv_wino4g.hip) cannot do without
+            # the transformed input B^T pro(x) B in HBM (2.25x the input): the two-kernel form (wino4_xform.hip + conv_wino4r.hip) cannot do without
             # it; in a training forward the one-kernel form leaves it behind as a by-product when the layer's weight gradient
             # takes the F(4x4,3x3) route (ssde_conv_args.wino_v -> ssde_wgrad_args.v_pre, backward.TrainEngine._bwd_branch:
             # alive until that weight gradient has been enqueued)
             ctot = main["c0"] + main["c1"]
             v_floats = 36 * self.n * (h_out // 4) * (w_out // 4) * ctot
             takes = getattr(self, "emit_wino_v", False) and v_floats * 4 < 2 ** 32 and self._wgrad_takes_wino4(fields)
-            if tile in (L.TILE_WINOGRAD4G, L.TILE_WINOGRAD4R) or takes:
+            if tile == L.TILE_WINOGRAD4R or takes:
                 fields["wino_v"] = self.b.buf(v_floats, name="wino_v")
                 fields["_v_for_wgrad"] = bool(takes)
         if stats and isinstance(dst, Buf):
@@ -653,16 +668,19 @@ class Lowering:
         self.b.add(L.OP_CONV, fields, FC_CONV3 if main is not None else FC_CONV1, flops)
 
     def _wino4_two_kernels(self, h, w, c_out, c_in):
-        """F(4x4,3x3) as a transform pass + a matrix kernel (conv_wino4g.hip) instead of the one fused kernel?  The pass costs
-        one more read of x and 2.25x of it written and read; the matrix kernel saves the prologue and transform VALU work that
-        serialises with fp32 MFMAs in EVERY 64-cout workgroup of a pixel tile.  Measured at batch 256 (profiles/
-        r4_wino4_two_kernels.txt): 256->256 @16x16 0.281 -> 0.245 ms, 512->256 @16x16 0.496 -> 0.457, level at 128 couts
-        (128->128 @32x32 0.357 -> 0.346, 256->128 0.599 -> 0.594), a loss at 384->128 @32x32 (0.78 -> 0.95: three times the
-        input for two cout tiles) -- so: from four cout tiles up.  SSDE_WINO4_TWO: 0 = never, 2 = wherever F(4x4,3x3) runs."""
+        """F(4x4,3x3) as a transform pass (wino4_xform.hip) + the register-fed matrix kernel (conv_wino4r.hip) instead of the one
+        fused kernel?  The pass costs one more read of x and 2.25x of it written and read; the matrix kernel saves the prologue
+        and transform VALU work that serialises with fp32 MFMAs in EVERY 64-cout workgroup of a pixel tile.  Measured at batch
+        256 (profiles/r5_wino4r_v3_two_stage_ring.txt, fused -> pair): 256->256 @16x16 0.29 -> 0.22 ms, 512->256 @16x16
+        0.51 -> 0.44, level at 128 couts (128->128 @32x32 0.36 -> 0.35, 256->128 0.58 -> 0.60), a loss at 384->128 @32x32
+        (0.79 -> 0.86: three times the input for two cout tiles) -- so: from four cout tiles up in inference programs.  In a
+        training program the pass's output is also the F(4x4,3x3) weight gradient's input (v_pre) and the input-gradient
+        convolutions have 4-8 cout tiles: the pair everywhere (step 0.0575 -> 0.0568 s, profiles/r5_wino4r_v3_bench_ab.txt).
+        SSDE_WINO4_TWO: 0 = never, 2 = wherever F(4x4,3x3) runs."""
         mode = os.environ.get("SSDE_WINO4_TWO", "1")
-        if mode == "0" or 36 * self.n * (h // 4) * (w // 4) * c_in * 4 >= 2 ** 32:
+        if mode == "0" or 36 * self.n * (h // 4) * (w // 4) * c_in * 4 >= 2 ** 32 or c_in % 8 != 0:
             return False
-        return mode == "2" or c_out >= 256
+        return mode == "2" or c_out >= 256 or bool(getattr(self, "emit_wino_v", False))
 
     def _wgrad_takes_wino4(self, f):
         """Would ssde_conv_wgrad run the weight gradient of this forward conv on the F(4x4,3x3) path?  (shape-only query with
@@ -700,7 +718,7 @@ class Lowering:
             return 0
         legal2 = h % 2 == 0 and w % 2 == 0 and h >= 8 and w >= 8 and c_out >= 32 and c_in >= 8 and c_in % 8 == 0
         legal4 = h % 4 == 0 and w % 4 == 0 and h >= 8 and w >= 8 and c_out >= 32 and c_in >= 8 and c_in % 4 == 0
-        four = lambda: 6 if (os.environ.get("SSDE_WINO4_FEED", "regs") != "lds" and self._wino4_two_kernels(h, w, c_out, c_in)) else 4  # noqa: E731
+        four = lambda: 6 if self._wino4_two_kernels(h, w, c_out, c_in) else 4  # noqa: E731
         if mode == "4" and legal4:
             return four()
         if mode == "2" or mode == "4":

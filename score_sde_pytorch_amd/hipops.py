@@ -70,10 +70,10 @@ def conv2d(x=None, weight=None, bias=None, stride=1, pad=1, x2=None, pro=L.PRO_N
         if out_hw is not None:      # top-left crop of the full result (transposed strided convolutions)
             h_out, w_out = out_hw
         _fill_src(a.main, x, x2, pro, gn)
-        packer = {L.TILE_WINOGRAD: pack_wino_weight, L.TILE_WINOGRAD4: pack_wino4_weight, L.TILE_WINOGRAD4G: pack_wino4_weight,
+        packer = {L.TILE_WINOGRAD: pack_wino_weight, L.TILE_WINOGRAD4: pack_wino4_weight,
                   L.TILE_WINOGRAD4R: pack_wino4r_weight}.get(tile, pack_conv_weight)
         wp = packer(weight.to(x.device)); keep.append(wp)
-        if tile in (L.TILE_WINOGRAD4G, L.TILE_WINOGRAD4R):      # the two-kernel forms need the transformed-input buffer
+        if tile == L.TILE_WINOGRAD4R:      # the two-kernel form needs the transformed-input buffer
             wv = torch.empty(36 * n * (h_in // 4) * (w_in // 4) * (x.shape[-1] + (x2.shape[-1] if x2 is not None else 0)), device=x.device)
             keep.append(wv)
             a.wino_v = _p(wv)
@@ -230,7 +230,8 @@ def wgrad_scratch_floats(a):
     return r
 
 
-def colsum(g, c=None, g_off=0, scale=1.0, per_sample=None, ps_off=0, total=None, total2=None):
+def colsum(g, c=None, g_off=0, scale=1.0, per_sample=None, ps_off=0, total=None, total2=None, defer=False):
+    """defer=True: only the pass over g runs; returns the job (a dict with the partials) for colsum_finish()."""
     _need_cuda(g)
     n = g.shape[0]
     hw = int(np.prod(g.shape[1:-1])) if g.dim() > 2 else 1
@@ -242,8 +243,34 @@ def colsum(g, c=None, g_off=0, scale=1.0, per_sample=None, ps_off=0, total=None,
         a.per_sample, a.ps_ld, a.ps_off = _p(per_sample), per_sample.shape[-1], ps_off
     scratch = torch.empty(n * (colsum_slices(hw) + 1) * a.c, device=g.device)
     a.scratch = _p(scratch)
+    if defer:
+        a.per_sample, a.flags = None, L.COLSUMF_DEFER
+        L.check(L.load().ssde_colsum(C.byref(a), _stream()), "ssde_colsum")
+        return dict(part=scratch, per_sample=per_sample, total=total, total2=total2, n=n, slices=colsum_slices(hw), c=a.c,
+                    ps_ld=per_sample.shape[-1] if per_sample is not None else 0, ps_off=ps_off)
     a.total, a.total2 = _p(total), _p(total2)
     L.check(L.load().ssde_colsum(C.byref(a), _stream()), "ssde_colsum")
+
+
+def colsum_finish(jobs):
+    """One launch that finishes up to L.FINISH_JOBS deferred column sums (ssde_colsum_finish)."""
+    a = L.ColsumFinishArgs()
+    a.count = len(jobs)
+    for i, j in enumerate(jobs):
+        q = a.job[i]
+        q.part, q.per_sample, q.total, q.total2 = _p(j["part"]), _p(j["per_sample"]), _p(j["total"]), _p(j["total2"])
+        q.n, q.slices, q.c, q.ps_ld, q.ps_off = j["n"], j["slices"], j["c"], j["ps_ld"], j["ps_off"]
+    L.check(L.load().ssde_colsum_finish(C.byref(a), _stream()), "ssde_colsum_finish")
+
+
+def gn_bwd_finish(jobs):
+    """One launch that writes dgamma / dbeta of up to L.FINISH_JOBS deferred GroupNorm backward calls (ssde_gn_bwd_finish)."""
+    a = L.GnBwdFinishArgs()
+    a.count = len(jobs)
+    for i, j in enumerate(jobs):
+        q = a.job[i]
+        q.scratch, q.dgamma, q.dbeta, q.rows, q.c = _p(j["scratch"]), _p(j["dgamma"]), _p(j["dbeta"]), j["rows"], j["c"]
+    L.check(L.load().ssde_gn_bwd_finish(C.byref(a), _stream()), "ssde_gn_bwd_finish")
 
 
 def colsum_slices(hw):
@@ -251,7 +278,7 @@ def colsum_slices(hw):
 
 
 def gn_backward(x, dp, gn, pro, x2=None, dropout=None, slices=1, scale=1.0, acc=(False, False), want=(True, True), one_call=True,
-                dx=None, dx2=None):
+                dx=None, dx2=None, defer_params=False):
     """GroupNorm(+SiLU)(+dropout) backward: returns (dx, dx2, dgamma, dbeta) for dp = d loss / d pro(x).
     one_call: ssde_gn_bwd_reduce with its gradient destinations set (ABI 7: one pass over dp and x where the shape allows);
     otherwise the reduction and ssde_prologue_bwd as two calls."""
@@ -275,6 +302,12 @@ def gn_backward(x, dp, gn, pro, x2=None, dropout=None, slices=1, scale=1.0, acc=
         dx2 = torch.zeros_like(x2) if (x2 is not None and want[1]) else None
     if one_call and (dx is not None or dx2 is not None):
         r.g0, r.g1, r.acc0, r.acc1, r.scale = _p(dx), _p(dx2), int(acc[0]), int(acc[1]), scale
+        if defer_params:         # dgamma / dbeta by a finishing launch (here: of this one job) instead of the call's own
+            r.flags |= L.GNBWDF_DEFER_PARAMS
+            r.dgamma = r.dbeta = None
+            L.check(L.load().ssde_gn_bwd_reduce(C.byref(r), _stream()), "ssde_gn_bwd_reduce")
+            gn_bwd_finish([dict(scratch=scratch, dgamma=dgamma, dbeta=dbeta, rows=int(L.load().ssde_gn_bwd_scratch_rows(C.byref(r))), c=ctot)])
+            return dx, dx2, dgamma, dbeta
         L.check(L.load().ssde_gn_bwd_reduce(C.byref(r), _stream()), "ssde_gn_bwd_reduce")
         return dx, dx2, dgamma, dbeta
     L.check(L.load().ssde_gn_bwd_reduce(C.byref(r), _stream()), "ssde_gn_bwd_reduce")

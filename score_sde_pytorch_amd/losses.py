@@ -281,8 +281,7 @@ class FusedTrainStep:
         self.batch.copy_(batch)
         self.z.copy_(z)
 
-    def loss_and_grads(self, batch, t=None, z=None, seed=None):
-        """Forward + loss (+ backward when built for training); returns the device scalar loss."""
+    def _draw_and_perturb(self, batch, t, z):
         spec = self.spec
         if t is None and spec["kind"] in ("smld", "ddpm"):
             t = torch.randint(0, spec["sde"].N, (batch.shape[0],), device=batch.device)                         # losses.py:116,136
@@ -291,6 +290,11 @@ class FusedTrainStep:
         if z is None:
             z = torch.randn_like(batch)                                                                         # losses.py:85
         self.perturb_inputs(batch, t, z)
+
+    def loss_and_grads(self, batch, t=None, z=None, seed=None):
+        """Forward + loss (+ backward when built for training); returns the device scalar loss."""
+        spec = self.spec
+        self._draw_and_perturb(batch, t, z)
         eng = self.eng
         eng.weights.refresh()
         eng.set_dropout_seed(self._dropout_seed() if seed is None else seed)
@@ -311,6 +315,59 @@ class FusedTrainStep:
                 eng.run_backward()
         return self.loss
 
+    # ------------------------------------------------------------------ the whole step as ONE hipGraph
+    def _step_graph(self, optimizer, ema):
+        """perturb -> forward -> loss head -> backward -> clip + Adam + EMA -> weight re-pack as one captured graph (no gradient
+        exchange: a single replica, or bench.py's no-exchange leg).  Everything that changes from step to step lives in device
+        buffers the host refreshes before the replay (batch, z, per-sample coefficients, the hyper-parameter record, the dropout
+        seed word), so the ~1400 launches of a step cost one hipGraphLaunch.  SSDE_TRAIN_GRAPH=0 keeps the program runs."""
+        import os
+        if os.environ.get("SSDE_TRAIN_GRAPH", "1") == "0" or not self.spec["train"] or self.device.type != "cuda":
+            return None
+        opt = self._optimizer_program(optimizer, ema)
+        ws = self.eng.weights
+        if getattr(ws, "_tables", None) is None or \
+                ws._tables[1] != tuple(s_.data_ptr() for e in ws.entries if e[4] is not None for s_ in e[1]):
+            ws._build_tables()
+        key = (id(opt), id(ws._tables))
+        if getattr(self, "_graph", None) is not None and self._graph[0] == key:
+            return self._graph[1]
+        L, E, eng = self.L, self.E, self.eng
+        ops = [self._head[0].ops[0]]
+        ops += [eng.program.ops[i] for i in range(eng.n_fwd)]
+        ops += [self._head[1].ops[0]]
+        ops += [eng.program.ops[i] for i in range(eng.n_fwd, eng.program.n)]
+        ops += [opt.ops[i] for i in range(opt.n)]
+        ops += [L.make_op(L.OP_PACK, args) for args, _ in ws._tables[0]]
+        prog = E.Program(L.op_array(ops), [0] * len(ops), [0.0] * len(ops), (self, opt, ws._tables))
+        if getattr(self, "_gstream", None) is None:
+            self._gstream = torch.cuda.Stream(device=self.device)
+        self._gstream.wait_stream(torch.cuda.current_stream())
+        prog.capture(self._gstream)
+        torch.cuda.current_stream().wait_stream(self._gstream)
+        self._graph = (key, prog)
+        return prog
+
+    def train_step(self, batch, optimizer, ema, step, hyper, t=None, z=None, seed=None):
+        """One optimisation step (losses.py:179-208's train branch); returns the device scalar loss (of the parameters BEFORE the
+        update, as the reference's step_fn does)."""
+        prog = None if self._exchanges() else self._step_graph(optimizer, ema)
+        if prog is None:
+            loss = self.loss_and_grads(batch, t=t, z=z, seed=seed)
+            loss = loss.clone()
+            self.optimizer_step(optimizer, ema, step, hyper)
+            return loss
+        self._draw_and_perturb(batch, t, z)
+        self.eng.weights.refresh()                    # (a no-op unless somebody wrote parameters behind the step's back)
+        self.eng.set_dropout_seed(self._dropout_seed() if seed is None else seed)
+        self._upload_hyper(optimizer, ema, step, hyper)
+        s = self._gstream
+        s.wait_stream(torch.cuda.current_stream())
+        prog.replay(s)
+        torch.cuda.current_stream().wait_stream(s)
+        self._after_update(optimizer, repacked=True)
+        return self.loss.clone()
+
     def _dropout_seed(self):
         """Mask stream of this step: torch's seed (torch.manual_seed), the data-parallel rank and a per-call counter
         that a resumed run continues from `state['step']` (the reference's dropout draws from torch's generator, so
@@ -330,6 +387,11 @@ class FusedTrainStep:
                 self._pending = []
             else:
                 dist.all_reduce(self.flat.grad)
+        self._upload_hyper(optimizer, ema, step, hyper)
+        self._optimizer_program(optimizer, ema).run()
+        self._after_update(optimizer, repacked=False)
+
+    def _upload_hyper(self, optimizer, ema, step, hyper):
         group = optimizer.param_groups[0]
         lr = hyper["lr"]
         if hyper["warmup"] > 0:
@@ -354,11 +416,15 @@ class FusedTrainStep:
         if self.hyper.is_cuda:
             slot[1] = torch.cuda.Event()
             slot[1].record()
-        self._optimizer_program(optimizer, ema).run()
+
+    def _after_update(self, optimizer, repacked):
         for p in self.flat.params:
             optimizer.state[p]["step"] += 1
         self.flat.touch()                            # every engine lowered from this model re-packs on its next refresh
-        self.eng.weights.refresh()                   # packed weight copies follow the in-place parameter update
+        if repacked:
+            self.eng.weights.mark_fresh()            # (this engine's packed copies were re-packed inside the step's graph)
+        else:
+            self.eng.weights.refresh()               # packed weight copies follow the in-place parameter update
         self.steps_done += 1
 
 
@@ -407,8 +473,7 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
             fs = fused_for(state, batch)
             if train:
                 fs.step_offset = int(state['step']) - fs.steps_done      # a restored checkpoint continues its mask stream
-                loss = fs.loss_and_grads(batch).clone()
-                fs.optimizer_step(state['optimizer'], state['ema'], state['step'], optimize_fn.ssde_hyper)
+                loss = fs.train_step(batch, state['optimizer'], state['ema'], state['step'], optimize_fn.ssde_hyper)
                 state['step'] += 1
             else:
                 ema = state['ema']

@@ -53,16 +53,7 @@ class PlanParam(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("region", C.c_int32), ("_pad0", C.c_int32), ("offset", C.c_int64), ("numel", C.c_int64)]
 
 
-def _pointer_fields(struct_cls, base=0):
-    """(byte offset, ) of every pointer field of a ctypes structure, nested structures included."""
-    out = []
-    for name, typ in struct_cls._fields_:
-        off = base + getattr(struct_cls, name).offset
-        if typ is C.c_void_p:
-            out.append(off)
-        elif isinstance(typ, type) and issubclass(typ, C.Structure):
-            out.extend(_pointer_fields(typ, off))
-    return out
+_pointer_fields = L.pointer_offsets      # (byte offset, ) of every pointer field: nested structures and arrays of them included
 
 
 _OP_PTRS = {}

@@ -58,7 +58,7 @@ def _kernel_mix(engine):
     for i in range(engine.program.n):
         op = engine.program.ops[i]
         if op.kind == L.OP_CONV and op.u.conv.ksize == 3:
-            if op.u.conv.tile in (L.TILE_WINOGRAD, L.TILE_WINOGRAD4, L.TILE_WINOGRAD4G):
+            if op.u.conv.tile in (L.TILE_WINOGRAD,) + L.TILES_WINOGRAD4:
                 wino += 1
             else:
                 direct += 1
@@ -101,7 +101,7 @@ def test_cifar_forward_f4x4_split_reduction_batch48(monkeypatch):
         ys = [model(x.cuda(), sig.cuda()).clone() for _ in range(3)]
     from score_sde_pytorch_amd import _lib as L
     eng = next(iter(model._engines.values()))
-    n4 = sum(1 for i in range(eng.program.n) if eng.program.ops[i].kind == L.OP_CONV and eng.program.ops[i].u.conv.tile in (L.TILE_WINOGRAD4, L.TILE_WINOGRAD4G))
+    n4 = sum(1 for i in range(eng.program.n) if eng.program.ops[i].kind == L.OP_CONV and eng.program.ops[i].u.conv.tile in (L.TILE_WINOGRAD4, L.TILE_WINOGRAD4R))
     assert n4 >= 60, n4                                         # 8x8 maps included
     for y in ys:
         assert torch.equal(y, y1)

@@ -97,8 +97,7 @@ def test_unet_forward_on_the_bf16_matrix_pipe(monkeypatch):
 
 def test_unet_forward_winograd_f4x4_in_two_kernels(monkeypatch):
     """every legal 3x3 layer as a transform pass + a matrix kernel (SSDE_WINO4_TWO=2 forces what the lowering otherwise takes by
-    its cout-tile rule): the register-fed kernel of conv_wino4r.hip (the product's), then round 4's LDS-fed kernel of
-    conv_wino4g.hip (SSDE_WINO4_FEED=lds), emulated"""
+    its cout-tile rule), emulated"""
     from score_sde_pytorch_amd import engine as E, _lib as L
     monkeypatch.setenv("SSDE_WINOGRAD", "4")
     monkeypatch.setenv("SSDE_WINO4_TWO", "2")
@@ -110,11 +109,7 @@ def test_unet_forward_winograd_f4x4_in_two_kernels(monkeypatch):
         seen.append(self.b.specs[-1][1]["tile"])
     monkeypatch.setattr(E.Lowering, "conv", spy)
     test_unet_forward_matches_reference_golden("unet_small_ffhq")
-    assert seen.count(L.TILE_WINOGRAD4R) >= 8 and L.TILE_WINOGRAD4 not in seen and L.TILE_WINOGRAD4G not in seen
-    del seen[:]
-    monkeypatch.setenv("SSDE_WINO4_FEED", "lds")
-    test_unet_forward_matches_reference_golden("unet_small_ffhq")
-    assert seen.count(L.TILE_WINOGRAD4G) >= 8 and L.TILE_WINOGRAD4 not in seen and L.TILE_WINOGRAD4R not in seen
+    assert seen.count(L.TILE_WINOGRAD4R) >= 8 and L.TILE_WINOGRAD4 not in seen
 
 
 @pytest.mark.parametrize("name", list(CASES))

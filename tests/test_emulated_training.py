@@ -69,7 +69,7 @@ def test_whole_network_gradients_winograd_f4x4(monkeypatch):
 
 
 def test_whole_network_gradients_winograd_f4x4_in_two_kernels(monkeypatch):
-    """forward and input-gradient convolutions as transform pass + matrix kernel (conv_wino4g.hip); the weight gradients read
+    """forward and input-gradient convolutions as transform pass + matrix kernel (conv_wino4r.hip); the weight gradients read
     the transform pass's output (ssde_wgrad_args.v_pre)"""
     monkeypatch.setenv("SSDE_WINOGRAD", "4")
     monkeypatch.setenv("SSDE_WINO4_TWO", "2")
@@ -139,8 +139,9 @@ def test_1x1_weight_gradients_pipelined_and_chunked():
     T.check_wgrad_1x1("cpu")
 
 
-def test_weight_gradient_fed_by_the_forward_launch(monkeypatch):
-    T.check_wino_v_from_forward("cpu", monkeypatch)
+@pytest.mark.parametrize("dropout", [False, True])
+def test_weight_gradient_fed_by_the_forward_launch(monkeypatch, dropout):
+    T.check_wino_v_from_forward("cpu", monkeypatch, dropout=dropout)
 
 
 def test_conv3x3_winograd_f4x4_register_fed_matrix_kernel():

@@ -52,7 +52,7 @@ def _main_loop(body):
 
 
 @pytest.mark.parametrize("src,kernel", [("conv_wino4.hip", "conv_wino4_kernel"), ("conv_wino.hip", "conv_wino_kernel"),
-                                        ("conv_wino4g.hip", "conv_wino4g_kernel"), ("conv_wino4r.hip", "conv_wino4r_kernel")])
+                                        ("conv_wino4r.hip", "conv_wino4r_kernel")])
 def test_winograd_kernels_own_m0_and_keep_scratch_out_of_the_loop(src, kernel, tmp_path):
     isa = _isa(src, tmp_path)
     for sym, body in _kernels(isa, kernel):
@@ -114,46 +114,36 @@ def test_asm_halo_loads_are_not_read_before_their_counted_wait(tmp_path):
                     j += 1
 
 
-def test_two_kernel_winograd_matrix_loop_counts_its_own_dma_pieces(tmp_path):
-    """conv_wino4g.hip: the steady-state stage of the matrix kernel is 18 MFMAs, 18 fragment reads and 8 LDS-DMA pieces per wave
-    with the hand-counted waits 6 / 6 / 7 / 8 / 8 (the comment above the stage body derives them) and ONE barrier; hipcc must not
-    add a vmcnt wait of its own inside the loop (it would be a vmcnt(0): a full memory latency per stage)."""
-    isa = _isa("conv_wino4g.hip", tmp_path)
-    (sym, body), = _kernels(isa, "conv_wino4g_kernel")
-    loop = _main_loop(body)
-    assert sum("v_mfma_f32_32x32x2" in l for l in loop) == 18
-    assert sum("global_load_lds_dwordx4" in l for l in loop) == 8
-    assert 9 <= sum(l.strip().startswith("ds_read") for l in loop) <= 18      # (18 fragments of 8 bytes; hipcc pairs some as ds_read2)
-    assert sum(l.strip().startswith("s_barrier") for l in loop) == 1
-    waits = [int(m.group(1)) for l in loop for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", l)] if m]
-    assert waits == [6, 6, 7, 8, 8], waits
-
-
 def test_register_fed_winograd_matrix_loop_counts_its_own_loads(tmp_path):
-    """conv_wino4r.hip: the steady-state stage is 18 MFMAs fed by 14 global loads per wave (nine dwordx2 runs of V, four dwordx4 +
-    one dwordx2 of the per-lane weight image) issued from inline asm into the very registers the MFMAs read, with the hand-counted
-    waits 11 / 11 / 11 / 11 / 12 (the comment above the stage body derives them); no LDS access, no barrier, no wait hipcc added.
-    hipcc does not know the destination registers are in flight: replay the loop against a model of the in-order VMEM queue and
-    require that no instruction reads a register whose load has not been waited for (two trips: the second starts from the
-    queue the first left behind, as every trip after the prologue does).  The peeled last stage re-issues nothing: 11 / 8 / 5 / 2 / 0."""
+    """conv_wino4r.hip: the steady-state loop body is TWO stages (register sets 0 and 1), each 18 MFMAs fed by 14 global loads per
+    wave (nine dwordx2 runs of V, four dwordx4 + one dwordx2 of the per-lane weight image) issued from inline asm into the very
+    registers the MFMAs of stage + 2 read, with the hand-counted waits 25 / 25 / 25 / 25 / 26 (the comment above the stage body
+    derives them); no LDS access, no barrier, no wait hipcc added.  hipcc does not know the destination registers are in flight:
+    replay the loop against a model of the in-order VMEM queue and require that no instruction reads a register whose load has not
+    been waited for (two trips: the second starts from the queue the first left behind, as every trip after the prologue does).
+    The two peeled last stages issue nothing: 25 / 22 / 19 / 16 / 14, then 11 / 8 / 5 / 2 / 0."""
     isa = _isa("conv_wino4r.hip", tmp_path)
     (sym, body), = _kernels(isa, "conv_wino4r_kernel")
+    _check_register_fed_loop(sym, body)
+
+
+def _check_register_fed_loop(sym, body):
     loop = _main_loop(body)
     code = [l.split(";")[0].strip() for l in loop]
     code = [l for l in code if l and not l.startswith(".") and not l.endswith(":")]
-    assert sum("v_mfma_f32_32x32x2" in l for l in code) == 18
-    assert sum(l.startswith("global_load_dwordx2") for l in code) == 10 and sum(l.startswith("global_load_dwordx4") for l in code) == 4
+    assert sum("v_mfma_f32_32x32x2" in l for l in code) == 36
+    assert sum(l.startswith("global_load_dwordx2") for l in code) == 20 and sum(l.startswith("global_load_dwordx4") for l in code) == 8
     assert not any(l.startswith(("ds_", "s_barrier", "scratch_", "buffer_")) or "global_load_lds" in l for l in code), sym
     waits = [int(m.group(1)) for l in code for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", l)] if m]
-    assert waits == [11, 11, 11, 11, 12], waits
+    assert waits == [25, 25, 25, 25, 26] * 2, waits
     assert not any(re.match(r"s_waitcnt\s+(?!vmcnt)", l) for l in code), [l for l in code if l.startswith("s_waitcnt")]
 
     def replay(instrs, queue, check):
         for l in instrs:
             m = re.match(r"global_load_dwordx[24] (v\[\d+:\d+\]), (v\d+), s\[", l)
             if m:
-                if check:
-                    assert not (_regs(m.group(2)) & set().union(*queue)) if queue else True, (sym, l)
+                if check and queue:
+                    assert not (_regs(m.group(2)) & set().union(*queue)), (sym, l)
                 queue.append(_regs(m.group(1)))
                 continue
             w = re.match(r"s_waitcnt vmcnt\((\d+)\)", l)
@@ -165,10 +155,10 @@ def test_register_fed_winograd_matrix_loop_counts_its_own_loads(tmp_path):
                 assert not (_regs(l.split(None, 1)[1]) & busy), (sym, l, sorted(_regs(l.split(None, 1)[1]) & busy))
         return queue
     q = replay(code, [], False)
-    assert len(q) == 14, len(q)                   # a whole round of loads is in flight at the loop boundary
+    assert len(q) == 28, len(q)                   # two whole rounds of loads are in flight at the loop boundary
     q = replay(code, q, True)
-    assert len(q) == 14
-    # the peeled last stage: the 18 MFMAs after the loop with no load between them
+    assert len(q) == 28
+    # the two peeled last stages: the 36 MFMAs after the loop with no load between them
     lines = [l.split(";")[0].strip() for l in body.split("\n")]
     end = max(i for i, l in enumerate(lines) if l == loop[-1].split(";")[0].strip())
     tail, n = [], 0
@@ -176,8 +166,8 @@ def test_register_fed_winograd_matrix_loop_counts_its_own_loads(tmp_path):
         if l and not l.startswith(".") and not l.endswith(":"):
             tail.append(l)
             n += "v_mfma_f32_32x32x2" in l
-            if n == 18:
+            if n == 36:
                 break
-    assert n == 18 and not any(l.startswith("global_load") for l in tail)
-    assert [int(m.group(1)) for l in tail for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", l)] if m] == [11, 8, 5, 2, 0]
+    assert n == 36 and not any(l.startswith("global_load") for l in tail)
+    assert [int(m.group(1)) for l in tail for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", l)] if m] == [25, 22, 19, 16, 14, 11, 8, 5, 2, 0]
     assert replay(tail, q, True) == []

@@ -148,8 +148,9 @@ def test_1x1_weight_gradients_pipelined_and_chunked():
     T.check_wgrad_1x1("cuda")
 
 
-def test_weight_gradient_fed_by_the_forward_launch(monkeypatch):
-    T.check_wino_v_from_forward("cuda", monkeypatch)
+@pytest.mark.parametrize("dropout", [False, True])
+def test_weight_gradient_fed_by_the_forward_launch(monkeypatch, dropout):
+    T.check_wino_v_from_forward("cuda", monkeypatch, dropout=dropout)
 
 
 def test_conv3x3_winograd_f4x4_register_fed_matrix_kernel():

@@ -53,7 +53,7 @@ def test_forward_on_the_bf16_matrix_pipe(name, monkeypatch):
 
 @pytest.mark.parametrize("name", ["unet_small_ncsnpp", "unet_small_ffhq", "unet_cifar_ncsnpp"])
 def test_forward_winograd_f4x4_in_two_kernels(name, monkeypatch):
-    """SSDE_WINO4_TWO=2: every F(4x4,3x3) layer as a transform pass + the matrix kernel (conv_wino4g.hip); the production rule
+    """SSDE_WINO4_TWO=2: every F(4x4,3x3) layer as a transform pass + the register-fed matrix kernel (conv_wino4r.hip); the production rule
     (from four cout tiles up) is what test_forward_matches_reference_golden runs on the CIFAR network"""
     monkeypatch.setenv("SSDE_WINOGRAD", "4")
     monkeypatch.setenv("SSDE_WINO4_TWO", "2")

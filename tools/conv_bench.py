@@ -25,8 +25,7 @@ def time_conv(n, cin, cout, h, tile, gn=False, reps=5, resid=False, flags=0):
         mean, rstd = ops.groupnorm_stats(x, G, 1e-6)
         gnt = (mean, rstd, torch.ones(cin, device=dev), torch.zeros(cin, device=dev), G)
     ops._fill_src(a.main, x, None, {0: L.PRO_NONE, 1: L.PRO_GN_SILU, 2: L.PRO_GN, 3: L.PRO_SILU}[int(gn)], gnt)
-    wp = {L.TILE_WINOGRAD: pack_wino_weight, L.TILE_WINOGRAD4: pack_wino4_weight, L.TILE_WINOGRAD4G: pack_wino4_weight,
-          L.TILE_WINOGRAD4R: pack_wino4r_weight}.get(tile, pack_conv_weight)(w)
+    wp = {L.TILE_WINOGRAD: pack_wino_weight, L.TILE_WINOGRAD4: pack_wino4_weight, L.TILE_WINOGRAD4R: pack_wino4r_weight}.get(tile, pack_conv_weight)(w)
     dst = torch.empty(n, h, h, cout, device=dev)
     if resid:
         rs = torch.randn(n, h, h, cout, device=dev)
@@ -34,7 +33,7 @@ def time_conv(n, cin, cout, h, tile, gn=False, reps=5, resid=False, flags=0):
     a.w_main, a.ksize, a.stride, a.pad, a.h_in, a.w_in = wp.data_ptr(), 3, 1, 1, h, h
     a.n, a.h_out, a.w_out, a.c_out, a.out_scale, a.dst, a.tile = n, h, h, cout, 1.0, dst.data_ptr(), tile
     a.flags = L.conv_route_flags() | flags
-    if tile in (L.TILE_WINOGRAD4G, L.TILE_WINOGRAD4R) or os.environ.get("CONV_BENCH_EMIT_V"):      # the transformed-input buffer (36 / 16 of the tensor)
+    if tile == L.TILE_WINOGRAD4R or os.environ.get("CONV_BENCH_EMIT_V"):      # the transformed-input buffer (36 / 16 of the tensor)
         vbuf = torch.empty(36 * n * (h // 4) * (h // 4) * cin, device=dev)
         a.wino_v = vbuf.data_ptr()
     lib = L.load()

@@ -1,9 +1,9 @@
 // 3x3 / stride 1 / pad 1 convolution by Winograd F(4x4, 3x3), two-kernel form, matrix kernel fed from REGISTERS.
 //
-//   wino4_xform_vq_kernel (wino4_xform.hip)   V[pos][Cin/4][t][4] = B^T pro(x) B      HBM-bound pass
+//   wino4_xform_vq_kernel (conv_wino4g.hip)   V[pos][Cin/4][t][4] = B^T pro(x) B      HBM-bound pass
 //   conv_wino4r_kernel (this file)            Y = A^T [ sum_ci U .* V ] A             no LDS, no barrier in the main loop
 //
-// Round 4's matrix kernel (conv_wino4g.hip, now tools/experiments/conv_wino4g_lds_fed/) moved both operands through LDS by LDS-DMA and sits at ~3050 cycles per 4-channel
+// Round 4's matrix kernel (conv_wino4g.hip) moves both operands through LDS by LDS-DMA and sits at ~3050 cycles per 4-channel
 // stage for 2304 matrix cycles.  tools/microbench/fill_path.hip (profiles/r5_fill_path_microbench.txt) separates the causes:
 // beside a running fp32 MFMA chain the CU takes 64 KB per stage from L2 at NO cost by either route (LDS-DMA 2376 cycles per
 // stage, global_load_dwordx4 into VGPRs 2304 = the matrix bound), so neither the TA, nor the TCP -> LDS write, nor the L2 is the
@@ -48,20 +48,25 @@ constexpr int kNP = 9, kPS = 4;                     // positions per wave; wave 
 constexpr int kPos = 36, kTiles = 32;
 constexpr int kURegion = kNP * 32 * 4;              // floats of a stage's weight image only wave (q, h) reads (4.5 KB)
 constexpr int kUFloats = 8 * kURegion;              // one (stage, 64-cout tile) of the image
-// 8 waves, 32 tiles x 64 couts, one workgroup per CU (conv_wino4.hip's shape).  A 4-wave form with two workgroups per CU, the
-// second one started half a tile late so that one's epilogue would run under the other's MFMAs, was built and measured level:
-// the epilogue is VALU / issue work and fp32 MFMAs share the VALU datapath (tools/experiments/conv_wino4r_two_workgroups_per_cu/)
-constexpr int kWaves = 8, kThreads = 64 * kWaves, kBN = 64;
-constexpr int kLdm = kBN + 2, kLdt = kBN + 4;       // pitches of the product exchange and of the parked output tile
-constexpr int kLds = kPos * 16 * kLdm * 4;          // the epilogue's product exchange (the parked tile fits inside)
-static_assert(256 * kLdt <= kPos * 16 * kLdm, "parked tile");
+// kNH = cout halves per workgroup: 2 = 8 waves, 32 tiles x 64 couts, one workgroup per CU (conv_wino4.hip's shape);
+// 1 = 4 waves, 32 tiles x 32 couts, TWO workgroups per CU (each half the registers, half the epilogue LDS): while one is in its
+// epilogue -- 27 k cycles without an MFMA, 15-25 % of a workgroup's life at 128-256 input channels -- the other's waves have
+// the matrix pipes to themselves
+template <int kNH> struct W4R {
+  static constexpr int kWaves = 4 * kNH, kThreads = 64 * kWaves, kBN = 32 * kNH;
+  static constexpr int kLdm = kBN + 2, kLdt = kBN + 4;      // pitches of the product exchange and of the parked output tile
+  static constexpr int kLds = kPos * 16 * kLdm * 4;        // the epilogue's product exchange (the parked tile fits inside)
+  static_assert(256 * kLdt <= kPos * 16 * kLdm, "parked tile");
+};
 
 struct Wino4rParams {
   const float* v;          // [36][Ctot / 4][T][4]
   const float* wpk;        // SSDE_PACK_WINO4R: [Ctot / 4][n_tiles][8 waves][4 x [64 lanes][4] | [64 lanes][2]]
   int N, H, W, Cout, Ctot;
   int lTWt, lTHt;
-  int tiles_x, tiles_per_img, m_tiles, n_tiles;
+  int tiles_x, tiles_per_img, m_tiles, n_tiles;       // n_tiles: cout tiles of 32 kNH channels
+  int n_tiles64;                                      // 64-cout tiles of the weight image
+  int stagger_mode, stagger_cycles, first_fill;       // kNH == 1: see the kernel's head
   const float* bias; const float* chan_add; int chan_add_ld;
   const float* resid; int resid_post;
   float scale;
@@ -70,7 +75,9 @@ struct Wino4rParams {
   int T, tiles_h, tiles_w;
 };
 
-__global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rParams p) {
+template <int kNH>
+__global__ __launch_bounds__(W4R<kNH>::kThreads, 2) void conv_wino4r_kernel(const Wino4rParams p) {
+  constexpr int kThreads = W4R<kNH>::kThreads, kBN = W4R<kNH>::kBN, kLdm = W4R<kNH>::kLdm, kLdt = W4R<kNH>::kLdt;
   SSDE_LDS(smem);                               // the epilogue's only
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
   const int nt = l % p.n_tiles;
   const int mt = (l / p.n_tiles) * 8 + xcd;
 #ifdef SSDE_W4R_TRACE
-  const bool tr_on = lane == 0 && (wave == 0 || wave == kWaves - 1) && bid == 0 && g_w4r_trace != nullptr;
+  const bool tr_on = lane == 0 && (wave == 0 || wave == W4R<kNH>::kWaves - 1) && bid == 0 && g_w4r_trace != nullptr;
   const int tr_base = (wave == 0 ? 0 : 1) * 128;
 #endif
   SSDE_RT(0);
@@ -95,7 +102,25 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
   const int ty = trem / p.tiles_x, tx = trem % p.tiles_x;
   const int n0 = nt * kBN;
   const int nst = p.Ctot >> 2;
-  const int wq = wave >> 1, wh = wave & 1;
+  const int wq = kNH == 2 ? wave >> 1 : wave;
+  const int wh = kNH == 2 ? (wave & 1) : (nt & 1);           // which half of a 64-cout tile of the weight image
+  const int nt64 = kNH == 2 ? nt : nt >> 1;
+#ifndef SSDE_EMULATED
+  if (kNH == 1 && p.stagger_mode != 0 && bid < p.first_fill) {
+    // Two of these workgroups share a CU.  Started together they stay in step -- both in their main loops (each at half the
+    // matrix rate), then both in their epilogues (the matrix pipes idle).  The workgroup that finds itself SECOND on its CU
+    // therefore starts half a tile late (the first one runs alone, at up to twice the rate, meanwhile); after that the two are
+    // out of phase for the rest of the launch, later workgroups inheriting the phase of the one whose place they take.
+    bool second;
+    if (p.stagger_mode == 1) second = (__builtin_amdgcn_s_getreg((31 << 11) | 6) & 0x1ff) != 0;        // HW_REG_LDS_ALLOC: LDS base != 0
+    else if (p.stagger_mode == 2) second = (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1) != 0;        // HW_REG_HW_ID: wave slot parity
+    else second = ((bid >> 3) & 63) >= 32;                                                             // dispatch order within the XCD
+    if (second) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)p.stagger_cycles) __builtin_amdgcn_s_sleep(32);
+    }
+  }
+#endif
 
   // ---- A operand: the lane's byte offset of position slot j inside one stage's [36][Q][T][4] view of V (32-bit: the launcher
   // checks V < 4 GB); the stage rides in the scalar base.  Tiles outside the batch / the image read tile 0's run (a valid
@@ -115,8 +140,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
   // ---- B operand: the wave's 4.5 KB of a stage, lane-major; four 1 KB pieces at immediates -2048 .. 1024 around the base and
   // one 512-byte piece behind them
   const uint32_t u_off = (uint32_t)lane * 16u, u_off8 = 2048u + (uint32_t)lane * 8u;
-  const char* us = reinterpret_cast<const char*>(p.wpk + ((size_t)nt * kWaves + wave) * kURegion) + 2048;
-  const size_t u_stage = (size_t)p.n_tiles * kUFloats * 4;
+  const char* us = reinterpret_cast<const char*>(p.wpk + ((size_t)nt64 * 8 + 2 * wq + wh) * kURegion) + 2048;
+  const size_t u_stage = (size_t)p.n_tiles64 * kUFloats * 4;
 
   f32x16 acc[kNP];
 #pragma unroll
@@ -220,7 +245,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
       for (int r8 = 0; r8 < 8; ++r8) {
         const int r = rnd * 8 + r8;
         const int tl = (r & 3) + 4 * lh + 8 * ((r >> 2) & 1);
-        smem[((wq + kPS * j) * 16 + tl) * kLdm + wh * 32 + li] = acc[j][r];
+        smem[((wq + kPS * j) * 16 + tl) * kLdm + (kNH == 2 ? wh * 32 : 0) + li] = acc[j][r];
       }
     SSDE_LDS_BARRIER();      // (LDS-only barriers throughout: a __syncthreads() would wait out the previous round's global stores)
     float2 y[4][4];
@@ -283,15 +308,10 @@ int pow2_floor(int v) { int q = 1; while (q * 2 <= v) q *= 2; return q; }
 }  // namespace
 
 // stream == (void*)1 with lds_out: plan-only query of the GroupNorm slices per image (conv_mfma.hip, ssde_conv_gn_slices)
-int ssde_conv_wino4r_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
-  SSDE_REQUIRE(a && a->dst && a->main.p0 && a->w_main, "conv(winograd 4x4, register-fed): null args");
-  SSDE_REQUIRE(a->ksize == 3 && a->stride == 1 && a->pad == 1, "conv(winograd 4x4, register-fed): needs 3x3, stride 1, pad 1");
-  SSDE_REQUIRE(a->aux.p0 == nullptr, "conv(winograd 4x4, register-fed): fused 1x1 source not supported (issue it as a second conv)");
-  SSDE_REQUIRE(a->h_in == a->h_out && a->w_in == a->w_out && a->h_out % 4 == 0 && a->w_out % 4 == 0 && a->h_out >= 8 && a->w_out >= 8,
-               "conv(winograd 4x4, register-fed): same-size output, multiples of 4, at least 8x8 (got %dx%d)", a->h_out, a->w_out);
+template <int kNH>
+static int wino4r_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
+  constexpr int kThreads = W4R<kNH>::kThreads, kBN = W4R<kNH>::kBN;
   const ssde_src& s = a->main;
-  SSDE_REQUIRE(s.c0 > 0 && s.c0 % 4 == 0 && s.c1 % 4 == 0 && (s.c1 == 0 || s.p1), "conv(winograd 4x4, register-fed): channels must be multiples of 4");
-  SSDE_REQUIRE((s.c0 + s.c1) % 8 == 0, "conv(winograd 4x4, register-fed): input channels must be a multiple of 8 (the stage loop runs in pairs)");
   Wino4rParams p;
   p.v = a->wino_v; p.wpk = a->w_main;
   p.N = a->n; p.H = a->h_out; p.W = a->w_out; p.Cout = a->c_out; p.Ctot = s.c0 + s.c1;
@@ -304,6 +324,7 @@ int ssde_conv_wino4r_launch(const ssde_conv_args* a, void* stream, int* lds_out)
   p.tiles_per_img = p.tiles_x * ssde_cdiv(a->h_out, 4 * tht);
   p.m_tiles = ssde_cdiv(a->n, imgs) * p.tiles_per_img;
   p.n_tiles = ssde_cdiv(a->c_out, kBN);
+  p.n_tiles64 = ssde_cdiv(a->c_out, 64);
   p.bias = a->bias; p.chan_add = a->chan_add; p.chan_add_ld = a->chan_add_ld;
   p.resid = a->resid; p.resid_post = a->resid_post; p.scale = a->out_scale; p.dst = a->dst;
   p.gn_part = a->gn_part;
@@ -314,20 +335,37 @@ int ssde_conv_wino4r_launch(const ssde_conv_args* a, void* stream, int* lds_out)
     *lds_out = gn_ok ? (imgs == 1 ? 2 * p.tiles_per_img : 1) * (kThreads / 64) : 0;
     return SSDE_OK;
   }
-  const int lds = kLds;
-  SSDE_REQUIRE(lds <= 160 * 1024, "conv(winograd 4x4, register-fed): %d bytes of LDS", lds);
+  const int lds = W4R<kNH>::kLds;
+  SSDE_REQUIRE(lds * (3 - kNH) <= 160 * 1024, "conv(winograd 4x4, register-fed): %d bytes of LDS", lds);
   if (lds_out) { *lds_out = lds; return SSDE_OK; }
   SSDE_REQUIRE(a->wino_v, "conv(winograd 4x4, register-fed): the transformed-input buffer (ssde_conv_args.wino_v) is missing");
   SSDE_REQUIRE(36ull * (unsigned long long)p.T * (unsigned)p.Ctot * 4ull < (1ull << 32),
                "conv(winograd 4x4, register-fed): a transformed input of 4 GB or more is not addressable by this kernel");
   const int wgs = ssde_cdiv(p.m_tiles, 8) * 8 * p.n_tiles;
+  // the second workgroup of a CU starts half a tile late: the matrix time of one workgroup's main loop (18 MFMAs of 64 cycles
+  // per 4-channel stage with the pipe to itself)
+  p.stagger_mode = kNH == 1 ? ssde_debug_int("w4r_stagger", 0) : 0;
+  p.stagger_cycles = 18 * 64 * (p.Ctot >> 2);
+  p.first_fill = 2 * ssde_num_cus();
   static std::atomic<bool> attr_set;
   if (!attr_set) {                              // once, before any stream capture
-    SSDE_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    SSDE_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4r_kernel<kNH>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      160 * 1024) == hipSuccess, "conv(winograd 4x4, register-fed): hipFuncSetAttribute failed");
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_wino4r_kernel, dim3(wgs), dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
+  hipLaunchKernelGGL(conv_wino4r_kernel<kNH>, dim3(wgs), dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;
+}
+
+int ssde_conv_wino4r_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
+  SSDE_REQUIRE(a && a->dst && a->main.p0 && a->w_main, "conv(winograd 4x4, register-fed): null args");
+  SSDE_REQUIRE(a->ksize == 3 && a->stride == 1 && a->pad == 1, "conv(winograd 4x4, register-fed): needs 3x3, stride 1, pad 1");
+  SSDE_REQUIRE(a->aux.p0 == nullptr, "conv(winograd 4x4, register-fed): fused 1x1 source not supported (issue it as a second conv)");
+  SSDE_REQUIRE(a->h_in == a->h_out && a->w_in == a->w_out && a->h_out % 4 == 0 && a->w_out % 4 == 0 && a->h_out >= 8 && a->w_out >= 8,
+               "conv(winograd 4x4, register-fed): same-size output, multiples of 4, at least 8x8 (got %dx%d)", a->h_out, a->w_out);
+  const ssde_src& s = a->main;
+  SSDE_REQUIRE(s.c0 > 0 && s.c0 % 4 == 0 && s.c1 % 4 == 0 && (s.c1 == 0 || s.p1), "conv(winograd 4x4, register-fed): channels must be multiples of 4");
+  SSDE_REQUIRE((s.c0 + s.c1) % 8 == 0, "conv(winograd 4x4, register-fed): input channels must be a multiple of 8 (the stage loop runs in pairs)");
+  return (a->flags & SSDE_CONVF_W4R_WIDE) ? wino4r_launch<2>(a, stream, lds_out) : wino4r_launch<1>(a, stream, lds_out);
 }

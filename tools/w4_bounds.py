@@ -15,9 +15,10 @@ if __name__ == "__main__":
         tf, ms = cb.time_conv(n, cin, cout, h, L.TILE_WINOGRAD4, 1, reps=10)
         out.append("%d->%d@%d %.4f ms (%.0f TF/s)" % (cin, cout, h, ms, tf))
         if os.environ.get("W4_BOUNDS_TWO"):                        # + the two-kernel forms: both kernels, the matrix kernel alone
-            for label, tile in (("LDS-fed", L.TILE_WINOGRAD4G), ("register-fed", L.TILE_WINOGRAD4R)):
-                tf, ms = cb.time_conv(n, cin, cout, h, tile, 1, reps=10)
-                tf2, ms2 = cb.time_conv(n, cin, cout, h, tile, 1, reps=10, flags=L.CONVF_V_GIVEN)
+            forms = (("two kernels", L.TILE_WINOGRAD4R, 0),)
+            for label, tile, fl in forms:
+                tf, ms = cb.time_conv(n, cin, cout, h, tile, 1, reps=10, flags=fl)
+                tf2, ms2 = cb.time_conv(n, cin, cout, h, tile, 1, reps=10, flags=fl | L.CONVF_V_GIVEN)
                 out[-1] += " ; %s %.4f ms (%.0f TF/s) = transform pass %.4f + matrix kernel %.4f (%.0f TF/s)" % (label, ms, tf, ms - ms2, ms2, tf2)
             out[-1] += "\n"
     print(os.path.basename(os.environ.get("SSDE_LIB_PATH", "product")), " | ".join(out), flush=True)

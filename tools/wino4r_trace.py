@@ -26,6 +26,6 @@ for (cin, cout, h) in [(128, 128, 32), (256, 256, 16), (512, 256, 16)]:
     for wv in range(2):
         r = t[wv].astype(np.int64)
         d = lambda a, b: int(r[b] - r[a]) if r[a] and r[b] else -1   # noqa: E731
-        print(" wave %d: setup %d | first loads issued %d | loop %d (%d stages: %.0f per stage) | epilogue half0 %d half1 %d | total %d"
-              % (wv * 7, d(0, 1), d(1, 2), d(2, 3), cin // 4, d(2, 3) / (cin // 4), d(3, 4), d(4, 5), d(0, 5)))
+        print(" wave %s: setup %d | first loads issued %d | loop %d (%d stages: %.0f per stage) | epilogue half0 %d half1 %d | total %d"
+              % (("0", "last")[wv], d(0, 1), d(1, 2), d(2, 3), cin // 4, d(2, 3) / (cin // 4), d(3, 4), d(4, 5), d(0, 5)))
         print("   stages 0-7: " + " | ".join("%d + %d" % (d(8 + 2 * k, 9 + 2 * k), d(9 + 2 * k, 10 + 2 * k)) for k in range(7)) + "   (slots 0-5 + slots 6-8)")
