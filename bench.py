@@ -66,6 +66,13 @@ def parse(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the compact ffhq256 / subvp_ode measurements")
     ap.add_argument("--dump-ops", type=str, default="")
     ap.add_argument("--no-train", action="store_true", help="skip the DSM training-step measurement")
+    ap.add_argument("--train-only", action="store_true",
+                    help="only the DSM training step (the leg that has a collective): what a multi-GPU scaling run needs per N")
+    ap.add_argument("--matrix", default=os.environ.get("SSDE_MATRIX", "bf16x6"), choices=["bf16x6", "f32"],
+                    help="matrix mode of the headline legs: bf16x6 = the 1x1 / NIN / Linear GEMMs as exact-fp32 products of a 3-way "
+                         "bf16 split on the BF16 matrix pipe (fp32 accumulation; no further from fp64 than the fp32 MFMA, "
+                         "tests/test_ops_gpu.py), f32 = the exact-fp32 MFMA kernels everywhere.  The other mode is measured beside it")
+    ap.add_argument("--no-other-matrix", action="store_true", help="skip the legs in the other matrix mode")
     ap.add_argument("--workload", default="cifar10", choices=["cifar10", "ffhq256", "subvp_ode", "subvp_likelihood"],
                     help="cifar10 = BASELINE configs[1] (the headline line); ffhq256 = configs[3] (NCSN++ 256x256, N=2000, batch "
                          "16/GPU); subvp_ode = configs[4] (DDPM++ sub-VP, probability-flow ODE sampler with RK45; 1 step = 1 solve); "
@@ -122,10 +129,13 @@ def bench_train(args, cfg, dev, dist, world, rank, sync_all):
         loss = step_fn(state, pool[(w + i) % len(pool)])
     sync_all()
     dt = time.perf_counter() - t0
+    per_rank_ms = [dt / k * 1e3]
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # every rank's own time goes into the line (a straggler or a fallback transport shows as a spread), the MAX is the step
+        ts = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(ts, torch.tensor([dt], device=dev, dtype=torch.float64))
+        per_rank_ms = [float(t.item()) / k * 1e3 for t in ts]
+        dt = max(float(t.item()) for t in ts)
     sec = dt / k
     fs = step_fn.fused_for(state, batch)
     eng = fs.eng
@@ -162,6 +172,8 @@ def bench_train(args, cfg, dev, dist, world, rank, sync_all):
            "algorithmic_tflops": float(fl.sum()) / sec / 1e12, "gflop_per_image": float(fl.sum()) / Bt / 1e9,
            "grad_allreduce_mb": eng.flat.numel * 4 / 1e6 if world > 1 else 0.0, "allreduce_exposed_ms": exposed_ms,
            "replicas_bit_identical_after_timed_steps": replicas_equal,
+           "per_rank_ms_per_step": [round(v, 3) for v in per_rank_ms],
+           "rank_spread_max_over_min": max(per_rank_ms) / min(per_rank_ms),
            "arena_gb": eng.b.arena_bytes / 1e9}
     if rank == 0 and not args.no_roofline:
         ms = np.array(eng.program.run_range_timed(0, eng.program.n))
@@ -265,12 +277,40 @@ def _sync_factory(dev, dist):
     return sync_all
 
 
-def _max_over_ranks(dt, dev, dist):
+def _max_over_ranks(dt, dev, dist, per_rank=None):
+    """MAX over the ranks of a timed region (the job's time); per_rank (a list) receives every rank's own time."""
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        ts = [torch.zeros(1, device=dev, dtype=torch.float64) for _ in range(dist.get_world_size())]
+        dist.all_gather(ts, torch.tensor([dt], device=dev, dtype=torch.float64))
+        if per_rank is not None:
+            per_rank.extend(float(t.item()) for t in ts)
+        dt = max(float(t.item()) for t in ts)
+    elif per_rank is not None:
+        per_rank.append(dt)
     return dt
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def matrix_mode(mode):
+    """SSDE_MATRIX for the programs lowered inside the block (the host maps it to SSDE_CONVF_BF16X6 when it builds launch
+    arguments); the caller's own setting is restored afterwards."""
+    prev = os.environ.get("SSDE_MATRIX")
+    os.environ["SSDE_MATRIX"] = mode
+    try:
+        yield
+    finally:
+        if prev is None:
+            os.environ.pop("SSDE_MATRIX", None)
+        else:
+            os.environ["SSDE_MATRIX"] = prev
+
+
+DTYPE = {"f32": "f32 (exact-fp32 MFMA kernels everywhere)",
+         "bf16x6": "f32 via 3-way bf16 split, fp32 accumulate (the 1x1 / NIN / Linear GEMMs as exact-fp32 products on the BF16 matrix pipe; "
+                   "3x3 convolutions and attention on the fp32-MFMA kernels)"}
 
 
 def op_bytes(op):
@@ -415,9 +455,11 @@ def bench_pc(args, cfg_name, B, N, dev, dist, world, rank, steps, warmup, detail
     t0 = time.perf_counter()
     eng.run_steps(prog, steps, use_graph)
     sync_all()
-    dt = _max_over_ranks(time.perf_counter() - t0, dev, dist)
+    per_rank = []
+    dt = _max_over_ranks(time.perf_counter() - t0, dev, dist, per_rank)
     ms_per_step = dt / steps * 1e3
     res = {"value": world * B / (N * ms_per_step * 1e-3), "unit": "images/s", "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup,
+           "per_rank_ms_per_step": [round(t / steps * 1e3, 3) for t in per_rank], "rank_spread_max_over_min": max(per_rank) / min(per_rank),
            "workload": "configs/%s PC sampler (reverse_diffusion+langevin), batch %d/GPU, N=%d, %dx%d; 1 step = 1 PC iteration = "
                        "2 U-Net evaluations" % (cfg_name, B, N, R, R),
            "batch_per_gpu": B, "sde_steps": N, "nfe_per_step": eng.nfe_per_step(), "path": eng.last_path,
@@ -633,6 +675,14 @@ def _phase(msg):
     print("[bench %7.1f s] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
 
+def _rccl_version():
+    """What NCCL_DEBUG=VERSION would print: the collective library torch.distributed's "nccl" backend is linked against."""
+    try:
+        return "RCCL %s (torch %s, HIP %s)" % (".".join(str(v) for v in torch.cuda.nccl.version()), torch.__version__, torch.version.hip)
+    except Exception as e:                        # noqa: BLE001
+        return "unavailable: %s" % e
+
+
 def mfma_probe(dev, iters=20000, reps=5):
     """TFLOP/s of back-to-back fp32 MFMAs on every SIMD (the C ABI's diagnostic ssde_mfma_probe), best of `reps`."""
     import ctypes as C
@@ -663,7 +713,7 @@ def main():
         raise SystemExit(_self_launch(args.gpus, args.share_device))
     n_dev = torch.cuda.device_count()
     lr = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(lr % n_dev if args.share_device else lr)
+    torch.cuda.set_device(lr % max(n_dev, 1) if args.share_device else lr)
     world, rank, dev, dist, rccl_ranks = rank_setup(args, os.environ, n_dev)
 
     import _util
@@ -690,19 +740,37 @@ def main():
     else:
         cfg_name = "ve/cifar10_ncsnpp_continuous"
     sync_all = _sync_factory(dev, dist)
-    res, eng, model, sd, cfg = bench_pc(args, cfg_name, args.batch, args.sde_steps, dev, dist, world, rank, args.steps, args.warmup, True)
+    other = "f32" if args.matrix == "bf16x6" else "bf16x6"
+    if world > 1:
+        # a multi-GPU run is a scaling point: the headline legs only (no CPU baseline, no other configs, no other matrix mode)
+        args.no_extras = args.no_other_matrix = True
+    if args.train_only:
+        with matrix_mode(args.matrix):
+            tr = bench_train(args, _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous"), dev, dist, world, rank, sync_all)
+        tr.update(n_gpus=world, scaling="weak", vs_baseline=None, dtype=DTYPE[args.matrix], data="synthetic", rccl_ranks=rccl_ranks,
+                  ms_per_step=tr["value"] * 1e3, dist_backend=args.dist_backend if world > 1 else None,
+                  rccl_version=_rccl_version(), config={"workload": "configs/ve/cifar10_ncsnpp_continuous DSM training step, batch %d/GPU" % args.train_batch,
+                                                        "matrix_mode": args.matrix, "parallelism": "data parallel x%d" % world})
+        if rank == 0:
+            print(json.dumps(tr))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    with matrix_mode(args.matrix):
+        res, eng, model, sd, cfg = bench_pc(args, cfg_name, args.batch, args.sde_steps, dev, dist, world, rank, args.steps, args.warmup, True)
     B, R = args.batch, cfg.data.image_size
     roof = res.pop("_roof", None)
     out = {
         "metric": "pc_sampler_images_per_sec", "value": res["value"], "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "rccl_ranks": rccl_ranks, "dist_backend": args.dist_backend if world > 1 else None,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[args.matrix], "data": "synthetic",
+        "rccl_ranks": rccl_ranks, "dist_backend": args.dist_backend if world > 1 else None, "rccl_version": _rccl_version(),
+        "per_rank_ms_per_step": res["per_rank_ms_per_step"], "rank_spread_max_over_min": res["rank_spread_max_over_min"],
         "config": {"workload": res["workload"], "batch_per_gpu": B, "sde_steps": args.sde_steps, "nfe_per_step": res["nfe_per_step"],
                    "path": res["path"], "state_finite": res["state_finite"], "unet_gflop_per_image": res["unet_gflop_per_image"],
                    "end_to_end_tflops": res["end_to_end_tflops"],
                    "direct_form_ceiling_images_per_sec": res["direct_form_ceiling_images_per_sec"],
-                   "parallelism": "replicas x%d (no collectives)" % world},
+                   "matrix_mode": args.matrix, "parallelism": "replicas x%d (no collectives)" % world},
     }
 
     if roof is not None:
@@ -784,13 +852,41 @@ def main():
     torch.cuda.empty_cache()
     if not args.no_train:
         # second headline quantity of BASELINE.json's metric ("... + sec/train-step"): reported inside the same JSON line
-        tr = bench_train(args, _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous"), dev, dist, world, rank, sync_all)
+        with matrix_mode(args.matrix):
+            tr = bench_train(args, _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous"), dev, dist, world, rank, sync_all)
         out["train"] = tr
         torch.cuda.empty_cache()
         _phase("train step done")
+    if not args.no_other_matrix and args.workload == "cifar10":
+        # the other matrix mode beside the headline, in the same run: the sampler of the headline mode once more (minutes into
+        # the run the device is warmer than it was for the headline), then the other mode, then its training step
+        with matrix_mode(args.matrix):
+            ra, ea, ma, _, _ = bench_pc(args, "ve/cifar10_ncsnpp_continuous", args.batch, args.sde_steps, dev, dist, world, rank,
+                                        args.steps, args.warmup, False)
+        del ea, ma
+        torch.cuda.empty_cache()
+        with matrix_mode(other):
+            rb, eb, mb, _, _ = bench_pc(args, "ve/cifar10_ncsnpp_continuous", args.batch, args.sde_steps, dev, dist, world, rank,
+                                        args.steps, args.warmup, False)
+            del eb, mb
+            torch.cuda.empty_cache()
+            mx = {"dtype": DTYPE[other], "matrix_mode": other,
+                  "sampler": {k: rb[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "state_finite")},
+                  "sampler_%s_measured_just_before" % args.matrix: {k: ra[k] for k in ("value", "unit", "ms_per_step")},
+                  "headline_mode_over_this_mode": ra["value"] / rb["value"]}
+            if not args.no_train:
+                a2 = argparse.Namespace(**vars(args))
+                a2.no_roofline = True
+                a2.train_steps, a2.train_warmup = min(args.train_steps, 30), min(args.train_warmup, 5)
+                tb = bench_train(a2, _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous"), dev, dist, world, rank, sync_all)
+                mx["train"] = {k: tb[k] for k in ("value", "unit", "steps", "warmup", "loss")}
+                torch.cuda.empty_cache()
+        out["matrix_" + other] = mx
+        _phase("other matrix mode (%s) done" % other)
     if not args.no_extras:
         # the other BASELINE configs, compact, so that the driver's default run witnesses them
         extra = {}
+        os.environ["SSDE_MATRIX"] = args.matrix       # (the other configs run in the headline's matrix mode)
         r3, e3, m3, _, _ = bench_pc(args, "ve/ffhq_256_ncsnpp_continuous", 16, 2000, dev, dist, world, rank, min(args.steps, 5), 2, False)
         extra["ffhq256"] = r3
         _phase("ffhq256 done")
@@ -803,36 +899,6 @@ def main():
         # evaluations of forward + input gradient, ~110 s); --likelihood-tol loosens it for quick runs
         extra["subvp_likelihood"] = bench_likelihood(args, dev, dist, world, rank, tol=args.likelihood_tol)
         _phase("subvp_likelihood done")
-        # SSDE_MATRIX=bf16x6 (opt-in): the GEMM-shaped kernels on the BF16 matrix pipe through a 3-way split of both
-        # operands (exact products, fp32 accumulation; error table in profiles/r4_bf16_split_error_budget.txt).  The headline
-        # `value` above stays on the fp32-MFMA kernels; this is the same sampler / training step measured in the same run.
-        # (the fp32 sampler is measured again right before it: minutes into the run the device is warmer than for the headline)
-        ra, ea, ma, _, _ = bench_pc(args, "ve/cifar10_ncsnpp_continuous", args.batch, args.sde_steps, dev, dist, world, rank,
-                                    args.steps, args.warmup, False)
-        del ea, ma
-        torch.cuda.empty_cache()
-        os.environ["SSDE_MATRIX"] = "bf16x6"
-        try:
-            rb, eb, mb, _, _ = bench_pc(args, "ve/cifar10_ncsnpp_continuous", args.batch, args.sde_steps, dev, dist, world, rank,
-                                        args.steps, args.warmup, False)
-            del eb, mb
-            torch.cuda.empty_cache()
-            mx = {"dtype": "f32 via 3-way bf16 split on the BF16 matrix pipe (1x1 / NIN / Linear GEMMs), fp32 accumulate; 3x3 convolutions "
-                           "and attention on the fp32-MFMA kernels",
-                  "sampler": {k: rb[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "state_finite")},
-                  "sampler_f32_measured_just_before": {k: ra[k] for k in ("value", "unit", "ms_per_step")},
-                  "sampler_speedup_over_f32": rb["value"] / ra["value"]}
-            if not args.no_train:
-                a2 = argparse.Namespace(**vars(args))
-                a2.no_roofline = True
-                a2.train_steps, a2.train_warmup = min(args.train_steps, 30), min(args.train_warmup, 5)
-                tb = bench_train(a2, _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous"), dev, dist, world, rank, sync_all)
-                mx["train"] = {k: tb[k] for k in ("value", "unit", "steps", "warmup", "loss")}
-                torch.cuda.empty_cache()
-            extra["matrix_bf16x6"] = mx
-        finally:
-            os.environ.pop("SSDE_MATRIX", None)
-        _phase("matrix_bf16x6 done")
         out["extra"] = extra
 
     if rank == 0:

@@ -21,6 +21,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# the 3-way bf16 split of the GEMM-shaped contractions (SSDE_MATRIX=bf16x6 -> SSDE_CONVF_BF16X6) is the mode
+# bench.py's headline runs in, so EVERY GPU test runs in both matrix modes inside one `pytest -m gpu` invocation -- forwards,
+# trajectories, training steps, the 571 gradients, bench sizes, C-host plans -- at unchanged tolerances.  (The mode reaches the
+# library as a flag of the launch arguments the host builds, _lib.conv_route_flags; tests that pin a mode themselves override it.)
+MATRIX_MODES = ("f32", "bf16x6")
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.definition.get_closest_marker("gpu") is not None and "ssde_matrix_mode" in metafunc.fixturenames:
+        metafunc.parametrize("ssde_matrix_mode", MATRIX_MODES, indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def ssde_matrix_mode(request, monkeypatch):
+    mode = getattr(request, "param", None)
+    if mode is not None:
+        monkeypatch.setenv("SSDE_MATRIX", mode)
+    yield mode
+
+
 def pytest_collection_modifyitems(config, items):
     import torch
     if torch.cuda.is_available():

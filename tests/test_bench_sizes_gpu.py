@@ -43,11 +43,27 @@ def _model(cfg):
     return model.cuda().eval(), sd
 
 
+# Every test here runs once per matrix mode (conftest.MATRIX_MODES); the CPU oracle's answer for a test's seeded inputs does not
+# depend on the mode, so it is computed once per test function and kept (the oracle is the 2-3 minutes of this file).
+_ORACLE_MEMO = {}
+
+
+def _memo(key, fn):
+    if key not in _ORACLE_MEMO:
+        _ORACLE_MEMO[key] = fn()
+    return _ORACLE_MEMO[key]
+
+
 def _oracle_forward(cfg, sd, x, cond, chunk):
     from oracle import unet_oracle
-    with torch.no_grad():
-        return torch.cat([unet_oracle.ncsnpp_forward(cfg, sd, x[i:i + chunk], cond[i:i + chunk])
-                          for i in range(0, x.shape[0], chunk)])
+    import inspect
+    caller = inspect.stack()[1].function
+
+    def run():
+        with torch.no_grad():
+            return torch.cat([unet_oracle.ncsnpp_forward(cfg, sd, x[i:i + chunk], cond[i:i + chunk])
+                              for i in range(0, x.shape[0], chunk)])
+    return _memo(caller, run)
 
 
 def _kernel_mix(engine):
@@ -126,8 +142,8 @@ def test_cifar_pc_iteration_batch256():
                                       denoise=False, eps=1e-5, device="cuda")
     out, _ = sampler(model, x_init=x_T, noises=noises, max_steps=1)
     assert sampler.last_path == "fused-eager"
-    ref = sampler_oracle.pc_sample(cfg, sd, "vesde", dict(sigma_min=0.01, sigma_max=50, N=N), x_T, noises, snr=0.16,
-                                   n_steps=1, eps=1e-5, denoise=False, max_steps=1)
+    ref = _memo("test_cifar_pc_iteration_batch256", lambda: sampler_oracle.pc_sample(
+        cfg, sd, "vesde", dict(sigma_min=0.01, sigma_max=50, N=N), x_T, noises, snr=0.16, n_steps=1, eps=1e-5, denoise=False, max_steps=1))
     r = ref["x_steps"][0]
     _util.assert_trajectory_close(out, r, "PC iteration at batch 256")          # north_star's pixel-MSE yardstick, sharpened
     # score-norm yardstick: ||score|| of the second evaluation, read back from the engine, vs the oracle's
@@ -147,11 +163,14 @@ def test_cifar_gradients_batch128():
     x = torch.randn(B, 3, 32, 32, generator=g) * 2
     cond = torch.exp(torch.rand(B, generator=g) * 4 - 2)
     gout = torch.randn(B, 3, 32, 32, generator=g)
-    ys, gxs, ref = [], [], None
-    for i in range(0, B, chunk):
-        y_c, gx_c, gr = T.oracle_grads(cfg, sd, x[i:i + chunk], cond[i:i + chunk], gout[i:i + chunk])
-        ys.append(y_c); gxs.append(gx_c)
-        ref = gr if ref is None else {k: ref[k] + v for k, v in gr.items()}
+    def oracle():
+        ys, gxs, ref = [], [], None
+        for i in range(0, B, chunk):
+            y_c, gx_c, gr = T.oracle_grads(cfg, sd, x[i:i + chunk], cond[i:i + chunk], gout[i:i + chunk])
+            ys.append(y_c); gxs.append(gx_c)
+            ref = gr if ref is None else {k: ref[k] + v for k, v in gr.items()}
+        return ys, gxs, ref
+    ys, gxs, ref = _memo("test_cifar_gradients_batch128", oracle)
     eng = Bk.TrainEngine(model, B, 32, 32, torch.device("cuda"), input_grad=True, dropout=False)
     y = eng.forward_train(x.cuda(), cond.cuda()).clone()
     assert rel_err(y, torch.cat(ys)) < 1e-4
@@ -201,7 +220,8 @@ def test_ffhq256_pc_iteration_batch16():
     assert sampler.last_path == "fused-eager"
     wino, direct = _kernel_mix(sampler.engine.unet)
     assert wino >= 40, (wino, direct)
-    ref = sampler_oracle.pc_sample(cfg, sd, "vesde", kw, x_T, noises, snr=snr, n_steps=1, eps=1e-5, denoise=False, max_steps=1)
+    ref = _memo("test_ffhq256_pc_iteration_batch16", lambda: sampler_oracle.pc_sample(
+        cfg, sd, "vesde", kw, x_T, noises, snr=snr, n_steps=1, eps=1e-5, denoise=False, max_steps=1))
     r = ref["x_steps"][0]
     _util.assert_trajectory_close(out, r, "FFHQ-256 PC iteration")
     s = sampler.engine.unet.output_view()

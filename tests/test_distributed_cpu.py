@@ -52,10 +52,11 @@ def _worker(rank, world, port, out_dir):
     from score_sde_pytorch_amd import parallel
     parallel.init_from_env(backend="gloo")
     assert parallel.world_size() == world
-    _, model, state, step_fn, optimize_fn, batch, t, z = _build(4)
+    per = 2 if world == 2 else 1                      # samples per rank
+    _, model, state, step_fn, optimize_fn, batch, t, z = _build(world * per)
     with emu.emulated():
         parallel.broadcast_parameters(model)
-        sl = slice(rank * 2, rank * 2 + 2)
+        sl = slice(rank * per, rank * per + per)
         assert torch.equal(parallel.shard_batch(batch), batch[sl])
         loss, g_local, g_sum, params = _one_step(state, step_fn, optimize_fn, batch[sl].clone(), t[sl].clone(), z[sl].clone())
     torch.save(dict(loss=loss, g_sum=g_sum, params=params), os.path.join(out_dir, "rank%d.pt" % rank))
@@ -63,20 +64,23 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_allreduce_matches_full_batch(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])            # 8 = the node the driver's scaling run uses (one sample per rank here)
+def test_gradient_allreduce_matches_full_batch(tmp_path, world):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0, r1 = (torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in (0, 1))
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
+    r0 = rs[0]
     # replicas agree bit for bit after the exchange and the update
-    assert torch.equal(r0["g_sum"], r1["g_sum"]) and torch.equal(r0["params"], r1["params"])
+    for r in rs[1:]:
+        assert torch.equal(r0["g_sum"], r["g_sum"]) and torch.equal(r0["params"], r["params"])
     # one process, full batch
-    _, model, state, step_fn, optimize_fn, batch, t, z = _build(4)
+    _, model, state, step_fn, optimize_fn, batch, t, z = _build(4 if world == 2 else world)
     with emu.emulated():
         loss, g_full, _, params = _one_step(state, step_fn, optimize_fn, batch, t, z)
-    assert abs(0.5 * (r0["loss"] + r1["loss"]) - loss) / abs(loss) < 1e-6
+    assert abs(sum(r["loss"] for r in rs) / world - loss) / abs(loss) < 1e-6
     scale = float(g_full.abs().max())
     assert float((r0["g_sum"] - g_full).abs().max()) / scale < 2e-5
     assert float((r0["params"] - params).abs().max()) / float(params.abs().max()) < 1e-5
@@ -124,22 +128,25 @@ def _bench_rank_worker(rank, world, port, out_dir):
     assert (w, r, ranks) == (world, rank, world) and d is not None
     sync_all = bench._sync_factory(dev, d)
     sync_all()
-    # max over ranks of a per-rank wall time (the contract's "take the MAX over ranks")
-    mx = bench._max_over_ranks(1.0 + rank, dev, d)
+    # max over ranks of a per-rank wall time (the contract's "take the MAX over ranks"), every rank's own time beside it
+    per_rank = []
+    mx = bench._max_over_ranks(1.0 + rank, dev, d, per_rank)
+    assert per_rank == [1.0 + i for i in range(world)]
     torch.save(dict(mx=mx, rank=r, world=w), os.path.join(out_dir, "bench_rank%d.pt" % rank))
     sync_all()
     d.destroy_process_group()
 
 
-def test_bench_rank_setup_two_gloo_ranks_share_one_device(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_rank_setup_gloo_ranks_share_one_device(tmp_path, world):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_bench_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    for r in (0, 1):
+    mp.spawn(_bench_rank_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
         got = torch.load(os.path.join(str(tmp_path), "bench_rank%d.pt" % r))
-        assert got == dict(mx=2.0, rank=r, world=2)
+        assert got == dict(mx=float(world), rank=r, world=world)
 
 
 def test_bench_launch_line_and_rank_guards():
@@ -153,6 +160,8 @@ def test_bench_launch_line_and_rank_guards():
     # world 1: no process group, device 0
     args = bench.parse([])
     assert bench.rank_setup(args, {}, n_devices=1, on_gpu=False)[:2] == (1, 0)
+    assert args.matrix == os.environ.get("SSDE_MATRIX", "bf16x6") and not args.train_only
+    assert bench.parse(["--train-only", "--matrix", "f32"]).train_only
     # a launcher whose world size disagrees with --gpus, a local rank without a GPU, RCCL with two ranks per device
     with pytest.raises(AssertionError):
         bench.rank_setup(bench.parse(["--gpus", "2"]), {"WORLD_SIZE": "4"}, n_devices=8, on_gpu=False)

@@ -380,3 +380,24 @@ def test_wgrad_winograd_kernel(n, h, w, c1, c2, cout, pro, drop, wmode, monkeypa
         act = act * mask
     F.conv2d(act.clone().requires_grad_(False), wt, padding=1).backward(gy)
     assert rel_err(dw.cpu(), 0.5 * wt.grad) < TOL_GEMM
+
+
+@pytest.mark.parametrize("h,k,cout", [(16, 256, 256), (16, 256, 768), (16, 512, 256), (32, 256, 128), (32, 128, 128), (8, 512, 256),
+                                      (8, 384, 256), (16, 1024, 256), (4, 2048, 256)])
+def test_bf16_split_gemm_is_no_further_from_fp64_than_the_fp32_mfma_gemm(h, k, cout, monkeypatch):
+    """per GEMM shape of the BASELINE networks, the error of the 3-way bf16 split (exact products on the
+    BF16 matrix pipe, fp32 accumulation) against an fp64 product of the same operands is not larger than the error of the
+    exact-fp32 MFMA kernel -- the split is fp32 arithmetic in effect, not a narrower type."""
+    import numpy as np
+    from score_sde_pytorch_amd import hipops, _lib as L
+    n = 64
+    g = torch.Generator().manual_seed(h * 1000 + k)
+    x = (torch.randn(n, h, h, k, generator=g) * (1 + torch.rand(1, 1, 1, k, generator=g) * 3)).cuda()
+    w = (torch.randn(cout, k, generator=g) / np.sqrt(k)).cuda()
+    ref = x.reshape(-1, k).double() @ w.double().t()
+    err = {}
+    for mode, flags in (("f32", 0), ("bf16x6", L.CONVF_BF16X6)):
+        y = hipops.conv2d(aux=x, aux_weight=w, flags=flags)
+        err[mode] = float(((y.reshape(-1, cout).double() - ref).norm() / ref.norm()).item())
+    assert err["f32"] < 2e-6, err
+    assert err["bf16x6"] <= err["f32"], err
