@@ -928,16 +928,18 @@ __global__ __launch_bounds__(256) void pack_wino4_kernel(const ssde_pack_desc* _
 #pragma unroll
       for (int b = 0; b < 6; ++b)
       {
-        const int pos = a * 6 + b, wv = (pos & 3) * 2 + (cs >> 5), j = pos >> 2;
+        const int pos = a * 6 + b, wv = (pos & 3) * 2 + (cs >> 5), j = pos >> 2;      // (conv_wino4.hip: wave (q, h) owns positions q + 4 j of cout half h)
         const float u = (float)(t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2]);
         if (!kPerLane) {
           d.dst[(((r * 8 + wv) * 9 + j) * 32 + (cs & 31)) * 4 + e] = u;
         } else {
-          // SSDE_PACK_WINO4R (conv_wino4r.hip): lane (lh = e >> 1, li = cout & 31) of wave wv holds channels 2 lh, 2 lh + 1 of
-          // positions 2 i, 2 i + 1 in piece i (four floats per lane), position 8 in a last piece of two floats per lane
-          const int lane = (e >> 1) * 32 + (cs & 31);
-          const size_t base = (r * 8 + wv) * (size_t)(9 * 32 * 4);
-          d.dst[base + (j < 8 ? ((j >> 1) * 64 + lane) * 4 + (j & 1) * 2 + (e & 1) : 1024 + lane * 2 + (e & 1))] = u;
+          // SSDE_PACK_WINO4R (conv_wino4r.hip): wave w owns positions 4 w .. 4 w + 3 with both cout halves -- lane (lh = e >> 1,
+          // li = cout & 31) holds channels 2 lh, 2 lh + 1 of couts li and 32 + li as four floats per position -- and cout half
+          // w & 1 of position 32 + (w >> 1) as a last piece of two floats per lane
+          const int lane = (e >> 1) * 32 + (cs & 31), half = cs >> 5;
+          const int w = pos < 32 ? (pos >> 2) : 2 * (pos - 32) + half;
+          const size_t base = (r * 8 + w) * (size_t)(9 * 32 * 4);
+          d.dst[base + (pos < 32 ? ((pos & 3) * 64 + lane) * 4 + half * 2 + (e & 1) : 1024 + lane * 2 + (e & 1))] = u;
         }
       }
   }

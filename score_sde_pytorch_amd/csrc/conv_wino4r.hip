@@ -11,17 +11,21 @@
 // for the slowest LDS-DMA piece of the stage (V streams from HBM), with the weights fetched only half a stage ahead.  And the
 // 36 KB of weights per stage are wave-PRIVATE: the LDS round trip shares them with nobody.
 //
-// This kernel therefore keeps NOTHING in LDS during the main loop.  A wave (q, h) owns transform positions q + 4 j (j = 0..8)
-// and cout half h of a 32-tile x 64-cout workgroup tile, as in conv_wino4.hip; per 4-channel stage it needs
-//   A: V[q + 4 j][stage][tile = lane & 31][2 (lane >> 5) .. + 1]        one global_load_dwordx2 per position (512-byte runs)
-//   B: U[q + 4 j][cout = 32 h + (lane & 31)][2 (lane >> 5) .. + 1]      packed per LANE (SSDE_PACK_WINO4R): four dwordx4
-//                                                                       (two positions each) + one dwordx2 per stage
-// straight into the registers its 18 v_mfma_f32_32x32x2_f32 read.  A register is re-loaded for the NEXT stage right after the
-// MFMAs that consumed it, so every load has a whole stage (~1.1 us) to land, 11-13 loads are in flight per wave at any time, and
-// the only synchronisation is the wave's own counted s_waitcnt vmcnt (five per stage).  Waves drift freely: a late V piece
-// stalls one wave while its SIMD sibling keeps the matrix pipe busy.  The two cout halves of a position load the same V run
-// (L1 / L2 serve the second).  LDS is used by the epilogue only (conv_wino4.hip's: products -> LDS, A^T M A, parked tile,
-// shared coalesced store with GroupNorm partials).
+// This kernel therefore keeps NOTHING in LDS during the main loop.  A workgroup is 8 waves = 32 tiles x 64 couts x 36 transform
+// positions, as in conv_wino4.hip, but the 72 (position, cout half) blocks of 32 x 32 are dealt so that a wave needs as few
+// DIFFERENT operand bytes as possible: wave w owns positions 4 w .. 4 w + 3 with BOTH cout halves (two MFMA blocks share one A
+// fragment) and one cout half (w & 1) of position 32 + (w >> 1): nine accumulator blocks, 18 MFMAs per 4-channel stage, fed by
+//   A: V[pos][stage][tile = lane & 31][2 (lane >> 5) .. + 1]        one global_load_dwordx2 per position: FIVE per stage
+//   B: U[pos][cout = (lane & 31), 32 + (lane & 31)][2 (lane >> 5) .. + 1]   packed per LANE (SSDE_PACK_WINO4R): one dwordx4 per
+//                                                                   full position + one dwordx2 for the half position
+// straight into the registers its v_mfma_f32_32x32x2_f32 read.  (The first version dealt wave (q, h) the positions q + 4 j of cout
+// half h: every V run was loaded by two waves, 72 KB per stage and CU -- and the CU's path from L2 saturates at ~28 B/clk when
+// every CU pulls at once, tools/microbench/fill_path.hip and profiles/r5_wino4r_simd_pair_balance_ab.txt: ~2500 cycles per stage
+// whatever the waves' priorities.  This dealing moves 56 KB.)  A register is re-loaded for stage st + 2 right after the MFMAs
+// that consumed it in stage st (two register sets), so every load has two whole stages to land, ~18 loads are in flight per wave
+// at any time, and the only synchronisation is the wave's own counted s_waitcnt vmcnt (five per stage).  Waves drift freely: a
+// late V piece stalls one wave while its SIMD sibling keeps the matrix pipe busy.  LDS is used by the epilogue only
+// (conv_wino4.hip's: products -> LDS, A^T M A, parked tile, shared coalesced store with GroupNorm partials).
 #include "ssde_common.h"
 #include <atomic>
 #include <type_traits>
@@ -42,9 +46,11 @@ extern "C" int ssde_debug_w4r_trace(void* buf) {
 #define SSDE_RT(slot) do { } while (0)
 #endif
 
+
 namespace {
 
-constexpr int kNP = 9, kPS = 4;                     // positions per wave; wave (q, h) owns positions q + kPS * j
+constexpr int kNP = 9;                              // accumulator blocks per wave: (4 positions) x (2 cout halves) + 1
+constexpr int kNV = 5;                              // positions a wave loads V for
 constexpr int kPos = 36, kTiles = 32;
 constexpr int kURegion = kNP * 32 * 4;              // floats of a stage's weight image only wave (q, h) reads (4.5 KB)
 constexpr int kUFloats = 8 * kURegion;              // one (stage, 64-cout tile) of the image
@@ -58,7 +64,7 @@ static_assert(256 * kLdt <= kPos * 16 * kLdm, "parked tile");
 
 struct Wino4rParams {
   const float* v;          // [36][Ctot / 4][T][4]
-  const float* wpk;        // SSDE_PACK_WINO4R: [Ctot / 4][n_tiles][8 waves][4 x [64 lanes][4] | [64 lanes][2]]
+  const float* wpk;        // SSDE_PACK_WINO4R: [Ctot / 4][n_tiles][8 waves][4 positions x [64 lanes][4] | [64 lanes][2]]
   int N, H, W, Cout, Ctot;
   int lTWt, lTHt;
   int tiles_x, tiles_per_img, m_tiles, n_tiles;
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
   const int nt = l % p.n_tiles;
   const int mt = (l / p.n_tiles) * 8 + xcd;
 #ifdef SSDE_W4R_TRACE
-  const bool tr_on = lane == 0 && (wave == 0 || wave == kWaves - 1) && bid == 0 && g_w4r_trace != nullptr;
+  const bool tr_on = lane == 0 && (wave == 0 || wave == kWaves - 1) && g_w4r_trace != nullptr && bid == (int)g_w4r_trace[255];   // (the host names the workgroup)
   const int tr_base = (wave == 0 ? 0 : 1) * 128;
 #endif
   SSDE_RT(0);
@@ -95,12 +101,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
   const int ty = trem / p.tiles_x, tx = trem % p.tiles_x;
   const int n0 = nt * kBN;
   const int nst = p.Ctot >> 2;
-  const int wq = wave >> 1, wh = wave & 1;
+  // wave w: positions 4 w + i (i = 0..3), both cout halves -> blocks 2 i, 2 i + 1; position 32 + (w >> 1), cout half w & 1 -> block 8
+  auto pos_of = [&](int i) { return i < 4 ? 4 * wave + i : 32 + (wave >> 1); };
 
   // ---- A operand: the lane's byte offset of position slot j inside one stage's [36][Q][T][4] view of V (32-bit: the launcher
   // checks V < 4 GB); the stage rides in the scalar base.  Tiles outside the batch / the image read tile 0's run (a valid
   // address; their outputs are never stored).
-  uint32_t v_off[kNP];
+  uint32_t v_off[kNV];
   {
     const int il = li >> (p.lTWt + p.lTHt);
     const int tr = (li >> p.lTWt) & (THt - 1), tc = li & (TWt - 1);
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
     const uint32_t t = (img < p.N && yy < p.tiles_h && xx < p.tiles_w) ? (uint32_t)((img * p.tiles_h + yy) * p.tiles_w + xx) : 0u;
     const uint32_t QT = (uint32_t)(p.Ctot >> 2) * (uint32_t)p.T;
 #pragma unroll
-    for (int j = 0; j < kNP; ++j) v_off[j] = ((uint32_t)(wq + kPS * j) * QT + t) * 16u + 8u * (uint32_t)lh;
+    for (int j = 0; j < kNV; ++j) v_off[j] = ((uint32_t)pos_of(j) * QT + t) * 16u + 8u * (uint32_t)lh;
   }
   const char* vs = reinterpret_cast<const char*>(p.v);                 // stage st: + st * T * 16 bytes
   const size_t v_stage = (size_t)p.T * 16;
@@ -127,41 +134,39 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
   // whole stages of loads in flight.  (With one set -- the first version -- a stage could not be shorter than one memory
   // latency: ~3000 cycles for a wave alone on its SIMD, profiles/r5_wino4r_v2_two_workgroups_per_cu.txt, against 1152 matrix
   // cycles; two waves per SIMD at 2304 cycles each sat right at that bound.)
-  ssde_f32x2 va[2][kNP], u2[2];
+  ssde_f32x2 va[2][kNV], u2[2];
   ssde_f32x4 u4[2][4];
 
-  // The VMEM queue of a wave is a ring of 14 loads per stage, always in this order (loads return in order):
-  //   V0 V1 U0 | V2 V3 U1 | V4 V5 U2 | V6 V7 U3 | V8 U4            (Ui = positions 2 i and 2 i + 1 of the weights, U4 = position 8)
-  // each re-issued for stage st + 2 in the slot that consumed it in stage st.  Slot 2 i needs Ui of this stage: the loads issued
-  // since are indices 3 i + 3 .. 13 of its own round (11 - 3 i), the whole round of stage st + 1 (14) and indices 0 .. 3 i - 1 of
-  // the round being issued now (3 i) = 25, so s_waitcnt vmcnt(25) (which covers V(2 i) and V(2 i + 1), both older); slot 8 needs
-  // U4: vmcnt(26).  kMode 1 = the stage before the last (nothing is issued any more, the last stage's round is in flight):
-  // vmcnt(25 - 3 i) and vmcnt(14); kMode 2 = the last stage: vmcnt(11 - 3 i) and vmcnt(0).
+  // The VMEM queue of a wave is a ring of 10 loads per stage, always in this order (loads return in order):
+  //   V0 U0 | V1 U1 | V2 U2 | V3 U3 | V4 U4              (position i of the wave: its V run, then its weights)
+  // each re-issued for stage st + 2 right after the MFMAs that consumed it in stage st.  Position i needs Ui of this stage (index
+  // 2 i + 1; Vi is older): the loads issued since are the rest of its own round (8 - 2 i), the whole round of stage st + 1 (10)
+  // and what this stage has re-issued so far (2 i) = 18, so s_waitcnt vmcnt(18) before every position.  kMode 1 = the stage
+  // before the last (nothing is issued any more, the last stage's round is in flight): vmcnt(18 - 2 i); kMode 2 = the last
+  // stage: vmcnt(8 - 2 i).
 #define SSDE_W4R_LOADV(S, J) SSDE_GLOAD8_I(va[S][J], v_off[J], vn, 0)
-#define SSDE_W4R_MFMA(S, J, B0, B1)                                                                \
+#define SSDE_W4R_MFMA(S, J, BLK, B0, B1)                                                           \
   do {                                                                                             \
-    acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[S][J].x, (B0), acc[J], 0, 0, 0);              \
-    acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[S][J].y, (B1), acc[J], 0, 0, 0);              \
+    acc[BLK] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[S][J].x, (B0), acc[BLK], 0, 0, 0);          \
+    acc[BLK] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[S][J].y, (B1), acc[BLK], 0, 0, 0);          \
   } while (0)
-#define SSDE_W4R_PAIR(S, I, IMM)                                                                   \
+#define SSDE_W4R_POS(S, I, IMM)                                                                    \
   do {                                                                                             \
-    SSDE_WAIT_VMCNT_FOR3(kMode == 0 ? 25 : kMode == 1 ? 25 - 3 * (I) : 11 - 3 * (I), va[S][2 * (I)], va[S][2 * (I) + 1], u4[S][I]); \
-    SSDE_W4R_MFMA(S, 2 * (I), u4[S][I].x, u4[S][I].y);                                             \
+    SSDE_WAIT_VMCNT_FOR(kMode == 0 ? 18 : kMode == 1 ? 18 - 2 * (I) : 8 - 2 * (I), va[S][I], u4[S][I]); \
+    SSDE_W4R_MFMA(S, I, 2 * (I), u4[S][I].x, u4[S][I].y);                                          \
     __builtin_amdgcn_sched_barrier(0);                                                             \
-    if (kMode == 0) SSDE_W4R_LOADV(S, 2 * (I));                                                    \
+    SSDE_W4R_MFMA(S, I, 2 * (I) + 1, u4[S][I].z, u4[S][I].w);                                      \
     __builtin_amdgcn_sched_barrier(0);                                                             \
-    SSDE_W4R_MFMA(S, 2 * (I) + 1, u4[S][I].z, u4[S][I].w);                                         \
-    __builtin_amdgcn_sched_barrier(0);                                                             \
-    if (kMode == 0) { SSDE_W4R_LOADV(S, 2 * (I) + 1); SSDE_GLOAD16_I(u4[S][I], u_off, un, IMM); }  \
+    if (kMode == 0) { SSDE_W4R_LOADV(S, I); SSDE_GLOAD16_I(u4[S][I], u_off, un, IMM); }            \
     __builtin_amdgcn_sched_barrier(0);                                                             \
   } while (0)
 #define SSDE_W4R_ROUND(S)                                                                          \
   do {                                                                                             \
-    SSDE_W4R_LOADV(S, 0); SSDE_W4R_LOADV(S, 1); SSDE_GLOAD16_I(u4[S][0], u_off, un, -2048);        \
-    SSDE_W4R_LOADV(S, 2); SSDE_W4R_LOADV(S, 3); SSDE_GLOAD16_I(u4[S][1], u_off, un, -1024);        \
-    SSDE_W4R_LOADV(S, 4); SSDE_W4R_LOADV(S, 5); SSDE_GLOAD16_I(u4[S][2], u_off, un, 0);            \
-    SSDE_W4R_LOADV(S, 6); SSDE_W4R_LOADV(S, 7); SSDE_GLOAD16_I(u4[S][3], u_off, un, 1024);         \
-    SSDE_W4R_LOADV(S, 8); SSDE_GLOAD8_I(u2[S], u_off8, un, 0);                                     \
+    SSDE_W4R_LOADV(S, 0); SSDE_GLOAD16_I(u4[S][0], u_off, un, -2048);                              \
+    SSDE_W4R_LOADV(S, 1); SSDE_GLOAD16_I(u4[S][1], u_off, un, -1024);                              \
+    SSDE_W4R_LOADV(S, 2); SSDE_GLOAD16_I(u4[S][2], u_off, un, 0);                                  \
+    SSDE_W4R_LOADV(S, 3); SSDE_GLOAD16_I(u4[S][3], u_off, un, 1024);                               \
+    SSDE_W4R_LOADV(S, 4); SSDE_GLOAD8_I(u2[S], u_off8, un, 0);                                     \
   } while (0)
 
   SSDE_RT(1);
@@ -178,15 +183,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
     const char* vn = vs + (size_t)(st + 2) * v_stage;
     const char* un = us + (size_t)(st + 2) * u_stage;
     if (st < 8) SSDE_RT(8 + st * 2);
-    SSDE_W4R_PAIR(S, 0, -2048);
-    SSDE_W4R_PAIR(S, 1, -1024);
-    SSDE_W4R_PAIR(S, 2, 0);
+    SSDE_W4R_POS(S, 0, -2048);
+    SSDE_W4R_POS(S, 1, -1024);
+    SSDE_W4R_POS(S, 2, 0);
     if (st < 8) SSDE_RT(8 + st * 2 + 1);
-    SSDE_W4R_PAIR(S, 3, 1024);
-    SSDE_WAIT_VMCNT_FOR(kMode == 0 ? 26 : kMode == 1 ? 14 : 0, va[S][8], u2[S]);
-    SSDE_W4R_MFMA(S, 8, u2[S].x, u2[S].y);
+    SSDE_W4R_POS(S, 3, 1024);
+    SSDE_WAIT_VMCNT_FOR(kMode == 0 ? 18 : kMode == 1 ? 10 : 0, va[S][4], u2[S]);
+    SSDE_W4R_MFMA(S, 4, 8, u2[S].x, u2[S].y);
     __builtin_amdgcn_sched_barrier(0);
-    if (kMode == 0) { SSDE_W4R_LOADV(S, 8); SSDE_GLOAD8_I(u2[S], u_off8, un, 0); }
+    if (kMode == 0) { SSDE_W4R_LOADV(S, 4); SSDE_GLOAD8_I(u2[S], u_off8, un, 0); }
     __builtin_amdgcn_sched_barrier(0);
   };
   {
@@ -195,12 +200,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
     // (the launcher admits even stage counts only -- input channels a multiple of 8 -- so the tail is the same straight-line
     //  code for every launch: a branch per tail shape made hipcc spill hundreds of registers around the joins)
     int st = 0;
+    // (The two waves of a SIMD share its matrix pipe and the older one wins every arbitration; a balance -- each wave posts its
+    //  stage number in LDS, reads its partner's and takes the lower issue priority while it is ahead -- evened them out and
+    //  changed nothing: the pair is bound by the bytes it pulls, not by who runs first.  profiles/r5_wino4r_simd_pair_balance_ab.txt)
     for (; st + 3 < nst; st += 2) { stage(S0{}, Steady{}, st); stage(S1{}, Steady{}, st + 1); }
     stage(S0{}, Penult{}, st);
     stage(S1{}, Last{}, st + 1);
   }
 #undef SSDE_W4R_ROUND
-#undef SSDE_W4R_PAIR
+#undef SSDE_W4R_POS
 #undef SSDE_W4R_MFMA
 #undef SSDE_W4R_LOADV
   SSDE_RT(3);
@@ -220,9 +228,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
       for (int r8 = 0; r8 < 8; ++r8) {
         const int r = rnd * 8 + r8;
         const int tl = (r & 3) + 4 * lh + 8 * ((r >> 2) & 1);
-        smem[((wq + kPS * j) * 16 + tl) * kLdm + wh * 32 + li] = acc[j][r];
+        const int pos = pos_of(j >> 1), half = j < 8 ? (j & 1) : (wave & 1);      // block j of this wave
+        smem[(pos * 16 + tl) * kLdm + half * 32 + li] = acc[j][r];
       }
+    SSDE_RT(32 + rnd * 4);   // products written (before the barrier)
     SSDE_LDS_BARRIER();      // (LDS-only barriers throughout: a __syncthreads() would wait out the previous round's global stores)
+    SSDE_RT(33 + rnd * 4);
     float2 y[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -252,6 +263,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
         for (int dx = 0; dx < 4; ++dx)
           if (kA[px][dx] != 0.f) { y[dy][dx].x += kA[px][dx] * t[dy].x; y[dy][dx].y += kA[px][dx] * t[dy].y; }
     }
+    SSDE_RT(34 + rnd * 4);                     // output transform done
     SSDE_LDS_BARRIER();                        // every thread has read its products: the parked tile may overwrite them
 #pragma unroll
     for (int dy = 0; dy < 4; ++dy)
@@ -259,6 +271,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
       for (int dx = 0; dx < 4; ++dx)
         *reinterpret_cast<float2*>(park + (e_tl * 16 + dy * 4 + dx) * kLdt + 2 * e_cp) = y[dy][dx];
     SSDE_LDS_BARRIER();
+    SSDE_RT(35 + rnd * 4);                     // tile parked: the store phase starts
     const int gn_entry = gn_base < 0 ? -1 : (IMGS == 1 ? gn_base + rnd : gn_base + rnd * (IMGS >> 1));
     auto pixfn = [&](int row, size_t& pix, int& img) {
       const int tile = rnd * 16 + (row >> 4), dy = (row >> 2) & 3, dx = row & 3;

@@ -333,17 +333,23 @@ def pack_wino4_weight(w):
 
 
 def pack_wino4r_weight(w):
-    """[Cout, Cin, 3, 3] -> the F(4x4,3x3) weights of pack_wino4_weight arranged per LANE for conv_wino4r.hip, which loads them
-    straight into MFMA operand registers (SSDE_TILE_WINOGRAD4R / SSDE_PACK_WINO4R):
-    [ceil(Cin/4)][ceil(Cout/64)][8 waves (q, h)][4 pieces x [64 lanes][4] | [64 lanes][2]] -- lane (lh, li) of wave (q, h) holds, of
-    cout 64 nt + 32 h + li and channels 2 lh, 2 lh + 1, positions q + 4 (2 i) and q + 4 (2 i + 1) in piece i, position q + 32 last."""
-    img = pack_wino4_weight(w)                                   # [c4, nt, q, h, j, cl, e]
-    c4, nt = img.shape[0], img.shape[1]
-    v = img.reshape(c4, nt, 8, 9, 32, 2, 2)                      # [.., wave, j, cl, lh, e2]
-    pieces = v[:, :, :, :8].reshape(c4, nt, 8, 4, 2, 32, 2, 2)   # [.., wave, i, jj, cl, lh, e2]
-    pieces = pieces.permute(0, 1, 2, 3, 6, 5, 4, 7).reshape(c4, nt, 8, 4 * 64 * 4)      # [.., i, lh, cl, jj, e2]
-    last = v[:, :, :, 8].permute(0, 1, 2, 4, 3, 5).reshape(c4, nt, 8, 64 * 2)           # [.., lh, cl, e2]
-    return torch.cat([pieces, last], dim=3).contiguous()
+    """[Cout, Cin, 3, 3] -> the F(4x4,3x3) weights U = G g G^T (formed in fp64, stored in fp32) arranged per LANE for
+    conv_wino4r.hip, which loads them straight into MFMA operand registers (SSDE_TILE_WINOGRAD4R / SSDE_PACK_WINO4R):
+    [ceil(Cin/4)][ceil(Cout/64)][8 waves][4 positions x [64 lanes][4] | [64 lanes][2]] -- wave w owns transform positions
+    4 w .. 4 w + 3 with both 32-cout halves of the tile and half w & 1 of position 32 + (w >> 1); lane (lh, li) holds channels
+    2 lh, 2 lh + 1 of couts li and 32 + li (four floats per full position), of cout 32 (w & 1) + li for the half position."""
+    cout, cin = w.shape[0], w.shape[1]
+    G = _WINO4_G.to(w.device)
+    u = torch.einsum("ak,ockl,bl->ocab", G, w.detach().to(torch.float64), G).to(torch.float32)     # [Cout, Cin, 6, 6]
+    c4, nt = (cin + 3) // 4, (cout + 63) // 64
+    full = torch.zeros(nt * 64, c4 * 4, 36, dtype=torch.float32, device=w.device)
+    full[:cout, :cin] = u.reshape(cout, cin, 36)
+    v = full.reshape(nt, 2, 32, c4, 2, 2, 36)                    # [nt, half, li, c4, lh, e2, pos]
+    # full positions: [c4, nt, wave, i, lh, li, half, e2]  (pos = 4 wave + i)
+    fp = v[..., :32].reshape(nt, 2, 32, c4, 2, 2, 8, 4).permute(3, 0, 6, 7, 4, 2, 1, 5).reshape(c4, nt, 8, 4 * 64 * 4)
+    # half positions 32 + k: wave = 2 k + half -> [c4, nt, k, half, lh, li, e2]
+    hp = v[..., 32:].permute(3, 0, 6, 1, 4, 2, 5).reshape(c4, nt, 8, 64 * 2)
+    return torch.cat([fp, hp], dim=3).contiguous()
 
 
 def pack_matrix(w):
@@ -670,17 +676,23 @@ class Lowering:
     def _wino4_two_kernels(self, h, w, c_out, c_in):
         """F(4x4,3x3) as a transform pass (wino4_xform.hip) + the register-fed matrix kernel (conv_wino4r.hip) instead of the one
         fused kernel?  The pass costs one more read of x and 2.25x of it written and read; the matrix kernel saves the prologue
-        and transform VALU work that serialises with fp32 MFMAs in EVERY 64-cout workgroup of a pixel tile.  Measured at batch
-        256 (profiles/r5_wino4r_v3_two_stage_ring.txt, fused -> pair): 256->256 @16x16 0.29 -> 0.22 ms, 512->256 @16x16
-        0.51 -> 0.44, level at 128 couts (128->128 @32x32 0.36 -> 0.35, 256->128 0.58 -> 0.60), a loss at 384->128 @32x32
-        (0.79 -> 0.86: three times the input for two cout tiles) -- so: from four cout tiles up in inference programs.  In a
-        training program the pass's output is also the F(4x4,3x3) weight gradient's input (v_pre) and the input-gradient
-        convolutions have 4-8 cout tiles: the pair everywhere (step 0.0575 -> 0.0568 s, profiles/r5_wino4r_v3_bench_ab.txt).
-        SSDE_WINO4_TWO: 0 = never, 2 = wherever F(4x4,3x3) runs."""
-        mode = os.environ.get("SSDE_WINO4_TWO", "1")
+        and transform VALU work that serialises with fp32 MFMAs in EVERY 64-cout workgroup of a pixel tile, and runs at 0.6-0.9
+        of the matrix peak against the fused kernel's 0.40-0.45.  Measured at batch 256 (profiles/
+        r5_wino4r_v4_one_v_load_per_workgroup.txt, fused -> pair): 256->256 @16x16 0.28 -> 0.22 ms, 512->256 @16x16 0.50 -> 0.40,
+        256->128 @32x32 0.61 -> 0.55, 128->128 @32x32 0.350 -> 0.326, 384->128 @32x32 0.77 -> 0.85 (three times the input for
+        two cout tiles: the one shape where the pair loses in isolation).  In the networks (profiles/r5_two_kernel_rule_ab.txt,
+        CIFAR sampler, images/s on one box): four cout tiles up 4.68-4.70, + input at most twice the output 4.71-4.73, everywhere
+        4.75 -- so: wherever F(4x4,3x3) runs and the kernel's shape limits allow.  In a training program the pass's output is
+        also the F(4x4,3x3) weight gradient's input (v_pre).
+        SSDE_WINO4_TWO: 0 = never, 1 = from four cout tiles up or input <= 2 x output, 3 = round 4's rule (four cout tiles)."""
+        mode = os.environ.get("SSDE_WINO4_TWO", "2")
         if mode == "0" or 36 * self.n * (h // 4) * (w // 4) * c_in * 4 >= 2 ** 32 or c_in % 8 != 0:
             return False
-        return mode == "2" or c_out >= 256 or bool(getattr(self, "emit_wino_v", False))
+        if mode == "3":
+            return c_out >= 256
+        if mode == "1":
+            return c_out >= 256 or c_in <= 2 * c_out or bool(getattr(self, "emit_wino_v", False))
+        return True
 
     def _wgrad_takes_wino4(self, f):
         """Would ssde_conv_wgrad run the weight gradient of this forward conv on the F(4x4,3x3) path?  (shape-only query with

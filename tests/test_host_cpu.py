@@ -167,10 +167,10 @@ def test_dry_lowering_of_baseline_configs(name, batch, gflop_per_img):
         eng.program.run()
 
 
-def test_two_kernel_winograd_is_taken_from_four_cout_tiles_up(monkeypatch):
-    """engine.Lowering._wino4_two_kernels: at the BASELINE sampler shape every F(4x4,3x3) layer of 256 output channels and more
-    is lowered as transform pass + matrix kernel (SSDE_TILE_WINOGRAD4R) and owns a transformed-input buffer of 36/16 of its
-    input; the 128-cout layers stay on the fused kernel without one; SSDE_WINO4_TWO=0 switches the form off."""
+def test_two_kernel_winograd_is_the_form_of_every_f4x4_layer(monkeypatch):
+    """engine.Lowering._wino4_two_kernels: at the BASELINE sampler shape every F(4x4,3x3) layer is lowered as transform pass +
+    register-fed matrix kernel (SSDE_TILE_WINOGRAD4R) and owns a transformed-input buffer of 36/16 of its input; SSDE_WINO4_TWO=3
+    is round 4's rule (from four cout tiles up: the 128-cout layers on the fused kernel), SSDE_WINO4_TWO=0 switches the form off."""
     from score_sde_pytorch_amd import engine, _lib as L
     from score_sde_pytorch_amd.models import utils as mutils
     monkeypatch.setenv("SSDE_WINOGRAD", "1")               # the production heuristic (the suite's default forces F(2x2,3x3))
@@ -185,12 +185,15 @@ def test_two_kernel_winograd_is_taken_from_four_cout_tiles_up(monkeypatch):
         return out
     cs = convs(engine.UNetEngine(model, 256, 32, 32, torch.device("cpu")))
     two = [c for c in cs if c[0] == L.TILE_WINOGRAD4R]
-    one = [c for c in cs if c[0] == L.TILE_WINOGRAD4]
-    assert len(two) >= 15 and len(one) >= 15
-    assert all(c[1] >= 256 and c[2] >= 16 for c in two) and all(c[1] < 256 for c in one)
+    assert len(two) >= 40 and not [c for c in cs if c[0] == L.TILE_WINOGRAD4]
+    assert all(c[2] >= 16 and c[3] % 8 == 0 for c in two)
     for tile, c_out, h, c_in, v in two:
         assert v is not None and v.numel == 36 * 256 * (h // 4) ** 2 * c_in
     assert all(c[4] is None for c in cs if c[0] != L.TILE_WINOGRAD4R)          # inference: nobody else wants the transformed input
+    monkeypatch.setenv("SSDE_WINO4_TWO", "3")
+    cs = convs(engine.UNetEngine(model, 256, 32, 32, torch.device("cpu")))
+    two, one = [c for c in cs if c[0] == L.TILE_WINOGRAD4R], [c for c in cs if c[0] == L.TILE_WINOGRAD4]
+    assert len(two) >= 15 and len(one) >= 15 and all(c[1] >= 256 for c in two) and all(c[1] < 256 for c in one)
     monkeypatch.setenv("SSDE_WINO4_TWO", "0")
     assert not [c for c in convs(engine.UNetEngine(model, 256, 32, 32, torch.device("cpu"))) if c[0] == L.TILE_WINOGRAD4R]
 
