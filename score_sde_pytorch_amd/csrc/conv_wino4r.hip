@@ -74,10 +74,21 @@ struct Wino4rParams {
   float* dst;
   float* gn_part;
   int T, tiles_h, tiles_w;
+  int ksplit;              // 1, 2 or 4 workgroups per tile, each reducing its share of the channel stages (the kernel's kKs)
+  unsigned* sync;          // ksplit > 1: this launch's (shares started, shares handed over) pairs, one per tile (conv_mfma.hip's
+                           // g_conv_sync: zero before and after)
+  int ticket_off;          // float index of the hand-over ticket in LDS (behind the epilogue's exchange area)
 };
 
+// kKs = 2 or 4: that many workgroups per tile, each reducing its share of the channel stages (conv_wino4.hip's split, the same
+// protocol: shares are dealt in the order the workgroups START -- an atomic counter per tile -- so share k only ever waits for
+// shares < k, which are resident or done; the sums are formed in the fixed order ((s0 + s1) + s2) + s3).  The maps this is for
+// are the 8x8 ones at batch 256: 1024 tiles = 32 workgroup tiles x 4 cout tiles = 128 workgroups on 256 CUs; two shares each
+// cover the chip with one workgroup per CU, and the matrix loop of a share is half as long.
+template <int kKs>
 __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rParams p) {
-  SSDE_LDS(smem);                               // the epilogue's only
+  constexpr bool kSplit = kKs > 1;
+  SSDE_LDS(smem);                               // the epilogue's only (+ the split's ticket)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
@@ -86,7 +97,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
   const int bid = blockIdx.x;
   const int xcd = bid & 7, l = bid >> 3;
   const int nt = l % p.n_tiles;
-  const int mt = (l / p.n_tiles) * 8 + xcd;
+  const int mt = (l / (p.n_tiles * kKs)) * 8 + xcd;      // (the kKs workgroups of a tile: same XCD, 8 * n_tiles blocks apart)
 #ifdef SSDE_W4R_TRACE
   const bool tr_on = lane == 0 && (wave == 0 || wave == kWaves - 1) && g_w4r_trace != nullptr && bid == (int)g_w4r_trace[255];   // (the host names the workgroup)
   const int tr_base = (wave == 0 ? 0 : 1) * 128;
@@ -100,7 +111,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
   const int trem = mt % p.tiles_per_img;
   const int ty = trem / p.tiles_x, tx = trem % p.tiles_x;
   const int n0 = nt * kBN;
-  const int nst = p.Ctot >> 2;
+  // this workgroup's share of the reduction: stages st_off .. st_off + nst (an even count: the launcher splits only channel
+  // counts that are multiples of 8 kKs)
+  int nst = p.Ctot >> 2, ks = 0, st_off = 0;
+  unsigned* sy = kSplit ? p.sync + 2 * ((size_t)mt * p.n_tiles + nt) : nullptr;
+  if constexpr (kSplit) {
+    int* ticket = reinterpret_cast<int*>(smem + p.ticket_off);
+    if (tid == 0) *ticket = (int)atomicAdd(sy, 1u);
+    __syncthreads();
+    ks = __builtin_amdgcn_readfirstlane(*ticket);
+    const int nst_all = nst;
+    st_off = nst_all * ks / kKs;
+    nst = nst_all * (ks + 1) / kKs - st_off;
+  }
   // wave w: positions 4 w + i (i = 0..3), both cout halves -> blocks 2 i, 2 i + 1; position 32 + (w >> 1), cout half w & 1 -> block 8
   auto pos_of = [&](int i) { return i < 4 ? 4 * wave + i : 32 + (wave >> 1); };
 
@@ -117,13 +140,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
 #pragma unroll
     for (int j = 0; j < kNV; ++j) v_off[j] = ((uint32_t)pos_of(j) * QT + t) * 16u + 8u * (uint32_t)lh;
   }
-  const char* vs = reinterpret_cast<const char*>(p.v);                 // stage st: + st * T * 16 bytes
   const size_t v_stage = (size_t)p.T * 16;
+  const char* vs = reinterpret_cast<const char*>(p.v) + (size_t)st_off * v_stage;      // (local) stage st: + st * T * 16 bytes
   // ---- B operand: the wave's 4.5 KB of a stage, lane-major; four 1 KB pieces at immediates -2048 .. 1024 around the base and
   // one 512-byte piece behind them
   const uint32_t u_off = (uint32_t)lane * 16u, u_off8 = 2048u + (uint32_t)lane * 8u;
-  const char* us = reinterpret_cast<const char*>(p.wpk + ((size_t)nt * kWaves + wave) * kURegion) + 2048;
   const size_t u_stage = (size_t)p.n_tiles * kUFloats * 4;
+  const char* us = reinterpret_cast<const char*>(p.wpk + ((size_t)nt * kWaves + wave) * kURegion) + 2048 + (size_t)st_off * u_stage;
 
   f32x16 acc[kNP];
 #pragma unroll
@@ -284,6 +307,67 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
       return true;
     };
     const int gn_max = IMGS == 1 ? p.N * p.tiles_per_img * 2 : p.N;
+    if constexpr (kSplit) {
+      // split reduction (conv_wino4.hip's hand-over): share 0 leaves its raw 4x4 outputs in the tile's own part of dst, shares
+      // 1 .. kKs - 2 add theirs to them in turn, the last share adds its own and runs the epilogue, round by round.  The sums travel as agent-scope 16-byte accesses, coherent at the device level by themselves
+      // (no __threadfence(): that is a write-back of the whole L2 per workgroup, conv_mfma.hip)
+      const bool first = ks == 0, last = ks == kKs - 1;
+      // (sy[1]: the shares that have handed over round 0 in its low half, round 1 in its high half -- share k starts adding to
+      //  round 0 while share k - 1 is still busy with its round 1)
+      if (!first) {
+        if (tid == 0)
+          while (((__hip_atomic_load(sy + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (16 * rnd)) & 0xffffu) != (unsigned)ks)
+            __builtin_amdgcn_s_sleep(4);
+        __syncthreads();
+      }
+      constexpr int kIters = 256 * 16 / kThreads, kBatch = 4;      // (4 float4 of a thread at a time: round 0 still holds half of the accumulators)
+      static_assert(kBatch == 4, "SSDE_WAIT_VMCNT_FOR4");
+#pragma unroll
+      for (int ib = 0; ib < kIters; ib += kBatch) {
+        float* tp[kBatch];
+        float* dp[kBatch];
+#pragma unroll
+        for (int it = 0; it < kBatch; ++it) {
+          const int q = tid + (ib + it) * kThreads;
+          const int row = q >> 4, j = (q & 15) * 4;
+          size_t pix; int img;
+          const bool ok = pixfn(row, pix, img) && n0 + j < p.Cout;       // c_out % 4 == 0 on this path
+          tp[it] = park + row * kLdt + j;
+          dp[it] = ok ? p.dst + pix * p.Cout + n0 + j : nullptr;
+        }
+        // (16 bytes per access at agent scope: as dword atomics -- conv_wino4.hip's form -- the hand-over was 64 loads and 64
+        //  stores per thread and share)
+        ssde_f32x4 o[kBatch];
+        if (!first) {
+#pragma unroll
+          for (int it = 0; it < kBatch; ++it) SSDE_GLOAD16_AGENT(o[it], dp[it] ? dp[it] : p.dst);     // the batch's loads in flight before the first add
+          SSDE_WAIT_VMCNT_FOR4(0, o[0], o[1], o[2], o[3]);
+#pragma unroll
+          for (int it = 0; it < kBatch; ++it) o[it] += *reinterpret_cast<const ssde_f32x4*>(tp[it]);   // (sum so far) + own share
+        } else {
+#pragma unroll
+          for (int it = 0; it < kBatch; ++it) o[it] = *reinterpret_cast<const ssde_f32x4*>(tp[it]);
+        }
+        if (last) {
+#pragma unroll
+          for (int it = 0; it < kBatch; ++it) *reinterpret_cast<ssde_f32x4*>(tp[it]) = o[it];
+        } else {
+#pragma unroll
+          for (int it = 0; it < kBatch; ++it)
+            if (dp[it]) SSDE_GSTORE16_AGENT(dp[it], o[it]);
+        }
+      }
+      if (!last) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0);      // every store of this thread is acknowledged ...
+        __syncthreads();                    // ... and every thread's (and park may be refilled by round 1)
+        if (tid == 0) atomicAdd(sy + 1, rnd == 0 ? 1u : 0x10000u);
+        if (rnd == 0) continue;
+        return;
+      }
+      __syncthreads();
+      if (rnd == 1 && tid == 0) { sy[0] = 0u; sy[1] = 0u; }              // ready for the next launch that is dealt these slots
+    }
     if (rnd == 0) ssde_store_tile<256, kBN, kThreads, 4, 0>(park, kLdt, n0, e, pixfn, gn_entry, rpi_log2, gn_max);
     else ssde_store_tile<256, kBN, kThreads, 8, 0>(park, kLdt, n0, e, pixfn, gn_entry, rpi_log2, gn_max);
     if (rnd == 0) { SSDE_LDS_BARRIER(); SSDE_RT(4); }
@@ -294,6 +378,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
 int pow2_floor(int v) { int q = 1; while (q * 2 <= v) q *= 2; return q; }
 
 }  // namespace
+
+// over how many workgroups per tile (1, 2 or 4) a launch of `wgs` tiles over `ctot` input channels splits its reduction: the
+// shares must fit ONE round of workgroups (one per CU: the kernel owns a CU's registers), every share an even number of at least
+// 8 channel stages.  SSDE_CONVF_NO_KSPLIT in the launch's flags switches it off.
+int ssde_conv_wino4r_splits(int wgs, int ctot, int c_out, unsigned flags) {
+  if ((flags & SSDE_CONVF_NO_KSPLIT) || c_out % 4 != 0) return 1;
+  const int cus = ssde_num_cus();
+  // (measured at batch 256 on 8x8 maps, profiles/r5_wino4r_split_8x8.txt: two shares of 32 / 64 stages win 7 / 20 % over the
+  //  unsplit kernel, two shares of 16 stages -- 128 input channels -- lose 20 %: the hand-over costs what 8-10 stages do)
+  if (wgs * 4 <= cus && ctot % 32 == 0 && ctot >= 512) return 4;
+  if (wgs * 2 <= cus && ctot % 16 == 0 && ctot >= 256) return 2;
+  return 1;
+}
 
 // stream == (void*)1 with lds_out: plan-only query of the GroupNorm slices per image (conv_mfma.hip, ssde_conv_gn_slices)
 int ssde_conv_wino4r_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
@@ -327,20 +424,33 @@ int ssde_conv_wino4r_launch(const ssde_conv_args* a, void* stream, int* lds_out)
     *lds_out = gn_ok ? (imgs == 1 ? 2 * p.tiles_per_img : 1) * (kThreads / 64) : 0;
     return SSDE_OK;
   }
-  const int lds = kLds;
+  p.ticket_off = kLds / 4;
+  const int lds = kLds + 16;
   SSDE_REQUIRE(lds <= 160 * 1024, "conv(winograd 4x4, register-fed): %d bytes of LDS", lds);
   if (lds_out) { *lds_out = lds; return SSDE_OK; }
   SSDE_REQUIRE(a->wino_v, "conv(winograd 4x4, register-fed): the transformed-input buffer (ssde_conv_args.wino_v) is missing");
   SSDE_REQUIRE(36ull * (unsigned long long)p.T * (unsigned)p.Ctot * 4ull < (1ull << 32),
                "conv(winograd 4x4, register-fed): a transformed input of 4 GB or more is not addressable by this kernel");
+  // Split the reduction when the launch would leave half of the CUs or more without a workgroup (8x8 maps at batch 256: 128
+  // tiles of 8 images x 64 couts): ssde_conv_wino4r_splits, the rule engine.Lowering.wino_ok mirrors.  (dst is the hand-over
+  // buffer: not when the residual aliases it)
   const int wgs = ssde_cdiv(p.m_tiles, 8) * 8 * p.n_tiles;
-  static std::atomic<bool> attr_set;
-  if (!attr_set) {                              // once, before any stream capture
-    SSDE_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024) == hipSuccess, "conv(winograd 4x4, register-fed): hipFuncSetAttribute failed");
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(conv_wino4r_kernel, dim3(wgs), dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
+  p.ksplit = a->resid != a->dst ? ssde_conv_wino4r_splits(wgs, p.Ctot, a->c_out, a->flags) : 1;
+  p.sync = p.ksplit > 1 ? ssde_conv_sync_slots(p.m_tiles * p.n_tiles) : nullptr;
+  if (!p.sync) p.ksplit = 1;
+  const dim3 grid(wgs * p.ksplit);
+  auto go = [&](auto kfn, std::atomic<bool>& attr_set) {
+    if (!attr_set) {                            // once per instantiation, before any stream capture
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return false;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
+    return true;
+  };
+  static std::atomic<bool> set[3];
+  const bool ok = p.ksplit == 4 ? go(conv_wino4r_kernel<4>, set[2]) : p.ksplit == 2 ? go(conv_wino4r_kernel<2>, set[1]) : go(conv_wino4r_kernel<1>, set[0]);
+  SSDE_REQUIRE(ok, "conv(winograd 4x4, register-fed): hipFuncSetAttribute failed");
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;
 }

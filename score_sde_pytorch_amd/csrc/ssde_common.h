@@ -22,6 +22,7 @@ bool ssde_conv1x1_wants(const ssde_conv_args* a);                               
 int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out);
 unsigned* ssde_conv_sync_slots(int need);                                            // conv_mfma.hip
 int ssde_conv_wino4_splits(int wgs, int ctot, int c_out, unsigned flags);                         // conv_wino4.hip
+int ssde_conv_wino4r_splits(int wgs, int ctot, int c_out, unsigned flags);                        // conv_wino4r.hip
 bool ssde_wgrad_wino_wants(const ssde_wgrad_args* a);                                // wgrad_wino.hip
 int64_t ssde_wgrad_wino_scratch_floats(const ssde_wgrad_args* a);
 int ssde_wgrad_wino_launch(const ssde_wgrad_args* a, void* stream);
@@ -126,6 +127,15 @@ typedef float ssde_f32x4 __attribute__((ext_vector_type(4)));
 #define SSDE_GLOAD8_I(dst, voff, sbase, imm) \
   asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(imm) :)
 #define SSDE_WAIT_VMCNT_FOR3(n, a, b, c) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(n) : "memory")
+#endif
+
+// 16-byte accesses at AGENT scope (sc1, what a relaxed agent-scope atomic dword access compiles to): the partial sums a split
+// reduction hands from workgroup to workgroup cross XCDs, whose L2s are not coherent with each other; as dword atomics they
+// were four times the transactions (conv_wino4r.hip).  The load is asynchronous to the compiler: SSDE_WAIT_VMCNT_FOR4 before use.
+#ifndef SSDE_GLOAD16_AGENT
+#define SSDE_GLOAD16_AGENT(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(ptr) : "memory")
+#define SSDE_GSTORE16_AGENT(ptr, val) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(ptr), "v"(val) : "memory")
+#define SSDE_WAIT_VMCNT_FOR4(n, a, b, c, d) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(n) : "memory")
 #endif
 
 // An LDS address the compiler must treat as one opaque 32-bit register (so that constant distances from it become the

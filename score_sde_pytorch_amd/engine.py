@@ -751,6 +751,17 @@ class Lowering:
                 splits = 4 if wgs4 <= self.cus // 4 and c_in >= 256 else 2 if wgs4 <= self.cus // 2 and c_in >= 128 else 1
             if splits > 1 and wgs4 * splits >= int(os.environ["SSDE_W4_SPLIT_MIN_WGS"]):
                 return 4
+        # The register-fed matrix kernel splits its reduction too (conv_wino4r.hip, ssde_conv_wino4r_splits -- the same rule
+        # here): its channel stage is ~2450 cycles against the fused kernel's ~4600, so where TWO shares fill exactly one round of
+        # workgroups -- the 8x8 maps at batch 256: 128 tiles -> 256 workgroups -- transform pass + split matrix kernel beat
+        # F(2x2,3x3): 256->256 0.092 against 0.108 ms, 512->256 0.131 against 0.195 (profiles/r5_wino4r_split_8x8.txt); with 128
+        # input channels (16 stages per share) the hand-over costs more than the split saves and F(2x2,3x3) stays.  Four shares
+        # (batch 128 and smaller) are left to callers that name the tile.  SSDE_W4R_SPLIT=0 keeps round 4's choice.
+        if mode != "3" and legal4 and c_in % 16 == 0 and c_in >= 256 and c_out % 4 == 0 \
+                and os.environ.get("SSDE_W4R_SPLIT", "1") != "0" and os.environ.get("SSDE_CONV_KSPLIT", "1") != "0":
+            wgs4 = -(-(-(-(self.n * h * w) // 512)) // 8) * 8 * n_tiles
+            if self.cus // 2 < wgs4 * 2 <= self.cus and self._wino4_two_kernels(h, w, c_out, c_in):
+                return 6
         # tools/heuristic_sweep.py (profiles/r2_heuristic_sweep.txt): F(4x4,3x3) wins from one of its workgroups per CU (256),
         # F(2x2,3x3) over the direct kernel from half a workgroup per CU (128; by 2-6 %; at 64 the direct kernel is 1.5x
         # faster).  tools/batch_sweep.py: the sampler at batch 16 / 64 / 256 under this rule (profiles/r4_batch_sweep.txt)

@@ -1300,8 +1300,14 @@ def check_conv_winograd4(dev, big=False, regs=False):
     # (>= 128 / 256 input channels and few workgroups: the reduction is split over two / four workgroups per tile, checked
     # both ways)
     plain = [(1, 8, 64, 16), (2, 32, 64, 8), (3, 16, 96, 8), (1, 12, 128, 32), (3, 128, 64, 8), (9, 132, 72, 8), (2, 260, 96, 8)]
+    if regs:
+        # the register-fed kernel's own split (ssde_conv_wino4r_splits: shares of an even number of stages that fit one round of
+        # workgroups): two shares of 32 / 40 stages (256 / 320 channels, a ragged batch), four shares of 32 stages (512 channels)
+        plain += [(5, 256, 128, 8), (17, 320, 80, 8), (3, 512, 64, 8), (2, 256, 64, 16)]
     if big:
         plain += [(16, 128, 128, 32), (9, 256, 256, 16), (20, 256, 256, 8), (2, 128, 128, 64)]
+        if regs:
+            plain += [(256, 256, 256, 8), (256, 512, 256, 8), (128, 256, 256, 8)]      # the BASELINE sampler's 8x8 shapes: 2 / 2 / 4 shares
     for (n, cin, cout, h) in plain:
         if regs and cin % 8:
             continue                                # (the register-fed kernel runs its stages in pairs: input channels % 8 == 0)

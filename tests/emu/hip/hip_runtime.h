@@ -192,6 +192,9 @@ static inline void emu_global_load_lds(const void* g, __attribute__((address_spa
 #define SSDE_GLOAD16_I(dst, voff, sbase, imm) memcpy(&(dst), (const char*)(sbase) + (voff) + (imm), 16)
 #define SSDE_GLOAD8_I(dst, voff, sbase, imm) memcpy(&(dst), (const char*)(sbase) + (voff) + (imm), 8)
 #define SSDE_WAIT_VMCNT_FOR3(n, a, b, c) ((void)0)
+#define SSDE_GLOAD16_AGENT(dst, ptr) memcpy(&(dst), (const void*)(ptr), 16)
+#define SSDE_GSTORE16_AGENT(ptr, val) memcpy((void*)(ptr), &(val), 16)
+#define SSDE_WAIT_VMCNT_FOR4(n, a, b, c, d) ((void)0)
 #define SSDE_WAIT_VMCNT_FENCE(n) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)      /* only used on wave-uniform values */
 #define SSDE_GLDS16_OFF_SAME_BASE(gptr, lds_wave_base, imm) SSDE_GLDS16_OFF(gptr, lds_wave_base, imm)
