@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSDE_ABI_VERSION 8   /* 8: routing switches moved from environment variables into ssde_conv_args.flags / ssde_wgrad_args.flags / ssde_gn_bwd_reduce_args.flags, SSDE_TILE_WINOGRAD4R + SSDE_PACK_WINO4R (register-fed F(4x4,3x3) matrix kernel), SSDE_TILE_WINOGRAD4X removed; 7: ssde_gn_bwd_reduce_args.g0 / g1 (GroupNorm backward in one pass over dp and x); 6: ssde_conv_args.wino_v / ssde_wgrad_args.v_pre (forward by-product feeds the weight gradient); 5: SSDE_PACK_WINO4 image re-ordered per wave (plan blobs of version 4 carry the old image), ODE ops in programs */
+#define SSDE_ABI_VERSION 9   /* 9: SSDE_CONVF_NO_SMALL_COUT (3x3 convolutions onto at most four channels have their own kernel, conv_small.hip), the register-fed F(4x4,3x3) matrix kernel splits its reduction (no interface change); 8: routing switches moved from environment variables into ssde_conv_args.flags / ssde_wgrad_args.flags / ssde_gn_bwd_reduce_args.flags, SSDE_TILE_WINOGRAD4R + SSDE_PACK_WINO4R (register-fed F(4x4,3x3) matrix kernel), SSDE_TILE_WINOGRAD4X removed; 7: ssde_gn_bwd_reduce_args.g0 / g1 (GroupNorm backward in one pass over dp and x); 6: ssde_conv_args.wino_v / ssde_wgrad_args.v_pre (forward by-product feeds the weight gradient); 5: SSDE_PACK_WINO4 image re-ordered per wave (plan blobs of version 4 carry the old image), ODE ops in programs */
 
 /* ---- prologue applied to a source tensor while it is staged into LDS ---- */
 enum {
@@ -110,7 +110,9 @@ enum { SSDE_CONVF_V_GIVEN = 1u,      /* SSDE_TILE_WINOGRAD4R: wino_v already hol
        SSDE_CONVF_GEMM_PIPE = 16u,   /* 1x1 GEMM: force the persistent pipelined kernel (default: where it pays, bf16x6 only) */
        SSDE_CONVF_NO_GEMM_PIPE = 32u,/* 1x1 GEMM: never take it */
        SSDE_CONVF_X6_BM64 = 64u,     /* bf16x6 GEMM: 64 rows per workgroup instead of 128 */
-       SSDE_CONVF_X6_PF2 = 128u };   /* bf16x6 GEMM: rows loaded two stages ahead instead of one */
+       SSDE_CONVF_X6_PF2 = 128u,     /* bf16x6 GEMM: rows loaded two stages ahead instead of one */
+       SSDE_CONVF_NO_SMALL_COUT = 256u };/* 3x3 / stride 1 convolutions with at most four output channels (the image heads) on the general
+                                          direct kernel instead of conv_small.hip (A/B runs, tests) */
 enum { SSDE_TILE_AUTO = 0, SSDE_TILE_256x64 = 1, SSDE_TILE_128x64 = 2, SSDE_TILE_64x64 = 3, SSDE_TILE_256x32 = 4,
        /* Winograd F(2x2,3x3) kernel (3x3, stride 1, pad 1, even output, no aux): w_main must then be packed as
         * [ceil(Cin/8)][ceil(Cout/64)][16 positions][4 channel pairs][64 couts, bit 4 ^= pair parity][2], G g G^T */

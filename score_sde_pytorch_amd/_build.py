@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libssde_hip.so")
-SOURCES = ["runtime.hip", "conv_mfma.hip", "conv_wino.hip", "conv_wino4.hip", "wino4_xform.hip", "conv_wino4r.hip", "conv1x1.hip", "wgrad.hip", "wgrad_wino.hip", "wgrad_wino4.hip", "groupnorm.hip", "resample.hip", "attention.hip",
+SOURCES = ["runtime.hip", "conv_mfma.hip", "conv_wino.hip", "conv_wino4.hip", "wino4_xform.hip", "conv_wino4r.hip", "conv_small.hip", "conv1x1.hip", "wgrad.hip", "wgrad_wino.hip", "wgrad_wino4.hip", "groupnorm.hip", "resample.hip", "attention.hip",
            "elementwise.hip", "backward.hip", "plan.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fgpu-rdc" if False else "-fno-gpu-rdc",

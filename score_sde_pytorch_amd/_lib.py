@@ -10,15 +10,15 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SSDE_LIB_PATH: developer switch for A/B timing of kernel variants built by _build.build_variant (tools/ab_bench.sh)
 LIB_PATH = os.environ.get("SSDE_LIB_PATH") or os.path.join(_HERE, "libssde_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_SILU = 0, 1, 2, 3
 TILE_AUTO, TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32, TILE_WINOGRAD, TILE_WINOGRAD4 = 0, 1, 2, 3, 4, 5, 6
 TILE_WINOGRAD4R = 9       # (7, 8: the bf16-split and the LDS-fed F(4x4,3x3) kernels of round 4, tools/experiments/)
 TILES_WINOGRAD4 = (TILE_WINOGRAD4, TILE_WINOGRAD4R)
 # routing switches of a launch (include/ssde.h: SSDE_CONVF_*, SSDE_WGRADF_*, SSDE_GNBWDF_*)
-CONVF_V_GIVEN, CONVF_BF16X6, CONVF_NO_KSPLIT, CONVF_BKC8, CONVF_GEMM_PIPE, CONVF_NO_GEMM_PIPE, CONVF_X6_BM64, CONVF_X6_PF2 = \
-    1, 2, 4, 8, 16, 32, 64, 128
+CONVF_V_GIVEN, CONVF_BF16X6, CONVF_NO_KSPLIT, CONVF_BKC8, CONVF_GEMM_PIPE, CONVF_NO_GEMM_PIPE, CONVF_X6_BM64, CONVF_X6_PF2, \
+    CONVF_NO_SMALL_COUT = 1, 2, 4, 8, 16, 32, 64, 128, 256
 WGRADF_DIRECT, WGRADF_F2, WGRADF_F4_FORCE, WGRADF_NO_STREAMK, WGRADF_NO_XCD_ORDER, WGRADF_1X1_CHUNKED, WGRADF_XVEC1 = 1, 2, 4, 8, 16, 32, 64
 GNBWDF_THREE_KERNELS, GNBWDF_DEFER_PARAMS = 1, 2
 (OP_CONV, OP_GN_STATS, OP_UPFIRDN, OP_ATTN, OP_EMBED, OP_TO_NHWC, OP_TO_NCHW, OP_BIAS_ACT, OP_SUMSQ,
@@ -303,6 +303,8 @@ def conv_route_flags(env=None):
         f |= CONVF_X6_BM64
     if e.get("SSDE_X6_PF", "") == "2":
         f |= CONVF_X6_PF2
+    if e.get("SSDE_CONV_SMALL", "1") == "0":
+        f |= CONVF_NO_SMALL_COUT
     return f
 
 

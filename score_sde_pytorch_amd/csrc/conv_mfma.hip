@@ -579,6 +579,7 @@ extern "C" int ssde_conv2d(const ssde_conv_args* a, void* stream) {
     }
   }
   if (a && a->dst && ssde_conv1x1_wants(a)) return ssde_conv1x1_launch(a, stream, nullptr);   // 1x1-only: GEMM kernel (conv1x1.hip)
+  if (a && a->dst && ssde_conv_small_wants(a)) return ssde_conv_small_launch(a, stream, nullptr);   // image heads (conv_small.hip)
   ConvPlan pl;
   if (int rc = make_plan(a, &pl)) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -608,6 +609,7 @@ extern "C" int ssde_conv_gn_slices(const ssde_conv_args* a) {
     if (hw % 64 == 0) return (hw / 64) * 4;
     return (hw >= 8 && hw < 64 && 64 % hw == 0) ? 4 : 0;
   }
+  if (q.dst && ssde_conv_small_wants(&q)) return 0;             // (the image heads are not normalised by anybody)
   ConvPlan pl;
   if (make_plan(&q, &pl)) return 0;
   return pl.gn_slices;
@@ -622,6 +624,11 @@ extern "C" int ssde_conv_lds_bytes(const ssde_conv_args* a) {
   if (a && a->dst && ssde_conv1x1_wants(a)) {
     int lds = 0;
     if (int rc = ssde_conv1x1_launch(a, nullptr, &lds)) return rc;
+    return lds;
+  }
+  if (a && a->dst && ssde_conv_small_wants(a)) {
+    int lds = 0;
+    if (int rc = ssde_conv_small_launch(a, nullptr, &lds)) return rc;
     return lds;
   }
   ConvPlan pl;

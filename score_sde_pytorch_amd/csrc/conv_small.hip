@@ -33,7 +33,7 @@ static_assert(kSlices * kTile * kTile * 4 <= kHaloFloats, "the slice partials re
 
 struct SmallParams {
   ssde_src src;
-  const float* wpk;        // SSDE_PACK_CONV: [ceil(C/8)][9][CoutPad][8]
+  const float* wpk;        // SSDE_PACK_CONV3: [ceil(C/8)][9][CoutPad][8]
   int N, H, W, Cout, CoutPad;
   int tiles_x, tiles_y;
   const float* bias; const float* chan_add; int chan_add_ld;

@@ -387,7 +387,7 @@ int ssde_conv_wino4r_splits(int wgs, int ctot, int c_out, unsigned flags) {
   const int cus = ssde_num_cus();
   // (measured at batch 256 on 8x8 maps, profiles/r5_wino4r_split_8x8.txt: two shares of 32 / 64 stages win 7 / 20 % over the
   //  unsplit kernel, two shares of 16 stages -- 128 input channels -- lose 20 %: the hand-over costs what 8-10 stages do)
-  if (wgs * 4 <= cus && ctot % 32 == 0 && ctot >= 512) return 4;
+  if (wgs * 4 <= cus && ctot % 32 == 0 && ctot >= 256) return 4;
   if (wgs * 2 <= cus && ctot % 16 == 0 && ctot >= 256) return 2;
   return 1;
 }

@@ -23,6 +23,8 @@ int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out);
 unsigned* ssde_conv_sync_slots(int need);                                            // conv_mfma.hip
 int ssde_conv_wino4_splits(int wgs, int ctot, int c_out, unsigned flags);                         // conv_wino4.hip
 int ssde_conv_wino4r_splits(int wgs, int ctot, int c_out, unsigned flags);                        // conv_wino4r.hip
+bool ssde_conv_small_wants(const ssde_conv_args* a);                                             // conv_small.hip (image heads: at most 4 couts)
+int ssde_conv_small_launch(const ssde_conv_args* a, void* stream, int* lds_out);
 bool ssde_wgrad_wino_wants(const ssde_wgrad_args* a);                                // wgrad_wino.hip
 int64_t ssde_wgrad_wino_scratch_floats(const ssde_wgrad_args* a);
 int ssde_wgrad_wino_launch(const ssde_wgrad_args* a, void* stream);

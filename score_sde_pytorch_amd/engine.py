@@ -762,6 +762,11 @@ class Lowering:
             wgs4 = -(-(-(-(self.n * h * w) // 512)) // 8) * 8 * n_tiles
             if self.cus // 2 < wgs4 * 2 <= self.cus and self._wino4_two_kernels(h, w, c_out, c_in):
                 return 6
+            # (four shares filling one round -- the 8x8 maps at batch 128, the training step: 256->256 0.102 -> 0.063 ms, 512->256 0.184 -> 0.082,
+            #  step 0.0548 -> 0.0530 s, profiles/r5_wino4r_split_8x8_batch128.txt, r5_wino4r_split4_train_ab.txt; SSDE_W4R_SPLIT4=0 switches it off)
+            if os.environ.get("SSDE_W4R_SPLIT4", "1") == "1" and c_in % 32 == 0 and self.cus // 2 < wgs4 * 4 <= self.cus \
+                    and self._wino4_two_kernels(h, w, c_out, c_in):
+                return 6
         # tools/heuristic_sweep.py (profiles/r2_heuristic_sweep.txt): F(4x4,3x3) wins from one of its workgroups per CU (256),
         # F(2x2,3x3) over the direct kernel from half a workgroup per CU (128; by 2-6 %; at 64 the direct kernel is 1.5x
         # faster).  tools/batch_sweep.py: the sampler at batch 16 / 64 / 256 under this rule (profiles/r4_batch_sweep.txt)

@@ -1280,6 +1280,60 @@ def check_conv_split_reduction(dev, monkeypatch, n, repeats=3):
             assert (m2 - mr).abs().max().item() < 1e-5 and ((r2 - rr).abs() / rr).max().item() < 1e-4
 
 
+def check_conv_small_cout(dev, big=False):
+    """conv_small.hip: 3x3 / stride 1 convolutions onto at most four channels (the image heads, ncsnpp.py:329-337,368-375) --
+    plain, then fully fused (concat source, GroupNorm + SiLU prologue, bias, per-image addend, residual before / after the
+    scale), on maps that are not multiples of the 8x8 tile, with one, two and three 128-channel chunks and a ragged last
+    chunk; against torch at the direct kernel's tolerance, and against the general direct kernel (SSDE_CONVF_NO_SMALL_COUT)."""
+    import ctypes as C
+    import numpy as np
+    import torch.nn.functional as F
+    from score_sde_pytorch_amd import hipops as ops, _lib as L
+    from score_sde_pytorch_amd.engine import pack_conv_weight
+    lib = L.load()
+    g = torch.Generator().manual_seed(11)
+    cases = [(2, 128, 0, 4, 32, 32), (3, 16, 0, 3, 8, 8), (1, 8, 0, 1, 12, 20), (2, 96, 64, 4, 16, 16), (1, 256, 128, 4, 8, 8), (5, 40, 0, 2, 4, 4)]
+    if big:
+        cases += [(256, 128, 0, 4, 32, 32), (16, 128, 0, 4, 128, 128), (7, 256, 0, 3, 64, 64)]
+    for (n, c0, c1, cout, h, w_) in cases:
+        cin = c0 + c1
+        x0 = torch.randn(n, h, w_, c0, generator=g) * 1.5 + 0.3
+        x1 = torch.randn(n, h, w_, c1, generator=g) if c1 else None
+        xcat = torch.cat([x0, x1], -1) if c1 else x0
+        wt = torch.randn(cout, cin, 3, 3, generator=g) / np.sqrt(9 * cin)
+        b, gamma, beta = torch.randn(cout, generator=g), torch.randn(cin, generator=g), torch.randn(cin, generator=g)
+        resid, ca = torch.randn(n, h, w_, cout, generator=g), torch.randn(n, cout, generator=g)
+        G = 32 if cin % 32 == 0 and (cin // 32) % 4 == 0 else cin // 4
+        x0d, x1d = x0.to(dev), (x1.to(dev) if c1 else None)
+        mean, rstd = ops.groupnorm_stats(x0d, G, 1e-6, x2=x1d)
+        gn = (mean, rstd, gamma.to(dev), beta.to(dev), G)
+        wp, bd, cad, rd = pack_conv_weight(wt.to(dev)), b.to(dev), ca.to(dev), resid.to(dev)
+        xn = F.silu(F.group_norm(xcat.permute(0, 3, 1, 2), G, gamma, beta, 1e-6))
+        for fused, post in ((False, 0), (True, 0), (True, 1)):
+            outs = []
+            for flags in (0, L.CONVF_NO_SMALL_COUT):
+                a = L.ConvArgs()
+                ops._fill_src(a.main, x0d, x1d, L.PRO_GN_SILU if fused else L.PRO_NONE, gn if fused else None)
+                dst = torch.full((n, h, w_, cout), float("nan"), device=dev)
+                a.w_main, a.ksize, a.stride, a.pad, a.h_in, a.w_in = wp.data_ptr(), 3, 1, 1, h, w_
+                a.n, a.h_out, a.w_out, a.c_out, a.dst, a.tile = n, h, w_, cout, dst.data_ptr(), L.TILE_AUTO
+                a.out_scale, a.flags = (0.7 if fused else 1.0), L.conv_route_flags() | flags
+                a.bias = bd.data_ptr()
+                if fused:
+                    a.chan_add, a.chan_add_ld, a.resid, a.resid_post = cad.data_ptr(), cout, rd.data_ptr(), post
+                assert flags or lib.ssde_conv_gn_slices(C.byref(a)) == 0
+                assert lib.ssde_conv_lds_bytes(C.byref(a)) > 0, lib.ssde_last_error()
+                L.check(lib.ssde_conv2d(C.byref(a), ops._stream()))
+                outs.append(dst.cpu())
+            if fused:
+                core = (F.conv2d(xn, wt, b, padding=1) + ca[:, :, None, None]).permute(0, 2, 3, 1)
+                ref = (core + resid) * 0.7 if not post else core * 0.7 + resid
+            else:
+                ref = F.conv2d(xcat.permute(0, 3, 1, 2), wt, b, padding=1).permute(0, 2, 3, 1)
+            assert _util.rel_err(outs[0], ref) < 2e-5, (n, c0, c1, cout, h, w_, fused, post, _util.rel_err(outs[0], ref))
+            assert _util.rel_err(outs[1], ref) < 2e-5 and _util.rel_err(outs[0], outs[1]) < 2e-5
+
+
 def check_conv_winograd4(dev, big=False, regs=False):
     """conv_wino4.hip (F(4x4,3x3)): plain convolutions over the tilings it knows (part of one image, several whole
     images, ragged batch tails, cout tiles that are not full), then the fully fused form (concat source, GroupNorm + SiLU

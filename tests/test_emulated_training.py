@@ -148,6 +148,10 @@ def test_conv3x3_winograd_f4x4_register_fed_matrix_kernel():
     T.check_conv_winograd4("cpu", big=False, regs=True)
 
 
+def test_conv3x3_onto_the_image_channels():
+    T.check_conv_small_cout("cpu")
+
+
 def test_conv3x3_winograd_f4x4_in_two_kernels():
     T.check_conv_winograd4_two_kernels("cpu")
 

@@ -157,6 +157,10 @@ def test_conv3x3_winograd_f4x4_register_fed_matrix_kernel():
     T.check_conv_winograd4("cuda", big=True, regs=True)
 
 
+def test_conv3x3_onto_the_image_channels():
+    T.check_conv_small_cout("cuda", big=True)
+
+
 def test_conv3x3_winograd_f4x4_in_two_kernels():
     T.check_conv_winograd4_two_kernels("cuda", big=True)
 
