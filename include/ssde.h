@@ -68,7 +68,11 @@ typedef struct ssde_src {
  * the strided conv of conv_downsample_2d (models/up_or_down_sampling.py:178) and
  * the residual tail "(x + h) / sqrt(2)" (layerspp.py:268-274, 87-91).
  * Weight packing (host side): w_main [ceil(Cin/8)][k*k][cout_pad][8],
- * w_aux [ceil(Cx/8)][cout_pad][8], cout_pad = roundup(c_out, 64), zero filled. */
+ * w_aux [ceil(Cx/8)][cout_pad][8], cout_pad = roundup(c_out, 64), zero filled.
+ * Under SSDE_TILE_AUTO the library routes by shape: 1x1-only launches to the GEMM kernels (conv1x1.hip), 3x3 / stride 1 /
+ * pad 1 launches onto at most four channels -- the image heads, ncsnpp.py:329-337,368-375 -- to conv_small.hip (ABI 9; same
+ * weight packing; ssde_conv_gn_slices is 0 for them), everything else to the direct matrix kernel (conv_mfma.hip); the
+ * Winograd kernels are taken by naming their tile (their weights are packed differently). */
 typedef struct ssde_conv_args {
   ssde_src main;         /* k x k source; ksize == 0 -> unused             */
   ssde_src aux;          /* 1 x 1 source at OUTPUT resolution; p0 == NULL -> unused */

@@ -28,7 +28,8 @@ constexpr int kChunk = 128, kSlices = kChunk / 8;                      // channe
 constexpr int kWPitch = 36;                                            // floats per (tap, slice): 32 weights + 4 of padding
 constexpr int kHaloFloats = kHaloPx * kChunk;                          // 12800
 constexpr int kWFloats = 9 * kSlices * kWPitch;                        // 5184
-constexpr int kLdsBytes = (kHaloFloats + kWFloats) * 4;                // 71936: two workgroups per CU
+constexpr int kGnFloats = 64 + 2 * kChunk;                             // (mean, rstd) per channel quad, gamma, beta of a chunk
+constexpr int kLdsBytes = (kHaloFloats + kWFloats + kGnFloats) * 4;    // 73216: two workgroups per CU
 static_assert(kSlices * kTile * kTile * 4 <= kHaloFloats, "the slice partials reuse the halo area");
 
 struct SmallParams {
@@ -65,31 +66,39 @@ __global__ __launch_bounds__(kThreads, 2) void conv_small_cout_kernel(const Smal
 #pragma unroll
   for (int j = 0; j < 4; ++j) { acc[j][0] = ssde_f32x2{0.f, 0.f}; acc[j][1] = ssde_f32x2{0.f, 0.f}; }
 
+  constexpr int kItems = (kHaloPx * (kChunk / 4) + kThreads - 1) / kThreads;      // 13 halo float4s per thread and chunk
+  float* gnl = wl + kWFloats;               // this chunk's GroupNorm tables: [32 quads](mean, rstd) | gamma[128] | beta[128]
   for (int c_base = 0; c_base < Ctot; c_base += kChunk) {
     if (c_base) __syncthreads();            // the previous chunk has been consumed
-    // ---- stage the halo tile of this chunk: item = (halo pixel, channel quad), 32 quads of a pixel are 512 contiguous bytes
-    for (int it = tid; it < kHaloPx * (kChunk / 4); it += kThreads) {
+    // ---- GroupNorm parameters of the chunk -> LDS (one division per channel quad here instead of one per staged item)
+    if (pro.gn) {
+      const int c = c_base + (tid & 31) * 4;
+      if (c < Ctot) {
+        if (tid < 32) {
+          const int gi = img * s.gn_groups + c / cpg;
+          *reinterpret_cast<float2*>(gnl + 2 * tid) = make_float2(s.gn_mean[gi], s.gn_rstd[gi]);
+        } else if (tid < 64) {
+          *reinterpret_cast<float4*>(gnl + 64 + (tid & 31) * 4) = *reinterpret_cast<const float4*>(s.gn_gamma + c);
+        } else if (tid < 96) {
+          *reinterpret_cast<float4*>(gnl + 64 + kChunk + (tid & 31) * 4) = *reinterpret_cast<const float4*>(s.gn_beta + c);
+        }
+      }
+    }
+    // ---- the halo tile of this chunk: item = (halo pixel, channel quad), the 32 quads of a pixel are 512 contiguous bytes.
+    // ALL loads of a thread are issued before the first one is used (branch-free: items outside the image / the channel range
+    // read a valid address and are zeroed below); the first version issued one load per loop trip and waited for each
+    float4 hv[kItems];
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+      const int it = tid + k * kThreads;
       const int hp = it >> 5, q = it & 31;
       const int hy = hp / kHalo, hx = hp - hy * kHalo;
       const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
       const int c = c_base + q * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < Ctot && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-        const size_t pix = ((size_t)img * p.H + iy) * p.W + ix;
-        const bool second = c >= s.c0;                      // (c0 % 4 == 0: a quad never straddles the sources)
-        v = *reinterpret_cast<const float4*>(second ? s.p1 + pix * s.c1 + (c - s.c0) : s.p0 + pix * s.c0 + c);
-        float mu = 0.f, rs = 1.f;
-        float4 ga = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pro.gn) {
-          mu = s.gn_mean[img * s.gn_groups + c / cpg];
-          rs = s.gn_rstd[img * s.gn_groups + c / cpg];
-          ga = *reinterpret_cast<const float4*>(s.gn_gamma + c);
-          be = *reinterpret_cast<const float4*>(s.gn_beta + c);
-        }
-        v = ssde_pro_apply(v, mu, rs, ga, be, (uint32_t)pix * (uint32_t)Ctot + (uint32_t)c, pro);
-      }
-      // channel c = slice * 8 + half * 4 + k  ->  [px][half][slice][k]
-      *reinterpret_cast<float4*>(halo + hp * kChunk + ((q & 1) * kSlices + (q >> 1)) * 4) = v;
+      const bool ok = it < kHaloPx * (kChunk / 4) && c < Ctot && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const size_t pix = ok ? ((size_t)img * p.H + iy) * p.W + ix : 0;
+      const bool second = ok && c >= s.c0;                  // (c0 % 4 == 0: a quad never straddles the sources)
+      hv[k] = *reinterpret_cast<const float4*>(second ? s.p1 + pix * s.c1 + (c - s.c0) : s.p0 + pix * s.c0 + (ok ? c : 0));
     }
     // ---- the chunk's weights: global [ci8 chunk][tap][CoutPad][8 ci] -> LDS [tap][slice][ci][co]
     for (int it = tid; it < 9 * kSlices * 8; it += kThreads) {
@@ -102,6 +111,31 @@ __global__ __launch_bounds__(kThreads, 2) void conv_small_cout_kernel(const Smal
         w4 = make_float4(g[0], g[8], g[16], g[24]);          // couts 0..3 (CoutPad >= 64: rows past Cout are zero)
       }
       *reinterpret_cast<float4*>(wl + (tap * kSlices + sx) * kWPitch + ci * 4) = w4;
+    }
+    if (pro.gn) __syncthreads();            // the GroupNorm tables are in place
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+      const int it = tid + k * kThreads;
+      if (it >= kHaloPx * (kChunk / 4)) continue;
+      const int hp = it >> 5, q = it & 31;
+      const int hy = hp / kHalo, hx = hp - hy * kHalo;
+      const int iy = oy0 - 1 + hy, ix = ox0 - 1 + hx;
+      const int c = c_base + q * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < Ctot && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+        const size_t pix = ((size_t)img * p.H + iy) * p.W + ix;
+        float mu = 0.f, rs = 1.f;
+        float4 ga = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pro.gn) {
+          const float2 mr = *reinterpret_cast<const float2*>(gnl + 2 * q);
+          mu = mr.x; rs = mr.y;
+          ga = *reinterpret_cast<const float4*>(gnl + 64 + q * 4);
+          be = *reinterpret_cast<const float4*>(gnl + 64 + kChunk + q * 4);
+        }
+        v = ssde_pro_apply(hv[k], mu, rs, ga, be, (uint32_t)pix * (uint32_t)Ctot + (uint32_t)c, pro);
+      }
+      // channel c = slice * 8 + half * 4 + k  ->  [px][half][slice][k]
+      *reinterpret_cast<float4*>(halo + hp * kChunk + ((q & 1) * kSlices + (q >> 1)) * 4) = v;
     }
     __syncthreads();
     // ---- 9 taps x 8 channels x 4 pixels x 4 couts

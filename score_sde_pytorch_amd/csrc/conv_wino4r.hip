@@ -84,7 +84,9 @@ struct Wino4rParams {
 // protocol: shares are dealt in the order the workgroups START -- an atomic counter per tile -- so share k only ever waits for
 // shares < k, which are resident or done; the sums are formed in the fixed order ((s0 + s1) + s2) + s3).  The maps this is for
 // are the 8x8 ones at batch 256: 1024 tiles = 32 workgroup tiles x 4 cout tiles = 128 workgroups on 256 CUs; two shares each
-// cover the chip with one workgroup per CU, and the matrix loop of a share is half as long.
+// cover the chip with one workgroup per CU, and the matrix loop of a share is half as long.  (Eight shares on the 4x4 maps -- one
+// tile per image -- were built and measured slower than the direct kernel: the hand-over chain outlasts the 8 stages a share
+// computes, profiles/r5_wino4r_4x4_maps_eight_shares_rejected.txt, tools/experiments/conv_wino4r_4x4_maps_eight_shares/.)
 template <int kKs>
 __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rParams p) {
   constexpr bool kSplit = kKs > 1;

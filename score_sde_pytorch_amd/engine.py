@@ -752,11 +752,11 @@ class Lowering:
             if splits > 1 and wgs4 * splits >= int(os.environ["SSDE_W4_SPLIT_MIN_WGS"]):
                 return 4
         # The register-fed matrix kernel splits its reduction too (conv_wino4r.hip, ssde_conv_wino4r_splits -- the same rule
-        # here): its channel stage is ~2450 cycles against the fused kernel's ~4600, so where TWO shares fill exactly one round of
-        # workgroups -- the 8x8 maps at batch 256: 128 tiles -> 256 workgroups -- transform pass + split matrix kernel beat
-        # F(2x2,3x3): 256->256 0.092 against 0.108 ms, 512->256 0.131 against 0.195 (profiles/r5_wino4r_split_8x8.txt); with 128
-        # input channels (16 stages per share) the hand-over costs more than the split saves and F(2x2,3x3) stays.  Four shares
-        # (batch 128 and smaller) are left to callers that name the tile.  SSDE_W4R_SPLIT=0 keeps round 4's choice.
+        # here): its channel stage is ~2450 cycles against the fused kernel's ~4600, so where the shares fill exactly one round of
+        # workgroups, transform pass + split matrix kernel beat F(2x2,3x3).  TWO shares -- the 8x8 maps at batch 256: 128 tiles ->
+        # 256 workgroups: 256->256 0.077 against 0.109 ms, 512->256 0.112 against 0.193 (profiles/r5_wino4r_split_8x8.txt); with 128
+        # input channels (16 stages per share) the hand-over costs what the split saves and F(2x2,3x3) stays.
+        # SSDE_W4R_SPLIT=0 keeps round 4's choice.
         if mode != "3" and legal4 and c_in % 16 == 0 and c_in >= 256 and c_out % 4 == 0 \
                 and os.environ.get("SSDE_W4R_SPLIT", "1") != "0" and os.environ.get("SSDE_CONV_KSPLIT", "1") != "0":
             wgs4 = -(-(-(-(self.n * h * w) // 512)) // 8) * 8 * n_tiles

@@ -1361,7 +1361,7 @@ def check_conv_winograd4(dev, big=False, regs=False):
     if big:
         plain += [(16, 128, 128, 32), (9, 256, 256, 16), (20, 256, 256, 8), (2, 128, 128, 64)]
         if regs:
-            plain += [(256, 256, 256, 8), (256, 512, 256, 8), (128, 256, 256, 8)]      # the BASELINE sampler's 8x8 shapes: 2 / 2 / 4 shares
+            plain += [(256, 256, 256, 8), (256, 512, 256, 8), (128, 256, 256, 8)]      # the BASELINE sampler's / training step's 8x8 shapes: 2 / 2 / 4 shares
     for (n, cin, cout, h) in plain:
         if regs and cin % 8:
             continue                                # (the register-fed kernel runs its stages in pairs: input channels % 8 == 0)

@@ -186,7 +186,20 @@ def test_two_kernel_winograd_is_the_form_of_every_f4x4_layer(monkeypatch):
     cs = convs(engine.UNetEngine(model, 256, 32, 32, torch.device("cpu")))
     two = [c for c in cs if c[0] == L.TILE_WINOGRAD4R]
     assert len(two) >= 40 and not [c for c in cs if c[0] == L.TILE_WINOGRAD4]
-    assert all(c[2] >= 16 and c[3] % 8 == 0 for c in two)
+    assert all(c[2] >= 8 and c[3] % 8 == 0 for c in two)
+    # the 8x8 maps (128 workgroup tiles at batch 256): two shares of the split matrix kernel fill the chip -- every layer with
+    # 256 input channels or more; the 128-channel one stays on F(2x2,3x3); SSDE_W4R_SPLIT=0 is round 4's choice
+    at8 = [c for c in cs if c[2] == 8 and c[0] in (L.TILE_WINOGRAD4R, L.TILE_WINOGRAD)]
+    assert len(at8) >= 20 and all((c[0] == L.TILE_WINOGRAD4R) == (c[3] >= 256) for c in at8)
+    monkeypatch.setenv("SSDE_W4R_SPLIT", "0")
+    assert not [c for c in convs(engine.UNetEngine(model, 256, 32, 32, torch.device("cpu"))) if c[0] == L.TILE_WINOGRAD4R and c[2] < 16]
+    monkeypatch.delenv("SSDE_W4R_SPLIT")
+    # batch 128 (the training step): four shares
+    cs128 = convs(engine.UNetEngine(model, 128, 32, 32, torch.device("cpu")))
+    assert len([c for c in cs128 if c[2] == 8 and c[0] == L.TILE_WINOGRAD4R]) >= 20
+    monkeypatch.setenv("SSDE_W4R_SPLIT4", "0")
+    assert not [c for c in convs(engine.UNetEngine(model, 128, 32, 32, torch.device("cpu"))) if c[2] == 8 and c[0] == L.TILE_WINOGRAD4R]
+    monkeypatch.delenv("SSDE_W4R_SPLIT4")
     for tile, c_out, h, c_in, v in two:
         assert v is not None and v.numel == 36 * 256 * (h // 4) ** 2 * c_in
     assert all(c[4] is None for c in cs if c[0] != L.TILE_WINOGRAD4R)          # inference: nobody else wants the transformed input

@@ -11,7 +11,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("conv_wino4r_kernel", "wino4_xform_vq_kernel", "conv_wino4x_kernel", "gn_bwd_fused_kernel", "gemm1x1_bf16x6_kernel", "gemm1x1_pipe_kernel",
+    for key in ("conv_wino4r_kernel", "wino4_xform_vq_kernel", "conv_small_cout_kernel", "conv_wino4x_kernel", "gn_bwd_fused_kernel", "gemm1x1_bf16x6_kernel", "gemm1x1_pipe_kernel",
                 "wgrad4_gemm_kernel", "wino4_xform_z_kernel", "wino4_xform_v_kernel", "wgrad1x1_gemm_kernel", "gn_part_finalize_kernel", "gn_bwd_finalize_kernel",
                 "conv_wino4_kernel", "conv_wino_kernel", "conv_mfma_kernel", "gemm1x1_kernel", "wgrad_wino_kernel", "wgrad_kernel", "wgrad_reduce_kernel", "attn_kernel", "attn_bwd_q_kernel",
                 "attn_bwd_kv_kernel", "gn_stats_kernel", "gn_bwd_reduce_kernel", "prologue_bwd_kernel", "colsum_kernel",
