@@ -755,6 +755,9 @@ def main():
                   ms_per_step=tr["value"] * 1e3, dist_backend=args.dist_backend if world > 1 else None,
                   rccl_version=_rccl_version(), config={"workload": "configs/ve/cifar10_ncsnpp_continuous DSM training step, batch %d/GPU" % args.train_batch,
                                                         "matrix_mode": args.matrix, "parallelism": "data parallel x%d" % world})
+        if args.share_device and world > 1:
+            tr["scaling"] = "none: %d ranks share %d GPU(s) over %s -- a functional run of the multi-rank code paths, not a scaling point" \
+                % (world, n_dev, args.dist_backend)
         if rank == 0:
             print(json.dumps(tr))
         if dist is not None:

@@ -322,6 +322,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
             __builtin_amdgcn_s_sleep(4);
         __syncthreads();
       }
+      SSDE_RT(40 + rnd);                     // (split) the previous share's round is there
       constexpr int kIters = 256 * 16 / kThreads, kBatch = 4;      // (4 float4 of a thread at a time: round 0 still holds half of the accumulators)
       static_assert(kBatch == 4, "SSDE_WAIT_VMCNT_FOR4");
 #pragma unroll
@@ -359,11 +360,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
             if (dp[it]) SSDE_GSTORE16_AGENT(dp[it], o[it]);
         }
       }
+      SSDE_RT(42 + rnd);                     // (split) sums formed: handed on, or parked for the epilogue
       if (!last) {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0);      // every store of this thread is acknowledged ...
         __syncthreads();                    // ... and every thread's (and park may be refilled by round 1)
         if (tid == 0) atomicAdd(sy + 1, rnd == 0 ? 1u : 0x10000u);
+        SSDE_RT(44 + rnd);                   // (split) stores acknowledged, round signalled
         if (rnd == 0) continue;
         return;
       }

@@ -720,7 +720,9 @@ class Lowering:
         to cover the 256 CUs (F(2x2,3x3): 64 tiles x 64 couts per workgroup -- measured x1.2-1.5 over the direct kernel
         from 8x8 up at batch 256, x0.5 at 4x4 where only 64 workgroups exist).  F(4x4,3x3) does 1.78x less matrix work
         again and is 15-23 % faster than F(2x2,3x3) from 16x16 maps up (profiles/r2_wino4_v3_interleaved.txt); its
-        workgroups cover 32 tiles = 512 pixels, so 8x8 maps at batch 256 give 128 of them and stay on F(2x2,3x3) (see below).
+        workgroups cover 32 tiles = 512 pixels, so 8x8 maps at batch 256 give 128 of them: there the register-fed matrix kernel
+        splits its reduction over two workgroups per tile (four at batch 128) and wins from 256 input channels up (round 5, see
+        below); with fewer channels, and on 4x4 maps, F(2x2,3x3) / the direct kernel stay.
         Rounding: ~5x coarser than the direct form, 2.5e-6 .. 1.3e-5 on the whole network against the 1e-4 the parity
         tests allow (tools/experiments/wino43_error_budget.py).
         SSDE_WINOGRAD: 0 = direct (bitwise fmaf-chain) kernel everywhere, 1 = this heuristic (default), 2 = F(2x2,3x3)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5, call 20: the default bench line of the final sources (what the driver runs), then rocprofv3 kernel-trace stats + the PMC
-# passes of tools/profile_gpu.sh (FETCH_SIZE, WRITE_SIZE, MFMA busy: one counter group per pass, --kernel-trace only)
+# passes of tools/profile_gpu.sh (FETCH_SIZE, WRITE_SIZE, MFMA busy: one counter group per pass, --kernel-trace only); cycle trace of the two shares of a split launch
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -16,3 +16,4 @@ print("   train", round(d["train"]["value"], 5), "| f32:", round(d["matrix_f32"]
 print("   extra", {k: (round(v.get("value", 0), 5), v.get("nfe")) for k, v in d.get("extra", {}).items()}, "| cpu", d.get("cpu_baseline", {}).get("value"))
 PY
 timeout 900 bash tools/profile_gpu.sh r5final 2>&1 | tail -25
+SSDE_LIB_PATH=$ROOT/tools/variants/libssde_hip_w4rtrace.so timeout 200 python tools/wino4r_split_trace.py 2>&1 | grep -v amdgpu.ids | tee $OUT/r5s_wino4r_split_trace.txt
