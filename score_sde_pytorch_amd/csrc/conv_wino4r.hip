@@ -311,8 +311,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
     const int gn_max = IMGS == 1 ? p.N * p.tiles_per_img * 2 : p.N;
     if constexpr (kSplit) {
       // split reduction (conv_wino4.hip's hand-over): share 0 leaves its raw 4x4 outputs in the tile's own part of dst, shares
-      // 1 .. kKs - 2 add theirs to them in turn, the last share adds its own and runs the epilogue, round by round.  The sums travel as agent-scope 16-byte accesses, coherent at the device level by themselves
-      // (no __threadfence(): that is a write-back of the whole L2 per workgroup, conv_mfma.hip)
+      // 1 .. kKs - 2 add theirs to them in turn, the last share adds its own and runs the epilogue, round by round.  The sums
+      // travel as agent-scope 16-byte accesses, coherent at the device level by themselves (no __threadfence(): that is a
+      // write-back of the whole L2 per workgroup, conv_mfma.hip)
       const bool first = ks == 0, last = ks == kKs - 1;
       // (sy[1]: the shares that have handed over round 0 in its low half, round 1 in its high half -- share k starts adding to
       //  round 0 while share k - 1 is still busy with its round 1)
@@ -390,8 +391,10 @@ int pow2_floor(int v) { int q = 1; while (q * 2 <= v) q *= 2; return q; }
 int ssde_conv_wino4r_splits(int wgs, int ctot, int c_out, unsigned flags) {
   if ((flags & SSDE_CONVF_NO_KSPLIT) || c_out % 4 != 0) return 1;
   const int cus = ssde_num_cus();
-  // (measured at batch 256 on 8x8 maps, profiles/r5_wino4r_split_8x8.txt: two shares of 32 / 64 stages win 7 / 20 % over the
-  //  unsplit kernel, two shares of 16 stages -- 128 input channels -- lose 20 %: the hand-over costs what 8-10 stages do)
+  // (measured on 8x8 maps, profiles/r5_wino4r_split_8x8.txt, r5_wino4r_split_8x8_batch128.txt: at batch 256 two shares of 32 / 64
+  //  stages take 0.077 / 0.112 ms against 0.098 / 0.163 unsplit, two shares of 16 stages -- 128 input channels -- are level; at
+  //  batch 128 four shares 0.063 / 0.082 against 0.092 / 0.153.  The last share spends 13-15 k cycles on the hand-over,
+  //  profiles/r5_wino4r_split_trace.txt: what ~6 stages cost)
   if (wgs * 4 <= cus && ctot % 32 == 0 && ctot >= 256) return 4;
   if (wgs * 2 <= cus && ctot % 16 == 0 && ctot >= 256) return 2;
   return 1;
