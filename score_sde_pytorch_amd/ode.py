@@ -170,18 +170,26 @@ def _once(fun, stages, t, yy, in_place):
     return out
 
 
-def rhs_cache_get(model, key, make, limit=4):
+def rhs_cache_get(model, key, make, limit=None):
     """The fused right-hand sides of a model (lowered program + arena + packed weights + hipGraph each), newest last.
-    Bounded: building samplers / likelihood closures with fresh SDE objects or varying batch shapes evicts the oldest
-    entry (its graph and arena are released with it) instead of growing until the device runs out of memory."""
+    Bounded PER KIND (key[0]: "drift" of the ODE sampler, "likelihood"): building samplers / likelihood closures with fresh SDE
+    objects or varying batch shapes evicts the oldest entry of that kind (its graph and arena are released with it) instead of
+    growing until the device runs out of memory -- and a loop that alternates sampling and likelihood evaluation over a few
+    shapes does not make the two kinds evict each other (every eviction is a re-lowering and a re-capture on the next call).
+    limit: entries kept per kind (default 4; SSDE_ODE_RHS_CACHE=<n> overrides)."""
+    import os
+    if limit is None:
+        limit = max(1, int(os.environ.get("SSDE_ODE_RHS_CACHE", "4")))
     cache = model.__dict__.setdefault("_ode_rhs", {})
     rhs = cache.pop(key, None)
     fresh = rhs is None
     if fresh:
         rhs = make()
     cache[key] = rhs                                   # (re-)inserted as the most recently used
-    while len(cache) > limit:
-        cache.pop(next(iter(cache)))
+    kind = key[0] if isinstance(key, tuple) and key else None
+    same = [k for k in cache if (k[0] if isinstance(k, tuple) and k else None) == kind]     # oldest first
+    for k in same[:max(0, len(same) - limit)]:
+        cache.pop(k)
     return rhs, fresh
 
 

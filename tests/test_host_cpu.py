@@ -319,3 +319,27 @@ def test_grad_run_extents_are_recorded():
     o1, n1 = flat.index[id(ws[1])]
     assert flat.write_extent(o1) == n1                                  # a plain parameter pointer covers that parameter
     assert flat.write_extent(o1 + 5) == n1 - 5
+
+
+def test_fused_rhs_cache_is_bounded_per_kind(monkeypatch):
+    """ode.rhs_cache_get: the ODE sampler's drift programs and the likelihood programs of a model are kept in one dict but bounded
+    per kind, newest last; a hit re-inserts the entry as the most recent one; SSDE_ODE_RHS_CACHE sets the bound."""
+    from score_sde_pytorch_amd import ode
+
+    class M:
+        pass
+    m, made = M(), []
+
+    def get(kind, i, **kw):
+        return ode.rhs_cache_get(m, (kind, i), lambda: made.append((kind, i)) or (kind, i), **kw)
+    for i in range(4):
+        assert get("drift", i) == (("drift", i), True)
+    for i in range(4):
+        assert get("likelihood", i) == (("likelihood", i), True)          # ... without evicting a drift entry
+    assert all(get("drift", i) == (("drift", i), False) for i in range(4)) and len(made) == 8
+    assert get("drift", 9)[1] and get("drift", 0)[1]                      # a fifth drift entry evicts the oldest one (0) only
+    assert not get("drift", 2)[1] and not get("likelihood", 0)[1]
+    monkeypatch.setenv("SSDE_ODE_RHS_CACHE", "1")
+    assert get("likelihood", 7)[1] and [k for k in m._ode_rhs if k[0] == "likelihood"] == [("likelihood", 7)]
+    assert len([k for k in m._ode_rhs if k[0] == "drift"]) == 4           # the other kind is untouched by that call
+    assert get("drift", 5, limit=2)[1] and len([k for k in m._ode_rhs if k[0] == "drift"]) == 2
