@@ -315,7 +315,7 @@ DTYPE = {"f32": "f32 (exact-fp32 MFMA kernels everywhere)",
 
 def op_bytes(op):
     """Algorithmic (compulsory) HBM bytes of one HBM-bound op of the program, from its arguments (fp32):
-    GroupNorm statistics = one read of the tensor; FIR = input + output; randn = one write; squared norms = two reads;
+    GroupNorm statistics = one read of the tensor; FIR = input + output (both outputs of a fused pair); randn = one write; squared norms = two reads;
     Langevin / predictor update = 3 reads (x, score, z) + 2 writes (x, x_mean)."""
     from score_sde_pytorch_amd import _lib as L
     k = int(op.kind)
@@ -324,7 +324,10 @@ def op_bytes(op):
         return 4.0 * a.n * a.hw * (a.c0 + a.c1)
     if k == L.OP_UPFIRDN:
         a = op.u.fir
-        return 4.0 * a.n * a.c * (a.h_in * a.w_in + a.h_out * a.w_out)
+        # (a fused pair -- act(GroupNorm(x)) and x resampled by one launch, ssde_upfirdn_args.dst2 -- writes two outputs; its
+        #  partner spec is not an op of its own.  An accumulating launch also reads its destination)
+        outs = (2 if a.dst2 else 1) + (1 if a.accumulate else 0)
+        return 4.0 * a.n * a.c * (a.h_in * a.w_in + outs * a.h_out * a.w_out)
     if k == L.OP_RANDN:
         return 4.0 * op.u.randn.numel
     if k == L.OP_SUMSQ:
