@@ -428,13 +428,19 @@ class FusedTrainStep:
         self.steps_done += 1
 
 
+def _on_device(t):
+    """Does this tensor live in HIP device memory?  (One place to ask, so that the CPU emulator of tests/emu, whose "device"
+    memory is host memory, can drive step_fn itself.)"""
+    return t.is_cuda
+
+
 def _fused_candidate(state, loss_fn, optimize_fn, train):
     from .models.ncsnpp import NCSNpp
     from .models.ema import ExponentialMovingAverage
     model = state['model']
     if not isinstance(model, NCSNpp) or getattr(loss_fn, "ssde_spec", None) is None:
         return False
-    if not next(model.parameters()).is_cuda:
+    if not _on_device(next(model.parameters())):
         return False
     if not isinstance(state.get('ema'), ExponentialMovingAverage):
         return False
@@ -469,7 +475,7 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
 
     def step_fn(state, batch):
         model = state['model']
-        if batch.is_cuda and _fused_candidate(state, loss_fn, optimize_fn, train):
+        if _on_device(batch) and _fused_candidate(state, loss_fn, optimize_fn, train):
             fs = fused_for(state, batch)
             if train:
                 fs.step_offset = int(state['step']) - fs.steps_done      # a restored checkpoint continues its mask stream

@@ -567,12 +567,13 @@ def check_autograd_bridge(dev):
 
 
 def check_fused_step(dev, steps=3, sde_kind="vesde"):
-    """losses.get_step_fn's fused path (perturb -> forward -> loss -> backward -> clip+Adam+EMA) for a few steps
-    against autograd through the oracle + torch.optim.Adam + clip_grad_norm_ + the reference's EMA rule, with
-    injected t and z."""
+    """FusedTrainStep's two halves (loss_and_grads, optimizer_step: perturb -> forward -> loss -> backward -> clip+Adam+EMA)
+    for a few steps with injected t and z against oracle/train_oracle.py -- the restatement of losses.py:151-210 +
+    models/ema.py that oracle/gen_golden_train.py pins to the reference's own run (rel err 0).  Same cases as the fixture test
+    (check_step_fn_against_reference_run), other draws and the engine-level entry points."""
     from score_sde_pytorch_amd.models import utils as mutils, ema as ema_mod
     from score_sde_pytorch_amd import losses, sde_lib
-    from oracle import unet_oracle
+    from oracle import train_oracle
     cfg = small_cfg("ncsnpp" if sde_kind in ("vesde", "smld") else "ddpmpp")
     if sde_kind == "smld":      # the discrete NCSN++ configs (configs/ve/cifar10_ncsnpp.py): positional labels, sigma gather
         cfg.model.embedding_type, cfg.model.num_scales, cfg.training.continuous = "positional", 24, False
@@ -587,16 +588,16 @@ def check_fused_step(dev, steps=3, sde_kind="vesde"):
     names = [n for n, p in model.named_parameters() if p.requires_grad]
     if sde_kind in ("vesde", "smld"):
         sde = sde_lib.VESDE(cfg.model.sigma_min, cfg.model.sigma_max, cfg.model.num_scales)
-    elif sde_kind == "ddpm":
-        sde = sde_lib.VPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales)
+        okind, okw = "vesde", dict(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=cfg.model.num_scales)
     else:
-        sde = sde_lib.subVPSDE(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales)
+        sde = (sde_lib.VPSDE if sde_kind == "ddpm" else sde_lib.subVPSDE)(cfg.model.beta_min, cfg.model.beta_max, cfg.model.num_scales)
+        okind = "vpsde" if sde_kind == "ddpm" else "subvpsde"
+        okw = dict(beta_min=cfg.model.beta_min, beta_max=cfg.model.beta_max, N=cfg.model.num_scales)
     discrete = sde_kind in ("smld", "ddpm")
+    orc = train_oracle.TrainState(cfg, sd, okind, okw, continuous=not discrete)
+    assert orc.names == names
     R, Bn = cfg.data.image_size, 3
     g = torch.Generator().manual_seed(3)
-    ref_params = {k: sd[k].clone().requires_grad_() for k in names}
-    ref_opt = torch.optim.Adam([ref_params[k] for k in names], lr=cfg.optim.lr, betas=(cfg.optim.beta1, 0.999), eps=cfg.optim.eps)
-    ref_ema = [ref_params[k].detach().clone() for k in names]
     opt = losses.get_optimizer(cfg, model.parameters())
     ema = ema_mod.ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate)
     optimize_fn = losses.optimization_manager(cfg)
@@ -606,58 +607,157 @@ def check_fused_step(dev, steps=3, sde_kind="vesde"):
     fs = step_fn.fused_for(state, torch.zeros(Bn, 3, R, R, device=dev))
     for step in range(steps):
         batch = torch.rand(Bn, 3, R, R, generator=g)
-        t = torch.rand(Bn, generator=g) * (1 - 1e-5) + 1e-5
+        u = torch.rand(Bn, generator=g)
         z = torch.randn(Bn, 3, R, R, generator=g)
-        full = dict(sd)
-        full.update(ref_params)
-        if sde_kind == "smld":                                                   # losses.py:111-124
-            t = torch.randint(0, sde.N, (Bn,), generator=g)
-            sigmas = torch.flip(sde.discrete_sigmas, dims=(0,))[t]
-            noise = z * sigmas[:, None, None, None]
-            score = unet_oracle.ncsnpp_forward(cfg, full, noise + batch, t)
-            target = -noise / (sigmas ** 2)[:, None, None, None]
-            ref_loss = (0.5 * torch.square(score - target).reshape(Bn, -1).sum(-1) * sigmas ** 2).mean()
-        elif sde_kind == "ddpm":                                                 # losses.py:135-147
-            t = torch.randint(0, sde.N, (Bn,), generator=g)
-            xt = sde.sqrt_alphas_cumprod[t, None, None, None] * batch + sde.sqrt_1m_alphas_cumprod[t, None, None, None] * z
-            eps_theta = unet_oracle.ncsnpp_forward(cfg, full, xt, t)
-            ref_loss = (0.5 * torch.square(eps_theta - z).reshape(Bn, -1).sum(-1)).mean()
-        else:
-            mean, std = sde.marginal_prob(batch, t)
-            xt = mean + std[:, None, None, None] * z
-            if sde_kind == "vesde":
-                score = unet_oracle.ncsnpp_forward(cfg, full, xt, std)
-            else:
-                score = -unet_oracle.ncsnpp_forward(cfg, full, xt, t * 999) / std[:, None, None, None]
-            ref_loss = (0.5 * torch.square(score * std[:, None, None, None] + z).reshape(Bn, -1).sum(-1)).mean()
-        ref_opt.zero_grad()
-        ref_loss.backward()
-        for gp in ref_opt.param_groups:
-            gp['lr'] = cfg.optim.lr * min(step / cfg.optim.warmup, 1.0)
-        torch.nn.utils.clip_grad_norm_([ref_params[k] for k in names], cfg.optim.grad_clip)
-        ref_opt.step()
-        decay = min(cfg.model.ema_rate, (1 + step + 1) / (10 + step + 1))
-        for s_, k in zip(ref_ema, names):
-            s_.sub_((1 - decay) * (s_ - ref_params[k].detach()))
+        labels = torch.randint(0, sde.N, (Bn,), generator=g)
+        ref_loss = orc.train_step(batch, u, labels, z)
+        t = labels if discrete else u * (1 - 1e-5) + 1e-5                          # losses.py:84 / :116,136
         loss = fs.loss_and_grads(batch.to(dev), t=t.to(dev), z=z.to(dev)).clone()
         fs.optimizer_step(opt, ema, state['step'], optimize_fn.ssde_hyper)
         state['step'] += 1
-        assert abs(float(loss) - float(ref_loss.detach())) / abs(float(ref_loss.detach())) < 1e-5
+        assert abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)) < 1e-5
         for n_, p in model.named_parameters():
             if not p.requires_grad:
                 continue
             if "NIN_1.b" in n_:      # analytically-zero gradient: Adam turns rounding noise into +-lr steps
-                assert float((p.detach().cpu() - ref_params[n_].detach()).abs().max()) < 4 * cfg.optim.lr * (step + 1)
+                assert float((p.detach().cpu() - orc.params[n_].detach()).abs().max()) < 4 * cfg.optim.lr * (step + 1)
                 continue
-            assert rel_err(p.detach(), ref_params[n_].detach()) < 2e-5, (step, n_)
+            assert rel_err(p.detach(), orc.params[n_].detach()) < 2e-5, (step, n_)
             if step > 0:    # Adam normalises away the gradient scale: zero-gradient tensors follow rounding noise
-                assert rel_err(p.detach().cpu() - sd[n_], ref_params[n_].detach() - sd[n_]) < 2e-2, (step, n_)
-        for s_, r_, n_ in zip(ema.shadow_params, ref_ema, names):
+                assert rel_err(p.detach().cpu() - sd[n_], orc.params[n_].detach() - sd[n_]) < 2e-2, (step, n_)
+        for s_, r_, n_ in zip(ema.shadow_params, orc.shadow, names):
             assert "NIN_1.b" in n_ or rel_err(s_, r_) < 2e-5
     # the optimizer object still exposes torch.optim.Adam state for checkpoints (utils.save_checkpoint)
     osd = opt.state_dict()
     assert len(osd["state"]) == len(names) and all(float(v["step"]) == steps for v in osd["state"].values())
     return float(loss)
+
+
+def _reference_train_state(dev, case, seed=1):
+    """state = {optimizer, model, ema, step} + the train / eval step functions of a tests/_util.TRAIN_CASES entry, built with
+    the product's public surface exactly as run_lib.train builds them (run_lib.py:63-112)."""
+    from score_sde_pytorch_amd.models import utils as mutils, ema as ema_mod
+    from score_sde_pytorch_amd import losses, sde_lib
+    _, _, _, continuous, reduce_mean, lw = case
+    cfg = _util.train_case_config(case)
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    init = {k: v.clone() for k, v in _util.load_seeded(model, seed=seed).items()}
+    model = model.to(dev)
+    sde = _util.train_case_sde(sde_lib, case, cfg)
+    opt = losses.get_optimizer(cfg, model.parameters())
+    ema = ema_mod.ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate)
+    optimize_fn = losses.optimization_manager(cfg)
+    kw = dict(optimize_fn=optimize_fn, reduce_mean=reduce_mean, continuous=continuous, likelihood_weighting=lw)
+    train_step = losses.get_step_fn(sde, train=True, **kw)
+    eval_step = losses.get_step_fn(sde, train=False, **kw)
+    return cfg, init, dict(optimizer=opt, model=model, ema=ema, step=0), train_step, eval_step
+
+
+def _compare_with_reference_step(gold, name, step, state, init, last):
+    """parameters and EMA shadows after `step` against the REFERENCE's run (tests/golden/train_small.npz)"""
+    model, ema = state['model'], state['ema']
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    cur = dict(model.named_parameters())
+    norms, ema_norms = gold[name + "/norms"][step], gold[name + "/ema_norms"][step]
+    assert len(names) == norms.shape[0] == len(ema.shadow_params)
+    for i, n in enumerate(names):
+        if "NIN_1.b" in n:        # analytically-zero gradient (softmax shift invariance): Adam turns rounding noise into +-lr steps
+            continue
+        p, s, p0 = cur[n].detach().cpu(), ema.shadow_params[i].detach().cpu(), init[n]
+        for got, ref in ((p, norms[i]), (s, ema_norms[i])):
+            assert abs(float(got.double().norm()) - ref[0]) <= 2e-5 * ref[0], (name, step, n)
+            d = float((got - p0).double().norm())
+            if ref[1] == 0.0:     # step 0 of the warm-up: lr = 0, nothing may move (losses.py:44-46)
+                assert d == 0.0, (name, step, n, d)
+            else:
+                assert abs(d - ref[1]) <= 2e-2 * ref[1], (name, step, n, d, ref[1])
+    if last:
+        probes = [k.split("/", 2)[2] for k in gold.files if k.startswith(name + "/p/")]
+        assert len(probes) >= 20
+        for n in probes:
+            if "NIN_1.b" in n:
+                continue
+            p, s, p0 = cur[n].detach().cpu(), ema.shadow_params[names.index(n)].detach().cpu(), init[n]
+            rp, rs = torch.from_numpy(gold["%s/p/%s" % (name, n)]), torch.from_numpy(gold["%s/e/%s" % (name, n)])
+            assert rel_err(p, rp) < 2e-5 and rel_err(s, rs) < 2e-5, (name, n)
+            assert rel_err(p - p0, rp - p0) < 2e-2 and rel_err(s - p0, rs - p0) < 2e-2, (name, n, rel_err(p - p0, rp - p0))
+
+
+def check_step_fn_against_reference_run(dev, name):
+    """losses.get_step_fn(...)(state, batch) -- the public entry, train and eval branches -- against what the REFERENCE's
+    get_step_fn + optimization_manager + get_optimizer + ExponentialMovingAverage produced on the same weights, batches and
+    injected draws (oracle/gen_golden_train.py ran /root/reference's losses.py:151-210 and models/ema.py:32-51)."""
+    gold = np.load(os.path.join(_util.GOLDEN, "train_small.npz"))
+    case = _util.TRAIN_CASES[name]
+    cfg, init, state, train_step, eval_step = _reference_train_state(dev, case)
+    inputs = _util.train_case_inputs(name, cfg.model.num_scales, size=cfg.data.image_size)
+    ref_loss = gold[name + "/loss"]
+    for step in range(_util.TRAIN_STEPS):
+        batch, u, labels, z = inputs[step]
+        with _util.inject_rng(u, labels, z):
+            loss = train_step(state, batch.to(dev))
+        assert state['step'] == step + 1 and state['ema'].num_updates == step + 1
+        assert abs(float(loss) - ref_loss[step]) <= 1e-5 * abs(ref_loss[step]), (name, step, float(loss), ref_loss[step])
+        _compare_with_reference_step(gold, name, step, state, init, last=step == _util.TRAIN_STEPS - 1)
+    assert int(gold[name + "/num_updates"]) == state['ema'].num_updates
+    # eval branch (losses.py:200-206): the loss of the EMA weights; raw parameters, EMA and counters untouched
+    batch, u, labels, z = inputs[_util.TRAIN_STEPS]
+    before = [p.detach().clone() for p in state['model'].parameters()]
+    shadows = [s_.clone() for s_ in state['ema'].shadow_params]
+    with _util.inject_rng(u, labels, z):
+        eval_loss = eval_step(state, batch.to(dev))
+    ref_eval = float(gold[name + "/eval_loss"])
+    assert abs(float(eval_loss) - ref_eval) <= 1e-5 * abs(ref_eval), (name, float(eval_loss), ref_eval)
+    assert state['step'] == _util.TRAIN_STEPS and state['ema'].num_updates == _util.TRAIN_STEPS
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, state['model'].parameters()))
+    assert all(torch.equal(a, b) for a, b in zip(shadows, state['ema'].shadow_params))
+    osd = state['optimizer'].state_dict()
+    assert all(float(v["step"]) == _util.TRAIN_STEPS for v in osd["state"].values())
+    return float(loss)
+
+
+def check_reference_checkpoint_resume(dev, tmp_path, warm):
+    """utils.restore_checkpoint on a checkpoint WRITTEN BY THE REFERENCE (tests/golden/ref_checkpoint_small.pth: DataParallel's
+    `module.` keys, torch.optim.Adam.state_dict(), the reference EMA's {decay, num_updates, shadow_params}; utils.py:22-29 after two
+    of the reference's steps), then the third step against the reference's third step.  warm: the state has already run a fused
+    step (flat buffers, re-homed moments and shadows exist) before the restore."""
+    from score_sde_pytorch_amd import utils as ssde_utils
+    gold = np.load(os.path.join(_util.GOLDEN, "train_small.npz"))
+    case = _util.TRAIN_CKPT_CASE
+    cfg, _, state, train_step, _ = _reference_train_state(dev, case, seed=9)       # other weights than the checkpoint's
+    inputs = _util.train_case_inputs("ckpt", cfg.model.num_scales, size=cfg.data.image_size)
+    if warm:
+        batch, u, labels, z = inputs[3]
+        with _util.inject_rng(u, labels, z):
+            train_step(state, batch.to(dev))
+    path = os.path.join(_util.GOLDEN, "ref_checkpoint_small.pth")
+    assert ssde_utils.restore_checkpoint(path, state, dev) is state
+    assert state['step'] == 2 and state['ema'].num_updates == 2 and state['ema'].decay == cfg.model.ema_rate
+    raw = ssde_utils.load_checkpoint_file(path, "cpu")
+    assert all(k.startswith("module.") for k in raw['model'])
+    for k, v in state['model'].state_dict().items():
+        assert torch.equal(v.cpu(), raw['model']["module." + k]), k
+    # the initial weights of the reference run are tests/_util's seed 1: the fixture's norms are relative to them
+    from score_sde_pytorch_amd.models import utils as mutils
+    init = _util.load_seeded(mutils.get_model("ncsnpp")(cfg), seed=1)
+    batch, u, labels, z = inputs[2]
+    with _util.inject_rng(u, labels, z):
+        loss = train_step(state, batch.to(dev))
+    ref = gold["ckpt/loss"][2]
+    assert abs(float(loss) - ref) <= 1e-5 * abs(ref), (float(loss), ref)
+    assert state['step'] == 3
+    _compare_with_reference_step(gold, "ckpt", 2, state, init, last=True)
+    # and back: what save_checkpoint writes for the reference to read has the reference's own structure
+    out = os.path.join(str(tmp_path), "checkpoint_3.pth")
+    ssde_utils.save_checkpoint(out, state, data_parallel_prefix=True)
+    mine = ssde_utils.load_checkpoint_file(out, "cpu")
+    assert set(mine) == set(raw) and list(mine['model']) == list(raw['model'])
+    assert set(mine['ema']) == set(raw['ema']) and len(mine['ema']['shadow_params']) == len(raw['ema']['shadow_params'])
+    assert mine['optimizer']['param_groups'][0]['params'] == raw['optimizer']['param_groups'][0]['params']
+    assert set(mine['optimizer']['state']) == set(raw['optimizer']['state'])
+    assert all(set(v) == {"step", "exp_avg", "exp_avg_sq"} for v in mine['optimizer']['state'].values())
+    assert mine['step'] == 3 and mine['ema']['num_updates'] == 3
 
 
 def check_device_repack(dev, kind="ncsnpp", need_kind=None):

@@ -179,3 +179,92 @@ def ode_case_inputs():
     data = torch.rand(B, 3, R, R, generator=g) * 2 - 1
     epsilon = torch.randint(0, 2, data.shape, generator=g).float() * 2 - 1.
     return z, data, epsilon
+
+
+# tests/golden/train_small.npz + ref_checkpoint_small.pth (oracle/gen_golden_train.py, from the reference's losses.get_step_fn,
+# optimization_manager, get_optimizer and models/ema.ExponentialMovingAverage run on CPU):
+# name -> (small-config kind, config overrides, sde kind, continuous, reduce_mean, likelihood_weighting)
+TRAIN_BATCH, TRAIN_STEPS, TRAIN_WARMUP = 3, 3, 2
+TRAIN_CASES = {
+    "ve_cont": ("ncsnpp", {}, "vesde", True, False, False),                       # configs/ve/cifar10_ncsnpp_continuous.py
+    "subvp_cont": ("ddpmpp", {}, "subvpsde", True, False, False),                 # configs/subvp/cifar10_ddpmpp_continuous.py
+    "smld": ("ncsnpp", dict(embedding_type="positional", num_scales=24), "vesde", False, False, False),   # configs/ve/cifar10_ncsnpp.py
+    "ddpm": ("ddpmpp", dict(num_scales=24), "vpsde", False, False, False),        # configs/vp/cifar10_ddpmpp.py
+    "ve_cont_lw": ("ncsnpp", {}, "vesde", True, False, True),                     # likelihood_weighting (losses.py:94-97)
+    "vp_cont_rm": ("ddpmpp", {}, "vpsde", True, True, False),                     # reduce_mean (losses.py:71)
+    "subvp_cont_lw_rm": ("ddpmpp", {}, "subvpsde", True, True, True),
+}
+# the resume case: the checkpoint is written after 2 steps by the reference's save_checkpoint dict (utils.py:22-29), the
+# fixture also holds the reference's third step
+TRAIN_CKPT_CASE = ("ncsnpp", dict(ch_mult=(1, 1)), "vesde", True, False, False)
+
+
+def train_case_config(case):
+    """config of a TRAIN_CASES entry (model overrides applied, warm-up shortened so that all three lr regimes occur)"""
+    kind, over, sde_kind, continuous, _, _ = case
+    over = dict(over)
+    kw = {}
+    if "ch_mult" in over:
+        kw["ch_mult"] = over.pop("ch_mult")
+    cfg = small_config(kind, **kw)
+    for k, v in over.items():
+        cfg.model[k] = v
+    cfg.training.continuous = continuous
+    cfg.optim.warmup = TRAIN_WARMUP
+    return cfg
+
+
+def train_case_sde(sde_lib, case, cfg):
+    sde_kind = case[2]
+    if sde_kind == "vesde":
+        return sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=cfg.model.num_scales)
+    cls = {"vpsde": sde_lib.VPSDE, "subvpsde": sde_lib.subVPSDE}[sde_kind]
+    return cls(beta_min=cfg.model.beta_min, beta_max=cfg.model.beta_max, N=cfg.model.num_scales)
+
+
+def train_case_inputs(name, n_scales, steps=TRAIN_STEPS + 1, size=16):
+    """per step: data batch in [0,1), the uniform draw behind t (losses.py:84), integer noise levels (losses.py:116,136),
+    and z (losses.py:85); the last entry feeds the eval step"""
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(("train_" + name).encode()) & 0xffff)
+    out = []
+    for _ in range(steps):
+        batch = torch.rand(TRAIN_BATCH, 3, size, size, generator=g)
+        u = torch.rand(TRAIN_BATCH, generator=g)
+        labels = torch.randint(0, n_scales, (TRAIN_BATCH,), generator=g)
+        z = torch.randn(TRAIN_BATCH, 3, size, size, generator=g)
+        out.append((batch, u, labels, z))
+    return out
+
+
+class inject_rng:
+    """Replace the three draws of a loss closure (torch.rand -> u, torch.randint -> labels, torch.randn_like -> z;
+    losses.py:84-85,116-118,136-140) by given tensors, moved to the device the call asks for."""
+
+    def __init__(self, u, labels, z):
+        self.u, self.labels, self.z = u, labels, z
+
+    def __enter__(self):
+        self._real = (torch.rand, torch.randint, torch.randn_like)
+        torch.rand = lambda *a, **kw: self.u.to(kw.get("device", "cpu"))
+        torch.randint = lambda *a, **kw: self.labels.to(kw.get("device", "cpu"))
+        torch.randn_like = lambda t, **kw: self.z.to(t.device)
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.randint, torch.randn_like = self._real
+        return False
+
+
+def train_probe_names(named_shapes, limit=10000):
+    """parameter tensors stored in full per step: the first tensor of every leaf class (Conv_0.weight, NIN_1.b, ...) that has
+    at most `limit` elements"""
+    seen, out = set(), []
+    for name, shape in named_shapes:
+        parts = name.split(".")
+        leaf = ".".join(parts[2:]) if len(parts) > 3 else "top." + parts[-1] + str(len(shape))
+        if leaf in seen or int(np.prod(shape)) > limit:
+            continue
+        seen.add(leaf)
+        out.append(name)
+    return out

@@ -95,6 +95,24 @@ def test_fused_training_step(sde_kind):
     T.check_fused_step("cpu", steps=2, sde_kind=sde_kind)
 
 
+@pytest.fixture
+def host_is_device(monkeypatch):
+    """step_fn itself under the emulator: the product asks losses._on_device whether a tensor is HIP memory"""
+    from score_sde_pytorch_amd import losses
+    monkeypatch.setattr(losses, "_on_device", lambda t: True)
+
+
+@pytest.mark.parametrize("name", ["ve_cont", "subvp_cont", "smld", "ddpm", "ve_cont_lw", "subvp_cont_lw_rm"])
+def test_step_fn_matches_the_reference_run(name, host_is_device):
+    """three optimisation steps + the eval step of losses.get_step_fn against the REFERENCE's own run of them"""
+    T.check_step_fn_against_reference_run("cpu", name)
+
+
+@pytest.mark.parametrize("warm", [False, True])
+def test_checkpoint_written_by_the_reference_resumes(tmp_path, warm, host_is_device):
+    T.check_reference_checkpoint_resume("cpu", tmp_path, warm)
+
+
 @pytest.mark.parametrize("kind", ["ncsnpp", "ffhq"])
 def test_device_weight_repack(kind):
     T.check_device_repack("cpu", kind)

@@ -240,6 +240,41 @@ def test_state_dict_keys_and_counts_match_reference_census():
     assert not model.all_modules[0].W.requires_grad
 
 
+def test_ema_update_and_optimizer_state_follow_the_reference_run():
+    """Host classes against data the REFERENCE produced (tests/golden/ref_checkpoint_small.pth after two of its steps,
+    train_small.npz `ckpt/*` after its third; oracle/gen_golden_train.py): models.ema.ExponentialMovingAverage.load_state_dict +
+    update() reproduce the reference's third shadow parameters (models/ema.py:32-51), and losses.get_optimizer's Adam loads
+    the reference's optimizer.state_dict() (the optimizer arithmetic itself is checked by the step_fn fixture tests)."""
+    import os
+    from score_sde_pytorch_amd.models.ema import ExponentialMovingAverage
+    from score_sde_pytorch_amd.models import utils as mutils
+    from score_sde_pytorch_amd import utils as ssde_utils, losses
+    gold = np.load(os.path.join(_util.GOLDEN, "train_small.npz"))
+    raw = ssde_utils.load_checkpoint_file(os.path.join(_util.GOLDEN, "ref_checkpoint_small.pth"), "cpu")
+    cfg = _util.train_case_config(_util.TRAIN_CKPT_CASE)
+    model = mutils.get_model("ncsnpp")(cfg)
+    state = dict(model=model, optimizer=losses.get_optimizer(cfg, model.parameters()),
+                 ema=ExponentialMovingAverage(model.parameters(), decay=0.5), step=0)
+    ssde_utils.restore_checkpoint(os.path.join(_util.GOLDEN, "ref_checkpoint_small.pth"), state, "cpu")
+    ema = state['ema']
+    assert state['step'] == 2 and ema.num_updates == 2 and ema.decay == cfg.model.ema_rate
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert len(ema.shadow_params) == len(names) == len(raw['ema']['shadow_params'])
+    osd = state['optimizer'].state_dict()
+    assert set(osd['state']) == set(raw['optimizer']['state']) and all(float(v['step']) == 2 for v in osd['state'].values())
+    probes = [k.split("/", 2)[2] for k in gold.files if k.startswith("ckpt/p/")]
+    cur = dict(model.named_parameters())
+    with torch.no_grad():
+        for n in probes:                    # the reference's third optimizer step, taken from the fixture
+            cur[n].copy_(torch.from_numpy(gold["ckpt/p/" + n]))
+    ema.update(model.parameters())
+    assert ema.num_updates == 3
+    for n in probes:
+        e_ref = torch.from_numpy(gold["ckpt/e/" + n])
+        assert torch.equal(ema.shadow_params[names.index(n)], e_ref) or \
+            _util.rel_err(ema.shadow_params[names.index(n)], e_ref) < 1e-7, n
+
+
 def test_ema_matches_reference_formula():
     from score_sde_pytorch_amd.models.ema import ExponentialMovingAverage
     p = [torch.nn.Parameter(torch.ones(4)), torch.nn.Parameter(torch.zeros(2), requires_grad=False)]

@@ -131,3 +131,35 @@ def test_ode_oracle_reproduces_reference():
     d, div = ode_oracle.rhs_augmented(cfg, sd, sde, data, torch.ones(data.shape[0]) * case["t_probe"], epsilon)
     assert rel_err(d, torch.from_numpy(gold["rhs_drift"])) < 2e-6
     assert rel_err(div, torch.from_numpy(gold["rhs_div"])) < 1e-4
+
+
+@pytest.mark.parametrize("name", list(_util.TRAIN_CASES))
+def test_train_oracle_reproduces_reference(name):
+    """oracle/train_oracle.py (loss closures, warm-up + clip + Adam, EMA, eval swap) against what the REFERENCE's
+    get_step_fn / optimization_manager / ExponentialMovingAverage produced (tests/golden/train_small.npz,
+    oracle/gen_golden_train.py): every step's loss, every tensor's norm and update norm, the probe tensors, the eval loss."""
+    from oracle import train_oracle
+    gold = np.load(os.path.join(_util.GOLDEN, "train_small.npz"))
+    case = _util.TRAIN_CASES[name]
+    _, _, sde_kind, continuous, reduce_mean, lw = case
+    cfg = _util.train_case_config(case)
+    sd = _sd_for(cfg)
+    kw = dict(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=cfg.model.num_scales) if sde_kind == "vesde" \
+        else dict(beta_min=cfg.model.beta_min, beta_max=cfg.model.beta_max, N=cfg.model.num_scales)
+    orc = train_oracle.TrainState(cfg, sd, sde_kind, kw, continuous, reduce_mean, lw)
+    inputs = _util.train_case_inputs(name, cfg.model.num_scales, size=cfg.data.image_size)
+    for step in range(_util.TRAIN_STEPS):
+        loss = orc.train_step(*inputs[step])
+        assert abs(float(loss) - gold[name + "/loss"][step]) <= 2e-6 * abs(gold[name + "/loss"][step])
+        for i, n in enumerate(orc.names):
+            ref = gold[name + "/norms"][step][i]
+            assert abs(float(orc.params[n].detach().double().norm()) - ref[0]) <= 2e-6 * ref[0], (step, n)
+            d = float((orc.params[n].detach() - sd[n]).double().norm())
+            assert abs(d - ref[1]) <= 1e-3 * ref[1] + 1e-12, (step, n, d, ref[1])
+    for k in gold.files:
+        if k.startswith(name + "/p/"):
+            n = k.split("/", 2)[2]
+            assert rel_err(orc.params[n].detach(), torch.from_numpy(gold[k])) < 2e-6, n
+            assert rel_err(orc.shadow[orc.names.index(n)], torch.from_numpy(gold["%s/e/%s" % (name, n)])) < 2e-6, n
+    ev = orc.eval_step(*inputs[_util.TRAIN_STEPS])
+    assert abs(float(ev) - float(gold[name + "/eval_loss"])) <= 2e-6 * abs(float(gold[name + "/eval_loss"]))

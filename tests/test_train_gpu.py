@@ -63,6 +63,20 @@ def test_fused_training_step(sde_kind):
     T.check_fused_step("cuda", steps=3, sde_kind=sde_kind)
 
 
+@pytest.mark.parametrize("graph", ["1", "0"])       # the whole step as one hipGraph replay / as program runs
+@pytest.mark.parametrize("name", list(_util.TRAIN_CASES))
+def test_step_fn_matches_the_reference_run(name, graph, monkeypatch):
+    """three optimisation steps + the eval step of losses.get_step_fn against the REFERENCE's own run of them
+    (tests/golden/train_small.npz: /root/reference's losses.py:151-210 + models/ema.py executed by oracle/gen_golden_train.py)"""
+    monkeypatch.setenv("SSDE_TRAIN_GRAPH", graph)
+    T.check_step_fn_against_reference_run("cuda", name)
+
+
+@pytest.mark.parametrize("warm", [False, True])
+def test_checkpoint_written_by_the_reference_resumes(tmp_path, warm):
+    T.check_reference_checkpoint_resume("cuda", tmp_path, warm)
+
+
 def test_step_fn_selects_fused_path_and_trains():
     """get_step_fn end to end with torch's own RNG (no injection): loss is finite and parameters move"""
     from score_sde_pytorch_amd.models import utils as mutils, ema as ema_mod
