@@ -324,6 +324,8 @@ class FusedTrainStep:
         import os
         if os.environ.get("SSDE_TRAIN_GRAPH", "1") == "0" or not self.spec["train"] or self.device.type != "cuda":
             return None
+        if getattr(self, "_graph_failed", None) is not None:
+            return None
         opt = self._optimizer_program(optimizer, ema)
         ws = self.eng.weights
         if getattr(ws, "_tables", None) is None or \
@@ -343,7 +345,16 @@ class FusedTrainStep:
         if getattr(self, "_gstream", None) is None:
             self._gstream = torch.cuda.Stream(device=self.device)
         self._gstream.wait_stream(torch.cuda.current_stream())
-        prog.capture(self._gstream)
+        try:
+            prog.capture(self._gstream)
+        except L.SsdeError as exc:
+            # a driver that refuses the capture (or the instantiation) must not stop training: the program runs of
+            # loss_and_grads + optimizer_step are the same launches, issued one by one.  Remembered, reported once.
+            import warnings
+            self._graph_failed = exc
+            warnings.warn("libssde_hip: capturing the training step as a hipGraph failed (%s); running it as program launches" % exc)
+            torch.cuda.current_stream().wait_stream(self._gstream)
+            return None
         torch.cuda.current_stream().wait_stream(self._gstream)
         self._graph = (key, prog)
         return prog
