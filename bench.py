@@ -68,6 +68,8 @@ def parse(argv=None):
     ap.add_argument("--prewarm-s", type=float, default=3.0,
                     help="seconds of the same work run (untimed, outside --warmup) right before every timed sampler / training leg, so "
                          "that the timed region sees the clock and power state of sustained load; reported as prewarm_s")
+    ap.add_argument("--no-exchange-probe", action="store_true",
+                    help="skip the one-rank-RCCL-group leg of the training step (the data-parallel step form on a single GPU)")
     ap.add_argument("--no-telemetry", action="store_true", help="do not sample clocks / power / temperature beside the timed legs")
     ap.add_argument("--dump-ops", type=str, default="")
     ap.add_argument("--no-train", action="store_true", help="skip the DSM training-step measurement")
@@ -176,8 +178,47 @@ def bench_train(args, cfg, dev, dist, world, rank, sync_all, leg="train"):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         exposed_ms = (sec - float(t.item()) / k) * 1e3
         fs.skip_exchange = False
+    one_rank = None
+    if dist is None and not args.no_exchange_probe and torch.device(dev).type == "cuda":
+        # The data-parallel form of the step on ONE GPU: a world-size-1 RCCL group with the gradient exchange forced on
+        # (SSDE_FORCE_GRAD_EXCHANGE=1) -- one hipGraph per gradient bucket, an all-reduce behind each, the optimizer graph behind the
+        # collectives (losses.FusedTrainStep._step_graph_segments).  A one-rank all-reduce moves nothing, so the ratio to the
+        # single-graph step above is what the segmentation itself costs before any xGMI time.
+        import socket
+        import torch.distributed as tdist
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        try:
+            tdist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device(dev))
+            os.environ["SSDE_FORCE_GRAD_EXCHANGE"] = "1"
+            try:
+                for i in range(5):
+                    step_fn(state, pool[i % len(pool)])
+                sync_all()
+                prewarm(_chunk, sync_all, min(args.prewarm_s, 1.0))
+                k2 = max(1, min(k, 50))
+                with tele_leg((leg or "train") + "_exchange_one_rank"):
+                    t0 = time.perf_counter()
+                    for i in range(k2):
+                        step_fn(state, pool[i % len(pool)])
+                    sync_all()
+                    sec2 = (time.perf_counter() - t0) / k2
+                segs = getattr(fs, "_graph_seg", None)
+                one_rank = {"value": sec2, "unit": "s/step", "steps": k2, "over_single_graph_step": sec2 / sec,
+                            "graphs_per_step": len([1 for p_, _ in segs[1] if p_ is not None]) if segs else None,
+                            "collectives_per_step": getattr(fs, "collectives_last_step", None),
+                            "bucket_mb": float(os.environ.get("SSDE_GRAD_BUCKET_MB", "32")),
+                            "note": "world-size-1 RCCL group, exchange forced on: the step as one hipGraph per gradient bucket + all-reduce "
+                                    "per bucket + optimizer graph; a one-rank all-reduce moves no data"}
+            finally:
+                os.environ.pop("SSDE_FORCE_GRAD_EXCHANGE", None)
+                tdist.destroy_process_group()
+        except Exception as exc:                                   # noqa: BLE001  (diagnostic leg)
+            one_rank = {"error": repr(exc)[:300]}
     fl = np.array(eng.program.flops)
     out = {"metric": "sec_per_train_step", "value": sec, "unit": "s/step", "higher_is_better": False,
+           "exchange_one_rank": one_rank,
            "batch_per_gpu": Bt, "global_batch": Bt * world, "images_per_sec": world * Bt / sec, "steps": k, "warmup": w,
            "prewarm_s": round(warm_s, 2),
            "loss": float(loss), "dropout": float(cfg.model.dropout), "path": "fused (losses.FusedTrainStep)",
@@ -768,7 +809,8 @@ def cpu_baseline(args, cfg, model, sd, R, N):
     cb = int(max(4, min(args.cpu_batch, args.cpu_seconds / max(t_probe, 1e-4))))
     # K = 5 whole PC iterations at the config batch when the budget holds them (the default 200 s does on this
     # host: ~35 s per iteration at batch 256), fewer on a slower host -- ONE timed run
-    k = int(max(1, min(5, args.cpu_seconds // max(t_probe * cb, 1e-3))))
+    # (the per-image cost of the batch-4 probe underestimates a batch-256 iteration: K is 1 below the 200 s budget)
+    k = int(max(1, min(5, args.cpu_seconds // max(t_probe * cb, 1e-3)))) if args.cpu_seconds >= 200 else 1
     t_k = cpu_iters(cb, k)
     out = {"value": cb / (N / k * t_k), "unit": "images/s", "cores": cores, "host_cores_total": total, "kind": "port",
            "sample": "K=%d PC iteration(s) (%d U-Net evaluations) at batch %d with the torch-CPU oracle (oracle/sampler_oracle.py) "
@@ -798,7 +840,7 @@ def cpu_baseline(args, cfg, model, sd, R, N):
         return time.perf_counter() - t0
     t_probe = train_step(4) / 4
     tb = int(max(4, min(128, (args.cpu_seconds / 4) / max(t_probe, 1e-4))))
-    n_timed = 3 if t_probe * tb * 4 <= args.cpu_seconds else 1          # 1 warm-up + 3 timed when the budget holds them
+    n_timed = 3 if (args.cpu_seconds >= 200 and t_probe * tb * 4 <= 2 * args.cpu_seconds) else 1   # 1 warm-up + 3 timed at the 200 s budget
     ts = [train_step(tb) for _ in range(1 + n_timed)][1:]
     out["train"] = {"value": float(np.mean(ts)) * 128.0 / tb, "unit": "s/step at batch 128 (linear in batch)", "measured_s_per_step": float(np.mean(ts)),
                     "measured_batch": tb, "cores": cores,
@@ -1085,7 +1127,7 @@ def main():
                   "headline_mode_over_this_mode": ra["value"] / rb["value"]}
             if not args.no_train:
                 a2 = argparse.Namespace(**vars(args))
-                a2.no_roofline = True
+                a2.no_roofline = a2.no_exchange_probe = True
                 a2.train_steps, a2.train_warmup = min(args.train_steps, 30), min(args.train_warmup, 5)
                 tb = bench_train(a2, _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous"), dev, dist, world, rank, sync_all,
                                  leg="train_" + other)

@@ -77,6 +77,10 @@ __global__ __launch_bounds__(256) void upfirdn_kernel(const FirParams p) {
 }
 
 
+#ifndef SSDE_FIR_STAGE_U
+#define SSDE_FIR_STAGE_U 4       // (1 = one load in flight per thread, the form of rounds 2-5: A/B variant only)
+#endif
+
 // ---- LDS-staged tiles for the 4x4 FIR -----------------------------------------------------------------------------
 constexpr int kFirCh = 32;        // channels per workgroup: 8 lanes x float4 = one 128-byte line per pixel
 struct FirTileParams {
@@ -113,13 +117,26 @@ __global__ __launch_bounds__(256) void upfirdn_tile_kernel(const FirTileParams p
   }
   const float* xin = p.src.p0 + (size_t)n * p.h_in * p.w_in * p.c + ch;
   // ---- stage the raw input tile (zeros outside the image) ----
-  for (int pix = slot; pix < npix; pix += 32) {
-    const int ly = pix / p.iw, lx = pix - ly * p.iw;
-    const int iy = iy0 + ly, ix = ix0 + lx;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in)
-      v = *reinterpret_cast<const float4*>(xin + ((size_t)iy * p.w_in + ix) * p.c);
-    *reinterpret_cast<float4*>(tile + pix * kFirCh + c4 * 4) = v;
+  // kStageU loads of a thread are issued before the first of them is parked: with one load in flight per thread (a loop the
+  // compiler cannot unroll: the tile size is a launch argument) the 4-12 round trips of a tile were paid one after the other
+  // and the pass sat at 0.3-0.5 of the HBM peak on every shape but the largest (profiles/r6_fir_staging_unroll.txt)
+  constexpr int kStageU = SSDE_FIR_STAGE_U;
+  for (int base = slot; base < npix; base += 32 * kStageU) {
+    float4 v[kStageU];
+#pragma unroll
+    for (int u = 0; u < kStageU; ++u) {
+      const int pix = base + 32 * u;
+      const int ly = pix / p.iw, lx = pix - ly * p.iw;
+      const int iy = iy0 + ly, ix = ix0 + lx;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pix < npix && iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in)
+        v[u] = *reinterpret_cast<const float4*>(xin + ((size_t)iy * p.w_in + ix) * p.c);
+    }
+#pragma unroll
+    for (int u = 0; u < kStageU; ++u) {
+      const int pix = base + 32 * u;
+      if (pix < npix) *reinterpret_cast<float4*>(tile + pix * kFirCh + c4 * 4) = v[u];
+    }
   }
   __syncthreads();
 

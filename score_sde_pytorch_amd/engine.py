@@ -375,13 +375,27 @@ class WeightStore:
     def add(self, sources, fn, meta=None, recipe=None):
         """recipe: descriptors for the device-side re-pack (ssde_pack_weights); fn is the same packing in torch, used for
         the first fill, for CPU dry lowering, and as the cross-check of the device kernels in the tests."""
+        lazy = recipe is not None and self._on_device() and os.environ.get("SSDE_TORCH_PACK", "0") != "1"
         with torch.no_grad():
-            packed = fn(*[s.detach() for s in sources]).to(self.device).contiguous()
-        self.entries.append([packed, list(sources), fn, self._stamp(sources), recipe])
+            if lazy:
+                # on the GPU the FIRST fill is the device re-pack too (ssde_pack_weights, four launches for the whole store on the
+                # first refresh()): no torch einsum -- hence no rocBLAS / Tensile kernel -- anywhere on the product path.  The
+                # torch packer only tells the shape (evaluated on meta tensors); zero padding comes from the zero fill.
+                try:
+                    shape = fn(*[torch.empty(s.shape, dtype=s.dtype, device="meta") for s in sources]).shape
+                except Exception:                                 # noqa: BLE001  (an op without a meta kernel: shape from CPU zeros)
+                    shape = fn(*[torch.zeros(s.shape, dtype=s.dtype) for s in sources]).shape
+                packed = torch.zeros(tuple(shape), dtype=torch.float32, device=self.device)
+            else:
+                packed = fn(*[s.detach() for s in sources]).to(self.device).contiguous()
+        self.entries.append([packed, list(sources), fn, None if lazy else self._stamp(sources), recipe])
         if meta is not None:
             self.meta[id(packed)] = meta
         self._tables = None
         return packed
+
+    def _on_device(self):
+        return self.device.type == "cuda" if isinstance(self.device, torch.device) else str(self.device).startswith("cuda")
 
     # -- typed registrations -------------------------------------------------------------------
     def conv3(self, param, cin_pad=None, cout_pad=None, wino=False):
@@ -528,11 +542,12 @@ class WeightStore:
         """Bring packed copies up to date.  force=True (after the fused optimizer wrote the flat parameter buffer behind
         torch's back) re-packs everything: with the device kernels when the library can run here, else in torch."""
         if on_device is None:
-            on_device = self.device.type == "cuda" if isinstance(self.device, torch.device) else str(self.device).startswith("cuda")
+            on_device = self._on_device()
         stamps = [self._stamp(e[1]) for e in self.entries]
         stale = [force or st != e[3] for e, st in zip(self.entries, stamps)]
-        # many stale entries (optimizer step, checkpoint load, EMA swap): four device launches re-pack everything
-        done_on_device = on_device and (force or sum(stale) > 16) and self.device_refresh()
+        # any stale entry that has a device recipe (first use, optimizer step, checkpoint load, EMA swap, a user's in-place
+        # edit): four device launches re-pack the whole store -- cheaper than one torch packer, and no rocBLAS kernel
+        done_on_device = on_device and any(old and e[4] is not None for e, old in zip(self.entries, stale)) and self.device_refresh()
         for e, st, old in zip(self.entries, stamps, stale):
             if old and not (done_on_device and e[4] is not None):
                 with torch.no_grad():

@@ -359,10 +359,92 @@ class FusedTrainStep:
         self._graph = (key, prog)
         return prog
 
+    def _step_graph_segments(self, optimizer, ema):
+        """The same step with the gradient exchange (data parallel, world > 1): ONE hipGraph PER GRADIENT BUCKET instead of ~1400
+        program launches.  Segment k holds the ops up to the point where bucket k of the flat gradient is final
+        (TrainEngine.grad_buckets: the tail of the buffer completes first); the host replays segment k, issues the RCCL
+        all-reduce of bucket k (its stream waits for the replay, the next segment's replay does not wait for it), and after
+        the last bucket a closing graph holds clip + Adam + EMA + weight re-pack behind the collectives.  At the default 32 MB
+        bucket that is 9 + 1 graph launches and 8 all-reduces per step.  Returns [(program, (lo, hi) or None)], or None when
+        graphs are off / unavailable (the program runs of loss_and_grads + optimizer_step are the fallback)."""
+        import os
+        if os.environ.get("SSDE_TRAIN_GRAPH", "1") == "0" or not self.spec["train"] or self.device.type != "cuda":
+            return None
+        if getattr(self, "_graph_failed", None) is not None:
+            return None
+        opt = self._optimizer_program(optimizer, ema)
+        ws = self.eng.weights
+        if getattr(ws, "_tables", None) is None or \
+                ws._tables[1] != tuple(s_.data_ptr() for e in ws.entries if e[4] is not None for s_ in e[1]):
+            ws._build_tables()
+        bucket = int(float(os.environ.get("SSDE_GRAD_BUCKET_MB", "32")) * 262144)
+        key = (id(opt), id(ws._tables), bucket)
+        if getattr(self, "_graph_seg", None) is not None and self._graph_seg[0] == key:
+            return self._graph_seg[1]
+        L, E, eng = self.L, self.E, self.eng
+        head = [self._head[0].ops[0]] + [eng.program.ops[i] for i in range(eng.n_fwd)] + [self._head[1].ops[0]]
+        plan, cur = [], eng.n_fwd
+        for lo, hi, op_end in eng.grad_buckets(bucket):
+            ops = head + [eng.program.ops[i] for i in range(cur, max(op_end, cur))]
+            head, cur = [], max(op_end, cur)
+            plan.append((ops, (lo, hi)))
+        tail = [eng.program.ops[i] for i in range(cur, eng.program.n)]
+        tail += [opt.ops[i] for i in range(opt.n)] + [L.make_op(L.OP_PACK, args) for args, _ in ws._tables[0]]
+        plan.append((tail, None))
+        if getattr(self, "_gstream", None) is None:
+            self._gstream = torch.cuda.Stream(device=self.device)
+        self._gstream.wait_stream(torch.cuda.current_stream())
+        segs = []
+        try:
+            for ops, span in plan:
+                prog = None
+                if ops:                              # (a bucket that is final at the same op as its predecessor: no launch)
+                    prog = E.Program(L.op_array(ops), [0] * len(ops), [0.0] * len(ops), (self, opt, ws._tables))
+                    prog.capture(self._gstream)
+                segs.append((prog, span))
+        except L.SsdeError as exc:
+            import warnings
+            self._graph_failed = exc
+            warnings.warn("libssde_hip: capturing the training step as hipGraphs failed (%s); running it as program launches" % exc)
+            torch.cuda.current_stream().wait_stream(self._gstream)
+            return None
+        torch.cuda.current_stream().wait_stream(self._gstream)
+        self._graph_seg = (key, segs)
+        return segs
+
+    def _train_step_exchange_graphs(self, segs, batch, optimizer, ema, step, hyper, t, z, seed):
+        import torch.distributed as dist
+        self._draw_and_perturb(batch, t, z)
+        self.eng.weights.refresh()
+        self.eng.set_dropout_seed(self._dropout_seed() if seed is None else seed)
+        self._upload_hyper(optimizer, ema, step, hyper)
+        s = self._gstream
+        s.wait_stream(torch.cuda.current_stream())
+        works = []
+        with torch.cuda.stream(s):                   # (the collective's stream waits for what `s` holds when it is issued)
+            for prog, span in segs:
+                if span is None:
+                    for w in works:
+                        w.wait()                     # `s` waits for the all-reduces; the host does not
+                if prog is not None:
+                    prog.replay(s)
+                if span is not None:
+                    works.append(dist.all_reduce(self.flat.grad[span[0]:span[1]], async_op=True))
+        self.collectives_last_step = len(works)
+        torch.cuda.current_stream().wait_stream(s)
+        self._after_update(optimizer, repacked=True)
+        return self.loss.clone()
+
     def train_step(self, batch, optimizer, ema, step, hyper, t=None, z=None, seed=None):
         """One optimisation step (losses.py:179-208's train branch); returns the device scalar loss (of the parameters BEFORE the
         update, as the reference's step_fn does)."""
-        prog = None if self._exchanges() else self._step_graph(optimizer, ema)
+        if self._exchanges():
+            segs = self._step_graph_segments(optimizer, ema)
+            if segs is not None:
+                return self._train_step_exchange_graphs(segs, batch, optimizer, ema, step, hyper, t, z, seed)
+            prog = None
+        else:
+            prog = self._step_graph(optimizer, ema)
         if prog is None:
             loss = self.loss_and_grads(batch, t=t, z=z, seed=seed)
             loss = loss.clone()
@@ -392,6 +474,7 @@ class FusedTrainStep:
     def optimizer_step(self, optimizer, ema, step, hyper):
         import torch.distributed as dist
         if self._exchanges():     # gradients were pre-scaled by 1/world in the loss head
+            self.collectives_last_step = len(getattr(self, "_pending", None) or []) or 1
             if getattr(self, "_pending", None):
                 for work in self._pending:           # bucketed all-reduces started during the backward program
                     work.wait()

@@ -1010,7 +1010,9 @@ def check_forced_exchange_one_rank(dev, backend, monkeypatch):
     batches = [(torch.rand(4, 3, 16, 16, generator=g), torch.rand(4, generator=g) * 0.9 + 0.05, torch.randn(4, 3, 16, 16, generator=g))
                for _ in range(3)]
 
-    def run():
+    def run(whole_step=False):
+        """whole_step: FusedTrainStep.train_step (on the GPU: one hipGraph without the exchange, one hipGraph per gradient bucket
+        with it -- _step_graph_segments); else its two halves as program launches"""
         torch.manual_seed(0)
         model = mutils.get_model("ncsnpp")(cfg)
         _util.load_seeded(model, seed=1)
@@ -1023,16 +1025,24 @@ def check_forced_exchange_one_rank(dev, backend, monkeypatch):
         fs = step_fn.fused_for(state, torch.zeros(4, 3, 16, 16, device=dev))
         ls, buckets = [], 0
         for i, (b, t, z) in enumerate(batches):
-            ls.append(float(fs.loss_and_grads(b.to(dev), t=t.to(dev), z=z.to(dev), seed=11 + i)))
-            buckets = max(buckets, len(fs._pending))
-            fs.optimizer_step(opt, ema, state["step"], optimize_fn.ssde_hyper)
+            if whole_step:
+                ls.append(float(fs.train_step(b.to(dev), opt, ema, state["step"], optimize_fn.ssde_hyper, t=t.to(dev), z=z.to(dev),
+                                              seed=11 + i)))
+                buckets = max(buckets, getattr(fs, "collectives_last_step", 0))
+            else:
+                ls.append(float(fs.loss_and_grads(b.to(dev), t=t.to(dev), z=z.to(dev), seed=11 + i)))
+                buckets = max(buckets, len(fs._pending))
+                fs.optimizer_step(opt, ema, state["step"], optimize_fn.ssde_hyper)
             state["step"] += 1
         if dev != "cpu":
             torch.cuda.synchronize()
-        return ls, fs.flat.data.clone(), fs.flat.grad.clone(), buckets
+        segmented = getattr(fs, "_graph_seg", None) is not None
+        return ls, fs.flat.data.clone(), fs.flat.grad.clone(), buckets, segmented
 
-    ref_loss, ref_p, ref_g, nb0 = run()
+    ref_loss, ref_p, ref_g, nb0, _ = run()
     assert nb0 == 0
+    ref_loss_w, ref_p_w, ref_g_w, _, seg0 = run(whole_step=True)        # the single-replica step (one graph on the GPU)
+    assert not seg0 and ref_loss_w == ref_loss and torch.equal(ref_p_w, ref_p)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -1041,12 +1051,16 @@ def check_forced_exchange_one_rank(dev, backend, monkeypatch):
     kw = dict(device_id=torch.device("cuda", torch.cuda.current_device())) if backend == "nccl" else {}
     dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, **kw)
     try:
-        loss, p, gr, nb = run()
+        loss, p, gr, nb, _ = run()
+        loss_w, p_w, gr_w, nb_w, seg = run(whole_step=True)
     finally:
         dist.destroy_process_group()
     assert nb >= 4, nb                          # several async all-reduces were in flight behind the backward program
     assert loss == ref_loss
     assert torch.equal(gr, ref_g) and torch.equal(p, ref_p)
+    # the whole step with the exchange: on the GPU one captured graph per gradient bucket + the closing optimizer graph
+    assert nb_w >= 4 and seg == (dev != "cpu"), (nb_w, seg)
+    assert loss_w == ref_loss and torch.equal(gr_w, ref_g) and torch.equal(p_w, ref_p)
 
 
 def _train_plan_case(dev, dropout):
