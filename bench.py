@@ -312,7 +312,7 @@ def bench_ode(args, dev, dist, world, rank):
                       "batch_per_gpu": B, "nfe_per_solve": nfes, "state_finite": bool(torch.isfinite(x).all()),
                       "ms_per_nfe": dt / max(sum(nfes), 1) * 1e3, "parallelism": "replicas x%d (no collectives)" % world}}
     if rank == 0:
-        print(json.dumps(out))
+        _emit(out)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -899,6 +899,27 @@ def rank_setup(args, env, n_devices, on_gpu=True):
 
 
 _T0 = time.perf_counter()
+_REAL_STDOUT = None
+
+
+def _own_stdout():
+    """From here on file descriptor 1 is stderr for everybody in this process -- RCCL prints a version banner on stdout when a
+    process group initialises, buffered by the C library and flushed at exit, i.e. AFTER the result line -- and the ONE JSON line
+    of the contract is written to the real stdout by _emit."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
 
 
 def _phase(msg):
@@ -941,6 +962,7 @@ def main():
         # `python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU over
         # RCCL (the same command line the driver uses); rank 0 of that job prints the JSON line on our stdout
         raise SystemExit(_self_launch(args.gpus, args.share_device))
+    _own_stdout()
     n_dev = torch.cuda.device_count()
     lr = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(lr % max(n_dev, 1) if args.share_device else lr)
@@ -960,7 +982,7 @@ def main():
         r.update(n_gpus=world, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32 (f64 integrator state)", data="synthetic",
                  steps=1, warmup=1, ms_per_step=r["seconds_per_solve"] * 1e3, config={"workload": r.pop("workload")})
         if rank == 0:
-            print(json.dumps(r))
+            _emit(r)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -991,7 +1013,7 @@ def main():
         if _TELE is not None:
             tr["telemetry"] = _TELE.report()
         if rank == 0:
-            print(json.dumps(tr))
+            _emit(tr)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -1159,7 +1181,7 @@ def main():
     if _TELE is not None:
         out["telemetry"] = _TELE.report()
     if rank == 0:
-        print(json.dumps(out))
+        _emit(out)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -369,17 +369,24 @@ __global__ __launch_bounds__(kGfThreads, 4) void gn_bwd_fused_kernel(const GfPar
       old[b] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (acc && px < hw) old[b] = *reinterpret_cast<const float4*>(gdst + ((size_t)n * hw + px) * Cs + cc);
     }
+    // values of the whole batch first, then its stores back to back: with the bounds test, the arithmetic and the store of a row
+    // in one loop trip hipcc put an s_waitcnt vmcnt(0) between the stores (gfx9 counts stores in vmcnt; the count state it
+    // merges at the joins of the skipped rows is "unknown"), and every store waited out its predecessor's acknowledgement
+    float4 w[kB];
 #pragma unroll
     for (int b = 0; b < kB; ++b) {
-      const int r = r0 + b, px = pl + r * PL;
-      if (px >= hw) continue;
+      const int r = r0 + b;
       const float du[4] = {dv[r].x, dv[r].y, dv[r].z, dv[r].w}, xh[4] = {xv[r].x, xv[r].y, xv[r].z, xv[r].w};
       float o[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] = rs * (du[k] * gm[k] - A - xh[k] * B) * p.scale;
-      float4 w = make_float4(o[0], o[1], o[2], o[3]);
-      if (acc) { w.x += old[b].x; w.y += old[b].y; w.z += old[b].z; w.w += old[b].w; }
-      *reinterpret_cast<float4*>(gdst + ((size_t)n * hw + px) * Cs + cc) = w;
+      w[b] = make_float4(o[0], o[1], o[2], o[3]);
+      if (acc) { w[b].x += old[b].x; w[b].y += old[b].y; w[b].z += old[b].z; w[b].w += old[b].w; }
+    }
+#pragma unroll
+    for (int b = 0; b < kB; ++b) {
+      const int px = pl + (r0 + b) * PL;
+      if (px < hw) *reinterpret_cast<float4*>(gdst + ((size_t)n * hw + px) * Cs + cc) = w[b];
     }
   }
 }

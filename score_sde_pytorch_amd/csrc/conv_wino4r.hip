@@ -247,6 +247,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
   float* park = smem;
 #pragma unroll
   for (int rnd = 0; rnd < 2; ++rnd) {
+    auto pixfn = [&](int row, size_t& pix, int& img) {
+      const int tile = rnd * 16 + (row >> 4), dy = (row >> 2) & 3, dx = row & 3;
+      const int il = tile >> (p.lTWt + p.lTHt);
+      const int tr = (tile >> p.lTWt) & (THt - 1), tc = tile & (TWt - 1);
+      img = img0 + il;
+      const int oy = (ty * THt + tr) * 4 + dy, ox = (tx * TWt + tc) * 4 + dx;
+      if (img >= p.N || oy >= p.H || ox >= p.W) return false;
+      pix = ((size_t)img * p.H + oy) * p.W + ox;
+      return true;
+    };
 #pragma unroll
     for (int j = 0; j < kNP; ++j)
 #pragma unroll
@@ -298,16 +308,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
     SSDE_LDS_BARRIER();
     SSDE_RT(35 + rnd * 4);                     // tile parked: the store phase starts
     const int gn_entry = gn_base < 0 ? -1 : (IMGS == 1 ? gn_base + rnd : gn_base + rnd * (IMGS >> 1));
-    auto pixfn = [&](int row, size_t& pix, int& img) {
-      const int tile = rnd * 16 + (row >> 4), dy = (row >> 2) & 3, dx = row & 3;
-      const int il = tile >> (p.lTWt + p.lTHt);
-      const int tr = (tile >> p.lTWt) & (THt - 1), tc = tile & (TWt - 1);
-      img = img0 + il;
-      const int oy = (ty * THt + tr) * 4 + dy, ox = (tx * TWt + tc) * 4 + dx;
-      if (img >= p.N || oy >= p.H || ox >= p.W) return false;
-      pix = ((size_t)img * p.H + oy) * p.W + ox;
-      return true;
-    };
     const int gn_max = IMGS == 1 ? p.N * p.tiles_per_img * 2 : p.N;
     if constexpr (kSplit) {
       // split reduction (conv_wino4.hip's hand-over): share 0 leaves its raw 4x4 outputs in the tile's own part of dst, shares
@@ -374,6 +374,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
       __syncthreads();
       if (rnd == 1 && tid == 0) { sy[0] = 0u; sy[1] = 0u; }              // ready for the next launch that is dealt these slots
     }
+    // (Fetching the residual rows ahead of the exchange / transform / park phases was built twice and measured neutral:
+    //  profiles/r6_w4r_epilogue_prefetch_v1_in_scratch_rejected.txt, r6_w4r_epilogue_prefetch_v2_neutral.txt)
     if (rnd == 0) ssde_store_tile<256, kBN, kThreads, 4, 0>(park, kLdt, n0, e, pixfn, gn_entry, rpi_log2, gn_max);
     else ssde_store_tile<256, kBN, kThreads, 8, 0>(park, kLdt, n0, e, pixfn, gn_entry, rpi_log2, gn_max);
     if (rnd == 0) { SSDE_LDS_BARRIER(); SSDE_RT(4); }

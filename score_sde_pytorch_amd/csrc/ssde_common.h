@@ -320,6 +320,41 @@ __device__ __forceinline__ void ssde_store_tile(float* tile, int ld, int n0, con
         if (ok[b] && e.resid) r[b] = *reinterpret_cast<const float4*>(e.resid + pix[b] * e.Cout + j);
         if (ok[b] && e.chan_add) a[b] = *reinterpret_cast<const float4*>(e.chan_add + (size_t)img * e.chan_add_ld + j);
       }
+      // Three straight passes over the batch -- values, stores, statistics -- instead of one loop trip per row that stored,
+      // updated the statistics and possibly flushed them: with the flush's branches between two stores hipcc put an
+      // `s_waitcnt vmcnt(0)` behind every global_store (gfx9 counts stores in vmcnt, and the count state it merges at those
+      // joins is "unknown"), so the 4-8 stores of a thread each waited out a write acknowledgement: 7.0-7.7 k cycles of a
+      // round's store phase in conv_wino4r_kernel (profiles/r5_wino4r_epilogue_trace.txt), the same pattern in every kernel
+      // that ends in this function.  SSDE_STORE_ROW_BY_ROW=1 (an A/B variant only) keeps the old loop.
+#if !defined(SSDE_STORE_ROW_BY_ROW) || !SSDE_STORE_ROW_BY_ROW
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        float v[4] = {t[b].x + bias4.x + a[b].x, t[b].y + bias4.y + a[b].y, t[b].z + bias4.z + a[b].z, t[b].w + bias4.w + a[b].w};
+        const float4 rr = r[b];
+        if (!e.resid_post) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= e.scale;
+        if (e.resid_post) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
+        t[b] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+#pragma unroll
+      for (int b = 0; b < B; ++b)
+        if (ok[b]) *reinterpret_cast<float4*>(e.dst + pix[b] * e.Cout + j) = t[b];
+      if (stats) {
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          if (ok[b]) {
+            if (st_n == 0.f) st_p = t[b].x;
+            const float d0 = t[b].x - st_p, d1 = t[b].y - st_p, d2 = t[b].z - st_p, d3 = t[b].w - st_p;
+            st_s1 += (d0 + d1) + (d2 + d3);
+            st_s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            st_n += 4.f;
+          }
+          // uniform over the workgroup: the rows of an image are complete after this trip
+          if ((((it0 + b + 1) * RSTEP) & rpi_mask) == 0) flush(it0 + b);
+        }
+      }
+#else
 #pragma unroll
       for (int b = 0; b < B; ++b) {
         if (ok[b]) {
@@ -341,6 +376,7 @@ __device__ __forceinline__ void ssde_store_tile(float* tile, int ld, int n0, con
         // uniform over the workgroup: the rows of an image are complete after this trip
         if (stats && (((it0 + b + 1) * RSTEP) & rpi_mask) == 0) flush(it0 + b);
       }
+#endif
     }
   } else {
     // channel counts that are not a multiple of 4 (the 3-channel image ends): element-wise
@@ -363,6 +399,7 @@ __device__ __forceinline__ void ssde_store_tile(float* tile, int ld, int n0, con
     }
   }
 }
+
 
 // ---- exact fp32 products on the BF16 matrix pipe (SSDE_MATRIX=bf16x6) --------------------------------------------------
 // An fp32 value is the exact sum of three bf16 pieces taken by truncation (8 significand bits each: p0 = the top 16 bits of

@@ -372,7 +372,13 @@ __global__ __launch_bounds__(kGemmThreads, 4) void wgrad4_gemm_kernel(const W4Pa
   }
   SSDE_WT(2);
 
-  // slab[split][pos][co][ci]: a lane's 32 consecutive ci are a 128-byte run
+  // slab[split][pos][co][ci]: a lane's 32 consecutive ci are a 128-byte run.
+  // Addresses = one SCALAR base per 32 x 32 block and accumulator row (the wave index read into an SGPR) + ONE per-lane byte
+  // offset.  Written with per-element 64-bit pointers hipcc hoisted sixteen row offsets out of the stream-K segment loop, spilled
+  // them (54 VGPRs), and every reload -- scratch loads count in vmcnt like the stores before them -- drew an s_waitcnt vmcnt(0)
+  // between two stores: 23-39 of a segment's 64 stores each waited out the write acknowledgement of its predecessor.
+  // Both channel counts are multiples of 32 (ssde_wgrad_wino4_wants): a block is inside or outside as a whole.
+#if defined(SSDE_WG4_ELEMENT_POINTERS) && SSDE_WG4_ELEMENT_POINTERS      // (rounds 3-5, A/B variant only)
   float* slab = p.slabs + ((size_t)slot * kPos + pos) * (size_t)p.Cout * p.Ctot;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -385,6 +391,24 @@ __global__ __launch_bounds__(kGemmThreads, 4) void wgrad4_gemm_kernel(const W4Pa
         if (co < p.Cout && ci < p.Ctot) slab[(size_t)co * p.Ctot + ci] = acc[a][c][r];
       }
     }
+#else
+  char* slab = reinterpret_cast<char*>(p.slabs + ((size_t)slot * kPos + pos) * (size_t)p.Cout * p.Ctot);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wm0u = (wave_u >> 1) * 64, wn0u = (wave_u & 1) * 64;
+  const uint32_t lane_off = ((uint32_t)(4 * lh) * (uint32_t)p.Ctot + (uint32_t)li) * 4u;
+  const size_t row_bytes = (size_t)p.Ctot * 4;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      if (co0 + wm0u + a * 32 < p.Cout && ci0 + wn0u + c * 32 < p.Ctot) {
+        char* blk = slab + ((size_t)(co0 + wm0u + a * 32) * p.Ctot + (size_t)(ci0 + wn0u + c * 32)) * 4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          *reinterpret_cast<float*>(blk + (size_t)((r & 3) + 8 * (r >> 2)) * row_bytes + lane_off) = acc[a][c][r];
+      }
+    }
+#endif
   }                                              // next segment of a stream-K run
   SSDE_WT(3);
 }
