@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extras --train-steps 3 --train-warmup 1"
+BENCH="python $ROOT/bench.py --steps 3 --warmup 1 --prewarm-s 0 --no-telemetry --no-exchange-probe --no-other-matrix --no-cpu-baseline --no-roofline --no-extras --train-steps 3 --train-warmup 1"
 echo "== kernel trace (sampler + train step)"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- $BENCH > $OUT/trace.log 2>&1
 echo "rc=$?"
