@@ -47,6 +47,10 @@ extern "C" int ssde_debug_w4r_trace(void* buf) {
 #endif
 
 
+#ifndef SSDE_W4R_PERSIST
+#define SSDE_W4R_PERSIST 1          // (0: one workgroup per tile everywhere -- rounds 5's launch shape, A/B variant only)
+#endif
+
 namespace {
 
 constexpr int kNP = 9;                              // accumulator blocks per wave: (4 positions) x (2 cout halves) + 1
@@ -78,6 +82,7 @@ struct Wino4rParams {
   unsigned* sync;          // ksplit > 1: this launch's (shares started, shares handed over) pairs, one per tile (conv_mfma.hip's
                            // g_conv_sync: zero before and after)
   int ticket_off;          // float index of the hand-over ticket in LDS (behind the epilogue's exchange area)
+  int total_work;          // kPersist: tiles (pixel tile, cout tile) of the launch, dealt bid, bid + grid, ...
 };
 
 // kKs = 2 or 4: that many workgroups per tile, each reducing its share of the channel stages (conv_wino4.hip's split, the same
@@ -87,28 +92,87 @@ struct Wino4rParams {
 // cover the chip with one workgroup per CU, and the matrix loop of a share is half as long.  (Eight shares on the 4x4 maps -- one
 // tile per image -- were built and measured slower than the direct kernel: the hand-over chain outlasts the 8 stages a share
 // computes, profiles/r5_wino4r_4x4_maps_eight_shares_rejected.txt, tools/experiments/conv_wino4r_4x4_maps_eight_shares/.)
-template <int kKs>
+//
+// kPersist (unsplit launches of more than one round of workgroups): the grid is one workgroup per CU and a workgroup walks the
+// tiles bid, bid + grid, bid + 2 grid, ... itself (the same tile -> XCD map: the grid is a multiple of 8).  What that buys is the
+// START of a tile: a freshly dispatched workgroup spends 6-15 k cycles before its first MFMA (dispatch of eight waves one after the
+// other, kernel arguments, address arithmetic, 20 loads whose first touches of V miss everywhere --
+// profiles/r5_wino4r_later_workgroups_trace.txt: "setup" + "first loads issued").  Here the first two stages' loads of the NEXT tile
+// are issued from the epilogue of the current one, after its second output round is parked and before that round is stored: they
+// land under the store phase, and the next tile's first MFMA follows the last store directly.  The loads sit in the very registers
+// the loop reads (the register sets are free during the epilogue); tests/test_isa_guards.py checks that nothing touches them
+// between the issue and the loop's first counted wait.  Stores count in vmcnt too: the waits of the first stage may see up to nine
+// younger stores outstanding and wait for a few more of the (older) loads than necessary -- never for fewer.
+template <int kKs, bool kPersist = false>
 __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rParams p) {
   constexpr bool kSplit = kKs > 1;
+  static_assert(!(kSplit && kPersist), "the split shares are dealt by tickets: one tile per workgroup");
   SSDE_LDS(smem);                               // the epilogue's only (+ the split's ticket)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
-
+  // wave w: positions 4 w + i (i = 0..3), both cout halves -> blocks 2 i, 2 i + 1; position 32 + (w >> 1), cout half w & 1 -> block 8
+  auto pos_of = [&](int i) { return i < 4 ? 4 * wave + i : 32 + (wave >> 1); };
+  const int TWt = 1 << p.lTWt, THt = 1 << p.lTHt;
+  const int IMGS = kTiles >> (p.lTWt + p.lTHt);
   // XCD-aware order (conv_wino4.hip): the cout tiles of one pixel tile run on one XCD at the same time -- they read the same V
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, l = bid >> 3;
-  const int nt = l % p.n_tiles;
-  const int mt = (l / (p.n_tiles * kKs)) * 8 + xcd;      // (the kKs workgroups of a tile: same XCD, 8 * n_tiles blocks apart)
+  auto mt_of = [&](int w) { return ((w >> 3) / (p.n_tiles * kKs)) * 8 + (w & 7); };   // (the kKs workgroups of a tile: same XCD, 8 * n_tiles blocks apart)
+  auto nt_of = [&](int w) { return (w >> 3) % p.n_tiles; };
+  // ---- operand addresses of a tile.  A: the lane's byte offset of position slot j inside one stage's [36][Q][T][4] view of V
+  // (32-bit: the launcher checks V < 4 GB); the stage rides in the scalar base.  Tiles outside the batch / the image read tile 0's
+  // run (a valid address; their outputs are never stored).  B: the wave's 4.5 KB of a stage, lane-major; four 1 KB pieces at
+  // immediates -2048 .. 1024 around the base and one 512-byte piece behind them
+  const size_t v_stage = (size_t)p.T * 16;
+  const size_t u_stage = (size_t)p.n_tiles * kUFloats * 4;
+  const uint32_t u_off = (uint32_t)lane * 16u, u_off8 = 2048u + (uint32_t)lane * 8u;
+  auto operands = [&](int mt_, int nt_, int st_off_, uint32_t (&vo)[kNV], const char*& vs_, const char*& us_) {
+    const int img0_ = (mt_ / p.tiles_per_img) * IMGS, trem_ = mt_ % p.tiles_per_img;
+    const int ty_ = trem_ / p.tiles_x, tx_ = trem_ % p.tiles_x;
+    const int il = li >> (p.lTWt + p.lTHt);
+    const int tr = (li >> p.lTWt) & (THt - 1), tc = li & (TWt - 1);
+    const int img = img0_ + il, yy = ty_ * THt + tr, xx = tx_ * TWt + tc;
+    const uint32_t t = (img < p.N && yy < p.tiles_h && xx < p.tiles_w) ? (uint32_t)((img * p.tiles_h + yy) * p.tiles_w + xx) : 0u;
+    const uint32_t QT = (uint32_t)(p.Ctot >> 2) * (uint32_t)p.T;
+#pragma unroll
+    for (int j = 0; j < kNV; ++j) vo[j] = ((uint32_t)pos_of(j) * QT + t) * 16u + 8u * (uint32_t)lh;
+    vs_ = reinterpret_cast<const char*>(p.v) + (size_t)st_off_ * v_stage;      // (local) stage st: + st * T * 16 bytes
+    us_ = reinterpret_cast<const char*>(p.wpk + ((size_t)nt_ * kWaves + wave) * kURegion) + 2048 + (size_t)st_off_ * u_stage;
+  };
+  // TWO register sets per operand: stage st lives in set st & 1 and is loaded while stage st - 2 is consumed, so a wave has two
+  // whole stages of loads in flight.  (With one set -- the first version -- a stage could not be shorter than one memory
+  // latency: ~3000 cycles for a wave alone on its SIMD, profiles/r5_wino4r_v2_two_workgroups_per_cu.txt, against 1152 matrix
+  // cycles; two waves per SIMD at 2304 cycles each sat right at that bound.)
+  ssde_f32x2 va[2][kNV], u2[2];
+  ssde_f32x4 u4[2][4];
+  uint32_t v_off[kNV];
+  const char* vs = nullptr;
+  const char* us = nullptr;
+  // the loads of one stage into register set S: V0 U0 | V1 U1 | V2 U2 | V3 U3 | V4 U4 (the order the loop's counted waits assume)
+#define SSDE_W4R_ROUND_AT(S, VO, VN, UN)                                                           \
+  do {                                                                                             \
+    SSDE_GLOAD8_I(va[S][0], VO[0], VN, 0); SSDE_GLOAD16_I(u4[S][0], u_off, UN, -2048);             \
+    SSDE_GLOAD8_I(va[S][1], VO[1], VN, 0); SSDE_GLOAD16_I(u4[S][1], u_off, UN, -1024);             \
+    SSDE_GLOAD8_I(va[S][2], VO[2], VN, 0); SSDE_GLOAD16_I(u4[S][2], u_off, UN, 0);                 \
+    SSDE_GLOAD8_I(va[S][3], VO[3], VN, 0); SSDE_GLOAD16_I(u4[S][3], u_off, UN, 1024);              \
+    SSDE_GLOAD8_I(va[S][4], VO[4], VN, 0); SSDE_GLOAD8_I(u2[S], u_off8, UN, 0);                    \
+  } while (0)
+  const int total_work = kPersist ? p.total_work : 0;
+  bool primed = false;                           // kPersist: the first two stages of this tile are already in flight
+
+  for (int work = blockIdx.x;;) {                // (one trip unless kPersist)
+  const int bid = work;
+  const int nt = nt_of(work);
+  const int mt = mt_of(work);
 #ifdef SSDE_W4R_TRACE
   const bool tr_on = lane == 0 && (wave == 0 || wave == kWaves - 1) && g_w4r_trace != nullptr && bid == (int)g_w4r_trace[255];   // (the host names the workgroup)
   const int tr_base = (wave == 0 ? 0 : 1) * 128;
 #endif
   SSDE_RT(0);
-  if (mt >= p.m_tiles) return;
+  if (mt >= p.m_tiles) {                         // (the grid is padded to whole groups of 8 pixel tiles)
+    if constexpr (kPersist) { work += gridDim.x; if (work < total_work) continue; }
+    return;
+  }
 
-  const int TWt = 1 << p.lTWt, THt = 1 << p.lTHt;
-  const int IMGS = kTiles >> (p.lTWt + p.lTHt);
   const int img0 = (mt / p.tiles_per_img) * IMGS;
   const int trem = mt % p.tiles_per_img;
   const int ty = trem / p.tiles_x, tx = trem % p.tiles_x;
@@ -126,42 +190,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
     st_off = nst_all * ks / kKs;
     nst = nst_all * (ks + 1) / kKs - st_off;
   }
-  // wave w: positions 4 w + i (i = 0..3), both cout halves -> blocks 2 i, 2 i + 1; position 32 + (w >> 1), cout half w & 1 -> block 8
-  auto pos_of = [&](int i) { return i < 4 ? 4 * wave + i : 32 + (wave >> 1); };
-
-  // ---- A operand: the lane's byte offset of position slot j inside one stage's [36][Q][T][4] view of V (32-bit: the launcher
-  // checks V < 4 GB); the stage rides in the scalar base.  Tiles outside the batch / the image read tile 0's run (a valid
-  // address; their outputs are never stored).
-  uint32_t v_off[kNV];
-  {
-    const int il = li >> (p.lTWt + p.lTHt);
-    const int tr = (li >> p.lTWt) & (THt - 1), tc = li & (TWt - 1);
-    const int img = img0 + il, yy = ty * THt + tr, xx = tx * TWt + tc;
-    const uint32_t t = (img < p.N && yy < p.tiles_h && xx < p.tiles_w) ? (uint32_t)((img * p.tiles_h + yy) * p.tiles_w + xx) : 0u;
-    const uint32_t QT = (uint32_t)(p.Ctot >> 2) * (uint32_t)p.T;
-#pragma unroll
-    for (int j = 0; j < kNV; ++j) v_off[j] = ((uint32_t)pos_of(j) * QT + t) * 16u + 8u * (uint32_t)lh;
-  }
-  const size_t v_stage = (size_t)p.T * 16;
-  const char* vs = reinterpret_cast<const char*>(p.v) + (size_t)st_off * v_stage;      // (local) stage st: + st * T * 16 bytes
-  // ---- B operand: the wave's 4.5 KB of a stage, lane-major; four 1 KB pieces at immediates -2048 .. 1024 around the base and
-  // one 512-byte piece behind them
-  const uint32_t u_off = (uint32_t)lane * 16u, u_off8 = 2048u + (uint32_t)lane * 8u;
-  const size_t u_stage = (size_t)p.n_tiles * kUFloats * 4;
-  const char* us = reinterpret_cast<const char*>(p.wpk + ((size_t)nt * kWaves + wave) * kURegion) + 2048 + (size_t)st_off * u_stage;
+  if (!primed) operands(mt, nt, st_off, v_off, vs, us);
 
   f32x16 acc[kNP];
 #pragma unroll
   for (int j = 0; j < kNP; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  // TWO register sets per operand: stage st lives in set st & 1 and is loaded while stage st - 2 is consumed, so a wave has two
-  // whole stages of loads in flight.  (With one set -- the first version -- a stage could not be shorter than one memory
-  // latency: ~3000 cycles for a wave alone on its SIMD, profiles/r5_wino4r_v2_two_workgroups_per_cu.txt, against 1152 matrix
-  // cycles; two waves per SIMD at 2304 cycles each sat right at that bound.)
-  ssde_f32x2 va[2][kNV], u2[2];
-  ssde_f32x4 u4[2][4];
-
   // The VMEM queue of a wave is a ring of 10 loads per stage, always in this order (loads return in order):
   //   V0 U0 | V1 U1 | V2 U2 | V3 U3 | V4 U4              (position i of the wave: its V run, then its weights)
   // each re-issued for stage st + 2 right after the MFMAs that consumed it in stage st.  Position i needs Ui of this stage (index
@@ -185,21 +220,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
     if (kMode == 0) { SSDE_W4R_LOADV(S, I); SSDE_GLOAD16_I(u4[S][I], u_off, un, IMM); }            \
     __builtin_amdgcn_sched_barrier(0);                                                             \
   } while (0)
-#define SSDE_W4R_ROUND(S)                                                                          \
-  do {                                                                                             \
-    SSDE_W4R_LOADV(S, 0); SSDE_GLOAD16_I(u4[S][0], u_off, un, -2048);                              \
-    SSDE_W4R_LOADV(S, 1); SSDE_GLOAD16_I(u4[S][1], u_off, un, -1024);                              \
-    SSDE_W4R_LOADV(S, 2); SSDE_GLOAD16_I(u4[S][2], u_off, un, 0);                                  \
-    SSDE_W4R_LOADV(S, 3); SSDE_GLOAD16_I(u4[S][3], u_off, un, 1024);                               \
-    SSDE_W4R_LOADV(S, 4); SSDE_GLOAD8_I(u2[S], u_off8, un, 0);                                     \
-  } while (0)
 
   SSDE_RT(1);
-  {
-    const char* vn = vs; const char* un = us;
-    SSDE_W4R_ROUND(0);
-    vn += v_stage; un += u_stage;
-    SSDE_W4R_ROUND(1);
+  if (!primed) {
+    SSDE_W4R_ROUND_AT(0, v_off, vs, us);
+    SSDE_W4R_ROUND_AT(1, v_off, vs + v_stage, us + u_stage);
   }
   SSDE_RT(2);
   // stage st in register set S (= st & 1, a compile-time constant: the loop below is unrolled by two)
@@ -232,7 +257,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
     stage(S0{}, Penult{}, st);
     stage(S1{}, Last{}, st + 1);
   }
-#undef SSDE_W4R_ROUND
 #undef SSDE_W4R_POS
 #undef SSDE_W4R_MFMA
 #undef SSDE_W4R_LOADV
@@ -243,10 +267,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
   SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, p.Cout, p.gn_part};
   const int gn_base = !p.gn_part ? -1 : (IMGS == 1 ? (img0 * p.tiles_per_img + trem) * 2 : img0);
   const int rpi_log2 = IMGS > 2 ? 8 - (4 - p.lTWt - p.lTHt) : 30;
-  const int e_tl = tid / (kBN / 2), e_cp = tid % (kBN / 2);
+  // (kPersist: the per-lane indices of the epilogue are re-derived from an opaque copy of the thread id in every tile -- as loop
+  //  invariants of the tile loop hipcc computed the ~70 LDS addresses of the exchange once, kept them across the matrix loop and
+  //  spilled 105 registers around it)
+  int tid_e = tid;
+  if constexpr (kPersist) asm volatile("" : "+v"(tid_e));
+  const int li_e = tid_e & 31, lh_e = (tid_e >> 5) & 1;
+  const int e_tl = tid_e / (kBN / 2), e_cp = tid_e % (kBN / 2);
   float* park = smem;
+  int next_work = 0;
 #pragma unroll
   for (int rnd = 0; rnd < 2; ++rnd) {
+    // (a later tile of a persistent workgroup: the exchange below overwrites the previous tile's parked rows -- every thread must be
+    //  done reading them; eight waves that just left the same matrix loop arrive here within a few hundred cycles of each other)
+    if (kPersist && rnd == 0 && primed) SSDE_LDS_BARRIER();
     auto pixfn = [&](int row, size_t& pix, int& img) {
       const int tile = rnd * 16 + (row >> 4), dy = (row >> 2) & 3, dx = row & 3;
       const int il = tile >> (p.lTWt + p.lTHt);
@@ -262,9 +296,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
 #pragma unroll
       for (int r8 = 0; r8 < 8; ++r8) {
         const int r = rnd * 8 + r8;
-        const int tl = (r & 3) + 4 * lh + 8 * ((r >> 2) & 1);
+        const int tl = (r & 3) + 4 * lh_e + 8 * ((r >> 2) & 1);
         const int pos = pos_of(j >> 1), half = j < 8 ? (j & 1) : (wave & 1);      // block j of this wave
-        smem[(pos * 16 + tl) * kLdm + half * 32 + li] = acc[j][r];
+        smem[(pos * 16 + tl) * kLdm + half * 32 + li_e] = acc[j][r];
       }
     SSDE_RT(32 + rnd * 4);   // products written (before the barrier)
     SSDE_LDS_BARRIER();      // (LDS-only barriers throughout: a __syncthreads() would wait out the previous round's global stores)
@@ -307,6 +341,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
         *reinterpret_cast<float2*>(park + (e_tl * 16 + dy * 4 + dx) * kLdt + 2 * e_cp) = y[dy][dx];
     SSDE_LDS_BARRIER();
     SSDE_RT(35 + rnd * 4);                     // tile parked: the store phase starts
+    if constexpr (kPersist) {
+      if (rnd == 1) {
+        // the next tile's first two stages, requested before this tile's last stores (the operand registers and v_off / vs / us
+        // are dead since the matrix loop ended)
+        next_work = work + (int)gridDim.x;
+        while (next_work < total_work && mt_of(next_work) >= p.m_tiles) next_work += (int)gridDim.x;
+        if (next_work < total_work) {
+          operands(mt_of(next_work), nt_of(next_work), 0, v_off, vs, us);
+          SSDE_W4R_ROUND_AT(0, v_off, vs, us);
+          SSDE_W4R_ROUND_AT(1, v_off, vs + v_stage, us + u_stage);
+        }
+      }
+    }
     const int gn_entry = gn_base < 0 ? -1 : (IMGS == 1 ? gn_base + rnd : gn_base + rnd * (IMGS >> 1));
     const int gn_max = IMGS == 1 ? p.N * p.tiles_per_img * 2 : p.N;
     if constexpr (kSplit) {
@@ -376,11 +423,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
     }
     // (Fetching the residual rows ahead of the exchange / transform / park phases was built twice and measured neutral:
     //  profiles/r6_w4r_epilogue_prefetch_v1_in_scratch_rejected.txt, r6_w4r_epilogue_prefetch_v2_neutral.txt)
-    if (rnd == 0) ssde_store_tile<256, kBN, kThreads, 4, 0>(park, kLdt, n0, e, pixfn, gn_entry, rpi_log2, gn_max);
-    else ssde_store_tile<256, kBN, kThreads, 8, 0>(park, kLdt, n0, e, pixfn, gn_entry, rpi_log2, gn_max);
+    if (rnd == 0) ssde_store_tile<256, kBN, kThreads, 4, 0>(park, kLdt, n0, e, pixfn, gn_entry, rpi_log2, gn_max, kPersist ? tid_e : -1);
+    else ssde_store_tile<256, kBN, kThreads, 8, 0>(park, kLdt, n0, e, pixfn, gn_entry, rpi_log2, gn_max, kPersist ? tid_e : -1);
     if (rnd == 0) { SSDE_LDS_BARRIER(); SSDE_RT(4); }
   }
   SSDE_RT(5);
+  if constexpr (kPersist) {
+    if (next_work < total_work) { work = next_work; primed = true; continue; }
+  }
+  return;
+  }                                              // the next tile of a persistent workgroup
+#undef SSDE_W4R_ROUND_AT
 }
 
 int pow2_floor(int v) { int q = 1; while (q * 2 <= v) q *= 2; return q; }
@@ -448,7 +501,12 @@ int ssde_conv_wino4r_launch(const ssde_conv_args* a, void* stream, int* lds_out)
   p.ksplit = a->resid != a->dst ? ssde_conv_wino4r_splits(wgs, p.Ctot, a->c_out, a->flags) : 1;
   p.sync = p.ksplit > 1 ? ssde_conv_sync_slots(p.m_tiles * p.n_tiles) : nullptr;
   if (!p.sync) p.ksplit = 1;
-  const dim3 grid(wgs * p.ksplit);
+  // more than one round of unsplit workgroups: one persistent workgroup per CU walks the tiles (the grid stays a multiple of 8:
+  // the tile -> XCD map).  SSDE_W4R_PERSIST=0 at compile time (A/B variant) keeps one workgroup per tile.
+  const int cus = ssde_num_cus() / 8 * 8;
+  const bool persist = SSDE_W4R_PERSIST && p.ksplit == 1 && cus >= 8 && wgs > cus;
+  p.total_work = wgs;
+  const dim3 grid(persist ? cus : wgs * p.ksplit);
   auto go = [&](auto kfn, std::atomic<bool>& attr_set) {
     if (!attr_set) {                            // once per instantiation, before any stream capture
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -458,8 +516,9 @@ int ssde_conv_wino4r_launch(const ssde_conv_args* a, void* stream, int* lds_out)
     hipLaunchKernelGGL(kfn, grid, dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
     return true;
   };
-  static std::atomic<bool> set[3];
-  const bool ok = p.ksplit == 4 ? go(conv_wino4r_kernel<4>, set[2]) : p.ksplit == 2 ? go(conv_wino4r_kernel<2>, set[1]) : go(conv_wino4r_kernel<1>, set[0]);
+  static std::atomic<bool> set[4];
+  const bool ok = p.ksplit == 4 ? go(conv_wino4r_kernel<4>, set[2]) : p.ksplit == 2 ? go(conv_wino4r_kernel<2>, set[1])
+                : persist ? go(conv_wino4r_kernel<1, true>, set[3]) : go(conv_wino4r_kernel<1>, set[0]);
   SSDE_REQUIRE(ok, "conv(winograd 4x4, register-fed): hipFuncSetAttribute failed");
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;

@@ -268,10 +268,13 @@ __device__ __forceinline__ void ssde_stat_merge(float& n, float& m, float& M2, f
 // is flushed when its last row has been stored, entries gn_entry, gn_entry + 1, ... (< gn_entry_max: the batch tail).
 template <int ROWS, int NCOLS, int NT, int BATCH = 4, int SWZ = 0, class PixFn>
 __device__ __forceinline__ void ssde_store_tile(float* tile, int ld, int n0, const SsdeEpi& e, PixFn pixfn, int gn_entry = -1,
-                                                int rpi_log2 = 30, int gn_entry_max = 0x7fffffff) {
+                                                int rpi_log2 = 30, int gn_entry_max = 0x7fffffff, int tid_in = -1) {
+  // tid_in: the caller's (opaque) copy of the thread id -- a persistent kernel passes one it re-derives per tile so that the row /
+  // pixel arithmetic below is not hoisted out of its tile loop and kept in registers across the matrix loop (conv_wino4r.hip)
+  const int tidx = tid_in >= 0 ? tid_in : (int)threadIdx.x;
   constexpr int C4N = NCOLS / 4, TOTAL = ROWS * C4N, ITERS = TOTAL / NT, RSTEP = NT / C4N;
   static_assert(TOTAL % NT == 0 && NT % C4N == 0 && 64 % C4N == 0, "a thread owns one channel quad of ITERS rows");
-  const int c = ((int)threadIdx.x % C4N) * 4, row0 = (int)threadIdx.x / C4N;
+  const int c = (tidx % C4N) * 4, row0 = tidx / C4N;
   const int j = n0 + c;
   const bool stats = e.gn_part != nullptr && gn_entry >= 0;
   float st_p = 0.f, st_s1 = 0.f, st_s2 = 0.f, st_n = 0.f;
@@ -283,10 +286,10 @@ __device__ __forceinline__ void ssde_store_tile(float* tile, int ld, int n0, con
     if (n > 0.f) { const float rn = __builtin_amdgcn_rcpf(n); m = st_p + st_s1 * rn; M2 = st_s2 - st_s1 * st_s1 * rn; M2 = M2 < 0.f ? 0.f : M2; }
     for (int o = C4N; o < 64; o <<= 1) {        // lanes l, l + C4N, l + 2 C4N, ... hold the same channel quad
       const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(m, o, 64), Mb = __shfl_xor(M2, o, 64);
-      if (threadIdx.x & o) { float tn = nb, tm = mb, tM = Mb; ssde_stat_merge(tn, tm, tM, n, m, M2); n = tn; m = tm; M2 = tM; }
+      if (tidx & o) { float tn = nb, tm = mb, tM = Mb; ssde_stat_merge(tn, tm, tM, n, m, M2); n = tn; m = tm; M2 = tM; }
       else ssde_stat_merge(n, m, M2, nb, mb, Mb);   // both partners merge lower-lane-first: identical results
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = tidx & 63, wave = tidx >> 6;
     const int entry = gn_entry + ((it * RSTEP) >> (rpi_log2 < 30 ? rpi_log2 : 30));
     if (lane < C4N && n0 + 4 * lane < e.Cout && entry < gn_entry_max) {
       float* o = e.gn_part + (((size_t)entry * (NT / 64) + wave) * (e.Cout >> 2) + (n0 >> 2) + lane) * 3;

@@ -174,5 +174,13 @@ def test_conv3x3_winograd_f4x4_in_two_kernels():
     T.check_conv_winograd4_two_kernels("cpu")
 
 
+def test_conv3x3_winograd_f4x4_matrix_kernel_persistent_workgroups(monkeypatch):
+    """the same cases on a pretend 8-CU device: launches of more than 8 tiles run as ONE workgroup per CU walking several tiles
+    (conv_wino4r_kernel<1, true>: the next tile's first loads are issued from the epilogue of the current one, empty padding tiles
+    are skipped) -- bit-identical to the one-kernel form when fed its by-product, like the one-tile-per-workgroup launch"""
+    monkeypatch.setenv("SSDE_NUM_CUS", "8")
+    T.check_conv_winograd4_two_kernels("cpu")
+
+
 def test_winograd_f4x4_weight_gradient_with_the_stream_k_split():
     T.check_wgrad_wino4_streamk("cpu")

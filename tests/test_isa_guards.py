@@ -124,7 +124,7 @@ def test_register_fed_winograd_matrix_loop_counts_its_own_loads(tmp_path):
     The two peeled last stages issue nothing: 18 / 16 / 14 / 12 / 10, then 8 / 6 / 4 / 2 / 0."""
     isa = _isa("conv_wino4r.hip", tmp_path)
     found = _kernels(isa, "conv_wino4r_kernel")
-    assert len(found) == 3                        # unsplit, and the reduction split over 2 / 4 workgroups per tile (kKs)
+    assert len(found) == 4                        # unsplit (one tile per workgroup / persistent), the reduction split over 2 / 4 workgroups per tile
     for sym, body in found:
         _check_register_fed_loop(sym, body)
         # (the split instantiations keep a few scalars in VGPR lanes: none of that inside the matrix loop)
@@ -175,3 +175,52 @@ def _check_register_fed_loop(sym, body):
     assert n == 36 and not any(l.startswith("global_load") for l in tail)
     assert [int(m.group(1)) for l in tail for m in [re.search(r"s_waitcnt vmcnt\((\d+)\)", l)] if m] == [18, 16, 14, 12, 10, 8, 6, 4, 2, 0]
     assert replay(tail, q, True) == []
+
+
+def test_persistent_register_fed_kernel_leaves_its_prefetched_operands_alone(tmp_path):
+    """conv_wino4r_kernel<1, true> (one workgroup per CU walking several tiles) issues the first two stages' loads of the NEXT tile
+    from the epilogue of the current one, into the very registers the matrix loop reads, 20 asm loads hipcc knows nothing about.
+    Between their issue and the loop's first counted wait (s_waitcnt vmcnt(18)) lie the second output round's store phase, the loop
+    back-edge and the next tile's set-up: walk every path from each of those loads (and from the 20 loads that prime the first tile)
+    to that wait and require that no instruction names a destination register -- no copy at the back-edge, no spill, no reuse as a
+    temporary of the store phase."""
+    isa = _isa("conv_wino4r.hip", tmp_path)
+    body = [b for sym, b in _kernels(isa, "conv_wino4r_kernel") if "ILi1ELb1E" in sym]
+    assert len(body) == 1
+    lines = [l.split(";")[0].rstrip() for l in body[0].split("\n")]
+    labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"(\.LBB\d+_\d+):", l)] if m}
+    mfma = [i for i, l in enumerate(lines) if "v_mfma" in l]
+    asm_load = re.compile(r"\s+global_load_dwordx[24] (v\[\d+:\d+\]), v\d+, s\[")
+    loads = [i for i, l in enumerate(lines) if asm_load.match(l)]
+    outside = [i for i in loads if i < mfma[0] or i > mfma[-1]]
+    assert len(outside) == 40 and sum(i > mfma[-1] for i in outside) == 20, (len(loads), len(outside))
+    for i in outside:
+        dst = _regs(asm_load.match(lines[i]).group(1))
+        seen, todo, reached = set(), [i + 1], False
+        while todo:
+            j = todo.pop()
+            while j < len(lines) and j not in seen:
+                seen.add(j)
+                l = lines[j].strip()
+                if re.match(r"s_waitcnt vmcnt\(18\)", l):
+                    reached = True
+                    break
+                if l and not l.startswith(".") and not l.endswith(":"):
+                    if asm_load.match(lines[j]):
+                        # another load of the round: its own destination -- or the priming load of the same register under
+                        # `if (!primed)`, which a prefetched tile never executes: a redefinition ends this path either way
+                        if _regs(asm_load.match(lines[j]).group(1)) & dst:
+                            reached = True
+                            break
+                    else:
+                        ops = l.split(None, 1)[1] if " " in l else ""
+                        assert not (_regs(ops) & dst), (lines[i].strip(), j, l)
+                    b = re.match(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", l)
+                    if b:
+                        todo.append(labels[b.group(1)])
+                        if l.startswith("s_branch"):
+                            break
+                    if l.startswith("s_endpgm"):
+                        break
+                j += 1
+        assert reached, lines[i].strip()
