@@ -48,7 +48,7 @@ extern "C" int ssde_debug_w4r_trace(void* buf) {
 
 
 #ifndef SSDE_W4R_PERSIST
-#define SSDE_W4R_PERSIST 1          // (0: one workgroup per tile everywhere -- rounds 5's launch shape, A/B variant only)
+#define SSDE_W4R_PERSIST 0          // (1: persistent workgroups for launches of more than one round -- until the GPU parity run is green, a variant only)
 #endif
 
 namespace {
@@ -150,11 +150,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wino4r_kernel(const Wino4rPa
   // the loads of one stage into register set S: V0 U0 | V1 U1 | V2 U2 | V3 U3 | V4 U4 (the order the loop's counted waits assume)
 #define SSDE_W4R_ROUND_AT(S, VO, VN, UN)                                                           \
   do {                                                                                             \
-    SSDE_GLOAD8_I(va[S][0], VO[0], VN, 0); SSDE_GLOAD16_I(u4[S][0], u_off, UN, -2048);             \
-    SSDE_GLOAD8_I(va[S][1], VO[1], VN, 0); SSDE_GLOAD16_I(u4[S][1], u_off, UN, -1024);             \
-    SSDE_GLOAD8_I(va[S][2], VO[2], VN, 0); SSDE_GLOAD16_I(u4[S][2], u_off, UN, 0);                 \
-    SSDE_GLOAD8_I(va[S][3], VO[3], VN, 0); SSDE_GLOAD16_I(u4[S][3], u_off, UN, 1024);              \
-    SSDE_GLOAD8_I(va[S][4], VO[4], VN, 0); SSDE_GLOAD8_I(u2[S], u_off8, UN, 0);                    \
+    SSDE_GLOAD8_I_SAFE(va[S][0], VO[0], VN, 0); SSDE_GLOAD16_I_SAFE(u4[S][0], u_off, UN, -2048);             \
+    SSDE_GLOAD8_I_SAFE(va[S][1], VO[1], VN, 0); SSDE_GLOAD16_I_SAFE(u4[S][1], u_off, UN, -1024);             \
+    SSDE_GLOAD8_I_SAFE(va[S][2], VO[2], VN, 0); SSDE_GLOAD16_I_SAFE(u4[S][2], u_off, UN, 0);                 \
+    SSDE_GLOAD8_I_SAFE(va[S][3], VO[3], VN, 0); SSDE_GLOAD16_I_SAFE(u4[S][3], u_off, UN, 1024);              \
+    SSDE_GLOAD8_I_SAFE(va[S][4], VO[4], VN, 0); SSDE_GLOAD8_I_SAFE(u2[S], u_off8, UN, 0);                    \
   } while (0)
   const int total_work = kPersist ? p.total_work : 0;
   bool primed = false;                           // kPersist: the first two stages of this tile are already in flight

@@ -130,6 +130,17 @@ typedef float ssde_f32x4 __attribute__((ext_vector_type(4)));
   asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(imm) :)
 #define SSDE_WAIT_VMCNT_FOR3(n, a, b, c) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(n) : "memory")
 #endif
+// The same loads for places OUTSIDE a kernel's hand-scheduled loop, where hipcc may have parked the scalar base in a VGPR lane
+// (an SGPR spill) and restores it with v_readlane_b32 right in front of the asm statement: a VALU write of an SGPR needs five
+// wait states before a VMEM instruction reads that SGPR as its address (gfx9 data hazard), and the hazard recogniser does not
+// look inside inline asm -- the load went out with a stale half of its 64-bit base (a memory access fault, round 6).  The
+// s_nop pays those wait states unconditionally.
+#ifndef SSDE_GLOAD16_I_SAFE
+#define SSDE_GLOAD16_I_SAFE(dst, voff, sbase, imm) \
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(imm) :)
+#define SSDE_GLOAD8_I_SAFE(dst, voff, sbase, imm) \
+  asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(imm) :)
+#endif
 
 // 16-byte accesses at AGENT scope (sc1, what a relaxed agent-scope atomic dword access compiles to): the partial sums a split
 // reduction hands from workgroup to workgroup cross XCDs, whose L2s are not coherent with each other; as dword atomics they

@@ -191,6 +191,8 @@ static inline void emu_global_load_lds(const void* g, __attribute__((address_spa
 #define SSDE_WAIT_VMCNT_FOR(n, a, b) ((void)0)
 #define SSDE_GLOAD16_I(dst, voff, sbase, imm) memcpy(&(dst), (const char*)(sbase) + (voff) + (imm), 16)
 #define SSDE_GLOAD8_I(dst, voff, sbase, imm) memcpy(&(dst), (const char*)(sbase) + (voff) + (imm), 8)
+#define SSDE_GLOAD16_I_SAFE(dst, voff, sbase, imm) SSDE_GLOAD16_I(dst, voff, sbase, imm)
+#define SSDE_GLOAD8_I_SAFE(dst, voff, sbase, imm) SSDE_GLOAD8_I(dst, voff, sbase, imm)
 #define SSDE_WAIT_VMCNT_FOR3(n, a, b, c) ((void)0)
 #define SSDE_GLOAD16_AGENT(dst, ptr) memcpy(&(dst), (const void*)(ptr), 16)
 #define SSDE_GSTORE16_AGENT(ptr, val) memcpy((void*)(ptr), &(val), 16)
