@@ -538,8 +538,8 @@ def prewarm(run_chunk, sync, seconds, dev=None, dist=None):
 
 
 DTYPE = {"f32": "f32 (exact-fp32 MFMA kernels everywhere)",
-         "bf16x6": "f32 via 3-way bf16 split, fp32 accumulate (the 1x1 / NIN / Linear GEMMs as exact-fp32 products on the BF16 matrix pipe; "
-                   "3x3 convolutions and attention on the fp32-MFMA kernels)"}
+         "bf16x6": "f32 via 3-way bf16 split, fp32 accumulate (the 1x1 / NIN / Linear GEMMs and the attention forward as exact-fp32 products "
+                   "on the BF16 matrix pipe, fp32 softmax; 3x3 convolutions and the attention backward on the fp32-MFMA kernels)"}
 
 
 def op_bytes(op):
@@ -642,6 +642,11 @@ def roofline_of(prog, E, L, reps=3):
             row["note"] = ("launch-bound, not bandwidth-bound: %d ssde_gn_finalize launches of %.1f us merging the producers' partial "
                            "statistics (the activations are not re-read); the fraction is kept for completeness"
                            % (row["launches"], row["ms"] * 1e3 / row["launches"]))
+        if name == "groupnorm_stats":
+            # ABI 10: the transform pass of a two-kernel F(4x4,3x3) convolution merges the partials of its source itself
+            # (ssde_conv_args.gn_in_part0); its time is the pass's, in the 3x3 class
+            row["merged_by_the_consuming_transform_pass"] = sum(
+                1 for i in range(prog.n) if int(prog.ops[i].kind) == L.OP_CONV and prog.ops[i].u.conv.gn_in_part0)
         by_class[name] = row
     # PC-update kernels (rocRAND noise, norms, Langevin and predictor updates): HBM-bound, grouped by op kind
     upd = np.array([int(prog.ops[i].kind) in (L.OP_RANDN, L.OP_SUMSQ, L.OP_LANGEVIN, L.OP_PREDICTOR) for i in range(prog.n)])

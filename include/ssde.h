@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSDE_ABI_VERSION 9   /* 9: SSDE_CONVF_NO_SMALL_COUT (3x3 convolutions onto at most four channels have their own kernel, conv_small.hip), the register-fed F(4x4,3x3) matrix kernel splits its reduction (no interface change); 8: routing switches moved from environment variables into ssde_conv_args.flags / ssde_wgrad_args.flags / ssde_gn_bwd_reduce_args.flags, SSDE_TILE_WINOGRAD4R + SSDE_PACK_WINO4R (register-fed F(4x4,3x3) matrix kernel), SSDE_TILE_WINOGRAD4X removed; 7: ssde_gn_bwd_reduce_args.g0 / g1 (GroupNorm backward in one pass over dp and x); 6: ssde_conv_args.wino_v / ssde_wgrad_args.v_pre (forward by-product feeds the weight gradient); 5: SSDE_PACK_WINO4 image re-ordered per wave (plan blobs of version 4 carry the old image), ODE ops in programs */
+#define SSDE_ABI_VERSION 10  /* 10: ssde_conv_args.gn_in_part0 / gn_in_part1 / gn_in_slices0 / gn_in_slices1 / gn_in_eps (the consuming launch merges the GroupNorm partials of its main source itself: no ssde_gn_finalize launch in front of it), ssde_gn_finalize merges with teams of 16 lanes, ssde_attn_args.flags (SSDE_ATTNF_BF16X6); 9: SSDE_CONVF_NO_SMALL_COUT (3x3 convolutions onto at most four channels have their own kernel, conv_small.hip), the register-fed F(4x4,3x3) matrix kernel splits its reduction (no interface change); 8: routing switches moved from environment variables into ssde_conv_args.flags / ssde_wgrad_args.flags / ssde_gn_bwd_reduce_args.flags, SSDE_TILE_WINOGRAD4R + SSDE_PACK_WINO4R (register-fed F(4x4,3x3) matrix kernel), SSDE_TILE_WINOGRAD4X removed; 7: ssde_gn_bwd_reduce_args.g0 / g1 (GroupNorm backward in one pass over dp and x); 6: ssde_conv_args.wino_v / ssde_wgrad_args.v_pre (forward by-product feeds the weight gradient); 5: SSDE_PACK_WINO4 image re-ordered per wave (plan blobs of version 4 carry the old image), ODE ops in programs */
 
 /* ---- prologue applied to a source tensor while it is staged into LDS ---- */
 enum {
@@ -104,6 +104,18 @@ typedef struct ssde_conv_args {
                           * (ssde_wgrad_args.v_pre); a by-product of the first 64-cout tile's staging.  NULL: not written.
                           * SSDE_TILE_WINOGRAD4R: REQUIRED -- the same tensor in the same layout, written by the launch's
                           * transform pass and read by its matrix kernel (and still good for v_pre afterwards). */
+  /* ABI 10 -- optional: main.gn_mean / main.gn_rstd are NOT filled yet; the launch merges them from the partials the producers
+   * of main.p0 / main.p1 wrote (their ssde_conv_args.gn_part, [N][slices][c/4][3]) exactly as ssde_gn_finalize(part0 =
+   * gn_in_part0, part1 = gn_in_part1, c0 = main.c0, c1 = main.c1, groups = main.gn_groups, eps = gn_in_eps) would -- bit for
+   * bit -- and also leaves them in main.gn_mean / main.gn_rstd (a training program's backward reads them).  With
+   * SSDE_TILE_WINOGRAD4R the transform pass does it for the (image, group) pairs of each workgroup while its pixel loads are
+   * in flight (95 finalize launches of 6-9 us per U-Net evaluation were 3.5 % of it); every other route issues the
+   * ssde_gn_finalize launch itself, in front of the kernel.  nn.GroupNorm: layerspp.py:67,219,231. */
+  const float* gn_in_part0;   /* NULL: main.gn_mean / gn_rstd are valid as they are */
+  const float* gn_in_part1;   /* main.c1 > 0 */
+  int32_t gn_in_slices0, gn_in_slices1;
+  float gn_in_eps;
+  int32_t _pad_gn_in;
 } ssde_conv_args;
 
 enum { SSDE_CONVF_V_GIVEN = 1u,      /* SSDE_TILE_WINOGRAD4R: wino_v already holds B^T pro(main) B -- skip the transform pass */
@@ -186,7 +198,12 @@ typedef struct ssde_upfirdn_args {
 typedef struct ssde_attn_args {
   const float* qkv; float* dst;  /* dst [N, L, C] */
   int32_t n, l, c; float scale;
+  uint32_t flags;                /* SSDE_ATTNF_* (ABI 10; 0 = the fp32-MFMA kernel) */
+  int32_t _pad0;
 } ssde_attn_args;
+enum { SSDE_ATTNF_BF16X6 = 1u }; /* both contractions (Q K^T and P V) on the BF16 matrix pipe as exact-fp32 products of a 3-way bf16
+                                  * split, fp32 accumulation and an fp32 softmax (attention.hip: attn_x6_kernel) -- the forward at
+                                  * L = 256 tokens and C <= 256 channels; other shapes and the backward stay on the fp32 kernels */
 
 /* ---- time / noise-level embeddings -------------------------------------------
  * kind 0: GaussianFourierProjection(log(cond)) (layerspp.py:39-41, ncsnpp.py:239)

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SSDE_LIB_PATH: developer switch for A/B timing of kernel variants built by _build.build_variant (tools/ab_bench.sh)
 LIB_PATH = os.environ.get("SSDE_LIB_PATH") or os.path.join(_HERE, "libssde_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 PRO_NONE, PRO_GN, PRO_GN_SILU, PRO_SILU = 0, 1, 2, 3
 TILE_AUTO, TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32, TILE_WINOGRAD, TILE_WINOGRAD4 = 0, 1, 2, 3, 4, 5, 6
@@ -46,7 +46,9 @@ class ConvArgs(C.Structure):
                 ("h_out", C.c_int32), ("w_out", C.c_int32), ("c_out", C.c_int32),
                 ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("tile", C.c_int32),
                 ("bias", _fp), ("chan_add", _fp), ("chan_add_ld", C.c_int32), ("resid_post", C.c_int32),
-                ("resid", _fp), ("out_scale", C.c_float), ("flags", C.c_uint32), ("dst", _fp), ("gn_part", _fp), ("wino_v", _fp)]
+                ("resid", _fp), ("out_scale", C.c_float), ("flags", C.c_uint32), ("dst", _fp), ("gn_part", _fp), ("wino_v", _fp),
+                ("gn_in_part0", _fp), ("gn_in_part1", _fp), ("gn_in_slices0", C.c_int32), ("gn_in_slices1", C.c_int32),
+                ("gn_in_eps", C.c_float), ("_pad_gn_in", C.c_int32)]
 
 
 class GnStatsArgs(C.Structure):
@@ -93,7 +95,8 @@ class UpfirdnArgs(C.Structure):
 
 
 class AttnArgs(C.Structure):
-    _fields_ = [("qkv", _fp), ("dst", _fp), ("n", C.c_int32), ("l", C.c_int32), ("c", C.c_int32), ("scale", C.c_float)]
+    _fields_ = [("qkv", _fp), ("dst", _fp), ("n", C.c_int32), ("l", C.c_int32), ("c", C.c_int32), ("scale", C.c_float),
+                ("flags", C.c_uint32), ("_pad0", C.c_int32)]
 
 
 class EmbedArgs(C.Structure):
@@ -306,6 +309,15 @@ def conv_route_flags(env=None):
     if e.get("SSDE_CONV_SMALL", "1") == "0":
         f |= CONVF_NO_SMALL_COUT
     return f
+
+
+ATTNF_BF16X6 = 1
+
+
+def attn_route_flags(env=None):
+    """SSDE_MATRIX=bf16x6 also moves the attention forward onto the BF16 matrix pipe (SSDE_ATTN_X6=0 keeps the fp32 kernel: A/B runs)"""
+    e = os.environ if env is None else env
+    return ATTNF_BF16X6 if e.get("SSDE_MATRIX", "").startswith("b") and e.get("SSDE_ATTN_X6", "1") != "0" else 0
 
 
 def wgrad_route_flags(env=None):

@@ -16,6 +16,7 @@
 //                                  dP^T = V dO^T;  dS^T = P^T o (dP^T - D);  dK = scale dS^T Q
 // qkv layout [N, L, 3C]: the fused NIN_0..2 projection output (q | k | v).
 #include "ssde_common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -244,6 +245,326 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
   gemm_pv<kFwdVch>(Ps, Lp, base + 2 * C, L, C3, C, Vs, dst + ((size_t)n * L + q0) * C, C, L - q0, 1.0f);
 }
 
+// ---- forward on the BF16 matrix pipe (SSDE_ATTNF_BF16X6): both contractions as exact-fp32 products of a 3-way bf16 split ------
+// The fp32-MFMA kernel above spends 2 x 32 k matrix cycles per wave on the two contractions of a 64-row block and sits at 0.48 of
+// that pipe's peak (0.217 ms per launch at 16x16, batch 256: five launches per U-Net evaluation).  v_mfma_f32_32x32x16_bf16 does
+// the same contraction in 6/16 of the time (ssde_common.h: SSDE_MFMA_BF16X6, the 1x1 GEMMs' split -- every partial product exact
+// in the fp32 accumulator, what is dropped is below the rounding of the product itself), so the kernel is re-cut around what then
+// bounds it -- staging and LDS traffic:
+//   * one workgroup of EIGHT waves per CU owns 64 query rows of one image and (almost) all of the CU's LDS;
+//   * Q is split ONCE into three bf16 planes for all channels (98 KB at C = 256); K arrives in 16-channel stages, V in
+//     16-token stages, split by the thread that loaded them, two stages in LDS and two more in flight in registers
+//     (loads return in order; the barriers wait for LDS only);
+//   * phase 1, S = Q K^T: wave w owns keys 32 w .. 32 w + 31 (two 32 x 32 blocks); phase 3, O = P V: channels 32 w .. 32 w + 31;
+//   * phase 2: scaled scores -> fp32 tile (over the dead Q planes) -> every thread takes 32 consecutive keys of one row into
+//     registers -> max / exp / sum over the 8 threads of a row by shuffles (the arithmetic of softmax_rows) -> P written as three
+//     bf16 planes in the A-fragment layout;
+//   * V is staged TRANSPOSED ([channel][16 tokens] bf16, the B fragment wants 8 consecutive tokens of a channel per lane): a
+//     thread holds two tokens x four channels, packs token pairs into dwords and writes channel (j + (quad >> 1)) & 3 in its j-th
+//     store, which spreads the 64 lanes of a store over the 64 banks;
+//   * the four workgroups of an image run on ONE XCD (they read the same K and V: L2 hits).
+// L == 256 and C % 64 == 0, C <= 256 only (the 16x16 attention of every shipped config); anything else stays on attn_kernel.
+#ifndef SSDE_ATTN_X6_SCORE_TERMS
+#define SSDE_ATTN_X6_SCORE_TERMS 8          // (6: an A/B variant)
+#endif
+namespace x6 {
+constexpr int kT = 512, kRows = 64, kL = 256;
+constexpr int kKStage = 3 * kL * 32;                      // bytes of one K stage: [3 pieces][256 keys][16 channels] bf16
+constexpr int kPPlane = kL * kRows * 2;                   // bytes of one P piece: [16 token steps][64 rows][16 tokens] bf16
+constexpr int kMain = 3 * kPPlane;                        // Q planes (<= this for C <= 256) | fp32 score tile | P planes
+constexpr int kLds = kMain + 2 * kKStage;                 // (a V stage is 3 * C * 32 <= kKStage bytes)
+static_assert(kRows * kLDP * 4 <= kMain, "score tile");
+
+// x -> its three bf16 pieces as the upper halves of three dwords (ssde_split3's arithmetic)
+__device__ __forceinline__ void split_hi(float x, uint32_t& a, uint32_t& b, uint32_t& c) {
+  a = __builtin_bit_cast(uint32_t, x);
+  const float r = x - __builtin_bit_cast(float, a & 0xffff0000u);
+  b = __builtin_bit_cast(uint32_t, r);
+  c = __builtin_bit_cast(uint32_t, r - __builtin_bit_cast(float, b & 0xffff0000u));
+}
+}  // namespace x6
+
+__global__ __launch_bounds__(x6::kT) void attn_x6_kernel(const float* __restrict__ qkv, float* __restrict__ dst, int N, int C, float scale) {
+  using namespace x6;
+  SSDE_LDS(smem);
+  char* lds = reinterpret_cast<char*>(smem);
+  char* stage0 = lds + kMain;
+  char* stage1 = stage0 + kKStage;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  // workgroup -> (image, 64-row block): the four blocks of an image are consecutive workgroups of ONE XCD
+  const int xcd = blockIdx.x & 7, k_in = blockIdx.x >> 3;
+  const int n = (k_in >> 2) * 8 + xcd, q0 = (k_in & 3) * kRows;
+  if (n >= N) return;
+  const int C3 = 3 * C;
+  const float* base = qkv + (size_t)n * kL * C3;
+  const int qplane = C * kRows * 2;                        // bytes of one Q piece: [C / 16][64 rows][16 channels] bf16
+  const int nst = C >> 4;                                   // K stages (a multiple of 4: C % 64 == 0)
+
+  f32x16 acc[2];
+  auto zero = [&]() {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  };
+  // The operands of a stage's MFMAs: A = rows (a * 32 + li) of the planes at `ap` (piece pitch a_pitch), B = row (32 wave + li) of
+  // the stage at `bp` (piece pitch b_pitch); a lane reads 16 bytes = 8 consecutive k of its row
+  struct Frags { ssde_u32x4 A[2][3], B[3]; };
+  auto read_frags = [&](Frags& f, const char* ap, int a_pitch, const char* bp, int b_pitch) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) f.A[a][q] = *reinterpret_cast<const ssde_u32x4*>(ap + q * a_pitch + (a * 32 + li) * 32 + lh * 16);
+      f.B[q] = *reinterpret_cast<const ssde_u32x4*>(bp + q * b_pitch + (wave * 32 + li) * 32 + lh * 16);
+    }
+  };
+  // smallest terms first.  Six terms (SSDE_MFMA_BF16X6) drop a1 b2 + a2 b1 + a2 b2 <= 2^-23 |a b| per product; the scores take
+  // EIGHT (all but a2 b2 <= 2^-32 |a b|): with pieces taken by truncation the dropped terms are a one-sided error, and the scores
+  // of a peaked query row (|q| ~ 10) carry it into the exponent.  P V, with P in [0, 1], keeps six.
+  auto mfmas = [&](auto Terms, const Frags& f) __attribute__((always_inline)) {
+    constexpr int kTerms = decltype(Terms)::value;
+    constexpr int TI[8] = {1, 2, 0, 2, 1, 0, 1, 0}, TJ[8] = {2, 1, 2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int t = 8 - kTerms; t < 8; ++t)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ssde_bf16x8, f.A[a][TI[t]]),
+                                                         __builtin_bit_cast(ssde_bf16x8, f.B[TJ[t]]), acc[a], 0, 0, 0);
+  };
+  using Six = std::integral_constant<int, 6>;
+  using ScoreTerms = std::integral_constant<int, SSDE_ATTN_X6_SCORE_TERMS>;
+
+  // ---- the streamed operands: K in nst stages of 16 channels, then V in 16 stages of 16 tokens, ONE stream through a register
+  // ring of four stages.  Element u + 4 of the stream is requested at the top of stage u -- the first V stages during the last K
+  // stages, so they land under the softmax -- and has three stages (3-5 k cycles) to land.  The loads are asm statements hipcc
+  // does not track, two per stage and thread, counted by the kernel itself: "element u + 1 has landed" is vmcnt(6) (elements
+  // u + 2 .. u + 4 are younger), 4 / 2 / 0 over the last V stages.  Every requested element is consumed, so no load lands in a
+  // register hipcc considers free; no load or wait sits behind a branch (no copies of a register that is still in flight at a
+  // join).  History: profiles/r6_attention_x6_versions.txt -- two stages ahead with loads hipcc tracked was one stage ahead in
+  // effect (its vmcnt(0) in front of every store), 50 us per workgroup.
+  ssde_f32x4 R[4][2];
+  const float* kbase = base + C;
+  const float* vbase = base + 2 * C;
+  // K: a thread stages (key row, channel quad) items tid and tid + 512 of the stage's 256 x 4
+  const int krow = tid >> 2, kf = tid & 3;
+  const uint32_t koff0 = (uint32_t)((krow * C3 + kf * 4) * 4), koff1 = koff0 + (uint32_t)(128 * C3 * 4);
+  // V: a thread stages tokens 2 tp, 2 tp + 1 of channel quad fq
+  const int tp = tid & 7, fq = tid >> 3;
+  const bool v_on = fq * 4 < C;
+  const uint32_t voff0 = (uint32_t)((2 * tp * C3 + (v_on ? fq * 4 : 0)) * 4), voff1 = voff0 + (uint32_t)(C3 * 4);
+  const int vpitch = C * 32;                                // bytes of one piece of a V stage: [C channels][16 tokens] bf16
+  auto request = [&](int u, ssde_f32x4 (&Rs)[2]) __attribute__((always_inline)) {      // stream element u (uniform)
+    const bool is_k = u < nst;
+    const float* sb = is_k ? kbase + u * 16 : vbase + (size_t)(u - nst) * 16 * C3;       // (scalar)
+    const uint32_t o0 = is_k ? koff0 : voff0, o1 = is_k ? koff1 : voff1;
+    SSDE_GLOAD16_I_SAFE(Rs[0], o0, sb, 0);
+    SSDE_GLOAD16_I_SAFE(Rs[1], o1, sb, 0);
+  };
+  // a K stage: split into registers (VALU, meant to run under the MFMAs of the stage before) ...
+  struct KPieces { uint2 p[2][3]; };
+  auto split_k = [&](const ssde_f32x4 (&Rs)[2], KPieces& kp) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ssde_split3(make_float4(Rs[i].x, Rs[i].y, Rs[i].z, Rs[i].w), kp.p[i][0], kp.p[i][1], kp.p[i][2]);
+  };
+  // ... and parked: [3 pieces][256 keys][16 channels] bf16
+  auto park_k = [&](const KPieces& kp, char* buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      char* d = buf + (krow + 128 * i) * 32 + kf * 8;
+      *reinterpret_cast<uint2*>(d) = kp.p[i][0];
+      *reinterpret_cast<uint2*>(d + kL * 32) = kp.p[i][1];
+      *reinterpret_cast<uint2*>(d + 2 * kL * 32) = kp.p[i][2];
+    }
+  };
+  // a V stage, TRANSPOSED: [3 pieces][C channels][16 tokens] bf16; w[piece][channel] = (token 2 tp) | (token 2 tp + 1) << 16
+  struct VPieces { uint32_t w[3][4]; };
+  auto split_v = [&](const ssde_f32x4 (&Rs)[2], VPieces& vp) __attribute__((always_inline)) {
+    const float f0[4] = {Rs[0].x, Rs[0].y, Rs[0].z, Rs[0].w}, f1[4] = {Rs[1].x, Rs[1].y, Rs[1].z, Rs[1].w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t a0, b0, c0, a1, b1, c1;
+      split_hi(f0[i], a0, b0, c0);
+      split_hi(f1[i], a1, b1, c1);
+      vp.w[0][i] = ssde_pack_hi16(a0, a1); vp.w[1][i] = ssde_pack_hi16(b0, b1); vp.w[2][i] = ssde_pack_hi16(c0, c1);
+    }
+  };
+  // the j-th store of a thread writes channel (j + rot) & 3, rot = (fq >> 1) & 3: the 64 lanes of one store hit 64 different
+  // banks.  The rotation of the four words is two rounds of selects (v_cndmask), no branches
+  const int rot = (fq >> 1) & 3;
+  const bool rot1 = (rot & 1) != 0, rot2 = (rot & 2) != 0;
+  auto park_v = [&](const VPieces& vp, char* buf) __attribute__((always_inline)) {
+    uint32_t y[3][4];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      uint32_t x[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[i] = rot1 ? vp.w[q][(i + 1) & 3] : vp.w[q][i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[q][i] = rot2 ? x[(i + 2) & 3] : x[i];
+    }
+    if (v_on) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        char* d = buf + (fq * 4 + ((j + rot) & 3)) * 32 + tp * 4;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<uint32_t*>(d + q * vpitch) = y[q][j];
+      }
+    }
+  };
+  // one MFMA, then `valu` vector-ALU instructions, `n` times over: the split of the next stage runs under this stage's MFMAs
+  // (the BF16 MFMAs co-issue with VALU; left alone, hipcc issues the MFMAs first and the split behind them, and the eight
+  // waves -- in lock step between two barriers -- leave the matrix pipe idle during every split)
+#define SSDE_X6_INTERLEAVE(n, valu)                                \
+  do {                                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {           \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           \
+      __builtin_amdgcn_sched_group_barrier(0x002, (valu), 0);      \
+    }                                                              \
+  } while (0)
+
+  // ---- phase 1: S = Q K^T ----
+  zero();
+  request(0, R[0]); request(1, R[1]); request(2, R[2]); request(3, R[3]);        // before Q: they land under its split
+  {
+    // Q: every channel of the 64 rows, split once (up to 8 float4 of a thread requested together)
+    const int cq4 = C >> 2, total = kRows * cq4;            // channel quads per row
+    for (int item0 = tid; item0 < total; item0 += 8 * kT) {
+      float4 qv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int item = min(item0 + u * kT, total - 1);
+        const int row = item / cq4, cq = item - row * cq4;
+        qv[u] = *reinterpret_cast<const float4*>(base + (size_t)(q0 + row) * C3 + cq * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int item = item0 + u * kT;
+        if (item < total) {
+          const int row = item / cq4, cq = item - row * cq4;
+          uint2 p0, p1, p2;
+          ssde_split3(qv[u], p0, p1, p2);
+          char* d = lds + (cq >> 2) * (kRows * 32) + row * 32 + (cq & 3) * 8;
+          *reinterpret_cast<uint2*>(d) = p0;
+          *reinterpret_cast<uint2*>(d + qplane) = p1;
+          *reinterpret_cast<uint2*>(d + 2 * qplane) = p2;
+        }
+      }
+    }
+  }
+  {
+    SSDE_WAIT_VMCNT_FOR(6, R[0][0], R[0][1]);
+    KPieces kp;
+    split_k(R[0], kp);
+    park_k(kp, stage0);
+    SSDE_LDS_BARRIER();                                    // (the Q planes and K stage 0 are complete)
+    for (int st = 0; st < nst; st += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int u = st + j;
+        request(u + 4, R[j]);                               // R[j] held element u: parked in LDS during stage u - 1
+        SSDE_WAIT_VMCNT_FOR(6, R[(j + 1) & 3][0], R[(j + 1) & 3][1]);       // element u + 1 (at u = nst - 1: V stage 0, parked in phase 3)
+        Frags f;
+        read_frags(f, lds + u * (kRows * 32), qplane, (j & 1) ? stage1 : stage0, kL * 32);
+        split_k(R[(j + 1) & 3], kp);
+        mfmas(ScoreTerms{}, f);
+        SSDE_X6_INTERLEAVE(2 * SSDE_ATTN_X6_SCORE_TERMS, 3);
+        park_k(kp, (j & 1) ? stage0 : stage1);              // (at u = nst - 1: V data in K's layout, overwritten at the start of phase 3)
+        SSDE_LDS_BARRIER();
+      }
+    }
+  }
+
+  // ---- phase 2: softmax of the 64 x 256 scores; P as three bf16 planes ----
+  {
+    float* tile = smem;                                    // [64][kLDP] over the Q planes (every wave is behind the last barrier)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        tile[row * kLDP + wave * 32 + li] = acc[a][r] * scale;
+      }
+    SSDE_LDS_BARRIER();
+    const int row = tid >> 3, sub = tid & 7;               // keys 32 sub .. 32 sub + 31 of the row
+    float x[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(tile + row * kLDP + sub * 32 + i * 4);
+      x[4 * i] = v.x; x[4 * i + 1] = v.y; x[4 * i + 2] = v.z; x[4 * i + 3] = v.w;
+    }
+    SSDE_LDS_BARRIER();                                    // the tile is in registers: the P planes may overwrite it
+    float m = x[0];
+#pragma unroll
+    for (int i = 1; i < 32; ++i) m = fmaxf(m, x[i]);
+    m = fmaxf(m, __shfl_xor(m, 1, 64));
+    m = fmaxf(m, __shfl_xor(m, 2, 64));
+    m = fmaxf(m, __shfl_xor(m, 4, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { x[i] = __expf(x[i] - m); sum += x[i]; }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    sum += __shfl_xor(sum, 4, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                          // 16-byte units: token step 2 sub + (u >> 1), half u & 1
+      uint2 a0, a1, a2, b0, b1, b2;
+      ssde_split3(make_float4(x[8 * u] * inv, x[8 * u + 1] * inv, x[8 * u + 2] * inv, x[8 * u + 3] * inv), a0, a1, a2);
+      ssde_split3(make_float4(x[8 * u + 4] * inv, x[8 * u + 5] * inv, x[8 * u + 6] * inv, x[8 * u + 7] * inv), b0, b1, b2);
+      char* d = lds + (2 * sub + (u >> 1)) * (kRows * 32) + row * 32 + (u & 1) * 16;
+      *reinterpret_cast<uint4*>(d) = make_uint4(a0.x, a0.y, b0.x, b0.y);
+      *reinterpret_cast<uint4*>(d + kPPlane) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+      *reinterpret_cast<uint4*>(d + 2 * kPPlane) = make_uint4(a2.x, a2.y, b2.x, b2.y);
+    }
+  }
+
+  // ---- phase 3: O = P V over 16 stages of 16 tokens (straight-line: every index below is a compile-time constant) ----
+  {
+    const bool w_on = wave * 32 < C;                        // (C < 256: the upper waves only stage)
+    zero();
+    VPieces vp;
+    SSDE_WAIT_VMCNT_FOR(6, R[0][0], R[0][1]);              // V stage 0 (waited for at the end of phase 1 already)
+    split_v(R[0], vp);
+    park_v(vp, stage0);
+    SSDE_LDS_BARRIER();                                    // (the P planes and V stage 0 are complete)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int j = v & 3;
+      if (v + 4 < 16) request(nst + v + 4, R[j]);
+      if (v + 1 < 16) {
+        if (v + 4 < 16) SSDE_WAIT_VMCNT_FOR(6, R[(j + 1) & 3][0], R[(j + 1) & 3][1]);
+        else if (v + 3 < 16) SSDE_WAIT_VMCNT_FOR(4, R[(j + 1) & 3][0], R[(j + 1) & 3][1]);
+        else if (v + 2 < 16) SSDE_WAIT_VMCNT_FOR(2, R[(j + 1) & 3][0], R[(j + 1) & 3][1]);
+        else SSDE_WAIT_VMCNT_FOR(0, R[(j + 1) & 3][0], R[(j + 1) & 3][1]);
+      }
+      if (w_on) {                                          // (uniform; one block, so that the split runs under the MFMAs)
+        Frags f;
+        read_frags(f, lds + v * (kRows * 32), kPPlane, (j & 1) ? stage1 : stage0, vpitch);
+        if (v + 1 < 16) split_v(R[(j + 1) & 3], vp);
+        mfmas(Six{}, f);
+        SSDE_X6_INTERLEAVE(12, 8);
+      } else if (v + 1 < 16) {
+        split_v(R[(j + 1) & 3], vp);
+      }
+      if (v + 1 < 16) park_v(vp, (j & 1) ? stage0 : stage1);
+      SSDE_LDS_BARRIER();
+    }
+    if (w_on) {
+      float* out = dst + ((size_t)n * kL + q0) * C + wave * 32 + li;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          out[(size_t)row * C] = acc[a][r];
+        }
+    }
+  }
+#undef SSDE_X6_INTERLEAVE
+}
+
 // ---- backward A: dQ (and the per-row softmax statistics + D for kernel B) ----
 __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                          const float* __restrict__ d_o, float* __restrict__ dqkv,
@@ -388,6 +709,14 @@ extern "C" int ssde_attention(const ssde_attn_args* a, void* stream) {
   SSDE_REQUIRE(a && a->qkv && a->dst, "attention: null args");
   SSDE_REQUIRE(a->n > 0 && a->l > 0 && a->l <= kLMax, "attention: token count %d outside 1..%d", a->l, kLMax);
   SSDE_REQUIRE(a->c > 0 && a->c % 32 == 0, "attention: channels must be a multiple of 32 (got %d)", a->c);
+  if ((a->flags & SSDE_ATTNF_BF16X6) && a->l == x6::kL && a->c <= 256 && a->c % 64 == 0) {
+    static std::atomic<bool> x6_set{false};
+    if (int rc = set_lds_once(attn_x6_kernel, x6::kLds, &x6_set)) return rc;
+    hipLaunchKernelGGL(attn_x6_kernel, dim3(ssde_cdiv(a->n, 8) * 8 * 4), dim3(x6::kT), x6::kLds, static_cast<hipStream_t>(stream),
+                       a->qkv, a->dst, a->n, a->c, a->scale);
+    SSDE_LAUNCH_CHECK();
+    return SSDE_OK;
+  }
   const int lds = kAttnLdsFloats * 4;
   static std::atomic<bool> attr_set{false};   // set once, outside any stream capture
   if (int rc = set_lds_once(attn_kernel, lds, &attr_set)) return rc;

@@ -570,6 +570,18 @@ static ssde_wino_launcher wino_launcher(int tile) {
 }
 
 extern "C" int ssde_conv2d(const ssde_conv_args* a, void* stream) {
+  if (a && a->gn_in_part0 && !ssde_wino4_xform_merges_gn(a)) {
+    // the statistics of main are still partials and this route has no kernel that merges them for itself: the finalize launch
+    // of ABI 3-9, issued here in front of the kernel
+    const ssde_src& s = a->main;
+    SSDE_REQUIRE(s.gn_mean && s.gn_rstd && s.gn_groups > 0 && a->ksize != 0, "conv: gn_in_part0 needs a k x k main source with a GroupNorm prologue");
+    ssde_gn_finalize_args f;
+    f.part0 = a->gn_in_part0; f.part1 = s.c1 > 0 ? a->gn_in_part1 : nullptr;
+    f.c0 = s.c0; f.c1 = s.c1; f.slices0 = a->gn_in_slices0; f.slices1 = s.c1 > 0 ? a->gn_in_slices1 : 0;
+    f.n = a->n; f.groups = s.gn_groups; f.eps = a->gn_in_eps;
+    f.mean = const_cast<float*>(s.gn_mean); f.rstd = const_cast<float*>(s.gn_rstd);
+    if (int rc = ssde_gn_finalize(&f, stream)) return rc;
+  }
   if (a) {
     if (ssde_wino_launcher fn = wino_launcher(a->tile)) {
       // the two-kernel forms: the input-transform pass into wino_v first, unless the caller says wino_v already holds it

@@ -118,42 +118,22 @@ __global__ void gn_finalize_kernel(const GnParams p) {
   p.rstd[idx] = 1.0f / sqrtf(var + p.eps);
 }
 
-// Statistics from the producers' partials (ssde_store_tile): one WAVE per (image, group).  Lane l merges the entries
-// l, l + 64, ... of the group's (slice, channel quad) list in order, then the 64 lane results are merged by xor shuffles,
-// lower lane first -- a fixed order, so the result is deterministic; a few hundred triples per group.
+// Statistics from the producers' partials (ssde_store_tile): a team of 16 lanes per (image, group), ssde_gn_merge16
+// (ssde_common.h) -- 16 (image, group) pairs per workgroup.  (Until round 6: one wave per pair, most of its lanes idle behind 16
+// to 64 entries and two more shuffle rounds in the chain.)
 struct GnFinParams {
   const float* part0; const float* part1;
   int c0, c1, s0, s1, n, groups; float eps;
   float* mean; float* rstd;
 };
 __global__ __launch_bounds__(256) void gn_part_finalize_kernel(const GnFinParams p) {
-  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (idx >= p.n * p.groups) return;
-  const int n = idx / p.groups, g = idx - n * p.groups;
-  const int cpq = (p.c0 + p.c1) / p.groups / 4;        // channel quads per group
-  const int q0 = g * cpq, Q0 = p.c0 >> 2, Q1 = p.c1 >> 2;
-  // the group's quads split at the concat boundary: [q0, qm) in part0, [qm, q0 + cpq) in part1
-  const int qm = min(max(Q0, q0), q0 + cpq);
-  const int e0 = (qm - q0) * p.s0, e1 = (q0 + cpq - qm) * p.s1;
-  float cnt = 0.f, m = 0.f, M2 = 0.f;
-  for (int k = lane; k < e0 + e1; k += 64) {
-    const float* e;
-    if (k < e0) {
-      const int nq = qm - q0, s = k / nq, q = q0 + (k - s * nq);
-      e = p.part0 + (((size_t)n * p.s0 + s) * Q0 + q) * 3;
-    } else {
-      const int kk = k - e0, nq = q0 + cpq - qm, s = kk / nq, q = qm - Q0 + (kk - s * nq);
-      e = p.part1 + (((size_t)n * p.s1 + s) * Q1 + q) * 3;
-    }
-    ssde_stat_merge(cnt, m, M2, e[2], e[0], e[1]);
-  }
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const float nb = __shfl_xor(cnt, o, 64), mb = __shfl_xor(m, o, 64), Mb = __shfl_xor(M2, o, 64);
-    if (lane & o) { float tn = nb, tm = mb, tM = Mb; ssde_stat_merge(tn, tm, tM, cnt, m, M2); cnt = tn; m = tm; M2 = tM; }
-    else ssde_stat_merge(cnt, m, M2, nb, mb, Mb);
-  }
-  if (lane == 0) {
+  const int idx = blockIdx.x * 16 + (threadIdx.x >> 4), l16 = threadIdx.x & 15;
+  const int tot = p.n * p.groups;
+  const int pair = idx < tot ? idx : tot - 1;          // (whole waves run the shuffles: a pair beyond the end repeats the last one)
+  const int n = pair / p.groups, g = pair - n * p.groups;
+  float cnt, m, M2;
+  ssde_gn_merge16(p.part0, p.part1, p.c0, p.c1, p.s0, p.s1, p.groups, n, g, l16, cnt, m, M2);
+  if (l16 == 0 && idx < tot) {
     const float var = cnt > 0.f ? M2 / cnt : 0.f;
     p.mean[idx] = m;
     p.rstd[idx] = 1.0f / sqrtf(var + p.eps);
@@ -169,7 +149,7 @@ extern "C" int ssde_gn_finalize(const ssde_gn_finalize_args* a, void* stream) {
   SSDE_REQUIRE(a->groups > 0 && C % a->groups == 0 && (C / a->groups) % 4 == 0, "gn_finalize: channels-per-group must be a multiple of 4");
   SSDE_REQUIRE(a->n > 0 && a->slices0 > 0 && (a->c1 == 0 || a->slices1 > 0), "gn_finalize: bad shape");
   GnFinParams p{a->part0, a->part1, a->c0, a->c1, a->slices0, a->slices1, a->n, a->groups, a->eps, a->mean, a->rstd};
-  hipLaunchKernelGGL(gn_part_finalize_kernel, dim3(ssde_cdiv(a->n * a->groups, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  hipLaunchKernelGGL(gn_part_finalize_kernel, dim3(ssde_cdiv(a->n * a->groups, 16)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;
 }

@@ -16,6 +16,7 @@ void ssde_set_error(const char* fmt, ...);
 // conv_wino.hip: launch (lds_out == NULL) or plan-only (returns the LDS bytes through lds_out)
 int ssde_conv_wino_launch(const ssde_conv_args* a, void* stream, int* lds_out);
 int ssde_conv_wino4_launch(const ssde_conv_args* a, void* stream, int* lds_out);   // conv_wino4.hip, same forms
+bool ssde_wino4_xform_merges_gn(const ssde_conv_args* a);                               // wino4_xform.hip: the pass merges the source's GroupNorm partials itself (gn_in_part0)
 int ssde_wino4_xform_vq_launch(const ssde_conv_args* a, void* stream);              // wino4_xform.hip: V = B^T pro(x) B into a->wino_v
 int ssde_conv_wino4r_launch(const ssde_conv_args* a, void* stream, int* lds_out);  // conv_wino4r.hip (two-kernel form, operands from registers)
 bool ssde_conv1x1_wants(const ssde_conv_args* a);                                    // conv1x1.hip
@@ -263,6 +264,66 @@ __device__ __forceinline__ void ssde_stat_merge(float& n, float& m, float& M2, f
   M2 += M2b + d * d * n * f;
   n = nt;
 }
+// The merge of the producers' partials into the statistics of one (image n, group g) by a TEAM OF 16 LANES (lanes 16 k .. 16 k + 15
+// of a wave; l16 = lane & 15): lane l merges the entries l, l + 16, ... of the group's (slice, channel quad) list in order -- 16
+// to 64 triples per group in the CIFAR networks --, then the 16 lane results are merged by xor shuffles, lower lane first: a fixed
+// order, so the result is deterministic, and every lane of the team ends with the same (count, mean, M2).  Run by
+// ssde_gn_finalize's kernel AND by the consumers that merge for themselves (wino4_xform.hip: ssde_conv_args.gn_in_part0): the
+// same function, the same bits.  The groups of a channel concatenation straddle the boundary: [q0, qm) in part0, the rest in part1.
+// (two phases, so that a consumer can put its own loads between them: the entries' loads are issued first and the chain of merges
+//  runs while the consumer's loads are in flight -- loads return in order, so a merge that FOLLOWED 36 pixel loads per thread
+//  waited for all of them first: wino4_xform.hip)
+struct SsdeGnTeam {
+  const float* part0; const float* part1;
+  int Q0, Q1, s0, s1, q0, qm, cpq, e0, etot, n;
+  float v[4][3];                                  // entries l16, l16 + 16, l16 + 32, l16 + 48 of the list (those that exist)
+  __device__ __forceinline__ const float* entry(int k) const {
+    if (k < e0) {
+      const int nq = qm - q0, s = k / nq, q = q0 + (k - s * nq);
+      return part0 + (((size_t)n * s0 + s) * Q0 + q) * 3;
+    }
+    const int kk = k - e0, nq = q0 + cpq - qm, s = kk / nq, q = qm - Q0 + (kk - s * nq);
+    return part1 + (((size_t)n * s1 + s) * Q1 + q) * 3;
+  }
+};
+__device__ __forceinline__ void ssde_gn_merge16_load(SsdeGnTeam& t, const float* part0, const float* part1, int c0, int c1, int s0, int s1,
+                                                     int groups, int n, int g, int l16) {
+  t.part0 = part0; t.part1 = part1; t.s0 = s0; t.s1 = s1; t.n = n;
+  t.cpq = (c0 + c1) / groups / 4;                 // channel quads per group
+  t.q0 = g * t.cpq; t.Q0 = c0 >> 2; t.Q1 = c1 >> 2;
+  t.qm = min(max(t.Q0, t.q0), t.q0 + t.cpq);
+  t.e0 = (t.qm - t.q0) * s0;
+  t.etot = t.e0 + (t.q0 + t.cpq - t.qm) * s1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = l16 + 16 * i;
+    const float* e = t.entry(k < t.etot ? k : 0);
+    t.v[i][0] = e[0]; t.v[i][1] = e[1]; t.v[i][2] = e[2];
+  }
+}
+__device__ __forceinline__ void ssde_gn_merge16_finish(const SsdeGnTeam& t, int l16, float& cnt, float& m, float& M2) {
+  cnt = 0.f; m = 0.f; M2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (l16 + 16 * i < t.etot) ssde_stat_merge(cnt, m, M2, t.v[i][2], t.v[i][0], t.v[i][1]);
+  for (int k = l16 + 64; k < t.etot; k += 16) {   // (more than 64 entries per group: none of the shipped configurations)
+    const float* e = t.entry(k);
+    ssde_stat_merge(cnt, m, M2, e[2], e[0], e[1]);
+  }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    const float nb = __shfl_xor(cnt, o, 64), mb = __shfl_xor(m, o, 64), Mb = __shfl_xor(M2, o, 64);
+    if (l16 & o) { float tn = nb, tm = mb, tM = Mb; ssde_stat_merge(tn, tm, tM, cnt, m, M2); cnt = tn; m = tm; M2 = tM; }
+    else ssde_stat_merge(cnt, m, M2, nb, mb, Mb);
+  }
+}
+__device__ __forceinline__ void ssde_gn_merge16(const float* part0, const float* part1, int c0, int c1, int s0, int s1, int groups,
+                                                int n, int g, int l16, float& cnt, float& m, float& M2) {
+  SsdeGnTeam t;
+  ssde_gn_merge16_load(t, part0, part1, c0, c1, s0, s1, groups, n, g, l16);
+  ssde_gn_merge16_finish(t, l16, cnt, m, M2);
+}
+
 // pixfn(row, pix, img) -> false when the row is outside the tensor.  ncols must be a multiple of 4.
 //
 // GroupNorm statistics of the tensor being written (e.gn_part != nullptr, gn_entry >= 0): the next layer normalises this

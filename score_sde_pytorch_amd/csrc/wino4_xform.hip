@@ -16,10 +16,20 @@ namespace {
 // A wave = 16 consecutive tiles x 4 consecutive quads, lane = quad * 16 + tile: a store instruction writes four 256-byte runs,
 // a load instruction reads 64 contiguous bytes (4 quads) of 16 pixels.  HBM-bound: x read ~2.25x through the tile overlap (L2),
 // V written once.
+// GroupNorm statistics merged by the pass itself (ssde_conv_args.gn_in_part0, ABI 10): a workgroup covers 16 tiles -- part of
+// one image, or up to four whole ones on the 8x8 maps -- and 16 channel quads, i.e. at most 4 x 16 (image, group) pairs.  While
+// its 36 pixel loads per thread are in flight, teams of 16 lanes merge the producers' partials of those pairs (ssde_gn_merge16,
+// the finalize kernel's function: the same bits) into an LDS table the threads then read their (mean, rstd) from; the workgroup
+// whose tiles hold an image's first tile also writes them to src.gn_mean / gn_rstd for the backward pass of a training program.
+// The merge costs a few KB of L2 reads per workgroup (147 KB in, 147 KB out otherwise) and one LDS barrier under the loads;
+// what it removes is a launch of 6-9 us in front of every pass (64 of the 95 per U-Net evaluation).
 struct XformVqParams {
   ssde_src src; float* v;
   int N, H, W, Ctot, T, tiles_h, tiles_w;
+  const float* part0; const float* part1;      // part0 != nullptr: merge here
+  int s0, s1; float eps;
 };
+constexpr int kXfPairs = 64;                   // (image, group) pairs of a workgroup, at most
 
 __device__ __forceinline__ void bt6q(const float4 (&d)[6], float4 (&o)[6]) {
 #define SSDE_BT6_LANE(c)                                                                                             \
@@ -40,9 +50,12 @@ __global__ __launch_bounds__(256, 2) void wino4_xform_vq_kernel(const XformVqPar
   pro.gn = kGn;
   const int Q = p.Ctot >> 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int t = blockIdx.x * 16 + (lane & 15);
-  const int q = (blockIdx.y * 4 + wave) * 4 + (lane >> 4);
-  if (t >= p.T || q >= Q) return;
+  const int t_raw = blockIdx.x * 16 + (lane & 15);
+  const int q_raw = (blockIdx.y * 4 + wave) * 4 + (lane >> 4);
+  const bool valid = t_raw < p.T && q_raw < Q;
+  const bool merging = kGn && p.part0 != nullptr;
+  if (!merging && !valid) return;                 // (a merging workgroup keeps whole waves: the teams' shuffles and the barrier)
+  const int t = valid ? t_raw : 0, q = valid ? q_raw : 0;
   const int c = q * 4;
   const int per_img = p.tiles_h * p.tiles_w;
   const int img = t / per_img, r = t - img * per_img;
@@ -52,12 +65,34 @@ __global__ __launch_bounds__(256, 2) void wino4_xform_vq_kernel(const XformVqPar
   const int C = second ? s.c1 : s.c0;
   float mu = 0.f, rs = 1.f;
   float4 ga = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int cpg = kGn ? p.Ctot / s.gn_groups : 4;     // (cpg % 4 == 0: a quad lies in one group)
   if (kGn) {
-    const int cpg = p.Ctot / s.gn_groups;             // (cpg % 4 == 0: a quad lies in one group)
-    mu = s.gn_mean[img * s.gn_groups + c / cpg];
-    rs = s.gn_rstd[img * s.gn_groups + c / cpg];
+    if (!merging) {
+      mu = s.gn_mean[img * s.gn_groups + c / cpg];
+      rs = s.gn_rstd[img * s.gn_groups + c / cpg];
+    }
     ga = *reinterpret_cast<const float4*>(s.gn_gamma + c);
     be = *reinterpret_cast<const float4*>(s.gn_beta + c);
+  }
+  // the pairs of this workgroup: images of tiles 16 bx .. 16 bx + 15, groups of quads 16 by .. 16 by + 15
+  const int t0 = blockIdx.x * 16, t1 = min(t0 + 15, p.T - 1);
+  const int img_lo = t0 / per_img, n_img = t1 / per_img - img_lo + 1;
+  const int qa = blockIdx.y * 16, qb = min(qa + 15, Q - 1);
+  const int g_lo = (qa * 4) / cpg, ng = (qb * 4) / cpg - g_lo + 1;
+  const int team = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+  const int npairs = n_img * ng;                      // <= kXfPairs
+  auto pair_of = [&](int pr0, int& pr, int& n, int& g) {        // (a team beyond the end repeats the last pair)
+    pr = min(pr0 + team, npairs - 1);
+    const int il = pr / ng;
+    n = img_lo + il; g = g_lo + (pr - il * ng);
+  };
+  // the partials of the first 16 pairs are requested BEFORE the pixels (loads return in order: a merge whose loads followed the
+  // 36 pixel loads of the thread would wait for all of them) and merged while the pixels are in flight
+  SsdeGnTeam team0;
+  if constexpr (kGn) if (merging) {
+    int pr, n, g;
+    pair_of(0, pr, n, g);
+    ssde_gn_merge16_load(team0, p.part0, p.part1, s.c0, s.c1, p.s0, p.s1, s.gn_groups, n, g, l16);
   }
   float4 v[6][6];
 #pragma unroll
@@ -69,6 +104,29 @@ __global__ __launch_bounds__(256, 2) void wino4_xform_vq_kernel(const XformVqPar
       const int pix = (img * p.H + (inb ? iy : 0)) * p.W + (inb ? ix : 0);
       v[a][b] = *reinterpret_cast<const float4*>(base + (size_t)pix * C);
     }
+  if constexpr (kGn) if (merging) {
+    SSDE_LDS(tab);
+    for (int pr0 = 0; pr0 < npairs; pr0 += 16) {     // (uniform trip count)
+      int pr, n, g;
+      pair_of(pr0, pr, n, g);
+      float cnt, m, M2;
+      if (pr0 == 0) ssde_gn_merge16_finish(team0, l16, cnt, m, M2);
+      else ssde_gn_merge16(p.part0, p.part1, s.c0, s.c1, p.s0, p.s1, s.gn_groups, n, g, l16, cnt, m, M2);
+      if (l16 == 0 && pr0 + team < npairs) {
+        const float var = cnt > 0.f ? M2 / cnt : 0.f;
+        const float r = 1.0f / sqrtf(var + p.eps);
+        tab[2 * pr] = m; tab[2 * pr + 1] = r;
+        if (n * per_img >= t0) {                      // the image's first tile is one of this workgroup's
+          const_cast<float*>(s.gn_mean)[n * s.gn_groups + g] = m;
+          const_cast<float*>(s.gn_rstd)[n * s.gn_groups + g] = r;
+        }
+      }
+    }
+    SSDE_LDS_BARRIER();                               // (LDS only: the pixel loads stay in flight)
+    if (!valid) return;
+    const int pr = (img - img_lo) * ng + (c / cpg - g_lo);
+    mu = tab[2 * pr]; rs = tab[2 * pr + 1];
+  }
 #pragma unroll
   for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -102,6 +160,17 @@ __global__ __launch_bounds__(256, 2) void wino4_xform_vq_kernel(const XformVqPar
 
 }  // namespace
 
+// does the pass of this launch merge the GroupNorm partials of its source itself (ssde_conv_args.gn_in_part0)?  Otherwise
+// ssde_conv2d issues the finalize launch in front of it.  16 tiles of a workgroup must not span more than four images.
+bool ssde_wino4_xform_merges_gn(const ssde_conv_args* a) {
+  const ssde_src& s = a->main;
+  const bool gn = s.pro_mode == SSDE_PRO_GN || s.pro_mode == SSDE_PRO_GN_SILU;
+  if (!gn || !a->gn_in_part0 || a->tile != SSDE_TILE_WINOGRAD4R || (a->flags & SSDE_CONVF_V_GIVEN)) return false;
+  if (a->gn_in_slices0 <= 0 || (s.c1 > 0 && (!a->gn_in_part1 || a->gn_in_slices1 <= 0))) return false;
+  const int per_img = (a->h_in / 4) * (a->w_in / 4);
+  return per_img >= 4 && s.gn_groups > 0 && s.gn_mean && s.gn_rstd;
+}
+
 int ssde_wino4_xform_vq_launch(const ssde_conv_args* a, void* stream) {
   SSDE_REQUIRE(a && a->main.p0 && a->wino_v, "conv(winograd 4x4, two kernels): the transformed-input buffer (ssde_conv_args.wino_v) is missing");
   const ssde_src& s = a->main;
@@ -114,11 +183,16 @@ int ssde_wino4_xform_vq_launch(const ssde_conv_args* a, void* stream) {
     SSDE_REQUIRE(s.gn_mean && s.gn_rstd && s.gn_gamma && s.gn_beta, "conv(winograd 4x4, two kernels): GroupNorm pointers missing");
   }
   SSDE_REQUIRE(s.drop_thresh == 0 || s.drop_seed, "conv(winograd 4x4, two kernels): dropout seed pointer missing");
-  XformVqParams p{s, a->wino_v, a->n, a->h_in, a->w_in, s.c0 + s.c1, a->n * (a->h_in / 4) * (a->w_in / 4), a->h_in / 4, a->w_in / 4};
+  XformVqParams p{s, a->wino_v, a->n, a->h_in, a->w_in, s.c0 + s.c1, a->n * (a->h_in / 4) * (a->w_in / 4), a->h_in / 4, a->w_in / 4,
+                  nullptr, nullptr, 0, 0, 0.f};
   SSDE_REQUIRE((unsigned long long)a->n * a->h_in * a->w_in * (unsigned)p.Ctot < (1ull << 32), "conv(winograd 4x4, two kernels): tensor too large");
+  if (ssde_wino4_xform_merges_gn(a)) {
+    p.part0 = a->gn_in_part0; p.part1 = s.c1 > 0 ? a->gn_in_part1 : nullptr;
+    p.s0 = a->gn_in_slices0; p.s1 = s.c1 > 0 ? a->gn_in_slices1 : 0; p.eps = a->gn_in_eps;
+  }
   const dim3 grid(ssde_cdiv(p.T, 16), ssde_cdiv(p.Ctot >> 2, 16));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (gn) hipLaunchKernelGGL(wino4_xform_vq_kernel<true>, grid, dim3(256), 0, st, p);
+  if (gn) hipLaunchKernelGGL(wino4_xform_vq_kernel<true>, grid, dim3(256), p.part0 ? kXfPairs * 2 * sizeof(float) : 0, st, p);
   else hipLaunchKernelGGL(wino4_xform_vq_kernel<false>, grid, dim3(256), 0, st, p);
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;

@@ -100,7 +100,8 @@ _STRUCT = {L.OP_CONV: L.ConvArgs, L.OP_GN_STATS: L.GnStatsArgs, L.OP_UPFIRDN: L.
            L.OP_COLSUM_FINISH: L.ColsumFinishArgs, L.OP_GN_BWD_FINISH: L.GnBwdFinishArgs}
 
 
-_ROUTE = {L.OP_CONV: L.conv_route_flags, L.OP_WGRAD: L.wgrad_route_flags, L.OP_GN_BWD_REDUCE: L.gn_bwd_route_flags}
+_ROUTE = {L.OP_CONV: L.conv_route_flags, L.OP_WGRAD: L.wgrad_route_flags, L.OP_GN_BWD_REDUCE: L.gn_bwd_route_flags,
+          L.OP_ATTN: L.attn_route_flags}
 
 
 class ProgramBuilder:
@@ -222,7 +223,7 @@ def _expand(kind, fields, fclass, fl):
     a.update(aux=_NOSRC, w_aux=None, resid=None, resid_post=0, out_scale=1.0, dst=fields["_split_tmp"], gn_part=None)
     b = dict(fields)
     b.update(main=_NOSRC, w_main=None, ksize=0, bias=None, chan_add=None, chan_add_ld=0, resid=fields["_split_tmp"],
-             resid_post=0, tile=L.TILE_AUTO, wino_v=None)
+             resid_post=0, tile=L.TILE_AUTO, wino_v=None, gn_in_part0=None, gn_in_part1=None, gn_in_slices0=0, gn_in_slices1=0)
     return [(a, fclass, fl - fl1), (b, FC_CONV1, fl1)]
 
 
@@ -561,6 +562,7 @@ def _src(t, c, t2=None, c2=0, pro=L.PRO_NONE, gn=None, drop=None):
              drop_thresh=0, drop_scale=1.0, drop_seed=None, drop_salt=0)
     if gn is not None:
         d.update(gn_groups=gn["groups"], gn_mean=gn["mean"], gn_rstd=gn["rstd"], gn_gamma=gn["gamma"], gn_beta=gn["beta"])
+        d["_gn"] = gn        # (lowering-time only: the statistics may still be partials, Lowering._materialize_stats)
     if drop is not None:
         p, seed_t, salt = drop
         d.update(drop_thresh=min(int(round(p * 2.0 ** 32)), 2 ** 32 - 1), drop_scale=1.0 / (1.0 - p), drop_seed=seed_t,
@@ -628,14 +630,22 @@ class Lowering:
         rstd = self.b.buf(self.n, groups, name="gn_rstd")
         p0, p1 = self.parts.get(id(t)), (self.parts.get(id(t2)) if t2 is not None else None)
         if p0 is not None and p0[2] == c and (t2 is None or (p1 is not None and p1[2] == c2)) and (ctot // groups) % 4 == 0:
-            # the producers' epilogues already reduced this tensor: merge their partials (no pass over the activations)
-            self.b.add(L.OP_GN_FINALIZE, dict(part0=p0[0], part1=p1[0] if p1 else None, c0=c, c1=c2, slices0=p0[1],
-                                              slices1=p1[1] if p1 else 0, n=self.n, groups=groups, eps=float(gn_module.eps),
-                                              mean=mean, rstd=rstd), FC_GN)
+            # the producers' epilogues already reduced this tensor: merge their partials (no pass over the activations).
+            # WHO merges is decided by the first consumer (_materialize_stats): the transform pass of a two-kernel F(4x4,3x3)
+            # convolution does it for itself under its pixel loads (ssde_conv_args.gn_in_part0, ABI 10); everybody else gets
+            # the ssde_gn_finalize launch in front
+            fin = dict(part0=p0[0], part1=p1[0] if p1 else None, c0=c, c1=c2, slices0=p0[1], slices1=p1[1] if p1 else 0,
+                       n=self.n, groups=groups, eps=float(gn_module.eps), mean=mean, rstd=rstd)
             gamma = self.w.vector([gn_module.weight])
             beta = self.w.vector([gn_module.bias])
             assert ctot == gn_module.num_channels
-            return dict(groups=groups, mean=mean, rstd=rstd, gamma=gamma, beta=beta)
+            gn = dict(groups=groups, mean=mean, rstd=rstd, gamma=gamma, beta=beta, pending=fin)
+            # (Measured level on the sampler -- profiles/r6_gn_merge_in_transform_pass_ab.txt: the pass sits at its 256-register
+            #  limit and pays for the merge what the 59 launches cost -- so the consumer-side merge is opt-in and the default
+            #  stays the finalize launch, now a 16-lane-team kernel: SSDE_GN_MERGE_IN_CONSUMER=1)
+            if os.environ.get("SSDE_GN_MERGE_IN_CONSUMER", "0") != "1":
+                self._materialize_stats(gn)
+            return gn
         slices = max(1, min(int(math.ceil(256 / self.n)), hw // 64)) if hw >= 128 else 1
         scratch = self.b.buf(self.n * slices * groups * 2, name="gn_scratch") if slices > 1 else None
         self.b.add(L.OP_GN_STATS, dict(p0=t, p1=t2, c0=c, c1=c2, n=self.n, hw=hw, groups=groups, eps=float(gn_module.eps),
@@ -644,6 +654,20 @@ class Lowering:
         beta = self.w.vector([gn_module.bias])
         assert ctot == gn_module.num_channels
         return dict(groups=groups, mean=mean, rstd=rstd, gamma=gamma, beta=beta)
+
+    def _materialize_stats(self, gn, fields=None):
+        """The statistics of `gn` are about to be read: if they are still the producers' partials, either hand the merge to the
+        consuming launch itself (fields: the spec of a two-kernel F(4x4,3x3) convolution whose main source they normalise) or
+        emit the finalize launch now."""
+        fin = gn.get("pending") if gn else None
+        if fin is None:
+            return
+        gn["pending"] = None
+        if fields is not None:
+            fields.update(gn_in_part0=fin["part0"], gn_in_part1=fin["part1"], gn_in_slices0=fin["slices0"],
+                          gn_in_slices1=fin["slices1"], gn_in_eps=fin["eps"])
+        else:
+            self.b.add(L.OP_GN_FINALIZE, fin, FC_GN)
 
     def conv(self, dst, h_out, w_out, c_out, main=None, w_main=None, h_in=0, w_in=0, stride=1, pad=1,
              aux=None, w_aux=None, bias=None, chan_add=None, chan_add_ld=0, resid=None, scale=1.0, tile=L.TILE_AUTO,
@@ -680,6 +704,13 @@ class Lowering:
             if tile == L.TILE_WINOGRAD4R or takes:
                 fields["wino_v"] = self.b.buf(v_floats, name="wino_v")
                 fields["_v_for_wgrad"] = bool(takes)
+        # GroupNorm statistics that are still partials (gn_stats): the transform pass of the two-kernel form merges those of
+        # its main source itself; any other reader gets the finalize launch in front
+        if aux is not None:
+            self._materialize_stats(aux.get("_gn"))
+        if main is not None:
+            in_pass = tile == L.TILE_WINOGRAD4R and h_in * w_in >= 64
+            self._materialize_stats(main.get("_gn"), fields if in_pass else None)
         if stats and isinstance(dst, Buf):
             slices = self._gn_slices(fields)
             if slices > 0:
@@ -794,6 +825,7 @@ class Lowering:
         h_out = (h_in * up + pad[0] + pad[1] - kh) // down + 1
         w_out = (w_in * up + pad[0] + pad[1] - kw) // down + 1
         dst = self.b.buf(self.n, h_out, w_out, n_ch, name=name)
+        self._materialize_stats(src.get("_gn"))
         k16 = [0.0] * 16
         for i, v in enumerate(taps.reshape(-1).tolist()):
             k16[i] = float(v)

@@ -128,6 +128,7 @@ def attention(qkv, channels):
     dst = torch.empty(n, l, channels, device=qkv.device)
     a = L.AttnArgs()
     a.qkv, a.dst, a.n, a.l, a.c, a.scale = _p(qkv), _p(dst), n, l, channels, float(int(channels) ** (-0.5))
+    a.flags = L.attn_route_flags()
     L.check(L.load().ssde_attention(C.byref(a), _stream()), "ssde_attention")
     return dst
 

@@ -60,6 +60,37 @@ def test_groupnorm_stats_and_attention(ops):
     assert rel_err(o, torch.softmax(q @ k.transpose(1, 2) * 32 ** -0.5, -1) @ v) < 2e-5
 
 
+@pytest.mark.parametrize("n,c", [(2, 64), (1, 256), (1, 192)])
+def test_attention_on_the_bf16_matrix_pipe(ops, n, c, monkeypatch):
+    """attn_x6_kernel (SSDE_ATTNF_BF16X6: L = 256 tokens; Q K^T and P V as exact-fp32 products of a 3-way bf16 split, fp32
+    softmax) against fp64 -- at the fp32 kernel's tolerance -- and a permutation check that catches a transposed operand."""
+    monkeypatch.setenv("SSDE_MATRIX", "bf16x6")
+    g = torch.Generator().manual_seed(30 + c)
+    l = 256
+    qkv = torch.randn(n, l, 3 * c, generator=g)
+    qkv[:, :, :c] *= 2.0                      # sharpen the softmax
+    qkv[0, 3, :c] *= 6.0                      # one very peaked query row
+    y = ops.attention(qkv, c)
+    q, k, v = qkv[..., :c].double(), qkv[..., c:2 * c].double(), qkv[..., 2 * c:].double()
+    ref = torch.softmax(q @ k.transpose(1, 2) * (c ** -0.5), dim=-1) @ v
+    # (the emulator adds the 16 products of a bf16 MFMA to the accumulator one by one -- 6 to 8 fp32 roundings per fp32 product;
+    #  the hardware's bound against the fp32 kernel is asserted on the GPU: test_ops_gpu.py)
+    assert rel_err(y, ref) < 6e-6
+    monkeypatch.setenv("SSDE_ATTN_X6", "0")
+    y32 = ops.attention(qkv, c)
+    assert rel_err(y32, ref) < 3e-6 and rel_err(y, y32) < 8e-6 and not torch.equal(y, y32)      # (two different kernels ran)
+    monkeypatch.delenv("SSDE_ATTN_X6")
+    if c == 64:
+        q = torch.zeros(1, l, c); k = torch.zeros(1, l, c)
+        perm = torch.randperm(l, generator=g)
+        for i in range(l):                    # query i picks key perm[i] through two channels: rows, keys and channels all asymmetric
+            q[0, i, i % c] = 400.0; q[0, i, (i // c) * 9 % c] += 300.0
+            k[0, perm[i], i % c] += 1.0; k[0, perm[i], (i // c) * 9 % c] += 1.0
+        vv = torch.arange(l * c, dtype=torch.float32).reshape(1, l, c) / 100.0
+        ref2 = torch.softmax(q.double() @ k.double().transpose(1, 2) * (c ** -0.5), dim=-1) @ vv.double()
+        assert rel_err(ops.attention(torch.cat([q, k, vv], -1), c), ref2) < 1e-5
+
+
 @pytest.mark.parametrize("up,down,pad", [(2, 1, (2, 1)), (1, 2, (1, 1)), (1, 1, (2, 2))])
 def test_upfirdn2d(ops, up, down, pad):
     from oracle import unet_oracle

@@ -190,6 +190,28 @@ def test_attention(n, l, c):
     assert rel_err(y, ref) < TOL_GEMM
 
 
+@pytest.mark.parametrize("n,c", [(3, 256), (2, 128), (2, 64)])
+def test_attention_on_the_bf16_matrix_pipe_is_as_close_to_fp64_as_the_fp32_kernel(n, c, monkeypatch):
+    """attn_x6_kernel (SSDE_ATTNF_BF16X6: Q K^T with eight, P V with six terms of the 3-way bf16 split) against the fp32-MFMA
+    kernel on the same inputs -- a sharpened softmax with one very peaked query row: its distance from fp64 may not exceed
+    1.5x the fp32 kernel's (+ 2e-7), and the two kernels must really be different launches."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(40 + c)
+    l = 256
+    qkv = torch.randn(n, l, 3 * c, generator=g)
+    qkv[:, :, :c] *= 2.0
+    qkv[0, 3, :c] *= 6.0
+    q, k, v = qkv[..., :c].double(), qkv[..., c:2 * c].double(), qkv[..., 2 * c:].double()
+    ref = torch.softmax(q @ k.transpose(1, 2) * (c ** -0.5), dim=-1) @ v
+    monkeypatch.setenv("SSDE_MATRIX", "bf16x6")
+    y6 = ops.attention(qkv.cuda(), c).cpu()
+    monkeypatch.setenv("SSDE_ATTN_X6", "0")
+    y32 = ops.attention(qkv.cuda(), c).cpu()
+    e6, e32 = rel_err(y6, ref), rel_err(y32, ref)
+    assert not torch.equal(y6, y32)
+    assert e32 < 5e-6 and e6 <= 1.5 * e32 + 2e-7, (e6, e32)
+
+
 def test_attention_transpose_detecting():
     """A = I style check with asymmetric data: q selects key j -> output must be v[j] (guide rule 16)."""
     ops = _ops()

@@ -30,6 +30,12 @@ def test_groupnorm_statistics_from_producer_epilogues(pipe, monkeypatch):
     T.check_fused_gn_statistics("cuda", monkeypatch)
 
 
+def test_groupnorm_statistics_merged_by_the_transform_pass(monkeypatch):
+    # F(4x4,3x3) in two kernels wherever it is legal: the pass merges the partials of its source itself (gn_in_part0)
+    monkeypatch.setenv("SSDE_WINOGRAD", "4")
+    T.check_fused_gn_statistics("cuda", monkeypatch)
+
+
 def test_conv3x3_winograd_f4x4():
     T.check_conv_winograd4("cuda", big=True)
 
