@@ -284,8 +284,12 @@ __device__ __forceinline__ void split_hi(float x, uint32_t& a, uint32_t& b, uint
 }
 }  // namespace x6
 
-__global__ __launch_bounds__(x6::kT) void attn_x6_kernel(const float* __restrict__ qkv, float* __restrict__ dst, int N, int C, float scale) {
+// kNst = C / 16, the number of K stages, is a template parameter: the producers' code is then straight-line from the first request to
+// the last wait (no loop-carried copies of a register whose load is in flight; tools/isa_inflight_check.py walks the emitted ISA)
+template <int kNst>
+__global__ __launch_bounds__(x6::kT) void attn_x6_kernel(const float* __restrict__ qkv, float* __restrict__ dst, int N, float scale) {
   using namespace x6;
+  constexpr int C = 16 * kNst;
   SSDE_LDS(smem);
   char* lds = reinterpret_cast<char*>(smem);
   char* stage0 = lds + kMain;
@@ -300,24 +304,34 @@ __global__ __launch_bounds__(x6::kT) void attn_x6_kernel(const float* __restrict
   const int C3 = 3 * C;
   const float* base = qkv + (size_t)n * kL * C3;
   const int qplane = C * kRows * 2;                        // bytes of one Q piece: [C / 16][64 rows][16 channels] bf16
-  const int nst = C >> 4;                                   // K stages (a multiple of 4: C % 64 == 0)
+  constexpr int nst = kNst;                                 // K stages (a multiple of 4: C % 64 == 0)
 
-  f32x16 acc[2];
+  // ---- roles.  Waves 0-3 are CONSUMERS: each owns a 64 x 64 block of the products (64 query rows x 64 keys in phase 1, x 64
+  // channels in phase 3: four 32 x 32 accumulators) and does nothing but read fragments and issue MFMAs.  Waves 4-7 are PRODUCERS:
+  // they stream K and V (requests, counted waits, the 3-way split, the parking in LDS).  A SIMD holds one wave of each kind, so the
+  // split runs beside the MFMAs by itself, and the fragments of a stage are read by four waves instead of eight (48 KB per
+  // stage instead of 72: in the first form -- eight waves with 64 x 32 blocks, each also staging -- the LDS reads behind every barrier,
+  // then the MFMAs, then the split took turns: 0.163 ms per launch, profiles/r6_attention_x6_versions.txt).
+  const bool consumer = wave < 4;                          // (uniform)
+  f32x16 acc[2][2];
   auto zero = [&]() {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   };
-  // The operands of a stage's MFMAs: A = rows (a * 32 + li) of the planes at `ap` (piece pitch a_pitch), B = row (32 wave + li) of
-  // the stage at `bp` (piece pitch b_pitch); a lane reads 16 bytes = 8 consecutive k of its row
-  struct Frags { ssde_u32x4 A[2][3], B[3]; };
+  // The operands of a stage's MFMAs: A = rows (a * 32 + li) of the planes at `ap` (piece pitch a_pitch), B = rows (64 wave + b * 32
+  // + li) of the stage at `bp` (piece pitch b_pitch); a lane reads 16 bytes = 8 consecutive k of its row
+  struct Frags { ssde_u32x4 A[2][3], B[2][3]; };
   auto read_frags = [&](Frags& f, const char* ap, int a_pitch, const char* bp, int b_pitch) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
 #pragma unroll
       for (int a = 0; a < 2; ++a) f.A[a][q] = *reinterpret_cast<const ssde_u32x4*>(ap + q * a_pitch + (a * 32 + li) * 32 + lh * 16);
-      f.B[q] = *reinterpret_cast<const ssde_u32x4*>(bp + q * b_pitch + (wave * 32 + li) * 32 + lh * 16);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) f.B[b][q] = *reinterpret_cast<const ssde_u32x4*>(bp + q * b_pitch + (wave * 64 + b * 32 + li) * 32 + lh * 16);
     }
   };
   // smallest terms first.  Six terms (SSDE_MFMA_BF16X6) drop a1 b2 + a2 b1 + a2 b2 <= 2^-23 |a b| per product; the scores take
@@ -330,105 +344,105 @@ __global__ __launch_bounds__(x6::kT) void attn_x6_kernel(const float* __restrict
     for (int t = 8 - kTerms; t < 8; ++t)
 #pragma unroll
       for (int a = 0; a < 2; ++a)
-        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ssde_bf16x8, f.A[a][TI[t]]),
-                                                         __builtin_bit_cast(ssde_bf16x8, f.B[TJ[t]]), acc[a], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ssde_bf16x8, f.A[a][TI[t]]),
+                                                              __builtin_bit_cast(ssde_bf16x8, f.B[b][TJ[t]]), acc[a][b], 0, 0, 0);
   };
   using Six = std::integral_constant<int, 6>;
   using ScoreTerms = std::integral_constant<int, SSDE_ATTN_X6_SCORE_TERMS>;
 
-  // ---- the streamed operands: K in nst stages of 16 channels, then V in 16 stages of 16 tokens, ONE stream through a register
-  // ring of four stages.  Element u + 4 of the stream is requested at the top of stage u -- the first V stages during the last K
-  // stages, so they land under the softmax -- and has three stages (3-5 k cycles) to land.  The loads are asm statements hipcc
-  // does not track, two per stage and thread, counted by the kernel itself: "element u + 1 has landed" is vmcnt(6) (elements
-  // u + 2 .. u + 4 are younger), 4 / 2 / 0 over the last V stages.  Every requested element is consumed, so no load lands in a
-  // register hipcc considers free; no load or wait sits behind a branch (no copies of a register that is still in flight at a
-  // join).  History: profiles/r6_attention_x6_versions.txt -- two stages ahead with loads hipcc tracked was one stage ahead in
-  // effect (its vmcnt(0) in front of every store), 50 us per workgroup.
-  ssde_f32x4 R[4][2];
+  // ---- the streamed operands (producers): K in nst stages of 16 channels, then V in 16 stages of 16 tokens, ONE stream through a
+  // register ring of four elements.  Element u + 4 is requested at the top of stage u -- the first V stages during the last K
+  // stages, so they land under the softmax -- and has three stages to land.  The loads are asm statements hipcc does not track,
+  // four per element and thread, counted by the kernel itself: "element u + 1 has landed" is vmcnt(12) (elements u + 2 .. u + 4 are
+  // younger), 8 / 4 / 0 over the last V stages.  Every requested element is consumed (no load lands in a register hipcc considers
+  // free) and the whole stream lives inside the producers' arm of the role branch (no copy of a register in flight at a join).
+  // History: loads hipcc tracked ran one stage ahead in effect -- it waits vmcnt(0) in front of every store once a guard sits
+  // near them: 50 us per workgroup.
+  const int ptid = tid & 255;                               // thread of the producer half
   const float* kbase = base + C;
   const float* vbase = base + 2 * C;
-  // K: a thread stages (key row, channel quad) items tid and tid + 512 of the stage's 256 x 4
-  const int krow = tid >> 2, kf = tid & 3;
-  const uint32_t koff0 = (uint32_t)((krow * C3 + kf * 4) * 4), koff1 = koff0 + (uint32_t)(128 * C3 * 4);
-  // V: a thread stages tokens 2 tp, 2 tp + 1 of channel quad fq
-  const int tp = tid & 7, fq = tid >> 3;
-  const bool v_on = fq * 4 < C;
-  const uint32_t voff0 = (uint32_t)((2 * tp * C3 + (v_on ? fq * 4 : 0)) * 4), voff1 = voff0 + (uint32_t)(C3 * 4);
+  // K: a producer thread stages (key row (ptid >> 2) + 64 i, channel quad ptid & 3), i = 0 .. 3, of the stage's 256 x 4
+  const int krow = ptid >> 2, kf = ptid & 3;
+  const uint32_t koff = (uint32_t)((krow * C3 + kf * 4) * 4), kstep = (uint32_t)(64 * C3 * 4);
+  // V: tokens 2 tp, 2 tp + 1 of the channel quads fq0 and fq0 + 32
+  const int tp = ptid & 7, fq0 = ptid >> 3;
+  const bool v_on0 = fq0 * 4 < C, v_on1 = (fq0 + 32) * 4 < C;
+  const uint32_t voff = (uint32_t)((2 * tp * C3 + (v_on0 ? fq0 * 4 : 0)) * 4), vtok = (uint32_t)(C3 * 4), vquad = v_on1 ? 512u : 0u;
   const int vpitch = C * 32;                                // bytes of one piece of a V stage: [C channels][16 tokens] bf16
-  auto request = [&](int u, ssde_f32x4 (&Rs)[2]) __attribute__((always_inline)) {      // stream element u (uniform)
+  auto request = [&](int u, ssde_f32x4 (&Rs)[4]) __attribute__((always_inline)) {      // stream element u (uniform)
     const bool is_k = u < nst;
     const float* sb = is_k ? kbase + u * 16 : vbase + (size_t)(u - nst) * 16 * C3;       // (scalar)
-    const uint32_t o0 = is_k ? koff0 : voff0, o1 = is_k ? koff1 : voff1;
+    const uint32_t o0 = is_k ? koff : voff;
+    const uint32_t o1 = o0 + (is_k ? kstep : vtok);                    // K: row + 64       V: token 2 tp + 1
+    const uint32_t o2 = is_k ? o0 + 2 * kstep : o0 + vquad;            // K: row + 128      V: quad fq0 + 32, token 2 tp
+    const uint32_t o3 = is_k ? o0 + 3 * kstep : o2 + vtok;             // K: row + 192      V: quad fq0 + 32, token 2 tp + 1
     SSDE_GLOAD16_I_SAFE(Rs[0], o0, sb, 0);
     SSDE_GLOAD16_I_SAFE(Rs[1], o1, sb, 0);
+    SSDE_GLOAD16_I_SAFE(Rs[2], o2, sb, 0);
+    SSDE_GLOAD16_I_SAFE(Rs[3], o3, sb, 0);
   };
-  // a K stage: split into registers (VALU, meant to run under the MFMAs of the stage before) ...
-  struct KPieces { uint2 p[2][3]; };
-  auto split_k = [&](const ssde_f32x4 (&Rs)[2], KPieces& kp) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) ssde_split3(make_float4(Rs[i].x, Rs[i].y, Rs[i].z, Rs[i].w), kp.p[i][0], kp.p[i][1], kp.p[i][2]);
-  };
-  // ... and parked: [3 pieces][256 keys][16 channels] bf16
-  auto park_k = [&](const KPieces& kp, char* buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      char* d = buf + (krow + 128 * i) * 32 + kf * 8;
-      *reinterpret_cast<uint2*>(d) = kp.p[i][0];
-      *reinterpret_cast<uint2*>(d + kL * 32) = kp.p[i][1];
-      *reinterpret_cast<uint2*>(d + 2 * kL * 32) = kp.p[i][2];
-    }
-  };
-  // a V stage, TRANSPOSED: [3 pieces][C channels][16 tokens] bf16; w[piece][channel] = (token 2 tp) | (token 2 tp + 1) << 16
-  struct VPieces { uint32_t w[3][4]; };
-  auto split_v = [&](const ssde_f32x4 (&Rs)[2], VPieces& vp) __attribute__((always_inline)) {
-    const float f0[4] = {Rs[0].x, Rs[0].y, Rs[0].z, Rs[0].w}, f1[4] = {Rs[1].x, Rs[1].y, Rs[1].z, Rs[1].w};
+#ifdef SSDE_EMULATED
+#define SSDE_X6_WAIT(n, Rs) ((void)0)
+#else
+#define SSDE_X6_WAIT(n, Rs) asm volatile("s_waitcnt vmcnt(%4)" : "+v"((Rs)[0]), "+v"((Rs)[1]), "+v"((Rs)[2]), "+v"((Rs)[3]) : "n"(n) : "memory")
+#endif
+  // a K element split and parked: [3 pieces][256 keys][16 channels] bf16
+  auto park_k = [&](const ssde_f32x4 (&Rs)[4], char* buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      uint32_t a0, b0, c0, a1, b1, c1;
-      split_hi(f0[i], a0, b0, c0);
-      split_hi(f1[i], a1, b1, c1);
-      vp.w[0][i] = ssde_pack_hi16(a0, a1); vp.w[1][i] = ssde_pack_hi16(b0, b1); vp.w[2][i] = ssde_pack_hi16(c0, c1);
+      uint2 p0, p1, p2;
+      ssde_split3(make_float4(Rs[i].x, Rs[i].y, Rs[i].z, Rs[i].w), p0, p1, p2);
+      char* d = buf + (krow + 64 * i) * 32 + kf * 8;
+      *reinterpret_cast<uint2*>(d) = p0;
+      *reinterpret_cast<uint2*>(d + kL * 32) = p1;
+      *reinterpret_cast<uint2*>(d + 2 * kL * 32) = p2;
     }
   };
-  // the j-th store of a thread writes channel (j + rot) & 3, rot = (fq >> 1) & 3: the 64 lanes of one store hit 64 different
+  // a V element, TRANSPOSED: [3 pieces][C channels][16 tokens] bf16, a dword = (token 2 tp) | (token 2 tp + 1) << 16.  The j-th
+  // store of a thread writes channel (j + rot) & 3 of its quad, rot = (fq >> 1) & 3: the 64 lanes of one store hit 64 different
   // banks.  The rotation of the four words is two rounds of selects (v_cndmask), no branches
-  const int rot = (fq >> 1) & 3;
+  const int rot = (fq0 >> 1) & 3;                           // (the same for fq0 + 32)
   const bool rot1 = (rot & 1) != 0, rot2 = (rot & 2) != 0;
-  auto park_v = [&](const VPieces& vp, char* buf) __attribute__((always_inline)) {
-    uint32_t y[3][4];
+  auto park_v = [&](const ssde_f32x4 (&Rs)[4], char* buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      uint32_t x[4];
+    for (int h = 0; h < 2; ++h) {                           // quad fq0 + 32 h
+      const float f0[4] = {Rs[2 * h].x, Rs[2 * h].y, Rs[2 * h].z, Rs[2 * h].w};
+      const float f1[4] = {Rs[2 * h + 1].x, Rs[2 * h + 1].y, Rs[2 * h + 1].z, Rs[2 * h + 1].w};
+      uint32_t w[3][4], y[3][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) x[i] = rot1 ? vp.w[q][(i + 1) & 3] : vp.w[q][i];
+      for (int i = 0; i < 4; ++i) {
+        uint32_t a0, b0, c0, a1, b1, c1;
+        split_hi(f0[i], a0, b0, c0);
+        split_hi(f1[i], a1, b1, c1);
+        w[0][i] = ssde_pack_hi16(a0, a1); w[1][i] = ssde_pack_hi16(b0, b1); w[2][i] = ssde_pack_hi16(c0, c1);
+      }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) y[q][i] = rot2 ? x[(i + 2) & 3] : x[i];
-    }
-    if (v_on) {
+      for (int q = 0; q < 3; ++q) {
+        uint32_t x[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        char* d = buf + (fq * 4 + ((j + rot) & 3)) * 32 + tp * 4;
+        for (int i = 0; i < 4; ++i) x[i] = rot1 ? w[q][(i + 1) & 3] : w[q][i];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<uint32_t*>(d + q * vpitch) = y[q][j];
+        for (int i = 0; i < 4; ++i) y[q][i] = rot2 ? x[(i + 2) & 3] : x[i];
+      }
+      if (h == 0 ? v_on0 : v_on1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          char* d = buf + ((fq0 + 32 * h) * 4 + ((j + rot) & 3)) * 32 + tp * 4;
+#pragma unroll
+          for (int q = 0; q < 3; ++q) *reinterpret_cast<uint32_t*>(d + q * vpitch) = y[q][j];
+        }
       }
     }
   };
-  // one MFMA, then `valu` vector-ALU instructions, `n` times over: the split of the next stage runs under this stage's MFMAs
-  // (the BF16 MFMAs co-issue with VALU; left alone, hipcc issues the MFMAs first and the split behind them, and the eight
-  // waves -- in lock step between two barriers -- leave the matrix pipe idle during every split)
-#define SSDE_X6_INTERLEAVE(n, valu)                                \
-  do {                                                             \
-    _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {           \
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           \
-      __builtin_amdgcn_sched_group_barrier(0x002, (valu), 0);      \
-    }                                                              \
-  } while (0)
 
   // ---- phase 1: S = Q K^T ----
+  ssde_f32x4 R[4][4];                                       // (producers)
   zero();
-  request(0, R[0]); request(1, R[1]); request(2, R[2]); request(3, R[3]);        // before Q: they land under its split
+  if (!consumer) { request(0, R[0]); request(1, R[1]); request(2, R[2]); request(3, R[3]); }       // before Q: they land under its split
   {
-    // Q: every channel of the 64 rows, split once (up to 8 float4 of a thread requested together)
+    // Q: every channel of the 64 rows, split once by all eight waves (up to 8 float4 of a thread requested together)
     const int cq4 = C >> 2, total = kRows * cq4;            // channel quads per row
     for (int item0 = tid; item0 < total; item0 += 8 * kT) {
       float4 qv[8];
@@ -453,39 +467,46 @@ __global__ __launch_bounds__(x6::kT) void attn_x6_kernel(const float* __restrict
       }
     }
   }
-  {
-    SSDE_WAIT_VMCNT_FOR(6, R[0][0], R[0][1]);
-    KPieces kp;
-    split_k(R[0], kp);
-    park_k(kp, stage0);
+  if (consumer) {
     SSDE_LDS_BARRIER();                                    // (the Q planes and K stage 0 are complete)
-    for (int st = 0; st < nst; st += 4) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int u = st + j;
-        request(u + 4, R[j]);                               // R[j] held element u: parked in LDS during stage u - 1
-        SSDE_WAIT_VMCNT_FOR(6, R[(j + 1) & 3][0], R[(j + 1) & 3][1]);       // element u + 1 (at u = nst - 1: V stage 0, parked in phase 3)
-        Frags f;
-        read_frags(f, lds + u * (kRows * 32), qplane, (j & 1) ? stage1 : stage0, kL * 32);
-        split_k(R[(j + 1) & 3], kp);
-        mfmas(ScoreTerms{}, f);
-        SSDE_X6_INTERLEAVE(2 * SSDE_ATTN_X6_SCORE_TERMS, 3);
-        park_k(kp, (j & 1) ? stage0 : stage1);              // (at u = nst - 1: V data in K's layout, overwritten at the start of phase 3)
-        SSDE_LDS_BARRIER();
-      }
+    for (int u = 0; u < nst; ++u) {
+      Frags f;
+      read_frags(f, lds + u * (kRows * 32), qplane, (u & 1) ? stage1 : stage0, kL * 32);
+      mfmas(ScoreTerms{}, f);
+      SSDE_LDS_BARRIER();
     }
+  } else {
+    // (the Q loads above are younger than the four requests and have been consumed: loads return in order, so the ring has landed)
+    SSDE_X6_WAIT(12, R[0]);
+    park_k(R[0], stage0);
+    SSDE_LDS_BARRIER();
+#pragma unroll
+    for (int u = 0; u < nst; ++u) {                        // (straight-line: every index is a compile-time constant)
+      const int j = u & 3;
+      request(u + 4, R[j]);                                 // R[j] held element u: parked in LDS during stage u - 1
+      SSDE_X6_WAIT(12, R[(j + 1) & 3]);                     // element u + 1 (at u = nst - 1: V stage 0, parked in phase 3)
+      if (u + 1 < nst) park_k(R[(j + 1) & 3], (j & 1) ? stage0 : stage1);
+      SSDE_LDS_BARRIER();
+    }
+    // V stages 1 .. 3 are still in flight: waited for HERE, before the softmax -- its 32 scores per thread could make hipcc move
+    // the ring, and a register must not be copied while its load is in flight (they were requested 1-3 stages ago)
+    SSDE_X6_WAIT(8, R[1]); SSDE_X6_WAIT(4, R[2]); SSDE_X6_WAIT(0, R[3]);
   }
 
-  // ---- phase 2: softmax of the 64 x 256 scores; P as three bf16 planes ----
+  // ---- phase 2: softmax of the 64 x 256 scores; P as three bf16 planes (all eight waves) ----
   {
     float* tile = smem;                                    // [64][kLDP] over the Q planes (every wave is behind the last barrier)
+    if (consumer) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        tile[row * kLDP + wave * 32 + li] = acc[a][r] * scale;
-      }
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            tile[row * kLDP + wave * 64 + b * 32 + li] = acc[a][b][r] * scale;
+          }
+    }
     SSDE_LDS_BARRIER();
     const int row = tid >> 3, sub = tid & 7;               // keys 32 sub .. 32 sub + 31 of the row
     float x[32];
@@ -520,49 +541,54 @@ __global__ __launch_bounds__(x6::kT) void attn_x6_kernel(const float* __restrict
     }
   }
 
-  // ---- phase 3: O = P V over 16 stages of 16 tokens (straight-line: every index below is a compile-time constant) ----
-  {
-    const bool w_on = wave * 32 < C;                        // (C < 256: the upper waves only stage)
+  // ---- phase 3: O = P V over 16 stages of 16 tokens ----
+  if (consumer) {
+    const bool w_on = wave * 64 < C;                        // (C < 256: the upper consumers only keep the barriers)
     zero();
-    VPieces vp;
-    SSDE_WAIT_VMCNT_FOR(6, R[0][0], R[0][1]);              // V stage 0 (waited for at the end of phase 1 already)
-    split_v(R[0], vp);
-    park_v(vp, stage0);
     SSDE_LDS_BARRIER();                                    // (the P planes and V stage 0 are complete)
-#pragma unroll
     for (int v = 0; v < 16; ++v) {
-      const int j = v & 3;
-      if (v + 4 < 16) request(nst + v + 4, R[j]);
-      if (v + 1 < 16) {
-        if (v + 4 < 16) SSDE_WAIT_VMCNT_FOR(6, R[(j + 1) & 3][0], R[(j + 1) & 3][1]);
-        else if (v + 3 < 16) SSDE_WAIT_VMCNT_FOR(4, R[(j + 1) & 3][0], R[(j + 1) & 3][1]);
-        else if (v + 2 < 16) SSDE_WAIT_VMCNT_FOR(2, R[(j + 1) & 3][0], R[(j + 1) & 3][1]);
-        else SSDE_WAIT_VMCNT_FOR(0, R[(j + 1) & 3][0], R[(j + 1) & 3][1]);
-      }
-      if (w_on) {                                          // (uniform; one block, so that the split runs under the MFMAs)
+      if (w_on) {
         Frags f;
-        read_frags(f, lds + v * (kRows * 32), kPPlane, (j & 1) ? stage1 : stage0, vpitch);
-        if (v + 1 < 16) split_v(R[(j + 1) & 3], vp);
+        read_frags(f, lds + v * (kRows * 32), kPPlane, (v & 1) ? stage1 : stage0, vpitch);
         mfmas(Six{}, f);
-        SSDE_X6_INTERLEAVE(12, 8);
-      } else if (v + 1 < 16) {
-        split_v(R[(j + 1) & 3], vp);
       }
-      if (v + 1 < 16) park_v(vp, (j & 1) ? stage0 : stage1);
       SSDE_LDS_BARRIER();
     }
     if (w_on) {
-      float* out = dst + ((size_t)n * kL + q0) * C + wave * 32 + li;
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b) {
+        float* out = dst + ((size_t)n * kL + q0) * C + wave * 64 + b * 32 + li;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          out[(size_t)row * C] = acc[a][r];
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            out[(size_t)row * C] = acc[a][b][r];
+          }
+      }
+    }
+  } else {
+    park_v(R[0], stage0);                                  // (V stages 0 .. 3 have landed: end of phase 1)
+    SSDE_LDS_BARRIER();
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {                         // (straight-line: every index below is a compile-time constant)
+      const int j = v & 3;
+      if (v + 4 < 16) request(nst + v + 4, R[j]);
+      if (v + 1 < 16) {
+        // element v + 1: stages 1 .. 3 landed before the softmax; from 4 on, the stages requested behind it are younger
+        // (v = 3: stages 5 .. 7 and nothing older in flight; the last ones: 8 / 4 / 0)
+        if (v + 1 >= 4) {
+          if (v + 4 < 16) SSDE_X6_WAIT(12, R[(j + 1) & 3]);
+          else if (v + 3 < 16) SSDE_X6_WAIT(8, R[(j + 1) & 3]);
+          else if (v + 2 < 16) SSDE_X6_WAIT(4, R[(j + 1) & 3]);
+          else SSDE_X6_WAIT(0, R[(j + 1) & 3]);
         }
+        park_v(R[(j + 1) & 3], (j & 1) ? stage0 : stage1);
+      }
+      SSDE_LDS_BARRIER();
     }
   }
-#undef SSDE_X6_INTERLEAVE
+#undef SSDE_X6_WAIT
 }
 
 // ---- backward A: dQ (and the per-row softmax statistics + D for kernel B) ----
@@ -710,10 +736,21 @@ extern "C" int ssde_attention(const ssde_attn_args* a, void* stream) {
   SSDE_REQUIRE(a->n > 0 && a->l > 0 && a->l <= kLMax, "attention: token count %d outside 1..%d", a->l, kLMax);
   SSDE_REQUIRE(a->c > 0 && a->c % 32 == 0, "attention: channels must be a multiple of 32 (got %d)", a->c);
   if ((a->flags & SSDE_ATTNF_BF16X6) && a->l == x6::kL && a->c <= 256 && a->c % 64 == 0) {
-    static std::atomic<bool> x6_set{false};
-    if (int rc = set_lds_once(attn_x6_kernel, x6::kLds, &x6_set)) return rc;
-    hipLaunchKernelGGL(attn_x6_kernel, dim3(ssde_cdiv(a->n, 8) * 8 * 4), dim3(x6::kT), x6::kLds, static_cast<hipStream_t>(stream),
-                       a->qkv, a->dst, a->n, a->c, a->scale);
+    static std::atomic<bool> x6_set[4];
+    const dim3 grid(ssde_cdiv(a->n, 8) * 8 * 4);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define SSDE_ATTN_X6_GO(NST, SLOT)                                                                       \
+    do {                                                                                                 \
+      if (int rc = set_lds_once(attn_x6_kernel<NST>, x6::kLds, &x6_set[SLOT])) return rc;                \
+      hipLaunchKernelGGL(attn_x6_kernel<NST>, grid, dim3(x6::kT), x6::kLds, st, a->qkv, a->dst, a->n, a->scale); \
+    } while (0)
+    switch (a->c) {
+      case 64: SSDE_ATTN_X6_GO(4, 0); break;
+      case 128: SSDE_ATTN_X6_GO(8, 1); break;
+      case 192: SSDE_ATTN_X6_GO(12, 2); break;
+      default: SSDE_ATTN_X6_GO(16, 3); break;
+    }
+#undef SSDE_ATTN_X6_GO
     SSDE_LAUNCH_CHECK();
     return SSDE_OK;
   }

@@ -877,6 +877,12 @@ class UNetEngine:
         if finalize:
             self.program = self.b.finalize()
 
+    @property
+    def cond_only_ops(self):
+        """How many leading ops of `program` read nothing but the noise level (embedding, temb MLP, all Dense_0 projections):
+        a caller that evaluates the network again at the SAME noise level may skip them -- their outputs are persistent."""
+        return int(self.program.spec_start[getattr(self, "_cond_specs", 0)])
+
     # ------------------------------------------------------------------ lowering
     def _lower(self):
         model, b, low, n = self.model, self.b, self.low, self.n
@@ -898,16 +904,19 @@ class UNetEngine:
             freqs = torch.exp(torch.arange(half, dtype=torch.float32) * -e)   # layers.py:519-521
             table = b.tensor(freqs.to(self.device))
             kind = 1
-        emb = b.buf(n, emb_dim, name="emb")
+        # (the conditioning chain -- embedding, the two Linear layers, every Dense_0 -- depends on the noise level only: its
+        #  buffers keep their own storage, so that a program which evaluates the network several times at ONE noise level -- a
+        #  PC iteration: corrector and predictor -- can run the chain once: cond_only_ops, pc_engine._assemble)
+        emb = b.buf(n, emb_dim, name="emb", persistent=True)
         self._emb = emb
         b.add(L.OP_EMBED, dict(cond=self.cond, w=table, dst=emb, n=n, dim=emb_dim, kind=kind))
         temb = None
         if model.conditional:
             lin0, lin1 = mods[idx], mods[idx + 1]; idx += 2
-            t0 = b.buf(n, 4 * nf, name="temb0")
+            t0 = b.buf(n, 4 * nf, name="temb0", persistent=True)
             low.conv(t0, 1, 1, 4 * nf, aux=_src(emb, emb_dim), w_aux=self.weights.matrix([(lin0.weight, False)]),
                      bias=self.weights.vector([lin0.bias]))
-            temb = b.buf(n, 4 * nf, name="temb")
+            temb = b.buf(n, 4 * nf, name="temb", persistent=True)
             low.conv(temb, 1, 1, 4 * nf, aux=_src(t0, 4 * nf, pro=L.PRO_SILU),
                      w_aux=self.weights.matrix([(lin1.weight, False)]),
                      bias=self.weights.vector([lin1.bias]))
@@ -920,8 +929,9 @@ class UNetEngine:
             self._tproj_ld = off
             wd = self.weights.matrix([(d.weight, False) for d in dense])
             bd = self.weights.vector([d.bias for d in dense])
-            self._tproj = b.buf(n, off, name="tproj")
+            self._tproj = b.buf(n, off, name="tproj", persistent=True)
             low.conv(self._tproj, 1, 1, off, aux=_src(temb, 4 * nf, pro=L.PRO_SILU), w_aux=wd, bias=bd)
+        self._cond_specs = len(b.specs)            # the leading specs that read nothing but the noise level
 
         # ---- input boundary: NCHW -> NHWC (C padded to 4), 2x-1 for un-centred data (ncsnpp.py:259-261)
         H, W = self.h, self.w

@@ -23,6 +23,7 @@ The Langevin step size needs a batch-wide reduction between the score evaluation
 (SURVEY F10), which is why the loop body is a kernel sequence rather than one persistent kernel.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -176,8 +177,19 @@ class FusedPCSampler:
                  coef=self.tabs["proj"], step_ptr=self.step, n=self.B, c=Cc, hw=self.per // Cc,
                  use_matrix=int(pj.get("M") is not None), M=list(pj.get("M") or [0.0] * 9), invM=list(pj.get("invM") or [0.0] * 9))
 
+        # Every evaluation of an iteration runs at the SAME noise level (the label is filled once, above all of them;
+        # sampling.py:403-407: corrector and predictor both take vec_t): the conditioning chain of the network -- embedding, the
+        # two Linear layers, the batched Dense_0 projections, ~0.2 ms of skinny GEMMs at batch 256 -- is evaluated by the first
+        # one only (UNetEngine.cond_only_ops; the same values, bit for bit) when SSDE_PC_SHARE_COND=1.  Off by default: the bench's
+        # headline counts two FULL evaluations per iteration, as the reference runs them.
+        share = os.environ.get("SSDE_PC_SHARE_COND", "0") == "1"
+        n_cond = self.unet.cond_only_ops if share else 0
+        emitted = [0]
+
         def emit_unet():
-            ops.extend(unet_ops); classes.extend(unet_cls); flops.extend(unet_fl)
+            lo = n_cond if emitted[0] else 0
+            emitted[0] += 1
+            ops.extend(unet_ops[lo:]); classes.extend(unet_cls[lo:]); flops.extend(unet_fl[lo:])
 
         score = self.unet.out.tensor
         emit(L.OP_FILL, L.FillArgs, dst=self.unet.cond.tensor, tab=self.tabs["label"], step_ptr=self.step, n=self.B)

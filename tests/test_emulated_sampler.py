@@ -39,6 +39,35 @@ def test_fused_step_program_variants(name):
     assert rel_err(out, torch.from_numpy(gold[name])) < 2e-4
 
 
+def test_conditioning_chain_evaluated_once_per_iteration(monkeypatch):
+    """SSDE_PC_SHARE_COND=1: the evaluations of one PC iteration run at one noise level, so the second one skips the network's
+    conditioning chain (embedding, temb MLP, Dense_0 projections: persistent buffers) -- fewer launches, the same bits."""
+    from score_sde_pytorch_amd import sde_lib, sampling, pc_engine
+    from score_sde_pytorch_amd.models import utils as mutils
+    name = "vp_em_langevin"
+    kind, sde_kind, kw, pred, corr, n_steps, continuous, pflow, denoise, eps = _util.PC_VARIANTS[name]
+    cfg = _util.small_config(kind)
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg).eval()
+    _util.load_seeded(model, seed=1)
+    sde = sde_lib.VPSDE(**kw)
+    B, R = _util.PC_VARIANT_BATCH, _util.PC_VARIANT_SIZE
+    x_T, noises = _util.pc_variant_inputs(name, B, kw["N"], R, 1.0)
+    outs, counts = {}, {}
+    with emulated():
+        for share in ("0", "1"):
+            monkeypatch.setenv("SSDE_PC_SHARE_COND", share)
+            plan = pc_engine.plan_fused(sde, sampling.get_predictor(pred), sampling.get_corrector(corr), model, continuous,
+                                        types.SimpleNamespace(is_cuda=True), pflow)
+            eng = pc_engine.FusedPCSampler(model, sde, plan, (B, 3, R, R), snr=0.16, n_steps=n_steps, probability_flow=pflow,
+                                           eps=eps, device=torch.device("cpu"))
+            outs[share] = eng.run(x_T, noises=noises, max_steps=3)
+            counts[share] = (eng.step_program(with_rng=False).n, eng.unet.cond_only_ops, eng.nfe_per_step())
+    n_cond, nfe = counts["1"][1], counts["1"][2]
+    assert n_cond >= 3 and nfe >= 2 and counts["0"][0] - counts["1"][0] == n_cond * (nfe - 1), counts
+    assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
+
+
 @pytest.mark.parametrize("name", ["inpaint_vp_ancestral_none", "colorize_ve_rd_langevin"])
 def test_fused_controllable_generation(name, monkeypatch):
     """get_pc_inpainter / get_pc_colorizer: the step program with ssde_project_update after the corrector and the

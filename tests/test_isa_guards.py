@@ -224,3 +224,25 @@ def test_persistent_register_fed_kernel_leaves_its_prefetched_operands_alone(tmp
                         break
                 j += 1
         assert reached, lines[i].strip()
+
+
+def test_attention_x6_no_instruction_touches_a_register_whose_asm_load_is_in_flight(tmp_path):
+    """attn_x6_kernel's streamed K / V loads are inline asm the compiler does not track (the kernel counts them: SSDE_X6_WAIT).
+    A compiler-inserted copy of a ring register between a request and its wait would copy stale data: replay the vmcnt queue over the
+    producers' straight-line code (tools/isa_inflight_check.py) for every instantiation -- and make sure the check can fail."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_inflight_check", os.path.join(ROOT, "tools", "isa_inflight_check.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    isa = _isa("attention.hip", tmp_path, defines=("-fno-gpu-rdc", "-munsafe-fp-atomics", "-fPIC"))
+    kernels = _kernels(isa, "attn_x6_kernel")
+    assert len(kernels) == 4
+    for sym, body in kernels:
+        lines = body[:body.index("s_endpgm")].split("\n")
+        n_asm, n_wait, bad = chk.check_kernel(sym, lines)
+        assert n_asm >= 80 and n_wait >= 20 and not bad, (sym, n_asm, n_wait, bad[:4])
+        # the same code with its first counted wait removed must be flagged (the parked element is read while in flight)
+        ks = [i for i, l in enumerate(lines) if "s_waitcnt vmcnt(12)" in l and "ASMSTART" in lines[i - 1]]
+        k = ks[len(ks) // 2]                               # (a wait in the steady state: the first one follows the Q loads' own wait)
+        broken = lines[:k] + lines[k + 1:]
+        assert chk.check_kernel(sym, broken)[2], sym

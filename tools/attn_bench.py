@@ -26,7 +26,7 @@ def time_mode(qkv, c, x6, reps=50):
 
 
 if __name__ == "__main__":
-    for n, c in [(256, 256), (128, 256), (64, 256), (256, 128)]:
+    for n, c in [(256, 256), (128, 256), (64, 256), (256, 128), (256, 64)]:
         qkv = torch.randn(n, 256, 3 * c, device="cuda")
         t32, t6 = time_mode(qkv, c, False), time_mode(qkv, c, True)
         fl = 4.0 * n * 256 * 256 * c
