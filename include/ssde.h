@@ -127,8 +127,10 @@ enum { SSDE_CONVF_V_GIVEN = 1u,      /* SSDE_TILE_WINOGRAD4R: wino_v already hol
        SSDE_CONVF_NO_GEMM_PIPE = 32u,/* 1x1 GEMM: never take it */
        SSDE_CONVF_X6_BM64 = 64u,     /* bf16x6 GEMM: 64 rows per workgroup instead of 128 */
        SSDE_CONVF_X6_PF2 = 128u,     /* bf16x6 GEMM: rows loaded two stages ahead instead of one */
-       SSDE_CONVF_NO_SMALL_COUT = 256u };/* 3x3 / stride 1 convolutions with at most four output channels (the image heads) on the general
+       SSDE_CONVF_NO_SMALL_COUT = 256u,/* 3x3 / stride 1 convolutions with at most four output channels (the image heads) on the general
                                           direct kernel instead of conv_small.hip (A/B runs, tests) */
+       SSDE_CONVF_X6_WIDE = 512u,    /* bf16x6 GEMM: force the 128 x 256 tile wherever c_out % 256 == 0 (default: where its workgroups fill the device) */
+       SSDE_CONVF_X6_NO_WIDE = 1024u };/* bf16x6 GEMM: never take it */
 enum { SSDE_TILE_AUTO = 0, SSDE_TILE_256x64 = 1, SSDE_TILE_128x64 = 2, SSDE_TILE_64x64 = 3, SSDE_TILE_256x32 = 4,
        /* Winograd F(2x2,3x3) kernel (3x3, stride 1, pad 1, even output, no aux): w_main must then be packed as
         * [ceil(Cin/8)][ceil(Cout/64)][16 positions][4 channel pairs][64 couts, bit 4 ^= pair parity][2], G g G^T */

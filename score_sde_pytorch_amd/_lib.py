@@ -18,7 +18,7 @@ TILE_WINOGRAD4R = 9       # (7, 8: the bf16-split and the LDS-fed F(4x4,3x3) ker
 TILES_WINOGRAD4 = (TILE_WINOGRAD4, TILE_WINOGRAD4R)
 # routing switches of a launch (include/ssde.h: SSDE_CONVF_*, SSDE_WGRADF_*, SSDE_GNBWDF_*)
 CONVF_V_GIVEN, CONVF_BF16X6, CONVF_NO_KSPLIT, CONVF_BKC8, CONVF_GEMM_PIPE, CONVF_NO_GEMM_PIPE, CONVF_X6_BM64, CONVF_X6_PF2, \
-    CONVF_NO_SMALL_COUT = 1, 2, 4, 8, 16, 32, 64, 128, 256
+    CONVF_NO_SMALL_COUT, CONVF_X6_WIDE, CONVF_X6_NO_WIDE = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024
 WGRADF_DIRECT, WGRADF_F2, WGRADF_F4_FORCE, WGRADF_NO_STREAMK, WGRADF_NO_XCD_ORDER, WGRADF_1X1_CHUNKED, WGRADF_XVEC1 = 1, 2, 4, 8, 16, 32, 64
 GNBWDF_THREE_KERNELS, GNBWDF_DEFER_PARAMS = 1, 2
 (OP_CONV, OP_GN_STATS, OP_UPFIRDN, OP_ATTN, OP_EMBED, OP_TO_NHWC, OP_TO_NCHW, OP_BIAS_ACT, OP_SUMSQ,
@@ -308,6 +308,10 @@ def conv_route_flags(env=None):
         f |= CONVF_X6_PF2
     if e.get("SSDE_CONV_SMALL", "1") == "0":
         f |= CONVF_NO_SMALL_COUT
+    if e.get("SSDE_X6_WIDE", "") == "1":
+        f |= CONVF_X6_WIDE
+    if e.get("SSDE_X6_WIDE", "") == "0":
+        f |= CONVF_X6_NO_WIDE
     return f
 
 

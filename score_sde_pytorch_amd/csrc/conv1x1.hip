@@ -256,17 +256,25 @@ __global__ __launch_bounds__(kThreads, SSDE_GEMM_OCC) void gemm1x1_kernel(const 
 //          stage earlier still -- a second register set and a loop unrolled by two, which costs a workgroup per CU of
 //          occupancy: hipcc needs ~190 / ~125 registers for it)
 // SSDE_X6_BM / SSDE_X6_PF pick the instantiation per call (A/B: tools/matrix_ab.py, profiles/r4_bf16x6_gemm_*.txt).
+//   kBN  = 128, or 256 (round 6, "wide": waves 2 x 2 of 64 x 128, 128 accumulator registers, 72 KB LDS, 2 workgroups per CU).
+//          With BN = 128 a 16-channel stage stages 4 float4 per thread (GroupNorm + split: ~140 VALU) for 24 MFMAs of a wave, and
+//          a layer with Cout = 768 normalises and splits its pixel rows six times; the wide tile stages 6 float4 for 48 MFMAs
+//          and reads 18 instead of 24 fragments per 48 MFMAs from LDS.
+#ifndef SSDE_X6_PF2_OCC_LOSS
+#define SSDE_X6_PF2_OCC_LOSS 1
+#endif
 constexpr int XBK = 16;
-template <int kBM> struct X6 {
-  static constexpr int kPlaneA = kBM * XBK * 2, kPlaneB = BN * XBK * 2;      // bytes of one piece plane
+template <int kBM, int kBN = 128> struct X6 {
+  static constexpr int kPlaneA = kBM * XBK * 2, kPlaneB = kBN * XBK * 2;     // bytes of one piece plane
   static constexpr int kStageBytes = 3 * kPlaneA + 3 * kPlaneB;
   static constexpr int NA = kBM / 64;                                        // 32-row blocks of a wave / staged rows per thread
+  static constexpr int NBW = kBN / 64;                                       // 32-column blocks of a wave / staged weight rows per thread
 };
 
-template <bool kGn, int kBM, int kPF>
-__global__ __launch_bounds__(kThreads, (kBM == 64 ? 4 : 3) - (kPF == 2 ? 1 : 0)) void gemm1x1_bf16x6_kernel(const GemmParams p) {
-  using X = X6<kBM>;
-  constexpr int NA = X::NA, NB = 2, RS = 64;
+template <bool kGn, int kBM, int kPF, int kBN = 128>
+__global__ __launch_bounds__(kThreads, kBN == 256 ? 2 : (kBM == 64 ? 4 : 3) - (kPF == 2 ? SSDE_X6_PF2_OCC_LOSS : 0)) void gemm1x1_bf16x6_kernel(const GemmParams p) {
+  using X = X6<kBM, kBN>;
+  constexpr int NA = X::NA, NB = X::NBW, NBW = X::NBW, RS = 64;
   SSDE_LDS(smem);
   char* lds = reinterpret_cast<char*>(smem);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -278,8 +286,8 @@ __global__ __launch_bounds__(kThreads, (kBM == 64 ? 4 : 3) - (kPF == 2 ? 1 : 0))
 #endif
   SSDE_GT(0);
   if (mt >= p.m_tiles) return;
-  const int m0 = mt * kBM, n0 = nt * BN;
-  const int wm0 = (wave >> 1) * (kBM / 2), wn0 = (wave & 1) * 64;
+  const int m0 = mt * kBM, n0 = nt * kBN;
+  const int wm0 = (wave >> 1) * (kBM / 2), wn0 = (wave & 1) * (kBN / 2);
   const ssde_src& s = p.src;
   SsdePro pro = ssde_pro_decode(s);
   pro.gn = kGn;
@@ -371,33 +379,39 @@ __global__ __launch_bounds__(kThreads, (kBM == 64 ? 4 : 3) - (kPF == 2 ? 1 : 0))
     }
   };
 
-  f32x16 acc[NA][2];
+  f32x16 acc[NA][NBW];
 #pragma unroll
   for (int a = 0; a < NA; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NBW; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   const int aoff = (wm0 + li) * (XBK * 2) + lh * 16, boff = 3 * X::kPlaneA + (wn0 + li) * (XBK * 2) + lh * 16;
-  // the 6 x NA x 2 MFMAs of a stage, term by term over the blocks: consecutive MFMAs never share an accumulator
+  // the 6 x NA x NBW MFMAs of a stage, term by term over the blocks of a column pair: consecutive MFMAs never share an
+  // accumulator; the weight fragments of one column pair at a time (12 registers per block: the wide tile would hold 48)
   auto mfma_stage = [&](const char* cur) __attribute__((always_inline)) {
-    ssde_u32x4 A[NA][3], B[2][3];
+    ssde_u32x4 A[NA][3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < 3; ++q)
 #pragma unroll
       for (int a = 0; a < NA; ++a) A[a][q] = *reinterpret_cast<const ssde_u32x4*>(cur + aoff + q * X::kPlaneA + a * 32 * (XBK * 2));
-#pragma unroll
-      for (int b = 0; b < 2; ++b) B[b][q] = *reinterpret_cast<const ssde_u32x4*>(cur + boff + q * X::kPlaneB + b * 32 * (XBK * 2));
-    }
     constexpr int TI[6] = {0, 2, 1, 0, 1, 0}, TJ[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int b0 = 0; b0 < NBW; b0 += 2) {
+      ssde_u32x4 B[2][3];
 #pragma unroll
-      for (int a = 0; a < NA; ++a)
+      for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ssde_bf16x8, A[a][TI[t]]),
-                                                              __builtin_bit_cast(ssde_bf16x8, B[b][TJ[t]]), acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 2; ++b) B[b][q] = *reinterpret_cast<const ssde_u32x4*>(cur + boff + q * X::kPlaneB + (b0 + b) * 32 * (XBK * 2));
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[a][b0 + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ssde_bf16x8, A[a][TI[t]]),
+                                                                     __builtin_bit_cast(ssde_bf16x8, B[b][TJ[t]]), acc[a][b0 + b], 0, 0, 0);
+    }
   };
 
   SSDE_GT(1);
@@ -425,14 +439,20 @@ __global__ __launch_bounds__(kThreads, (kBM == 64 ? 4 : 3) - (kPF == 2 ? 1 : 0))
     // needed before the end of stage st + 1 (two stage times of cover for their HBM latency); the loop is unrolled by two so
     // that both sets are compile-time names
     ARegs A0, A1;
+    // every load of the loop is UNCONDITIONAL (a stage index past the end is clamped to the last stage: a redundant L2 hit whose
+    // registers nobody parks): a load behind a guard is one hipcc's wait-count pass cannot rely on, and it then waits vmcnt(0/1)
+    // for the oldest set -- i.e. for the set it had just requested as well
+    const int last = nst - 1;
     load_a(0, A0); load_rest(0, R);
-    if (nst > 1) load_a(1, A1);
+    load_a(min(1, last), A1);
     store_stage(0, A0, R, buf0);
     __syncthreads();
     SSDE_GT(2);
     for (int st = 0; st < nst; st += 2) {
-      if (st + 2 < nst) load_a(st + 2, A0);
-      if (st + 1 < nst) load_rest(st + 1, R);
+      load_rest(min(st + 1, last), R);
+      __builtin_amdgcn_sched_barrier(0);          // (hipcc's scheduler would put the pixel rows' loads first again)
+      load_a(min(st + 2, last), A0);
+      __builtin_amdgcn_sched_barrier(0);
       mfma_stage(buf0);
       if (st < 8) SSDE_GT(4 + st * 4);
       if (st + 1 < nst) store_stage(st + 1, A1, R, buf1);
@@ -440,8 +460,10 @@ __global__ __launch_bounds__(kThreads, (kBM == 64 ? 4 : 3) - (kPF == 2 ? 1 : 0))
       __syncthreads();
       if (st < 8) SSDE_GT(6 + st * 4);
       if (st + 1 >= nst) break;
-      if (st + 3 < nst) load_a(st + 3, A1);
-      if (st + 2 < nst) load_rest(st + 2, R);
+      load_rest(min(st + 2, last), R);
+      __builtin_amdgcn_sched_barrier(0);
+      load_a(min(st + 3, last), A1);
+      __builtin_amdgcn_sched_barrier(0);
       mfma_stage(buf1);
       if (st + 1 < 8) SSDE_GT(4 + (st + 1) * 4);
       if (st + 2 < nst) store_stage(st + 2, A0, R, buf0);
@@ -453,13 +475,13 @@ __global__ __launch_bounds__(kThreads, (kBM == 64 ? 4 : 3) - (kPF == 2 ? 1 : 0))
   SSDE_GT(40);
 
   // epilogue: 64-row halves of the tile (kBM = 64: one) through the shared coalesced store
-  constexpr int LDT = BN + 4;
+  constexpr int LDT = kBN + 4;
   SsdeEpi e{p.bias, p.chan_add, p.chan_add_ld, p.resid, p.resid_post, p.scale, p.dst, p.Cout, p.gn_part};
 #pragma unroll
   for (int half = 0; half < kBM / 64; ++half) {
     if (kBM == 64 || (wave >> 1) == half) {
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < NBW; ++b)
 #pragma unroll
         for (int a = 0; a < NA; ++a)
 #pragma unroll
@@ -469,7 +491,7 @@ __global__ __launch_bounds__(kThreads, (kBM == 64 ? 4 : 3) - (kPF == 2 ? 1 : 0))
           }
     }
     __syncthreads();
-    ssde_store_tile<64, BN, kThreads, SSDE_GEMM_BATCH>(smem, LDT, n0, e, [&](int row, size_t& pix, int& img) {
+    ssde_store_tile<64, kBN, kThreads, SSDE_GEMM_BATCH>(smem, LDT, n0, e, [&](int row, size_t& pix, int& img) {
       const int m = m0 + half * 64 + row;
       if (m >= p.M) return false;
       pix = (size_t)m;
@@ -843,7 +865,12 @@ int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
     // VALU and the fp32 MFMAs share a datapath, and two workgroups per CU hide less than four -- so it is not taken there; with
     // the bf16 split it wins 9-10 % from 512 input or output channels up and loses up to 10 % below (the loop is too short for
     // the drain).  SSDE_CONVF_NO_GEMM_PIPE = never, SSDE_CONVF_GEMM_PIPE = always (tests), neither = this rule
-    const bool pays = x6 && (p.K >= 512 || a->c_out >= 512) && total > wgs;
+    // (round 6: from 512 output channels up the 128 x 256 tile of the plain kernel is ahead of it -- 256 -> 768 @16x16 with a
+    //  GroupNorm prologue 0.21-0.23 -> 0.17-0.18 ms, profiles/r6_gemm_wide_tile_ab.txt: the pixel rows are normalised and split
+    //  three times instead of six -- and level with it at 512 -> 256)
+    const bool wide_first = a->c_out >= 512 && a->c_out % 256 == 0 && !(a->flags & (SSDE_CONVF_X6_NO_WIDE | SSDE_CONVF_X6_BM64 | SSDE_CONVF_X6_PF2)) &&
+                            (long long)ssde_cdiv(p.M, 128) * (a->c_out / 256) >= 2ll * ssde_num_cus();
+    const bool pays = x6 && (p.K >= 512 || a->c_out >= 512) && total > wgs && !wide_first;
     // (round 5: the fp32 instantiation of the pipelined kernel is no longer built -- it lost everywhere)
     if (pipe_ok && x6 && (pays || (a->flags & SSDE_CONVF_GEMM_PIPE))) {
       const int lds = 2 * (x6 ? X6<128>::kStageBytes : kStage * 4) + 4 * kSlabFloats * 4;
@@ -865,13 +892,19 @@ int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
     }
   }
   // shape of the split kernel (see there): rows per workgroup and load-ahead depth; A/B-selectable per call
-  int xbm = 128, xpf = 1;
+  int xbm = 128, xpf = 1, xbn = BN;
   if (x6) {
     if (a->flags & SSDE_CONVF_X6_BM64) xbm = 64;
     if (a->flags & SSDE_CONVF_X6_PF2) xpf = 2;
+    // the wide tile (128 x 256): where the output channels fill it and its workgroups (two per CU) fill the device at least once
+    const bool wide_fits = a->c_out % 256 == 0 && xbm == 128 && xpf == 1;
+    const bool wide_pays = (long long)ssde_cdiv(p.M, 128) * (a->c_out / 256) >= 2ll * ssde_num_cus();
+    if (!(a->flags & SSDE_CONVF_X6_NO_WIDE) && wide_fits && (wide_pays || (a->flags & SSDE_CONVF_X6_WIDE))) xbn = 256;
     p.m_tiles = ssde_cdiv(p.M, xbm);
+    p.n_tiles = ssde_cdiv(a->c_out, xbn);
   }
-  const int lds_ops = x6 ? 2 * (xbm == 64 ? X6<64>::kStageBytes : X6<128>::kStageBytes) : 2 * kStage * 4, lds_epi = 64 * (BN + 4) * 4;
+  const int lds_ops = x6 ? 2 * (xbn == 256 ? X6<128, 256>::kStageBytes : xbm == 64 ? X6<64>::kStageBytes : X6<128>::kStageBytes) : 2 * kStage * 4;
+  const int lds_epi = 64 * (xbn + 4) * 4;
   const int lds = lds_ops > lds_epi ? lds_ops : lds_epi;
   if (lds_out) { *lds_out = lds; return SSDE_OK; }
   const dim3 grid(ssde_cdiv(p.m_tiles, 8) * 8 * p.n_tiles);
@@ -884,9 +917,10 @@ int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
     hipLaunchKernelGGL(kfn, grid, dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
     return true;
   };
-  static std::atomic<bool> set[10];
+  static std::atomic<bool> set[12];
   bool ok;
   if (!x6) ok = gn ? go(gemm1x1_kernel<true>, set[0]) : go(gemm1x1_kernel<false>, set[1]);
+  else if (xbn == 256) ok = gn ? go(gemm1x1_bf16x6_kernel<true, 128, 1, 256>, set[10]) : go(gemm1x1_bf16x6_kernel<false, 128, 1, 256>, set[11]);
   else if (xbm == 128 && xpf == 1) ok = gn ? go(gemm1x1_bf16x6_kernel<true, 128, 1>, set[2]) : go(gemm1x1_bf16x6_kernel<false, 128, 1>, set[3]);
   else if (xbm == 128) ok = gn ? go(gemm1x1_bf16x6_kernel<true, 128, 2>, set[4]) : go(gemm1x1_bf16x6_kernel<false, 128, 2>, set[5]);
   else if (xpf == 1) ok = gn ? go(gemm1x1_bf16x6_kernel<true, 64, 1>, set[6]) : go(gemm1x1_bf16x6_kernel<false, 64, 1>, set[7]);

@@ -585,8 +585,13 @@ extern "C" int ssde_conv2d(const ssde_conv_args* a, void* stream) {
   if (a) {
     if (ssde_wino_launcher fn = wino_launcher(a->tile)) {
       // the two-kernel forms: the input-transform pass into wino_v first, unless the caller says wino_v already holds it
-      if (a->tile == SSDE_TILE_WINOGRAD4R && !(a->flags & SSDE_CONVF_V_GIVEN))
+      if (a->tile == SSDE_TILE_WINOGRAD4R && !(a->flags & SSDE_CONVF_V_GIVEN)) {
+        // (the matrix kernel's launcher validates the arguments -- aux source, kernel size / stride / pad, map and channel limits,
+        //  V < 4 GB --: ask it in its plan-only form first, so that an invalid call enqueues nothing)
+        int lds = 0;
+        if (int rc = fn(a, nullptr, &lds)) return rc;
         if (int rc = ssde_wino4_xform_vq_launch(a, stream)) return rc;
+      }
       return fn(a, stream, nullptr);
     }
   }

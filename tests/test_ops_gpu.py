@@ -350,6 +350,27 @@ def test_conv1x1_gemm_kernel(n, h, c1, c2, cout, pro, extras, matrix, pipe, monk
     assert rel_err(nchw(y.cpu()), ref) < TOL_GEMM
 
 
+# rows per workgroup / load-ahead depth of the split kernel (SSDE_X6_BM, SSDE_X6_PF): the two-register-set loop issues every load
+# unconditionally with clamped stage indices -- odd and even stage counts, a ragged last stage, a single stage
+@pytest.mark.parametrize("bm,pf", [("128", "2"), ("64", "1"), ("64", "2")])
+@pytest.mark.parametrize("n,h,c1,c2,cout,pro,extras", [(3, 8, 40, 0, 96, 0, True), (1, 16, 32, 24, 200, 2, True), (2, 16, 64, 32, 256, 1, True),
+                                                       (5, 6, 8, 0, 130, 3, False), (2, 8, 16, 0, 128, 0, False)])
+def test_conv1x1_gemm_kernel_rows_and_load_ahead(n, h, c1, c2, cout, pro, extras, bm, pf, monkeypatch):
+    monkeypatch.setenv("SSDE_X6_BM", bm)
+    monkeypatch.setenv("SSDE_X6_PF", pf)
+    monkeypatch.setenv("SSDE_X6_WIDE", "0")
+    test_conv1x1_gemm_kernel(n, h, c1, c2, cout, pro, extras, "bf16x6", "0", monkeypatch)
+
+
+# the 128 x 256 tile of the split kernel (SSDE_X6_WIDE=1 forces it; it needs Cout % 256 == 0)
+@pytest.mark.parametrize("n,h,c1,c2,cout,pro,extras", [(3, 8, 40, 0, 256, 0, True), (1, 16, 32, 24, 512, 2, True),
+                                                       (2, 16, 64, 32, 256, 1, True), (5, 4, 64, 0, 256, 3, False),
+                                                       (16, 16, 256, 0, 768, 1, False), (9, 32, 128, 128, 256, 0, True)])
+def test_conv1x1_gemm_kernel_wide_tile(n, h, c1, c2, cout, pro, extras, monkeypatch):
+    monkeypatch.setenv("SSDE_X6_WIDE", "1")
+    test_conv1x1_gemm_kernel(n, h, c1, c2, cout, pro, extras, "bf16x6", "0", monkeypatch)
+
+
 # (n, h, w, cin1, cin2, cout, prologue, dropout): shapes that take the Winograd weight-gradient kernel (wgrad_wino.hip:
 # 3x3 / stride 1 / pad 1, h % 4 == 0, w % 8 == 0, channels % 64 == 0), with a virtual concat, every prologue, dropout
 WGRAD_WINO_CASES = [(1, 8, 8, 64, 0, 64, 0, 0.0), (2, 8, 16, 64, 0, 128, 3, 0.0), (3, 4, 8, 64, 64, 64, 2, 0.0),

@@ -60,6 +60,15 @@ def test_forward_winograd_f4x4_in_two_kernels(name, monkeypatch):
     test_forward_matches_reference_golden(name)
 
 
+@pytest.mark.parametrize("name", [n for n in CASES if "cifar" in n])
+def test_forward_with_the_wide_gemm_tile_forced(name, monkeypatch):
+    """SSDE_X6_WIDE=1: every 1x1 / NIN layer with Cout % 256 == 0 on the 128 x 256 tile of the split kernel (the production rule
+    takes it from 512 workgroups up, i.e. at bench sizes: test_bench_sizes_gpu.py) -- its GroupNorm partials feed the next layer"""
+    monkeypatch.setenv("SSDE_MATRIX", "bf16x6")
+    monkeypatch.setenv("SSDE_X6_WIDE", "1")
+    test_forward_matches_reference_golden(name)
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_forward_matches_reference_golden(name):
     path = os.path.join(_util.GOLDEN, name + ".npz")
