@@ -32,8 +32,21 @@ extern "C" int ssde_debug_gemm_trace(void* buf) {
   do {                                                                                 \
     if (gt_on) g_gemm_trace[(slot)] = __builtin_amdgcn_s_memtime();                    \
   } while (0)
+// every workgroup's start / end of loop / end (+ its hardware id): the rounds of a launch and how far they run in lock step
+__device__ unsigned long long* g_gemm_wg_trace;
+extern "C" int ssde_debug_gemm_wg_trace(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_wg_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -5;
+}
+#define SSDE_GW(slot)                                                                                          \
+  do {                                                                                                         \
+    if (threadIdx.x == 0 && g_gemm_wg_trace != nullptr) {                                                      \
+      g_gemm_wg_trace[(size_t)blockIdx.x * 4 + (slot)] = __builtin_amdgcn_s_memtime();                         \
+      if ((slot) == 0) g_gemm_wg_trace[(size_t)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32); \
+    }                                                                                                          \
+  } while (0)
 #else
 #define SSDE_GT(slot) do { } while (0)
+#define SSDE_GW(slot) do { } while (0)
 #endif
 
 // epilogue rows in flight per thread (12 registers each) and workgroups per CU the kernel is compiled for
@@ -286,6 +299,7 @@ __global__ __launch_bounds__(kThreads, kBN == 256 ? 2 : (kBM == 64 ? 4 : 3) - (k
 #endif
   SSDE_GT(0);
   if (mt >= p.m_tiles) return;
+  SSDE_GW(0);
   const int m0 = mt * kBM, n0 = nt * kBN;
   const int wm0 = (wave >> 1) * (kBM / 2), wn0 = (wave & 1) * (kBN / 2);
   const ssde_src& s = p.src;
@@ -473,6 +487,7 @@ __global__ __launch_bounds__(kThreads, kBN == 256 ? 2 : (kBM == 64 ? 4 : 3) - (k
     }
   }
   SSDE_GT(40);
+  SSDE_GW(1);
 
   // epilogue: 64-row halves of the tile (kBM = 64: one) through the shared coalesced store
   constexpr int LDT = kBN + 4;
@@ -502,6 +517,7 @@ __global__ __launch_bounds__(kThreads, kBN == 256 ? 2 : (kBM == 64 ? 4 : 3) - (k
     __syncthreads();
     SSDE_GT(42 + half * 2);
   }
+  SSDE_GW(2);
 }
 
 // ---- persistent, software-pipelined form (SSDE_GEMM_PIPE) -----------------------------------------------------------

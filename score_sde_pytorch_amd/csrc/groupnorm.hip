@@ -134,9 +134,8 @@ __global__ __launch_bounds__(256) void gn_part_finalize_kernel(const GnFinParams
   float cnt, m, M2;
   ssde_gn_merge16(p.part0, p.part1, p.c0, p.c1, p.s0, p.s1, p.groups, n, g, l16, cnt, m, M2);
   if (l16 == 0 && idx < tot) {
-    const float var = cnt > 0.f ? M2 / cnt : 0.f;
     p.mean[idx] = m;
-    p.rstd[idx] = 1.0f / sqrtf(var + p.eps);
+    p.rstd[idx] = ssde_gn_rstd(cnt, M2, p.eps);
   }
 }
 

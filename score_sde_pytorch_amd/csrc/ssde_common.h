@@ -256,7 +256,12 @@ struct SsdeEpi {
 };
 
 // Chan's pairwise merge of (count, mean, M2 = sum of squared deviations); exact for n_b == 0
+// (no contraction inside: the same merge is inlined into several kernels -- the finalize launch, the transform pass that merges for
+//  itself, the producers' epilogues -- and "bit-identical whoever merges" holds only if hipcc does not fuse a multiply-add in one
+//  of them and not in the other, which -ffp-contract=fast decides per call site; a clean build of round 6's sources showed it:
+//  test_groupnorm_statistics_merged_by_the_transform_pass on the GPU)
 __device__ __forceinline__ void ssde_stat_merge(float& n, float& m, float& M2, float nb, float mb, float M2b) {
+#pragma clang fp contract(off)
   const float nt = n + nb;
   const float d = mb - m;
   const float f = nt > 0.f ? nb * __builtin_amdgcn_rcpf(nt) : 0.f;      // counts are small integers: ~1 ulp is plenty
@@ -316,6 +321,12 @@ __device__ __forceinline__ void ssde_gn_merge16_finish(const SsdeGnTeam& t, int 
     if (l16 & o) { float tn = nb, tm = mb, tM = Mb; ssde_stat_merge(tn, tm, tM, cnt, m, M2); cnt = tn; m = tm; M2 = tM; }
     else ssde_stat_merge(cnt, m, M2, nb, mb, Mb);
   }
+}
+// (mean, M2, count) of a group -> rstd, by whoever merged (same reason: one function, no contraction)
+__device__ __forceinline__ float ssde_gn_rstd(float cnt, float M2, float eps) {
+#pragma clang fp contract(off)
+  const float var = cnt > 0.f ? M2 / cnt : 0.f;
+  return 1.0f / sqrtf(var + eps);
 }
 __device__ __forceinline__ void ssde_gn_merge16(const float* part0, const float* part1, int c0, int c1, int s0, int s1, int groups,
                                                 int n, int g, int l16, float& cnt, float& m, float& M2) {

@@ -113,8 +113,7 @@ __global__ __launch_bounds__(256, 2) void wino4_xform_vq_kernel(const XformVqPar
       if (pr0 == 0) ssde_gn_merge16_finish(team0, l16, cnt, m, M2);
       else ssde_gn_merge16(p.part0, p.part1, s.c0, s.c1, p.s0, p.s1, s.gn_groups, n, g, l16, cnt, m, M2);
       if (l16 == 0 && pr0 + team < npairs) {
-        const float var = cnt > 0.f ? M2 / cnt : 0.f;
-        const float r = 1.0f / sqrtf(var + p.eps);
+        const float r = ssde_gn_rstd(cnt, M2, p.eps);
         tab[2 * pr] = m; tab[2 * pr + 1] = r;
         if (n * per_img >= t0) {                      // the image's first tile is one of this workgroup's
           const_cast<float*>(s.gn_mean)[n * s.gn_groups + g] = m;

@@ -26,6 +26,7 @@ def time_gemm(n, h, k, cout, tile=L.TILE_AUTO, resid=False, reps=10):
     a.n, a.h_out, a.w_out, a.c_out, a.out_scale, a.dst, a.tile = n, h, h, cout, 1.0, dst.data_ptr(), tile
     if resid:
         a.resid = r.data_ptr()
+    a.flags = L.conv_route_flags()
     lib = L.load()
     st = ops._stream()
     L.check(lib.ssde_conv2d(C.byref(a), st))
