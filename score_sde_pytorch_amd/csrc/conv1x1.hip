@@ -912,6 +912,10 @@ int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
   if (x6) {
     if (a->flags & SSDE_CONVF_X6_BM64) xbm = 64;
     if (a->flags & SSDE_CONVF_X6_PF2) xpf = 2;
+    // launches whose 128-row tiles would not give every CU a workgroup (the 8x8 and 4x4 maps with 256 output channels, the temb
+    // projections [batch, 512] x [512, 9984]): 64 rows -- twice the workgroups, four per CU.  512 -> 256 @8x8 at batch 256:
+    // 0.044-0.047 -> 0.037-0.038 ms (profiles/r6_gemm_wide_tile_ab.txt)
+    if ((long long)ssde_cdiv(p.M, 128) * ssde_cdiv(a->c_out, BN) <= ssde_num_cus() && !(a->flags & SSDE_CONVF_X6_WIDE)) xbm = 64;
     // the wide tile (128 x 256): where the output channels fill it and its workgroups (two per CU) fill the device at least once
     const bool wide_fits = a->c_out % 256 == 0 && xbm == 128 && xpf == 1;
     const bool wide_pays = (long long)ssde_cdiv(p.M, 128) * (a->c_out / 256) >= 2ll * ssde_num_cus();

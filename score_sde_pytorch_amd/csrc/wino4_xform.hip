@@ -17,12 +17,18 @@ namespace {
 // a load instruction reads 64 contiguous bytes (4 quads) of 16 pixels.  HBM-bound: x read ~2.25x through the tile overlap (L2),
 // V written once.
 // GroupNorm statistics merged by the pass itself (ssde_conv_args.gn_in_part0, ABI 10): a workgroup covers 16 tiles -- part of
-// one image, or up to four whole ones on the 8x8 maps -- and 16 channel quads, i.e. at most 4 x 16 (image, group) pairs.  While
-// its 36 pixel loads per thread are in flight, teams of 16 lanes merge the producers' partials of those pairs (ssde_gn_merge16,
-// the finalize kernel's function: the same bits) into an LDS table the threads then read their (mean, rstd) from; the workgroup
-// whose tiles hold an image's first tile also writes them to src.gn_mean / gn_rstd for the backward pass of a training program.
-// The merge costs a few KB of L2 reads per workgroup (147 KB in, 147 KB out otherwise) and one LDS barrier under the loads;
-// what it removes is a launch of 6-9 us in front of every pass (64 of the 95 per U-Net evaluation).
+// one image, or up to four whole ones on the 8x8 maps -- and 16 channel quads, i.e. at most 4 x 16 (image, group) pairs.  A
+// merging workgroup does it FIRST: its sixteen teams of 16 lanes merge the producers' partials of those pairs (ssde_gn_merge16,
+// the finalize kernel's function: the same bits) into an LDS table -- one trip of ~0.5 us on the 16x16 and 32x32 maps --, then
+// every thread requests its 36 pixels and reads its (mean, rstd) from the table behind one LDS barrier, the pixels in flight.
+// (Round 6's first form requested the partials before the pixels and merged while the pixels were in flight: a team's twelve
+// partials and its index arithmetic were live across the 144 registers of pixels, the kernel went from 2 to 41 spilled
+// registers, and the pass paid back what the launches had cost -- profiles/r6_gn_merge_in_transform_pass_ab.txt.  A fifth wave
+// that only merges would halve the occupancy: five waves of 256 registers do not fit a CU twice.)  The workgroup whose tiles hold
+// an image's first tile also writes the
+// statistics to src.gn_mean / gn_rstd for the backward pass of a training program.  The merge costs a few KB of L2 reads per
+// workgroup (147 KB in, 147 KB out otherwise); what it removes is a launch of 6-9 us in front of every pass (59 of the 95 per
+// U-Net evaluation).
 struct XformVqParams {
   ssde_src src; float* v;
   int N, H, W, Ctot, T, tiles_h, tiles_w;
@@ -43,21 +49,50 @@ __device__ __forceinline__ void bt6q(const float4 (&d)[6], float4 (&o)[6]) {
 #undef SSDE_BT6_LANE
 }
 
-template <bool kGn>
-__global__ __launch_bounds__(256, 2) void wino4_xform_vq_kernel(const XformVqParams p) {
+constexpr int kXfThreads = 256;
+
+template <bool kGn, bool kMerge>
+__global__ __launch_bounds__(kXfThreads, 2) void wino4_xform_vq_kernel(const XformVqParams p) {
+  static_assert(kGn || !kMerge, "only a GroupNorm prologue has statistics to merge");
   const ssde_src& s = p.src;
   SsdePro pro = ssde_pro_decode(s);
   pro.gn = kGn;
   const int Q = p.Ctot >> 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per_img = p.tiles_h * p.tiles_w;
+  const int cpg = kGn ? p.Ctot / s.gn_groups : 4;     // (cpg % 4 == 0: a quad lies in one group)
+  // the pairs of this workgroup: images of tiles 16 bx .. 16 bx + 15, groups of quads 16 by .. 16 by + 15
+  const int t0 = blockIdx.x * 16, t1 = min(t0 + 15, p.T - 1);
+  const int img_lo = t0 / per_img;
+  const int qa = blockIdx.y * 16, qb = min(qa + 15, Q - 1);
+  const int g_lo = (qa * 4) / cpg, ng = (qb * 4) / cpg - g_lo + 1;
+  if constexpr (kMerge) {
+    SSDE_LDS(tab);
+    const int team = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+    const int npairs = (t1 / per_img - img_lo + 1) * ng;            // <= kXfPairs
+    for (int pr0 = 0; pr0 < npairs; pr0 += 16) {                    // (uniform trip count; a team beyond the end repeats the last pair)
+      const int pr = min(pr0 + team, npairs - 1);
+      const int il = pr / ng;
+      const int n = img_lo + il, g = g_lo + (pr - il * ng);
+      float cnt, m, M2;
+      ssde_gn_merge16(p.part0, p.part1, s.c0, s.c1, p.s0, p.s1, s.gn_groups, n, g, l16, cnt, m, M2);
+      if (l16 == 0 && pr0 + team < npairs) {
+        const float r = ssde_gn_rstd(cnt, M2, p.eps);
+        tab[2 * pr] = m; tab[2 * pr + 1] = r;
+        if (n * per_img >= t0) {                      // the image's first tile is one of this workgroup's
+          const_cast<float*>(s.gn_mean)[n * s.gn_groups + g] = m;
+          const_cast<float*>(s.gn_rstd)[n * s.gn_groups + g] = r;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                // (the pixel loads stay behind the merge: nothing of it is live across them)
+  }
   const int t_raw = blockIdx.x * 16 + (lane & 15);
   const int q_raw = (blockIdx.y * 4 + wave) * 4 + (lane >> 4);
   const bool valid = t_raw < p.T && q_raw < Q;
-  const bool merging = kGn && p.part0 != nullptr;
-  if (!merging && !valid) return;                 // (a merging workgroup keeps whole waves: the teams' shuffles and the barrier)
+  if (!kMerge && !valid) return;                  // (the waves of a merging workgroup all reach its barrier)
   const int t = valid ? t_raw : 0, q = valid ? q_raw : 0;
   const int c = q * 4;
-  const int per_img = p.tiles_h * p.tiles_w;
   const int img = t / per_img, r = t - img * per_img;
   const int ty = r / p.tiles_w, tx = r - ty * p.tiles_w;
   const bool second = c >= s.c0;                      // (c0 % 4 == 0: a quad never straddles the sources)
@@ -65,34 +100,13 @@ __global__ __launch_bounds__(256, 2) void wino4_xform_vq_kernel(const XformVqPar
   const int C = second ? s.c1 : s.c0;
   float mu = 0.f, rs = 1.f;
   float4 ga = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int cpg = kGn ? p.Ctot / s.gn_groups : 4;     // (cpg % 4 == 0: a quad lies in one group)
   if (kGn) {
-    if (!merging) {
+    if (!kMerge) {
       mu = s.gn_mean[img * s.gn_groups + c / cpg];
       rs = s.gn_rstd[img * s.gn_groups + c / cpg];
     }
     ga = *reinterpret_cast<const float4*>(s.gn_gamma + c);
     be = *reinterpret_cast<const float4*>(s.gn_beta + c);
-  }
-  // the pairs of this workgroup: images of tiles 16 bx .. 16 bx + 15, groups of quads 16 by .. 16 by + 15
-  const int t0 = blockIdx.x * 16, t1 = min(t0 + 15, p.T - 1);
-  const int img_lo = t0 / per_img, n_img = t1 / per_img - img_lo + 1;
-  const int qa = blockIdx.y * 16, qb = min(qa + 15, Q - 1);
-  const int g_lo = (qa * 4) / cpg, ng = (qb * 4) / cpg - g_lo + 1;
-  const int team = threadIdx.x >> 4, l16 = threadIdx.x & 15;
-  const int npairs = n_img * ng;                      // <= kXfPairs
-  auto pair_of = [&](int pr0, int& pr, int& n, int& g) {        // (a team beyond the end repeats the last pair)
-    pr = min(pr0 + team, npairs - 1);
-    const int il = pr / ng;
-    n = img_lo + il; g = g_lo + (pr - il * ng);
-  };
-  // the partials of the first 16 pairs are requested BEFORE the pixels (loads return in order: a merge whose loads followed the
-  // 36 pixel loads of the thread would wait for all of them) and merged while the pixels are in flight
-  SsdeGnTeam team0;
-  if constexpr (kGn) if (merging) {
-    int pr, n, g;
-    pair_of(0, pr, n, g);
-    ssde_gn_merge16_load(team0, p.part0, p.part1, s.c0, s.c1, p.s0, p.s1, s.gn_groups, n, g, l16);
   }
   float4 v[6][6];
 #pragma unroll
@@ -104,23 +118,8 @@ __global__ __launch_bounds__(256, 2) void wino4_xform_vq_kernel(const XformVqPar
       const int pix = (img * p.H + (inb ? iy : 0)) * p.W + (inb ? ix : 0);
       v[a][b] = *reinterpret_cast<const float4*>(base + (size_t)pix * C);
     }
-  if constexpr (kGn) if (merging) {
+  if constexpr (kMerge) {
     SSDE_LDS(tab);
-    for (int pr0 = 0; pr0 < npairs; pr0 += 16) {     // (uniform trip count)
-      int pr, n, g;
-      pair_of(pr0, pr, n, g);
-      float cnt, m, M2;
-      if (pr0 == 0) ssde_gn_merge16_finish(team0, l16, cnt, m, M2);
-      else ssde_gn_merge16(p.part0, p.part1, s.c0, s.c1, p.s0, p.s1, s.gn_groups, n, g, l16, cnt, m, M2);
-      if (l16 == 0 && pr0 + team < npairs) {
-        const float r = ssde_gn_rstd(cnt, M2, p.eps);
-        tab[2 * pr] = m; tab[2 * pr + 1] = r;
-        if (n * per_img >= t0) {                      // the image's first tile is one of this workgroup's
-          const_cast<float*>(s.gn_mean)[n * s.gn_groups + g] = m;
-          const_cast<float*>(s.gn_rstd)[n * s.gn_groups + g] = r;
-        }
-      }
-    }
     SSDE_LDS_BARRIER();                               // (LDS only: the pixel loads stay in flight)
     if (!valid) return;
     const int pr = (img - img_lo) * ng + (c / cpg - g_lo);
@@ -191,8 +190,9 @@ int ssde_wino4_xform_vq_launch(const ssde_conv_args* a, void* stream) {
   }
   const dim3 grid(ssde_cdiv(p.T, 16), ssde_cdiv(p.Ctot >> 2, 16));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (gn) hipLaunchKernelGGL(wino4_xform_vq_kernel<true>, grid, dim3(256), p.part0 ? kXfPairs * 2 * sizeof(float) : 0, st, p);
-  else hipLaunchKernelGGL(wino4_xform_vq_kernel<false>, grid, dim3(256), 0, st, p);
+  if (gn && p.part0) hipLaunchKernelGGL((wino4_xform_vq_kernel<true, true>), grid, dim3(kXfThreads), kXfPairs * 2 * sizeof(float), st, p);
+  else if (gn) hipLaunchKernelGGL((wino4_xform_vq_kernel<true, false>), grid, dim3(kXfThreads), 0, st, p);
+  else hipLaunchKernelGGL((wino4_xform_vq_kernel<false, false>), grid, dim3(kXfThreads), 0, st, p);
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;
 }

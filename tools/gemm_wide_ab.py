@@ -57,7 +57,8 @@ if __name__ == "__main__":
                 ("default", dict(SSDE_X6_WIDE="", SSDE_GEMM_PIPE="", SSDE_X6_BM="", SSDE_X6_PF="")))
     for h, k, cout, gn, res in [(16, 256, 768, True, False), (16, 256, 768, False, False), (16, 256, 256, False, True), (16, 512, 256, False, True),
                                 (16, 384, 256, False, True), (32, 256, 256, False, True), (8, 512, 256, False, True), (8, 256, 768, True, False),
-                                (32, 256, 128, False, True), (32, 384, 128, False, True), (16, 128, 256, False, True)]:
+                                (32, 256, 128, False, True), (32, 384, 128, False, True), (16, 128, 256, False, True), (1, 512, 9984, False, False), (1, 512, 512, False, False),
+                                (8, 256, 256, False, True), (4, 256, 256, False, True), (4, 256, 768, True, False)]:
         x = torch.randn(n, h, h, k, device="cuda") * (1 + torch.rand(1, 1, 1, k, device="cuda") * 3)
         w = torch.randn(cout, k, device="cuda") / np.sqrt(k)
         resid = torch.randn(n, h, h, cout, device="cuda") if res else None
