@@ -886,7 +886,10 @@ int ssde_conv1x1_launch(const ssde_conv_args* a, void* stream, int* lds_out) {
     //  three times instead of six -- and level with it at 512 -> 256)
     const bool wide_first = a->c_out >= 512 && a->c_out % 256 == 0 && !(a->flags & (SSDE_CONVF_X6_NO_WIDE | SSDE_CONVF_X6_BM64 | SSDE_CONVF_X6_PF2)) &&
                             (long long)ssde_cdiv(p.M, 128) * (a->c_out / 256) >= 2ll * ssde_num_cus();
-    const bool pays = x6 && (p.K >= 512 || a->c_out >= 512) && total > wgs && !wide_first;
+    // (the REAL tiles decide, not the grid padded to the 8 XCDs, and 512 output channels alone no longer do: where the wide tile
+    //  does not fill the device the plain kernel is ahead -- the temb projections [256, 512] x [512, 9984], 2 x 78 tiles, took this
+    //  kernel through the padded count and 0.088 instead of 0.046 ms; 256 -> 768 @8x8 0.062 against 0.052)
+    const bool pays = x6 && p.K >= 512 && (long long)p.m_tiles * p.n_tiles > wgs && !wide_first;
     // (round 5: the fp32 instantiation of the pipelined kernel is no longer built -- it lost everywhere)
     if (pipe_ok && x6 && (pays || (a->flags & SSDE_CONVF_GEMM_PIPE))) {
       const int lds = 2 * (x6 ? X6<128>::kStageBytes : kStage * 4) + 4 * kSlabFloats * 4;
