@@ -92,7 +92,11 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const ssde_colsum_fi
   if ((int)blockIdx.x * 32 >= j.c) return;               // (uniform per block: the grid is as wide as the widest job)
   const int jl = threadIdx.x & 31, nl = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + jl;
+  // (four samples of a lane at a time: their loads are independent and go out together -- as one sample per trip the 16 trips x
+  //  `slices` loads of a lane at batch 128 were one chain of L2 latencies, 52 us per launch, 9 launches per training step --;
+  //  every sample still sums its slices in order and the lane its samples in order: the same bits)
   float s = 0.f;
+#if defined(SSDE_COLSUM_FINISH_SERIAL) && SSDE_COLSUM_FINISH_SERIAL       // (an A/B variant only: the loop of rounds 4-5)
   if (col < j.c)
     for (int i = nl; i < j.n; i += 8) {
       const float* p = j.part + (size_t)i * j.slices * j.c + col;
@@ -101,6 +105,30 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const ssde_colsum_fi
       if (j.per_sample) j.per_sample[(size_t)i * j.ps_ld + j.ps_off + col] = t;
       s += t;
     }
+#else
+  if (col < j.c)
+    for (int i0 = nl; i0 < j.n; i0 += 32) {
+      float t[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* p[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) p[k] = j.part + (size_t)min(i0 + 8 * k, j.n - 1) * j.slices * j.c + col;
+      for (int sl = 0; sl < j.slices; ++sl) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = p[k][(size_t)sl * j.c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] += v[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + 8 * k;
+        if (i < j.n) {
+          if (j.per_sample) j.per_sample[(size_t)i * j.ps_ld + j.ps_off + col] = t[k];
+          s += t[k];
+        }
+      }
+    }
+#endif
   if (!j.total) return;
   smem[nl * 32 + jl] = s;
   __syncthreads();

@@ -135,6 +135,14 @@ def check_backward_ops(dev):
                 ops.colsum(d(gg), scale=0.7, per_sample=per3, ps_off=60, defer=True)]
         ops.colsum_finish(jobs)
         assert torch.equal(perd, per) and torch.equal(totd, tot) and torch.equal(tot1d, tot1)
+        # 37 samples: a sample lane of the finishing kernel owns five of them (four per trip of its loop, then one)
+        gm = torch.randn(37, 8, 8, 12, generator=g)
+        perm, totm = torch.zeros(37, 12, device=dev), torch.zeros(12, device=dev)
+        ops.colsum(d(gm), scale=1.1, per_sample=perm, total=totm)
+        permd, totmd = torch.zeros(37, 12, device=dev), torch.zeros(12, device=dev)
+        ops.colsum_finish([ops.colsum(d(gm), scale=1.1, per_sample=permd, total=totmd, defer=True)])
+        assert torch.equal(permd, perm) and torch.equal(totmd, totm)
+        assert rel_err(totm, 1.1 * gm.sum((0, 1, 2))) < TOL_OP
         per3r, tot3r = torch.zeros(3, 100, device=dev), torch.zeros(40, device=dev)
         ops.colsum(d(gg), scale=0.7, per_sample=per3r, ps_off=20, total=tot3r)
         ops.colsum(d(gg), scale=0.7, per_sample=per3r, ps_off=60)
