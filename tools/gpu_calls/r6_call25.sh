@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, call 25: the final sources -- the whole GPU suite, smoke, the default bench line (the driver's command), the per-launch
+# round 6, call 25 (and again as call 28 on the very last sources): the final sources -- the whole GPU suite, smoke, the default bench line (the driver's command), the per-launch
 # list of one evaluation, rocprofv3 kernel stats + PMC passes
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
