@@ -529,6 +529,38 @@ def check_unet_grads(kind, dev, cfg=None, batch=2):
     return compare_param_grads(model, eng.flat, ref)
 
 
+def check_deferred_finish_is_bit_identical(dev, monkeypatch, kind="ncsnpp"):
+    """SSDE_DEFER_FINISH=1 (default: bias / temb / dgamma / dbeta gradients left as partials and finished 16 jobs per launch,
+    flushed where a reader needs them) against =0 (every call finishes itself): two TrainEngines over the same weights, the
+    same forward and backward -- every gradient of the flat buffer and the input gradient bit for bit."""
+    from score_sde_pytorch_amd.models import utils as mutils
+    from score_sde_pytorch_amd import backward as B, _lib as L
+    cfg = small_cfg(kind)
+    torch.manual_seed(0)
+    model = mutils.get_model("ncsnpp")(cfg)
+    _util.load_seeded(model, seed=1)
+    model = model.to(dev)
+    R, batch = cfg.data.image_size, 3
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(batch, 3, R, R, generator=g) * 2
+    cond = torch.exp(torch.rand(batch, generator=g) * 4 - 2) if cfg.model.embedding_type == "fourier" \
+        else torch.rand(batch, generator=g) * 900 + 50
+    gout = torch.randn(batch, 3, R, R, generator=g)
+    grads, gxs, kinds = {}, {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SSDE_DEFER_FINISH", mode)
+        eng = B.TrainEngine(model, batch, R, R, torch.device(dev), input_grad=True, dropout=False)
+        prog = eng.program
+        kinds[mode] = [int(prog.ops[i].kind) for i in range(prog.n)]
+        eng.forward_train(x.to(dev), cond.to(dev))
+        eng.backward(gout.to(dev))
+        grads[mode] = eng.flat.grad.detach().cpu().clone()
+        gxs[mode] = eng.gx_view().cpu().clone()
+    assert kinds["1"].count(L.OP_COLSUM_FINISH) > 0 and kinds["0"].count(L.OP_COLSUM_FINISH) == 0, "the two forms must differ"
+    assert torch.isfinite(grads["1"]).all() and float(grads["1"].abs().max()) > 0
+    assert torch.equal(grads["1"], grads["0"]) and torch.equal(gxs["1"], gxs["0"])
+
+
 def check_wino_v_from_forward(dev, monkeypatch, dropout=False):
     """The F(4x4,3x3) weight gradient fed by the forward launch's by-product (ssde_conv_args.wino_v -> ssde_wgrad_args.v_pre,
     conv_wino4.hip kEmitV): with every legal 3x3 layer on the F(4x4,3x3) kernels, forward and weight gradient, the training

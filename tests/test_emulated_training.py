@@ -190,3 +190,8 @@ def test_conv3x3_winograd_f4x4_matrix_kernel_persistent_workgroups(monkeypatch):
 
 def test_winograd_f4x4_weight_gradient_with_the_stream_k_split():
     T.check_wgrad_wino4_streamk("cpu")
+
+
+@pytest.mark.parametrize("kind", ["ncsnpp", "ddpmpp"])
+def test_deferred_finishing_launches_are_bit_identical(kind, monkeypatch):
+    T.check_deferred_finish_is_bit_identical("cpu", monkeypatch, kind)

@@ -203,3 +203,8 @@ def test_whole_network_gradients_winograd_f4x4_in_two_kernels(monkeypatch):
 
 def test_winograd_f4x4_weight_gradient_with_the_stream_k_split():
     T.check_wgrad_wino4_streamk("cuda", big=True)
+
+
+@pytest.mark.parametrize("kind", ["ncsnpp", "ddpmpp"])
+def test_deferred_finishing_launches_are_bit_identical(kind, monkeypatch):
+    T.check_deferred_finish_is_bit_identical("cuda", monkeypatch, kind)
