@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SSDE_ABI_VERSION 10  /* 10: ssde_conv_args.gn_in_part0 / gn_in_part1 / gn_in_slices0 / gn_in_slices1 / gn_in_eps (the consuming launch merges the GroupNorm partials of its main source itself: no ssde_gn_finalize launch in front of it), ssde_gn_finalize merges with teams of 16 lanes, ssde_attn_args.flags (SSDE_ATTNF_BF16X6); 9: SSDE_CONVF_NO_SMALL_COUT (3x3 convolutions onto at most four channels have their own kernel, conv_small.hip), the register-fed F(4x4,3x3) matrix kernel splits its reduction (no interface change); 8: routing switches moved from environment variables into ssde_conv_args.flags / ssde_wgrad_args.flags / ssde_gn_bwd_reduce_args.flags, SSDE_TILE_WINOGRAD4R + SSDE_PACK_WINO4R (register-fed F(4x4,3x3) matrix kernel), SSDE_TILE_WINOGRAD4X removed; 7: ssde_gn_bwd_reduce_args.g0 / g1 (GroupNorm backward in one pass over dp and x); 6: ssde_conv_args.wino_v / ssde_wgrad_args.v_pre (forward by-product feeds the weight gradient); 5: SSDE_PACK_WINO4 image re-ordered per wave (plan blobs of version 4 carry the old image), ODE ops in programs */
+#define SSDE_ABI_VERSION 10  /* (still 10, no layout change: SSDE_CONVF_X6_WIDE / SSDE_CONVF_X6_NO_WIDE -- the 128 x 256 tile of the bf16x6 GEMM -- are new routing flags old callers never set) 10: ssde_conv_args.gn_in_part0 / gn_in_part1 / gn_in_slices0 / gn_in_slices1 / gn_in_eps (the consuming launch merges the GroupNorm partials of its main source itself: no ssde_gn_finalize launch in front of it), ssde_gn_finalize merges with teams of 16 lanes, ssde_attn_args.flags (SSDE_ATTNF_BF16X6); 9: SSDE_CONVF_NO_SMALL_COUT (3x3 convolutions onto at most four channels have their own kernel, conv_small.hip), the register-fed F(4x4,3x3) matrix kernel splits its reduction (no interface change); 8: routing switches moved from environment variables into ssde_conv_args.flags / ssde_wgrad_args.flags / ssde_gn_bwd_reduce_args.flags, SSDE_TILE_WINOGRAD4R + SSDE_PACK_WINO4R (register-fed F(4x4,3x3) matrix kernel), SSDE_TILE_WINOGRAD4X removed; 7: ssde_gn_bwd_reduce_args.g0 / g1 (GroupNorm backward in one pass over dp and x); 6: ssde_conv_args.wino_v / ssde_wgrad_args.v_pre (forward by-product feeds the weight gradient); 5: SSDE_PACK_WINO4 image re-ordered per wave (plan blobs of version 4 carry the old image), ODE ops in programs */
 
 /* ---- prologue applied to a source tensor while it is staged into LDS ---- */
 enum {
