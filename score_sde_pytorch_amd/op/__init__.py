@@ -66,15 +66,39 @@ class FusedLeakyReLUFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_output):
         (out,) = ctx.saved_tensors
-        slope, scale, channels, inner = ctx.cfg
-        grad_input = hipops.fused_bias_act(grad_output.contiguous(), None, act=3, alpha=slope, scale=scale, grad=1, ref=out)
-        dims = [0] + list(range(2, grad_input.dim()))
-        n, hw = grad_input.shape[0], inner
+        grad_input, grad_bias = FusedLeakyReLUBackward.apply(grad_output, out, ctx.cfg)
+        return grad_input, grad_bias, None, None
+
+
+class FusedLeakyReLUBackward(torch.autograd.Function):
+    """The gradient of fused_leaky_relu as a differentiable op of its own (op/fused_act.py:20-51: gradient penalties
+    differentiate through it).  Both directions are the same device kernel in gradient mode: the slope is chosen by the sign
+    of the saved forward output, so the map grad_output -> grad_input is linear and its adjoint is itself (plus the bias
+    broadcast, whose adjoint is the per-channel sum)."""
+
+    @staticmethod
+    def forward(ctx, grad_output, out, cfg):
+        slope, scale, channels, inner = cfg
+        ctx.save_for_backward(out)
+        ctx.cfg = cfg
+        grad_input = hipops.fused_bias_act(grad_output.contiguous().float(), None, act=3, alpha=slope, scale=scale, grad=1, ref=out)
+        n = grad_input.shape[0]
         # grad_bias = grad_input summed over every dim but the channel one (op/fused_act.py:33-38): column sums in NHWC
-        g = hipops.to_nhwc(grad_input.reshape(n, channels, hw, 1), c_pad=(channels + 3) // 4 * 4)
+        g = hipops.to_nhwc(grad_input.reshape(n, channels, inner, 1), c_pad=(channels + 3) // 4 * 4)
         total = torch.zeros(channels, device=g.device)
         hipops.colsum(g, c=channels, total=total)
-        return grad_input, total, None, None
+        return grad_input, total
+
+    @staticmethod
+    def backward(ctx, gradgrad_input, gradgrad_bias):
+        (out,) = ctx.saved_tensors
+        slope, scale, channels, inner = ctx.cfg
+        if gradgrad_input is None:
+            gradgrad_input = torch.zeros_like(out)
+        bias = gradgrad_bias.contiguous().float() if gradgrad_bias is not None else None
+        gradgrad_out = hipops.fused_bias_act(gradgrad_input.contiguous().float(), bias, channels=channels, inner=inner, act=3,
+                                             alpha=slope, scale=scale, grad=1, ref=out)
+        return gradgrad_out, None, None
 
 
 def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):

@@ -882,6 +882,18 @@ def check_op_package(dev):
     y = op.fused_leaky_relu(xd, bd)
     y.backward(go.to(dev))
     assert rel_err(y.detach(), ref.detach()) < 2e-6 and rel_err(xd.grad, xr.grad) < 2e-6 and rel_err(bd.grad, br.grad) < 2e-6
+    # double backward (op/fused_act.py:20-51: a penalty on the gradient differentiates through the gradient op)
+    w1, w2 = torch.randn(x.shape, generator=g), torch.randn(5, generator=g)
+    outs = []
+    for which, d in (("torch", "cpu"), ("op", dev)):
+        xx, bb, gg = x.to(d).requires_grad_(), b.to(d).requires_grad_(), go.to(d).requires_grad_()
+        yy = (F.leaky_relu(xx + bb[None, :, None, None], 0.2) * 2 ** 0.5) if which == "torch" else op.fused_leaky_relu(xx, bb)
+        gx, gb = torch.autograd.grad(yy, (xx, bb), gg, create_graph=True)
+        pen = (gx * w1.to(d)).sum() + (gb * w2.to(d)).sum()
+        (ggo,) = torch.autograd.grad(pen, gg)
+        outs.append((gx.detach().cpu(), gb.detach().cpu(), ggo.cpu()))
+    for a_, r_ in zip(outs[1], outs[0]):
+        assert rel_err(a_, r_) < 2e-6
 
 
 def check_input_gradient_only(dev):
