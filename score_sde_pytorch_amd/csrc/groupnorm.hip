@@ -139,6 +139,46 @@ __global__ __launch_bounds__(256) void gn_part_finalize_kernel(const GnFinParams
   }
 }
 
+// The same merge for groups with MANY entries (SSDE_GN_TEAM_MAX_ENTRIES: the 128x128 / 256x256 levels of FFHQ-256, 1024-4096
+// slices per image): one workgroup per (image, group).  Thread t merges the entries t, t + 256, ... in order -- four loads in
+// flight at a time --, then the 256 thread results are merged pairwise through LDS, lower index first: a fixed order, so the
+// result is deterministic (it is NOT the order of a 16-lane team: such a group is always merged here, by nobody else).
+// With teams of 16 these launches were 64-256 dependent loads per lane: 109 launches of an FFHQ-256 evaluation took 3.2 ms
+// (round 5's wave per group: 1.4 ms).
+__global__ __launch_bounds__(256) void gn_part_finalize_big_kernel(const GnFinParams p) {
+  SSDE_LDS(red);                                   // [256][3]
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  const int n = pair / p.groups, g = pair - n * p.groups;
+  SsdeGnTeam t;
+  ssde_gn_team_init(t, p.part0, p.part1, p.c0, p.c1, p.s0, p.s1, p.groups, n, g);
+  float cnt = 0.f, m = 0.f, M2 = 0.f;
+  for (int k0 = tid; k0 < t.etot; k0 += 4 * 256) {
+    float v[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + 256 * i;
+      const float* e = t.entry(k < t.etot ? k : 0);
+      v[i][0] = e[0]; v[i][1] = e[1]; v[i][2] = e[2];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (k0 + 256 * i < t.etot) ssde_stat_merge(cnt, m, M2, v[i][2], v[i][0], v[i][1]);
+  }
+  red[tid * 3] = cnt; red[tid * 3 + 1] = m; red[tid * 3 + 2] = M2;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    if ((tid & (2 * o - 1)) == 0) {
+      ssde_stat_merge(cnt, m, M2, red[(tid + o) * 3], red[(tid + o) * 3 + 1], red[(tid + o) * 3 + 2]);
+      red[tid * 3] = cnt; red[tid * 3 + 1] = m; red[tid * 3 + 2] = M2;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    p.mean[pair] = m;
+    p.rstd[pair] = ssde_gn_rstd(cnt, M2, p.eps);
+  }
+}
+
 }  // namespace
 
 extern "C" int ssde_gn_finalize(const ssde_gn_finalize_args* a, void* stream) {
@@ -148,7 +188,10 @@ extern "C" int ssde_gn_finalize(const ssde_gn_finalize_args* a, void* stream) {
   SSDE_REQUIRE(a->groups > 0 && C % a->groups == 0 && (C / a->groups) % 4 == 0, "gn_finalize: channels-per-group must be a multiple of 4");
   SSDE_REQUIRE(a->n > 0 && a->slices0 > 0 && (a->c1 == 0 || a->slices1 > 0), "gn_finalize: bad shape");
   GnFinParams p{a->part0, a->part1, a->c0, a->c1, a->slices0, a->slices1, a->n, a->groups, a->eps, a->mean, a->rstd};
-  hipLaunchKernelGGL(gn_part_finalize_kernel, dim3(ssde_cdiv(a->n * a->groups, 16)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  if (ssde_gn_group_is_big(a->c0, a->c1, a->slices0, a->slices1, a->groups))
+    hipLaunchKernelGGL(gn_part_finalize_big_kernel, dim3(a->n * a->groups), dim3(256), 256 * 3 * sizeof(float), static_cast<hipStream_t>(stream), p);
+  else
+    hipLaunchKernelGGL(gn_part_finalize_kernel, dim3(ssde_cdiv(a->n * a->groups, 16)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   SSDE_LAUNCH_CHECK();
   return SSDE_OK;
 }

@@ -291,14 +291,26 @@ struct SsdeGnTeam {
     return part1 + (((size_t)n * s1 + s) * Q1 + q) * 3;
   }
 };
-__device__ __forceinline__ void ssde_gn_merge16_load(SsdeGnTeam& t, const float* part0, const float* part1, int c0, int c1, int s0, int s1,
-                                                     int groups, int n, int g, int l16) {
+// the entry list of one (image n, group g): everything but the loads
+__device__ __forceinline__ void ssde_gn_team_init(SsdeGnTeam& t, const float* part0, const float* part1, int c0, int c1, int s0, int s1,
+                                                  int groups, int n, int g) {
   t.part0 = part0; t.part1 = part1; t.s0 = s0; t.s1 = s1; t.n = n;
   t.cpq = (c0 + c1) / groups / 4;                 // channel quads per group
   t.q0 = g * t.cpq; t.Q0 = c0 >> 2; t.Q1 = c1 >> 2;
   t.qm = min(max(t.Q0, t.q0), t.q0 + t.cpq);
   t.e0 = (t.qm - t.q0) * s0;
   t.etot = t.e0 + (t.q0 + t.cpq - t.qm) * s1;
+}
+// More entries per group than this (the 128x128 and 256x256 levels of the FFHQ-256 network: 1024-4096 slices per image) and a
+// team of 16 lanes is the wrong shape -- 64-256 dependent loads per lane --: ssde_gn_finalize gives such a group a whole
+// workgroup (groupnorm.hip), and no consumer merges it for itself (wino4_xform.hip).  Host and device use the same bound.
+#define SSDE_GN_TEAM_MAX_ENTRIES 256
+__host__ __device__ __forceinline__ bool ssde_gn_group_is_big(int c0, int c1, int s0, int s1, int groups) {
+  return (long long)((c0 + c1) / groups / 4) * ((long long)s0 + s1) > SSDE_GN_TEAM_MAX_ENTRIES;
+}
+__device__ __forceinline__ void ssde_gn_merge16_load(SsdeGnTeam& t, const float* part0, const float* part1, int c0, int c1, int s0, int s1,
+                                                     int groups, int n, int g, int l16) {
+  ssde_gn_team_init(t, part0, part1, c0, c1, s0, s1, groups, n, g);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int k = l16 + 16 * i;

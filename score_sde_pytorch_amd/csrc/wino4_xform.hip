@@ -166,6 +166,7 @@ bool ssde_wino4_xform_merges_gn(const ssde_conv_args* a) {
   if (!gn || !a->gn_in_part0 || a->tile != SSDE_TILE_WINOGRAD4R || (a->flags & SSDE_CONVF_V_GIVEN)) return false;
   if (a->gn_in_slices0 <= 0 || (s.c1 > 0 && (!a->gn_in_part1 || a->gn_in_slices1 <= 0))) return false;
   const int per_img = (a->h_in / 4) * (a->w_in / 4);
+  if (s.gn_groups > 0 && ssde_gn_group_is_big(s.c0, s.c1, a->gn_in_slices0, s.c1 > 0 ? a->gn_in_slices1 : 0, s.gn_groups)) return false;
   return per_img >= 4 && s.gn_groups > 0 && s.gn_mean && s.gn_rstd;
 }
 

@@ -1469,6 +1469,51 @@ def check_conv_split_reduction(dev, monkeypatch, n, repeats=3):
             assert (m2 - mr).abs().max().item() < 1e-5 and ((r2 - rr).abs() / rr).max().item() < 1e-4
 
 
+def check_gn_finalize_entry_counts(dev):
+    """ssde_gn_finalize over synthetic partials ([N][slices][C/4][3] = mean, M2, count per image, slice, channel quad) against an
+    fp64 merge: a group with few entries (a team of 16 lanes) and with many (SSDE_GN_TEAM_MAX_ENTRIES: a workgroup per group --
+    the 128x128 / 256x256 levels of FFHQ-256), a channel concatenation whose boundary cuts a group, empty entries."""
+    import ctypes as C
+    from score_sde_pytorch_amd import _lib as L, hipops as ops
+    lib = L.load()
+    g = torch.Generator().manual_seed(5)
+    for n, c0, c1, groups, s0, s1 in [(2, 64, 32, 8, 200, 100), (3, 32, 0, 8, 1024, 0), (2, 64, 32, 8, 8, 4), (1, 128, 0, 32, 4096, 0)]:
+        def parts(c, sl):
+            if c == 0:
+                return None
+            cnt = torch.randint(0, 3, (n, sl, c // 4, 1), generator=g).float() * 32.0          # some entries are empty
+            mean = torch.randn(n, sl, c // 4, 1, generator=g) * 2 + 0.5
+            M2 = torch.rand(n, sl, c // 4, 1, generator=g) * cnt * 3
+            return torch.cat([mean * (cnt > 0), M2, cnt], -1).contiguous()
+        p0, p1 = parts(c0, s0), parts(c1, s1)
+        cpq = (c0 + c1) // groups // 4
+        mean_ref, rstd_ref = torch.zeros(n, groups, dtype=torch.float64), torch.zeros(n, groups, dtype=torch.float64)
+        for i in range(n):
+            for gi in range(groups):
+                ent = []
+                for q in range(gi * cpq, (gi + 1) * cpq):
+                    src, qq = (p0, q) if q < c0 // 4 else (p1, q - c0 // 4)
+                    ent.append(src[i, :, qq, :].double())
+                e = torch.cat(ent, 0)
+                cnt = e[:, 2].sum()
+                m = (e[:, 0] * e[:, 2]).sum() / cnt
+                M2 = (e[:, 1] + e[:, 2] * (e[:, 0] - m) ** 2).sum()
+                mean_ref[i, gi], rstd_ref[i, gi] = m, 1.0 / torch.sqrt(M2 / cnt + 1e-6)
+        f = L.GnFinalizeArgs()
+        d0, d1 = p0.to(dev), (p1.to(dev) if p1 is not None else None)
+        mo, ro = torch.zeros(n, groups, device=dev), torch.zeros(n, groups, device=dev)
+        f.part0, f.part1 = d0.data_ptr(), (d1.data_ptr() if d1 is not None else None)
+        f.c0, f.c1, f.slices0, f.slices1, f.n, f.groups, f.eps = c0, c1, s0, s1, n, groups, 1e-6
+        f.mean, f.rstd = mo.data_ptr(), ro.data_ptr()
+        L.check(lib.ssde_gn_finalize(C.byref(f), ops._stream()))
+        mo2, ro2 = torch.zeros(n, groups, device=dev), torch.zeros(n, groups, device=dev)
+        f.mean, f.rstd = mo2.data_ptr(), ro2.data_ptr()
+        L.check(lib.ssde_gn_finalize(C.byref(f), ops._stream()))
+        assert torch.equal(mo, mo2) and torch.equal(ro, ro2), "the merge must be reproducible"
+        assert float((mo.cpu().double() - mean_ref).abs().max()) < 1e-5, (n, c0, c1, s0, s1)
+        assert float(((ro.cpu().double() - rstd_ref).abs() / rstd_ref).max()) < 1e-5, (n, c0, c1, s0, s1)
+
+
 def check_conv_small_cout(dev, big=False):
     """conv_small.hip: 3x3 / stride 1 convolutions onto at most four channels (the image heads, ncsnpp.py:329-337,368-375) --
     plain, then fully fused (concat source, GroupNorm + SiLU prologue, bias, per-image addend, residual before / after the

@@ -208,3 +208,7 @@ def test_winograd_f4x4_weight_gradient_with_the_stream_k_split():
 @pytest.mark.parametrize("kind", ["ncsnpp", "ddpmpp"])
 def test_deferred_finishing_launches_are_bit_identical(kind, monkeypatch):
     T.check_deferred_finish_is_bit_identical("cuda", monkeypatch, kind)
+
+
+def test_groupnorm_finalize_with_few_and_with_many_entries_per_group():
+    T.check_gn_finalize_entry_counts("cuda")
