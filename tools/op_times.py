@@ -43,15 +43,17 @@ def describe(op):
 if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     dev = torch.device("cuda")
-    cfg = _util.cfgs.get_config("ve/cifar10_ncsnpp_continuous")
+    name = sys.argv[2] if len(sys.argv) > 2 else "ve/cifar10_ncsnpp_continuous"      # e.g. 16 ve/ffhq_256_ncsnpp_continuous
+    cfg = _util.cfgs.get_config(name)
+    R = cfg.data.image_size
     torch.manual_seed(0)
     model = mutils.get_model("ncsnpp")(cfg)
     _util.load_seeded(model, seed=1)
     model = model.to(dev).eval()
-    eng = E.UNetEngine(model, B, 32, 32, dev)
+    eng = E.UNetEngine(model, B, R, R, dev)
     eng.weights.refresh()
     g = torch.Generator().manual_seed(3)
-    eng.load_inputs((torch.randn(B, 3, 32, 32, generator=g) * 5).to(dev), torch.full((B,), 3.0, device=dev))
+    eng.load_inputs((torch.randn(B, 3, R, R, generator=g) * 5).to(dev), torch.full((B,), 3.0, device=dev))
     prog = eng.program
     prog.run_timed()
     reps = 5
@@ -59,7 +61,7 @@ if __name__ == "__main__":
     for _ in range(reps):
         ms += np.array(prog.run_timed())
     ms /= reps
-    print("# %d launches, %.3f ms per evaluation (HIP events around every launch, program launches)" % (prog.n, ms.sum()))
+    print("# %s, batch %d: %d launches, %.3f ms per evaluation (HIP events around every launch, program launches)" % (name, B, prog.n, ms.sum()))
     groups = collections.OrderedDict()
     for i in range(prog.n):
         d = describe(prog.ops[i])
