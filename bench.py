@@ -202,8 +202,19 @@ def bench_train(args, cfg, dev, dist, world, rank, sync_all, leg="train"):
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
+        # (under torch.distributed.run with one process TORCHELASTIC_USE_AGENT_STORE tells a tcp:// rendezvous that the AGENT hosts
+        #  the store: rank 0 would then connect, as a client, to a port nobody listens on -- a 600 s timeout, seen in this round's
+        #  call 35.  This group is private to the process: the variable is put aside while it is created, and the creation itself
+        #  may take a minute at most)
+        import datetime
+        agent_store = os.environ.pop("TORCHELASTIC_USE_AGENT_STORE", None)
         try:
-            tdist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device(dev))
+            try:
+                tdist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device(dev),
+                                         timeout=datetime.timedelta(seconds=60))
+            finally:
+                if agent_store is not None:
+                    os.environ["TORCHELASTIC_USE_AGENT_STORE"] = agent_store
             os.environ["SSDE_FORCE_GRAD_EXCHANGE"] = "1"
             try:
                 for i in range(5):
